@@ -1,0 +1,89 @@
+// Internal helpers shared by the HIP translation units of libgantron_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/gantron_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+void gt_set_error(const char* fmt, ...);
+
+#define GT_REQUIRE(cond, code, ...)                 \
+    do {                                            \
+        if (!(cond)) {                              \
+            gt_set_error(__VA_ARGS__);              \
+            return (code);                          \
+        }                                           \
+    } while (0)
+
+#define GT_LAUNCH_CHECK()                                                           \
+    do {                                                                            \
+        hipError_t e__ = hipGetLastError();                                         \
+        if (e__ != hipSuccess) {                                                    \
+            gt_set_error("%s:%d launch failed: %s", __FILE__, __LINE__,             \
+                         hipGetErrorString(e__));                                   \
+            return (int)e__;                                                        \
+        }                                                                           \
+    } while (0)
+
+__host__ __device__ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+__host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// sum of `n` partial slabs at element index idx (slab s lives at p + s*stride)
+__device__ __forceinline__ float slab_sum(const float* p, int n, int64_t stride, int64_t idx) {
+    float acc = 0.f;
+    for (int s = 0; s < n; ++s) acc += p[(int64_t)s * stride + idx];
+    return acc;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block-wide sum for blockDim.x <= 1024 (multiple of 64); `red` needs 16 floats of LDS.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = red[0];
+    for (int i = 1; i < nw; ++i) t = fmaxf(t, red[i]);
+    return t;
+}
+
+// Counter-based uniform in [0,1): a 64-bit mix (splitmix64 finaliser) of (seed, counter); the
+// oracle/tests implement the identical integer recipe in numpy (tests/test_rng.py).
+__host__ __device__ __forceinline__ uint32_t gt_hash32(uint64_t seed, uint64_t ctr) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (ctr + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32);
+}
+__host__ __device__ __forceinline__ float gt_u01(uint64_t seed, uint64_t ctr) {
+    return (float)(gt_hash32(seed, ctr) >> 8) * (1.0f / 16777216.0f);
+}

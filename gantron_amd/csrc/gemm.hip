@@ -1,0 +1,316 @@
+// fp32 MFMA GEMM with conv-aware operand addressing (gfx950).
+//
+//   C[m,n] (=|+=) alpha * sum_k A(m,k) * B(n,k) (+ bias[n])
+//
+// One kernel family serves every dense contraction of the training step that is not inside a
+// recurrence: Linear layers, Conv1d forward / input-grad / weight-grad as implicit GEMMs over
+// channels-last activations (im2col addressing is done by the tile loader, nothing is
+// materialised), the deferred weight gradients of the decoder LSTMs (K = To*B), the STFT.
+//
+// Tiling: BMxBNx16 block tile, 256 threads = 4 waves in a 2x2 arrangement; each wave owns a
+// (BM/2)x(BN/2) sub-tile made of 32x32 MFMA tiles (v_mfma_f32_32x32x2_f32: exact fp32, runs at
+// the chip's fp32 peak).  Both operand tiles are staged k-major in LDS ([16][rows+4]) so that an
+// MFMA operand fetch is one conflict-free ds_read_b32 per lane; the next tile's global loads are
+// issued into registers before the current tile's MFMAs (register prefetch).
+#include "common.h"
+
+namespace {
+
+struct OpDev {
+    const float* p;
+    int mode, T, C, dil, pad, vec;
+    long ld;
+};
+
+struct GemmDev {
+    OpDev A, B;
+    float* C;
+    const float* bias;
+    long ldc, a_bs, b_bs, c_bs;
+    int M, N, K, accumulate, split_k, k_per_split;
+    float alpha;
+};
+
+constexpr int BK = 16;
+
+// float4 along k for row r (modes KC / IM2COL_K).  (b,t) = position of row r (im2col only).
+template <int MODE>
+__device__ __forceinline__ float4 load_kvec(const OpDev& o, const float* base, int r, int R, int k,
+                                            int K, int b, int t) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r >= R || k >= K) return v;
+    const float* p;
+    if (MODE == GT_OP_KC) {
+        p = base + (long)r * o.ld + k;
+    } else {
+        const int tap = k / o.C;
+        const int c = k - tap * o.C;
+        const int tt = t + tap * o.dil - o.pad;
+        if (tt < 0 || tt >= o.T) return v;
+        p = base + ((long)b * o.T + tt) * o.C + c;
+    }
+    if (o.vec && k + 3 < K) {
+        v = *reinterpret_cast<const float4*>(p);
+    } else {
+        v.x = p[0];
+        if (k + 1 < K) v.y = p[1];
+        if (k + 2 < K) v.z = p[2];
+        if (k + 3 < K) v.w = p[3];
+    }
+    return v;
+}
+
+// float4 along r at reduction index k (modes RC / IM2COL_R).  (tap,c) = decomposition of row r.
+template <int MODE>
+__device__ __forceinline__ float4 load_rvec(const OpDev& o, const float* base, int r, int R, int k,
+                                            int K, int tap, int c) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r >= R || k >= K) return v;
+    const float* p;
+    if (MODE == GT_OP_RC) {
+        p = base + (long)k * o.ld + r;
+    } else {
+        const int b = k / o.T;
+        const int t = k - b * o.T;
+        const int tt = t + tap * o.dil - o.pad;
+        if (tt < 0 || tt >= o.T) return v;
+        p = base + ((long)b * o.T + tt) * o.C + c;
+    }
+    if (o.vec && r + 3 < R) {
+        v = *reinterpret_cast<const float4*>(p);
+    } else {
+        v.x = p[0];
+        if (r + 1 < R) v.y = p[1];
+        if (r + 2 < R) v.z = p[2];
+        if (r + 3 < R) v.w = p[3];
+    }
+    return v;
+}
+
+template <int MODE>
+constexpr bool is_ktype() { return MODE == GT_OP_KC || MODE == GT_OP_IM2COL_K; }
+
+// Per-thread loader state for one operand tile of BR rows.
+template <int MODE, int BR>
+struct TileLoader {
+    static constexpr int NIT = BR / 64;
+    static constexpr int LD = BR + 4;
+    int p0[NIT], p1[NIT];   // (b,t) for IM2COL_K, (tap,c) for IM2COL_R
+    float4 reg[NIT];
+
+    __device__ __forceinline__ void init(const OpDev& o, int r0, int tid) {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            p0[i] = 0; p1[i] = 0;
+            if (MODE == GT_OP_IM2COL_K) {
+                const int r = r0 + (tid & 63) + 64 * i;
+                p0[i] = r / o.T; p1[i] = r - p0[i] * o.T;
+            } else if (MODE == GT_OP_IM2COL_R) {
+                const int f = tid + 256 * i;
+                const int r = r0 + 4 * (f % (BR / 4));
+                p0[i] = r / o.C; p1[i] = r - p0[i] * o.C;
+            }
+        }
+    }
+    __device__ __forceinline__ void load(const OpDev& o, const float* base, int r0, int R, int k0,
+                                         int K, int tid) {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            if (is_ktype<MODE>()) {
+                const int r = r0 + (tid & 63) + 64 * i;
+                const int k = k0 + 4 * (tid >> 6);
+                reg[i] = load_kvec<MODE>(o, base, r, R, k, K, p0[i], p1[i]);
+            } else {
+                const int f = tid + 256 * i;
+                const int r = r0 + 4 * (f % (BR / 4));
+                const int k = k0 + f / (BR / 4);
+                reg[i] = load_rvec<MODE>(o, base, r, R, k, K, p0[i], p1[i]);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float* S, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            if (is_ktype<MODE>()) {
+                const int rl = (tid & 63) + 64 * i;
+                const int kq = tid >> 6;
+                S[(4 * kq + 0) * LD + rl] = reg[i].x;
+                S[(4 * kq + 1) * LD + rl] = reg[i].y;
+                S[(4 * kq + 2) * LD + rl] = reg[i].z;
+                S[(4 * kq + 3) * LD + rl] = reg[i].w;
+            } else {
+                const int f = tid + 256 * i;
+                const int rq = f % (BR / 4), kl = f / (BR / 4);
+                *reinterpret_cast<float4*>(&S[kl * LD + 4 * rq]) = reg[i];
+            }
+        }
+    }
+};
+
+template <int BM, int BN, int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void sgemm_kernel(GemmDev g) {
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    __shared__ __attribute__((aligned(16))) float smem[BK * LDA + BK * LDB];
+    float* As = smem;
+    float* Bs = smem + BK * LDA;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int batch = blockIdx.z / g.split_k, kz = blockIdx.z - batch * g.split_k;
+    const int kbeg = kz * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    const float* Ab = g.A.p + (long)batch * g.a_bs;
+    const float* Bb = g.B.p + (long)batch * g.b_bs;
+    float* Cb = g.C + (long)batch * g.c_bs;
+
+    TileLoader<AMODE, BM> la;
+    TileLoader<BMODE, BN> lb;
+    la.init(g.A, m0, tid);
+    lb.init(g.B, n0, tid);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+
+    if (kbeg < kend) {
+        la.load(g.A, Ab, m0, g.M, kbeg, kend, tid);
+        lb.load(g.B, Bb, n0, g.N, kbeg, kend, tid);
+    }
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        la.store(As, tid);
+        lb.store(Bs, tid);
+        __syncthreads();
+        if (k0 + BK < kend) {
+            la.load(g.A, Ab, m0, g.M, k0 + BK, kend, tid);
+            lb.load(g.B, Bb, n0, g.N, k0 + BK, kend, tid);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            const int krow = 2 * kk + (lane >> 5);
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[krow * LDA + wm0 + 32 * i + (lane & 31)];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[krow * LDB + wn0 + 32 * j + (lane & 31)];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D map of the 32x32 MFMA: n = lane&31, m = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn0 + 32 * j + (lane & 31);
+            if (n >= g.N) continue;
+            const float bias = (g.bias != nullptr && kz == 0) ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= g.M) continue;
+                float* c = Cb + (long)m * g.ldc + n;
+                const float v = g.alpha * acc[i][j][r] + bias;
+                if (g.split_k > 1) atomicAdd(c, v);
+                else if (g.accumulate) *c += v;
+                else *c = v;
+            }
+        }
+}
+
+template <int BM, int BN>
+int launch_tile(const GemmDev& d, dim3 grid, hipStream_t st) {
+    const int am = d.A.mode, bm = d.B.mode;
+#define GT_CASE(AM, BMD)                                                                      \
+    if (am == AM && bm == BMD) {                                                              \
+        hipLaunchKernelGGL((sgemm_kernel<BM, BN, AM, BMD>), grid, dim3(256), 0, st, d);       \
+        return 0;                                                                             \
+    }
+    GT_CASE(GT_OP_KC, GT_OP_KC)
+    GT_CASE(GT_OP_KC, GT_OP_RC)
+    GT_CASE(GT_OP_RC, GT_OP_RC)
+    GT_CASE(GT_OP_RC, GT_OP_KC)
+    GT_CASE(GT_OP_IM2COL_K, GT_OP_KC)
+    GT_CASE(GT_OP_RC, GT_OP_IM2COL_R)
+#undef GT_CASE
+    return GT_E_ARG;
+}
+
+int prep_operand(const GtOperand& s, OpDev& o, int rows, int K, const char* name) {
+    GT_REQUIRE(s.p != nullptr, GT_E_ARG, "gt_sgemm: operand %s is NULL", name);
+    o.p = s.p; o.mode = s.mode; o.T = s.T; o.C = s.C; o.dil = s.dil; o.pad = s.pad; o.ld = s.ld;
+    switch (s.mode) {
+        case GT_OP_KC:
+            GT_REQUIRE(s.ld >= 1, GT_E_ARG, "gt_sgemm: %s ld", name);
+            o.vec = aligned16(s.p) && (s.ld % 4 == 0) && (s.batch_stride % 4 == 0);
+            break;
+        case GT_OP_RC:
+            GT_REQUIRE(s.ld >= rows, GT_E_ARG, "gt_sgemm: %s ld %ld < rows %d", name, (long)s.ld, rows);
+            o.vec = aligned16(s.p) && (s.ld % 4 == 0) && (s.batch_stride % 4 == 0);
+            break;
+        case GT_OP_IM2COL_K:
+            GT_REQUIRE(s.T > 0 && s.C > 0 && s.C % 4 == 0 && K % s.C == 0 && rows % s.T == 0, GT_E_ARG,
+                       "gt_sgemm: %s im2col_k needs C%%4==0, K%%C==0, rows%%T==0 (T=%d C=%d K=%d rows=%d)",
+                       name, s.T, s.C, K, rows);
+            o.vec = aligned16(s.p);
+            break;
+        case GT_OP_IM2COL_R:
+            GT_REQUIRE(s.T > 0 && s.C > 0 && s.C % 4 == 0 && rows % s.C == 0 && K % s.T == 0, GT_E_ARG,
+                       "gt_sgemm: %s im2col_r needs C%%4==0, rows%%C==0, K%%T==0 (T=%d C=%d K=%d rows=%d)",
+                       name, s.T, s.C, K, rows);
+            o.vec = aligned16(s.p);
+            break;
+        default:
+            GT_REQUIRE(false, GT_E_ARG, "gt_sgemm: %s bad mode %d", name, s.mode);
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int gt_sgemm(const GtGemm* g, void* stream) {
+    GT_REQUIRE(g != nullptr && g->C != nullptr, GT_E_ARG, "gt_sgemm: NULL argument");
+    GT_REQUIRE(g->M > 0 && g->N > 0 && g->K > 0 && g->batch >= 1 && g->split_k >= 1, GT_E_ARG,
+               "gt_sgemm: bad sizes M=%d N=%d K=%d batch=%d split=%d", g->M, g->N, g->K, g->batch, g->split_k);
+    GT_REQUIRE(g->ldc >= g->N, GT_E_ARG, "gt_sgemm: ldc %ld < N %d", (long)g->ldc, g->N);
+    GemmDev d;
+    int rc;
+    if ((rc = prep_operand(g->A, d.A, g->M, g->K, "A")) != 0) return rc;
+    if ((rc = prep_operand(g->B, d.B, g->N, g->K, "B")) != 0) return rc;
+    d.C = g->C; d.bias = g->bias; d.ldc = g->ldc;
+    d.a_bs = g->A.batch_stride; d.b_bs = g->B.batch_stride; d.c_bs = g->c_batch_stride;
+    d.M = g->M; d.N = g->N; d.K = g->K; d.accumulate = g->accumulate; d.alpha = g->alpha;
+    d.split_k = g->split_k;
+    const int kblocks = cdiv(g->K, BK);
+    d.k_per_split = cdiv(kblocks, g->split_k) * BK;
+    d.split_k = cdiv(g->K, d.k_per_split);   // drop empty splits
+    hipStream_t st = (hipStream_t)stream;
+
+    const long tiles128 = (long)cdiv(g->M, 128) * cdiv(g->N, 128) * g->batch * d.split_k;
+    const bool big = tiles128 >= 192 && g->M > 64 && g->N > 64;
+    const long gz = (long)g->batch * d.split_k;
+    GT_REQUIRE(gz <= 65535, GT_E_LIMIT, "gt_sgemm: batch*split_k too large");
+    if (big) {
+        dim3 grid(cdiv(g->N, 128), cdiv(g->M, 128), (unsigned)gz);
+        GT_REQUIRE(grid.y <= 65535, GT_E_LIMIT, "gt_sgemm: M too large for grid.y");
+        rc = launch_tile<128, 128>(d, grid, st);
+    } else {
+        dim3 grid(cdiv(g->N, 64), cdiv(g->M, 64), (unsigned)gz);
+        GT_REQUIRE(grid.y <= 65535, GT_E_LIMIT, "gt_sgemm: M too large for grid.y");
+        rc = launch_tile<64, 64>(d, grid, st);
+    }
+    GT_REQUIRE(rc == 0, rc, "gt_sgemm: unsupported operand mode pair (%d,%d)", g->A.mode, g->B.mode);
+    GT_LAUNCH_CHECK();
+    return 0;
+}

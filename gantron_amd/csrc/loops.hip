@@ -1,0 +1,160 @@
+// Host-side drivers of the two sequential loops of the generator: the teacher-forced decoder
+// (reference Decoder.forward / decode, model.py:378-454) and the encoder BiLSTM (model.py:202-210),
+// forward and backward-through-time.  A loop is one C call: launches are issued back-to-back on
+// the caller's stream from a tight C++ loop (no per-step Python), 7 launches per decoder step.
+//
+// Work that does not depend on the recurrence is hoisted out of the loop by the caller and runs
+// as large MFMA GEMMs: the prenet->attention-LSTM input projection for all steps (`pre1`), the
+// mel/gate projection of all steps (reads HC), every weight gradient (dW = dGates^T . inputs with
+// K = To*B) and d(memory) (batched W^T . dctx).  Inside the loop only the recurrent products
+// ([ctx|h] . W) remain, as weight-streaming small-M MFMA kernels (recurrent.hip).
+#include "common.h"
+
+extern "C" {
+
+#define GT_TRY(call)                \
+    do {                            \
+        int rc__ = (call);          \
+        if (rc__ != 0) return rc__; \
+    } while (0)
+
+static inline GtSlabs slabs(const float* p, int n, int64_t stride, int64_t ld) {
+    GtSlabs s; s.p = p; s.n = n; s.slab_stride = stride; s.ld = ld; return s;
+}
+static const GtSlabs kNoSlabs = {nullptr, 0, 0, 0};
+
+int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
+    GT_REQUIRE(a != nullptr, GT_E_ARG, "gt_decoder_fwd: NULL");
+    GT_REQUIRE(a->B > 0 && a->Bp >= a->B && a->Bp % 16 == 0 && a->Bp <= 64, GT_E_LIMIT,
+               "gt_decoder_fwd: batch %d (padded %d) must fit 64 rows per call", a->B, a->Bp);
+    GT_REQUIRE(a->To > 0 && a->Ti > 0 && a->Ha % 16 == 0 && a->Hd % 16 == 0 && a->Apad % 16 == 0, GT_E_ARG,
+               "gt_decoder_fwd: bad dims");
+    const int mt = a->Bp / 16;
+    const int N1 = 4 * a->Ha, N2 = 4 * a->Hd;
+    const int K1 = a->E + a->Ha, K2 = a->Ha + a->E + a->Hd;
+    const int64_t hc_ld = a->Hd + a->E;
+    GtAttnDims d; d.B = a->B; d.Ti = a->Ti; d.E = a->E; d.A = a->A; d.F = a->F; d.Kc = a->Kc;
+    const int64_t BT = (int64_t)a->B * a->Ti;
+    for (int t = 0; t < a->To; ++t) {
+        const uint8_t* k1 = a->att_keep ? a->att_keep + (int64_t)t * a->Bp * a->Ha : nullptr;
+        const uint8_t* k2 = a->dec_keep ? a->dec_keep + (int64_t)t * a->Bp * a->Hd : nullptr;
+        float* hc_t = a->HC + (int64_t)t * a->Bp * hc_ld;
+        // attention LSTM: [ctx_{t-1} | h_att_{t-1}] . W1r + pre1[t]
+        GT_TRY(gt_rec_gemm(a->X1, a->ld1, a->W1p, a->part, mt, N1, K1, a->S1, (int64_t)a->Bp * N1, 1, 0, 0, 0, stream));
+        GT_TRY(gt_lstm_cell_fwd(slabs(a->part, a->S1, (int64_t)a->Bp * N1, N1), a->pre1 + (int64_t)t * a->Bp * N1, N1,
+                                a->c1 + (int64_t)t * a->Bp * a->Ha, nullptr, 0, k1, a->p_att, nullptr,
+                                a->gates1 + (int64_t)t * a->Bp * N1, a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha,
+                                a->hatt + (int64_t)t * a->Bp * a->Ha, a->X1 + a->E, a->ld1, a->X2, a->ld2, nullptr, 0,
+                                a->B, a->Ha, stream));
+        // query projection, energies, softmax + context
+        GT_TRY(gt_rec_gemm(a->X2, a->ld2, a->Wqp, a->part, mt, a->Apad, a->Ha, a->Sq, (int64_t)a->Bp * a->Apad, 1, 0, 0,
+                           0, stream));
+        GT_TRY(gt_attn_energies_fwd(d, slabs(a->part, a->Sq, (int64_t)a->Bp * a->Apad, a->Apad),
+                                    a->w_hist + (int64_t)t * BT, a->cum_hist + (int64_t)t * BT, a->pm, a->Wc, a->Wd, a->v,
+                                    a->lengths, a->q_hist + (int64_t)t * a->B * a->A, a->energies, stream));
+        GT_TRY(gt_attn_context_fwd(d, a->energies, a->memory, a->ldE, a->w_hist + (int64_t)(t + 1) * BT,
+                                   a->cum_hist + (int64_t)t * BT, a->cum_hist + (int64_t)(t + 1) * BT, a->X1, a->ld1,
+                                   a->X2 + a->Ha, a->ld2, hc_t + a->Hd, hc_ld, stream));
+        // decoder LSTM: [h_att_t | ctx_t | h_dec_{t-1}] . W2 + bias
+        GT_TRY(gt_rec_gemm(a->X2, a->ld2, a->W2p, a->part, mt, N2, K2, a->S2, (int64_t)a->Bp * N2, 1, 0, 0, 0, stream));
+        GT_TRY(gt_lstm_cell_fwd(slabs(a->part, a->S2, (int64_t)a->Bp * N2, N2), a->bias2, 0,
+                                a->c2 + (int64_t)t * a->Bp * a->Hd, nullptr, 0, k2, a->p_dec, nullptr,
+                                a->gates2 + (int64_t)t * a->Bp * N2, a->c2 + (int64_t)(t + 1) * a->Bp * a->Hd, nullptr,
+                                a->X2 + a->Ha + a->E, a->ld2, hc_t, hc_ld, nullptr, 0, a->B, a->Hd, stream));
+    }
+    return 0;
+}
+
+int gt_decoder_bwd(const GtDecoderBwd* a, void* stream) {
+    GT_REQUIRE(a != nullptr, GT_E_ARG, "gt_decoder_bwd: NULL");
+    GT_REQUIRE(a->B > 0 && a->Bp >= a->B && a->Bp % 16 == 0 && a->Bp <= 64, GT_E_LIMIT, "gt_decoder_bwd: batch");
+    const int mt = a->Bp / 16;
+    const int N1 = 4 * a->Ha, N2 = 4 * a->Hd;
+    const int64_t hc_ld = a->Hd + a->E;
+    GtAttnDims d; d.B = a->B; d.Ti = a->Ti; d.E = a->E; d.A = a->A; d.F = a->F; d.Kc = a->Kc;
+    const int64_t BT = (int64_t)a->B * a->Ti;
+    const int64_t sX1 = (int64_t)a->Bp * a->N1pad, sX2 = (int64_t)a->Bp * a->N2pad, sQ = (int64_t)a->Bp * a->Ha;
+    for (int t = a->To - 1; t >= 0; --t) {
+        const bool last = (t == a->To - 1);
+        const uint8_t* k1 = a->att_keep ? a->att_keep + (int64_t)t * a->Bp * a->Ha : nullptr;
+        const uint8_t* k2 = a->dec_keep ? a->dec_keep + (int64_t)t * a->Bp * a->Hd : nullptr;
+        const float* dhc_t = a->dHC + (int64_t)t * a->Bp * hc_ld;
+        float* dG2_t = a->dG2 + (int64_t)t * a->Bp * N2;
+        float* dG1_t = a->dG1 + (int64_t)t * a->Bp * N1;
+        float* dq_t = a->dq_hist + (int64_t)t * a->Bp * a->Apad;
+        // decoder LSTM cell: dh = projection grad + recurrent grad from step t+1
+        GT_TRY(gt_lstm_cell_bwd(last ? kNoSlabs : slabs(a->partX2 + a->Ha + a->E, a->S2, sX2, a->N2pad), kNoSlabs,
+                                kNoSlabs, dhc_t, hc_ld, a->dc2, a->gates2 + (int64_t)t * a->Bp * N2,
+                                a->c2 + (int64_t)(t + 1) * a->Bp * a->Hd, a->c2 + (int64_t)t * a->Bp * a->Hd, k2,
+                                a->p_dec, nullptr, dG2_t, a->dc2, nullptr, a->B, a->Hd, stream));
+        GT_TRY(gt_rec_gemm(dG2_t, N2, a->W2Tp, a->partX2, mt, a->N2pad, N2, a->S2, sX2, 1, 0, 0, 0, stream));
+        // attention backward
+        float* dwcat_in = a->dwcat + (int64_t)((t + 1) & 1) * 2 * BT;
+        float* dwcat_out = a->dwcat + (int64_t)(t & 1) * 2 * BT;
+        GT_TRY(gt_attn_context_bwd(d, slabs(a->partX2 + a->Ha, a->S2, sX2, a->N2pad),
+                                   last ? kNoSlabs : slabs(a->partX1, a->S1, sX1, a->N1pad), dhc_t + a->Hd, hc_ld,
+                                   a->memory, a->ldE, dwcat_in, a->dcum_acc,
+                                   a->dalign ? a->dalign + (int64_t)t * BT : nullptr,
+                                   a->dctx_hist + (int64_t)t * a->B * a->E, a->E, dq_t, a->Apad, a->dw, stream));
+        GT_TRY(gt_attn_energies_bwd(d, a->dw, a->w_hist + (int64_t)(t + 1) * BT, a->q_hist + (int64_t)t * a->B * a->A,
+                                    a->w_hist + (int64_t)t * BT, a->cum_hist + (int64_t)t * BT, a->pm, a->Wc, a->Wd, a->v,
+                                    dq_t, a->Apad, a->dpm, dwcat_out, a->acc, stream));
+        GT_TRY(gt_rec_gemm(dq_t, a->Apad, a->WqTp, a->partQ, mt, a->Ha, a->A, a->Sq, sQ, 1, 0, 0, 0, stream));
+        // attention LSTM cell: dh = d(h_att as decoder-LSTM input) + d(query) + recurrent grad from t+1
+        GT_TRY(gt_lstm_cell_bwd(slabs(a->partX2, a->S2, sX2, a->N2pad), slabs(a->partQ, a->Sq, sQ, a->Ha),
+                                last ? kNoSlabs : slabs(a->partX1 + a->E, a->S1, sX1, a->N1pad), nullptr, 0, a->dc1,
+                                a->gates1 + (int64_t)t * a->Bp * N1, a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha,
+                                a->c1 + (int64_t)t * a->Bp * a->Ha, k1, a->p_att, nullptr, dG1_t, a->dc1, nullptr, a->B,
+                                a->Ha, stream));
+        if (t > 0)
+            GT_TRY(gt_rec_gemm(dG1_t, N1, a->W1Tp, a->partX1, mt, a->N1pad, N1, a->S1, sX1, 1, 0, 0, 0, stream));
+    }
+    return 0;
+}
+
+int gt_bilstm_run(const GtBiLstm* a, void* stream) {
+    GT_REQUIRE(a != nullptr, GT_E_ARG, "gt_bilstm_run: NULL");
+    GT_REQUIRE(a->B > 0 && a->Bp >= a->B && a->Bp % 16 == 0 && a->Bp <= 64 && a->H % 4 == 0 && a->T > 0, GT_E_LIMIT,
+               "gt_bilstm_run: bad dims B=%d Bp=%d H=%d T=%d", a->B, a->Bp, a->H, a->T);
+    const int mt = a->Bp / 16;
+    const int N = 4 * a->H;
+    const int64_t TB = (int64_t)a->T * a->Bp;
+    if (!a->backward) {
+        const int64_t pz = (int64_t)a->S * a->Bp * N;
+        for (int s = 0; s < a->T; ++s) {
+            GT_TRY(gt_rec_gemm(a->X, a->ldx, a->Whp, a->part, mt, N, a->H, a->S, (int64_t)a->Bp * N, 2,
+                               (int64_t)a->Bp * a->ldx, a->w_zstride, pz, stream));
+            for (int dir = 0; dir < 2; ++dir) {
+                float* X = a->X + (int64_t)dir * a->Bp * a->ldx;
+                GT_TRY(gt_lstm_cell_fwd(slabs(a->part + dir * pz, a->S, (int64_t)a->Bp * N, N),
+                                        a->pre + ((int64_t)dir * TB + (int64_t)s * a->Bp) * N, N,
+                                        a->c + ((int64_t)dir * (a->T + 1) + s) * a->Bp * a->H, X, a->ldx, nullptr, 0.f,
+                                        a->active + (int64_t)s * a->Bp, a->gates + ((int64_t)dir * TB + (int64_t)s * a->Bp) * N,
+                                        a->c + ((int64_t)dir * (a->T + 1) + s + 1) * a->Bp * a->H,
+                                        a->hs + ((int64_t)dir * TB + (int64_t)s * a->Bp) * a->H, X, a->ldx, nullptr, 0,
+                                        nullptr, 0, a->Bp, a->H, stream));
+            }
+        }
+    } else {
+        GT_REQUIRE(a->Hpad % 16 == 0 && a->Hpad >= a->H, GT_E_ARG, "gt_bilstm_run: Hpad");
+        const int64_t pz = (int64_t)a->S * a->Bp * a->Hpad;
+        for (int s = a->T - 1; s >= 0; --s) {
+            for (int dir = 0; dir < 2; ++dir) {
+                GT_TRY(gt_lstm_cell_bwd(s == a->T - 1 ? kNoSlabs : slabs(a->part + dir * pz, a->S, (int64_t)a->Bp * a->Hpad, a->Hpad),
+                                        kNoSlabs, kNoSlabs, a->dhs + ((int64_t)dir * TB + (int64_t)s * a->Bp) * a->H, a->H,
+                                        a->dc + (int64_t)dir * a->Bp * a->H,
+                                        a->gates + ((int64_t)dir * TB + (int64_t)s * a->Bp) * N,
+                                        a->c + ((int64_t)dir * (a->T + 1) + s + 1) * a->Bp * a->H,
+                                        a->c + ((int64_t)dir * (a->T + 1) + s) * a->Bp * a->H, nullptr, 0.f,
+                                        a->active + (int64_t)s * a->Bp, a->dG + ((int64_t)dir * TB + (int64_t)s * a->Bp) * N,
+                                        a->dc + (int64_t)dir * a->Bp * a->H, nullptr, a->Bp, a->H, stream));
+            }
+            if (s > 0)
+                GT_TRY(gt_rec_gemm(a->dG + (int64_t)s * a->Bp * N, N, a->Whp, a->part, mt, a->Hpad, N, a->S,
+                                   (int64_t)a->Bp * a->Hpad, 2, TB * N, a->w_zstride, pz, stream));
+        }
+    }
+    return 0;
+}
+
+}  // extern "C"

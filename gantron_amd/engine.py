@@ -1,0 +1,553 @@
+"""Forward/backward orchestration of the generator and the discriminator over the HIP kernels.
+
+This is the host side of the hot path: it sequences C-ABI calls (ops.py / include/gantron_hip.h),
+owns no arithmetic, and keeps the reference's tensor semantics:
+
+* generator forward = Tacotron2.forward (reference model.py:644-673): embedding -> encoder
+  (3x conv5+BN+ReLU+dropout, packed BiLSTM) -> teacher-forced decoder loop with location-sensitive
+  attention -> PostNet -> autograd-invisible padding mask;
+* generator backward = what autograd does for that graph, hand-scheduled: reverse-time decoder
+  loop (weight gradients deferred to large GEMMs over all steps), PostNet/encoder conv+BN backward;
+* discriminator forward/backward = Discriminator.forward / adversarial_loss (model.py:514-540).
+
+Parameters are passed as a dict {state_dict name: CUDA tensor} in PyTorch layouts; gradients are
+accumulated into a dict of same-shaped tensors.  Stochastic inputs (dropout keep-masks, style
+noise) are explicit (`rng`), in kernel layout (channels-last, Bp rows per decoder step).
+"""
+import math
+
+import torch
+
+from . import ops
+from .ops import (ACT_NONE, ACT_RELU, ACT_TANH, IM2COL_K, IM2COL_R, KC, RC, Operand, call, ptr, roundup, sgemm)
+from ._lib import GtBiLstm, GtDecoderBwd, GtDecoderFwd, check, lib
+
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+REC_SPLITS = 4          # K-splits of the per-step recurrent GEMMs: (4H/64) x 4 workgroups per launch
+
+
+def _f32(*shape, device, zero=True):
+    return (torch.zeros if zero else torch.empty)(*shape, device=device, dtype=torch.float32)
+
+
+def _run(name, struct):
+    import ctypes
+    check(getattr(lib(), name)(ctypes.byref(struct), ops._stream()), name)
+
+
+def acc_add(dst, src):
+    """dst += src through the axpby kernel (dst, src contiguous, same numel)."""
+    assert dst.is_contiguous() and src.is_contiguous() and dst.numel() == src.numel()
+    call('gt_axpby', dst, 1.0, src, 1.0, dst, dst.numel())
+
+
+def pack_rec(W2d, N, n_valid, K, transposed=False):
+    """Pack a (n_valid x K) [or (K x n_valid) when transposed] matrix for gt_rec_gemm."""
+    out = torch.empty(int(lib().gt_rec_weight_elems(N, K)), device=W2d.device, dtype=torch.float32)
+    call('gt_pack_rec_weight', W2d, W2d.stride(0), int(transposed), N, n_valid, K, out)
+    return out
+
+
+class ConvBNStack:
+    """[Conv1d(k) -> BatchNorm1d(train) -> act -> dropout] x n over channels-last rows; the encoder
+    convolutions (model.py:165-178,196-197) and the PostNet (model.py:113-151)."""
+
+    def __init__(self, prefix, n_layers, acts):
+        self.prefix, self.n, self.acts = prefix, n_layers, acts
+
+    def forward(self, P, x, B, T, keeps, training, save):
+        for i in range(self.n):
+            W = P[f'{self.prefix}.{i}.0.conv.weight']
+            cout, cin, k = W.shape
+            bn = f'{self.prefix}.{i}.1'
+            Wf = ops.conv_weight_fwd(W)
+            y = ops.conv1d_fwd(x, Wf, P[f'{self.prefix}.{i}.0.conv.bias'], B, T, cin, cout, k, 1)
+            rows = B * T
+            stats = mi = None
+            if training:
+                stats = _f32(2 * cout, device=x.device, zero=False)
+                call('gt_col_stats', y, y, rows, cout, stats)
+                mi = _f32(2 * cout, device=x.device, zero=False)
+            keep = keeps[i] if (keeps is not None and training) else None
+            out = _f32(rows, cout, device=x.device, zero=False)
+            call('gt_bn_act_drop_fwd', y, stats, rows, cout, P[bn + '.weight'], P[bn + '.bias'],
+                 P[bn + '.running_mean'], P[bn + '.running_var'], BN_MOMENTUM, BN_EPS, self.acts[i], keep, 0.5, out, mi,
+                 int(training))
+            if training and (bn + '.num_batches_tracked') in P:
+                P[bn + '.num_batches_tracked'] += 1
+            save.append(dict(x=x, y=y, mi=mi, keep=keep))
+            x = out
+        return x
+
+    def backward(self, P, G, dy, B, T, save, need_dx=True, first_input_override=None):
+        rows = B * T
+        for i in reversed(range(self.n)):
+            W = P[f'{self.prefix}.{i}.0.conv.weight']
+            cout, cin, k = W.shape
+            bn = f'{self.prefix}.{i}.1'
+            s = save[i]
+            dz = _f32(rows, cout, device=dy.device, zero=False)
+            sums = _f32(2 * cout, device=dy.device, zero=False)
+            call('gt_bn_act_drop_bwd1', dy, s['y'], s['mi'], P[bn + '.weight'], P[bn + '.bias'], rows, cout,
+                 self.acts[i], s['keep'], 0.5, dz, sums)
+            dconv = _f32(rows, cout, device=dy.device, zero=False)
+            call('gt_bn_act_drop_bwd2', dz, s['y'], s['mi'], P[bn + '.weight'], sums, rows, cout, dconv,
+                 G[bn + '.weight'], G[bn + '.bias'])
+            x_in = first_input_override if (i == 0 and first_input_override is not None) else s['x']
+            ops.conv1d_dw(dconv, x_in, B, T, cin, cout, k, 1, G[f'{self.prefix}.{i}.0.conv.weight'])
+            acc_add(G[f'{self.prefix}.{i}.0.conv.bias'], ops.col_sums(dconv, rows, cout))
+            if i > 0 or need_dx:
+                dy = ops.conv1d_dx(dconv, ops.conv_weight_bwd(W), B, T, cin, cout, k, 1)
+        return dy
+
+
+class GeneratorEngine:
+    def __init__(self, hp):
+        self.hp = hp
+        self.n_mel = hp.n_mel_channels
+        self.enc_dim = hp.encoder_embedding_dim
+        self.H = self.enc_dim // 2
+        self.P, self.Ha, self.Hd, self.A = hp.prenet_dim, hp.attention_rnn_dim, hp.decoder_rnn_dim, hp.attention_dim
+        self.F, self.Kc = hp.attention_location_n_filters, hp.attention_location_kernel_size
+        noise = hp.noise_size if hp.use_noise else 0
+        self.noise = noise
+        self.E = self.enc_dim + noise
+        self.vesus = bool(hp.vesus_path)
+        self.use_labels = bool(hp.use_labels and hp.vesus_path)
+        if self.vesus:
+            self.E += hp.speakers_embedding + (5 if self.use_labels else 0)
+        self.enc_stack = ConvBNStack('encoder.convolutions', hp.encoder_n_convolutions,
+                                     [ACT_RELU] * hp.encoder_n_convolutions)
+        self.post_stack = ConvBNStack('postnet.convolutions', hp.postnet_n_convolutions,
+                                      [ACT_TANH] * (hp.postnet_n_convolutions - 1) + [ACT_NONE])
+
+    # ------------------------------------------------------------------------------ helpers
+    @staticmethod
+    def step_major_index(lengths, T, Bp):
+        """Row maps of the packed BiLSTM.  fwd_idx/rev_idx: (T*Bp,) source row b*T+t of step-major row
+        (s,b) (or -1); inverse maps (B*T,) give the step-major row of (b,t) for each direction."""
+        B = len(lengths)
+        fwd = torch.full((T, Bp), -1, dtype=torch.int32)
+        rev = torch.full((T, Bp), -1, dtype=torch.int32)
+        ifwd = torch.full((B, T), -1, dtype=torch.int32)
+        irev = torch.full((B, T), -1, dtype=torch.int32)
+        active = torch.zeros(T, Bp, dtype=torch.int32)
+        for b, L in enumerate(lengths):
+            s = torch.arange(L, dtype=torch.int32)
+            fwd[:L, b] = b * T + s
+            rev[:L, b] = b * T + (L - 1 - s)
+            ifwd[b, :L] = s * Bp + b
+            irev[b, :L] = (L - 1 - s) * Bp + b
+            active[:L, b] = 1
+        return fwd.reshape(-1), rev.reshape(-1), ifwd.reshape(-1), irev.reshape(-1), active
+
+    # ------------------------------------------------------------------------------ forward
+    def forward(self, P, text, in_lens, mels, out_lens, rng, speaker_ids=None, emotions=None, training=True,
+                mask_padding=True):
+        """text (B,Ti) int64 cuda; in_lens/out_lens python lists; mels (B,n_mel,To) cuda.
+        Returns (mel (B,n_mel,To), mel_post, gate (B,To), align (B,To,Ti)), saved."""
+        hp, dev = self.hp, text.device
+        B, Ti = text.shape
+        To = mels.shape[2]
+        Bp = roundup(B, 16)
+        assert Bp <= 64, 'one call handles at most 64 utterances'
+        n_mel, H, E, A = self.n_mel, self.H, self.E, self.A
+        sv = dict(B=B, Bp=Bp, Ti=Ti, To=To, in_lens=list(in_lens), out_lens=list(out_lens), training=training,
+                  text=text)
+
+        # ---- embedding + encoder convolutions (channels-last rows = (b, t))
+        x = _f32(B * Ti, hp.symbols_embedding_dim, device=dev, zero=False)
+        call('gt_embedding_fwd', text, P['embedding.weight'], B * Ti, hp.symbols_embedding_dim, x,
+             hp.symbols_embedding_dim)
+        sv['enc_conv'] = []
+        x = self.enc_stack.forward(P, x, B, Ti, rng.get('enc_keep'), training, sv['enc_conv'])
+        sv['enc_x3'] = x
+
+        # ---- packed BiLSTM, step-major
+        fwd_i, rev_i, ifwd, irev, active = self.step_major_index(in_lens, Ti, Bp)
+        idx = {k: v.to(dev) for k, v in dict(fwd=fwd_i, rev=rev_i, ifwd=ifwd, irev=irev, active=active).items()}
+        sv['idx'] = idx
+        C = self.enc_dim
+        Xs = _f32(2, Ti * Bp, C, device=dev, zero=False)
+        call('gt_gather_rows', x, C, idx['fwd'], Ti * Bp, C, Xs[0], C, 0)
+        call('gt_gather_rows', x, C, idx['rev'], Ti * Bp, C, Xs[1], C, 0)
+        pre = _f32(2, Ti * Bp, 4 * H, device=dev, zero=False)
+        Whp = []
+        for d, sfx in enumerate(('', '_reverse')):
+            bias = _f32(4 * H, device=dev, zero=False)
+            call('gt_axpby', P['encoder.lstm.bias_ih_l0' + sfx], 1.0, P['encoder.lstm.bias_hh_l0' + sfx], 1.0, bias, 4 * H)
+            ops.linear(Xs[d], P['encoder.lstm.weight_ih_l0' + sfx], Ti * Bp, C, 4 * H, bias=bias, out=pre[d])
+            Whp.append(pack_rec(P['encoder.lstm.weight_hh_l0' + sfx], 4 * H, 4 * H, H))
+        Whp = torch.stack(Whp)
+        ldx = roundup(H, 16)
+        S = ops.pick_splits(H, REC_SPLITS)
+        a = GtBiLstm()
+        a.B, a.Bp, a.T, a.H, a.S, a.backward = B, Bp, Ti, H, S, 0
+        gates = _f32(2, Ti, Bp, 4 * H, device=dev, zero=False)
+        cst = _f32(2, Ti + 1, Bp, H, device=dev)
+        hs = _f32(2, Ti, Bp, H, device=dev, zero=False)
+        Xst = _f32(2, Bp, ldx, device=dev)
+        part = _f32(2, S, Bp, 4 * H, device=dev, zero=False)
+        a.pre, a.Whp, a.w_zstride, a.active = ptr(pre), ptr(Whp), Whp.stride(0), ptr(idx['active'])
+        a.X, a.ldx, a.part, a.gates, a.c, a.hs = ptr(Xst), ldx, ptr(part), ptr(gates), ptr(cst), ptr(hs)
+        _run('gt_bilstm_run', a)
+        sv.update(Xs=Xs, enc_gates=gates, enc_c=cst, enc_hs=hs)
+
+        # ---- decoder memory = [encoder outputs | speaker | labels | style noise]
+        memory = _f32(B, Ti, E, device=dev)
+        mem2 = memory.view(B * Ti, E)
+        call('gt_gather_rows', hs[0], H, idx['ifwd'], B * Ti, H, mem2, E, 0)
+        check(lib().gt_gather_rows(ptr(hs[1]), H, ptr(idx['irev']), B * Ti, H, ptr(memory, H), E, 0, ops._stream()),
+              'gt_gather_rows')
+        col = 2 * H
+        if self.vesus:
+            se = hp.speakers_embedding
+            spk = _f32(B, se, device=dev, zero=False)
+            call('gt_embedding_fwd', speaker_ids, P['speaker_embedding.weight'], B, se, spk, se)
+            memory[:, :, col:col + se] = spk[:, None, :]
+            col += se
+            if self.use_labels:
+                memory[:, :, col:col + 5] = emotions[:, None, :]
+                col += 5
+            sv['speaker_ids'] = speaker_ids
+        if self.noise:
+            memory[:, :, col:col + self.noise] = rng['noise'][:, None, :]
+        sv['memory'] = memory
+        Wmem = P['decoder.attention_layer.memory_layer.linear_layer.weight']
+        pm = ops.linear(mem2, Wmem, B * Ti, E, A)
+        sv['pm'] = pm
+
+        # ---- prenet over all teacher-forcing frames (go frame + mel[:, :, :To-1]), step-major (To, Bp, .)
+        x0 = _f32(To, Bp, n_mel, device=dev)
+        if To > 1:
+            check(lib().gt_permute3(ptr(mels), 1, n_mel * To, To, To - 1, B, n_mel, ptr(x0, Bp * n_mel), Bp * n_mel,
+                                    n_mel, 0, 1.0, ops._stream()), 'gt_permute3')
+        Pd = self.P
+        W0, W1 = P['decoder.prenet.layers.0.linear_layer.weight'], P['decoder.prenet.layers.1.linear_layer.weight']
+        pk = rng['prenet_keep']
+        p1 = ops.linear(x0, W0, To * Bp, n_mel, Pd)
+        call('gt_bias_act_drop_fwd', p1, None, To * Bp, Pd, ACT_RELU, 0, pk[0], 0.5, p1)
+        p2 = ops.linear(p1, W1, To * Bp, Pd, Pd)
+        call('gt_bias_act_drop_fwd', p2, None, To * Bp, Pd, ACT_RELU, 0, pk[1], 0.5, p2)
+        sv.update(x0=x0, p1=p1, p2=p2)
+
+        Ha, Hd = self.Ha, self.Hd
+        W1ih, W1hh = P['decoder.attention_rnn.weight_ih'], P['decoder.attention_rnn.weight_hh']
+        W2ih, W2hh = P['decoder.decoder_rnn.weight_ih'], P['decoder.decoder_rnn.weight_hh']
+        bias1 = _f32(4 * Ha, device=dev, zero=False)
+        call('gt_axpby', P['decoder.attention_rnn.bias_ih'], 1.0, P['decoder.attention_rnn.bias_hh'], 1.0, bias1, 4 * Ha)
+        bias2 = _f32(4 * Hd, device=dev, zero=False)
+        call('gt_axpby', P['decoder.decoder_rnn.bias_ih'], 1.0, P['decoder.decoder_rnn.bias_hh'], 1.0, bias2, 4 * Hd)
+        pre1 = ops.linear(p2, W1ih, To * Bp, Pd, 4 * Ha, bias=bias1, ldw=Pd + E)
+
+        # ---- decoder loop
+        K1, K2 = E + Ha, Ha + E + Hd
+        W1cat = torch.cat((W1ih[:, Pd:], W1hh), dim=1).contiguous()
+        W2cat = torch.cat((W2ih, W2hh), dim=1).contiguous()
+        Apad = roundup(A, 16)
+        d = GtDecoderFwd()
+        d.B, d.Bp, d.Ti, d.To, d.E, d.ldE, d.P, d.Ha, d.Hd, d.A, d.Apad, d.F, d.Kc = \
+            B, Bp, Ti, To, E, E, Pd, Ha, Hd, A, Apad, self.F, self.Kc
+        d.S1, d.S2, d.Sq = ops.pick_splits(K1, REC_SPLITS), ops.pick_splits(K2, REC_SPLITS), ops.pick_splits(Ha, 16)
+        d.p_att = hp.p_attention_dropout if training else 0.0
+        d.p_dec = hp.p_decoder_dropout if training else 0.0
+        keep_t = dict(W1p=pack_rec(W1cat, 4 * Ha, 4 * Ha, K1), W2p=pack_rec(W2cat, 4 * Hd, 4 * Hd, K2),
+                      Wqp=pack_rec(P['decoder.attention_layer.query_layer.linear_layer.weight'], Apad, A, Ha))
+        lens32 = torch.tensor(in_lens, dtype=torch.int32, device=dev)
+        ld1, ld2 = roundup(K1, 16), roundup(K2, 16)
+        ws = dict(X1=_f32(Bp, ld1, device=dev), X2=_f32(Bp, ld2, device=dev),
+                  part=_f32(max(d.S1 * Bp * 4 * Ha, d.S2 * Bp * 4 * Hd, d.Sq * Bp * Apad), device=dev, zero=False),
+                  energies=_f32(B, Ti, device=dev, zero=False))
+        hist = dict(gates1=_f32(To, Bp, 4 * Ha, device=dev), c1=_f32(To + 1, Bp, Ha, device=dev),
+                    gates2=_f32(To, Bp, 4 * Hd, device=dev), c2=_f32(To + 1, Bp, Hd, device=dev),
+                    hatt=_f32(To, Bp, Ha, device=dev), HC=_f32(To, Bp, Hd + E, device=dev),
+                    w_hist=_f32(To + 1, B, Ti, device=dev), cum_hist=_f32(To + 1, B, Ti, device=dev),
+                    q_hist=_f32(To, B, A, device=dev, zero=False))
+        al = 'decoder.attention_layer.'
+        d.memory, d.pm, d.lengths, d.pre1, d.bias2 = ptr(memory), ptr(pm), ptr(lens32), ptr(pre1), ptr(bias2)
+        d.W1p, d.Wqp, d.W2p = ptr(keep_t['W1p']), ptr(keep_t['Wqp']), ptr(keep_t['W2p'])
+        d.Wc = ptr(P[al + 'location_layer.location_conv.conv.weight'])
+        d.Wd = ptr(P[al + 'location_layer.location_dense.linear_layer.weight'])
+        d.v = ptr(P[al + 'v.linear_layer.weight'])
+        att_keep = rng.get('att_keep') if training else None
+        dec_keep = rng.get('dec_keep') if training else None
+        d.att_keep, d.dec_keep = ptr(att_keep), ptr(dec_keep)
+        d.X1, d.ld1, d.X2, d.ld2, d.part, d.energies = ptr(ws['X1']), ld1, ptr(ws['X2']), ld2, ptr(ws['part']), ptr(ws['energies'])
+        for k in ('gates1', 'c1', 'gates2', 'c2', 'hatt', 'HC', 'w_hist', 'cum_hist', 'q_hist'):
+            setattr(d, k, ptr(hist[k]))
+        _run('gt_decoder_fwd', d)
+        sv.update(hist=hist, pre1=pre1, lens32=lens32, att_keep=att_keep, dec_keep=dec_keep,
+                  prenet_keep=pk)
+
+        # ---- mel / gate projection of all steps, output layouts
+        hc = Hd + E
+        Wpg = torch.cat((P['decoder.linear_projection.linear_layer.weight'],
+                         P['decoder.gate_layer.linear_layer.weight']), dim=0).contiguous()
+        bpg = torch.cat((P['decoder.linear_projection.linear_layer.bias'], P['decoder.gate_layer.linear_layer.bias']))
+        nout = n_mel + 1
+        out81 = ops.linear(hist['HC'], Wpg, To * Bp, hc, nout, bias=bpg)
+        mel_cl = _f32(B * To, n_mel, device=dev, zero=False)        # (B, To, n_mel)
+        call('gt_permute3', out81, nout, Bp * nout, 1, B, To, n_mel, mel_cl, 0, 0, 0, 1.0)
+        mel = _f32(B, n_mel, To, device=dev, zero=False)
+        call('gt_permute3', out81, nout, 1, Bp * nout, B, n_mel, To, mel, 0, 0, 0, 1.0)
+        gate = _f32(B, To, device=dev, zero=False)
+        check(lib().gt_permute3(ptr(out81, n_mel), 0, nout, Bp * nout, 1, B, To, ptr(gate), 0, 0, 0, 1.0,
+                                ops._stream()), 'gt_permute3')
+        align = _f32(B, To, Ti, device=dev, zero=False)
+        check(lib().gt_permute3(ptr(hist['w_hist'], B * Ti), Ti, B * Ti, 1, B, To, Ti, ptr(align), 0, 0, 0, 1.0,
+                                ops._stream()), 'gt_permute3')
+        sv['Wpg'] = Wpg
+
+        # ---- PostNet + residual + padding mask
+        sv['post_conv'] = []
+        post_cl = self.post_stack.forward(P, mel_cl, B, To, rng.get('post_keep'), training, sv['post_conv'])
+        mel_post = mel.clone()
+        call('gt_permute3', post_cl, To * n_mel, 1, n_mel, B, n_mel, To, mel_post, 0, 0, 1, 1.0)
+        if mask_padding:
+            ol = torch.tensor(out_lens, dtype=torch.int64, device=dev)
+            call('gt_mask_outputs', mel, mel_post, gate, ol, B, n_mel, To)
+            # the reference masks `mel` in place after the PostNet consumed it: the first PostNet
+            # conv's weight gradient therefore sees the MASKED frames (model.py:638-640)
+            mel_cl_masked = _f32(B * To, n_mel, device=dev, zero=False)
+            call('gt_permute3', mel, n_mel * To, 1, To, B, To, n_mel, mel_cl_masked, 0, 0, 0, 1.0)
+            sv['mel_cl_masked'] = mel_cl_masked
+        return (mel, mel_post, gate, align), sv
+
+    # ------------------------------------------------------------------------------ backward
+    def backward(self, P, G, sv, dmel, dmel_post, dgate, dalign):
+        """Accumulate parameter gradients into G (dict name -> tensor).  d* are gradients of the four
+        outputs (any may be None)."""
+        hp = self.hp
+        B, Bp, Ti, To = sv['B'], sv['Bp'], sv['Ti'], sv['To']
+        n_mel, H, E, A, Pd, Ha, Hd = self.n_mel, self.H, self.E, self.A, self.P, self.Ha, self.Hd
+        dev = sv['memory'].device
+        hist = sv['hist']
+        hc, nout = Hd + E, n_mel + 1
+
+        # ---- PostNet backward (channels-last)
+        dmel_cl = _f32(B * To, n_mel, device=dev)
+        if dmel is not None:
+            call('gt_permute3', dmel.contiguous(), n_mel * To, 1, To, B, To, n_mel, dmel_cl, 0, 0, 1, 1.0)
+        if dmel_post is not None:
+            dpost_cl = _f32(B * To, n_mel, device=dev, zero=False)
+            call('gt_permute3', dmel_post.contiguous(), n_mel * To, 1, To, B, To, n_mel, dpost_cl, 0, 0, 0, 1.0)
+            call('gt_axpby', dmel_cl, 1.0, dpost_cl, 1.0, dmel_cl, B * To * n_mel)      # residual branch
+            dx = self.post_stack.backward(P, G, dpost_cl, B, To, sv['post_conv'],
+                                          first_input_override=sv.get('mel_cl_masked'))
+            call('gt_axpby', dmel_cl, 1.0, dx, 1.0, dmel_cl, B * To * n_mel)
+
+        # ---- projection backward: gradient w.r.t. [h_dec | ctx] of every step
+        dout = _f32(To, Bp, nout, device=dev)
+        call('gt_permute3', dmel_cl, n_mel, To * n_mel, 1, To, B, n_mel, dout, Bp * nout, nout, 0, 1.0)
+        if dgate is not None:
+            check(lib().gt_permute3(ptr(dgate.contiguous()), 1, To, 0, To, B, 1, ptr(dout, n_mel), Bp * nout, nout, 0, 1.0,
+                                    ops._stream()), 'gt_permute3')
+        dWpg = _f32(nout, hc, device=dev)
+        ops.linear_dw(dout, hist['HC'], To * Bp, nout, hc, dWpg)
+        acc_add(G['decoder.linear_projection.linear_layer.weight'], dWpg[:n_mel])
+        acc_add(G['decoder.gate_layer.linear_layer.weight'], dWpg[n_mel:])
+        bsum = ops.col_sums(dout, To * Bp, nout)
+        acc_add(G['decoder.linear_projection.linear_layer.bias'], bsum[:n_mel])
+        acc_add(G['decoder.gate_layer.linear_layer.bias'], bsum[n_mel:])
+        dHC = ops.linear_dx(dout, sv['Wpg'], To * Bp, nout, hc)
+
+        # ---- decoder loop backward
+        dalign_tm = None
+        if dalign is not None:
+            dalign_tm = _f32(To, B, Ti, device=dev, zero=False)
+            call('gt_permute3', dalign.contiguous(), Ti, To * Ti, 1, To, B, Ti, dalign_tm, 0, 0, 0, 1.0)
+        K1, K2 = E + Ha, Ha + E + Hd
+        N1pad, N2pad, Apad = roundup(K1, 16), roundup(K2, 16), roundup(A, 16)
+        W1ih, W1hh = P['decoder.attention_rnn.weight_ih'], P['decoder.attention_rnn.weight_hh']
+        W2ih, W2hh = P['decoder.decoder_rnn.weight_ih'], P['decoder.decoder_rnn.weight_hh']
+        W1cat = torch.cat((W1ih[:, Pd:], W1hh), dim=1).contiguous()
+        W2cat = torch.cat((W2ih, W2hh), dim=1).contiguous()
+        Wq = P['decoder.attention_layer.query_layer.linear_layer.weight']
+        W1Tp = pack_rec(W1cat, N1pad, K1, 4 * Ha, transposed=True)
+        W2Tp = pack_rec(W2cat, N2pad, K2, 4 * Hd, transposed=True)
+        WqTp = pack_rec(Wq, Ha, Ha, A, transposed=True)
+        b = GtDecoderBwd()
+        b.B, b.Bp, b.Ti, b.To, b.E, b.ldE, b.P, b.Ha, b.Hd, b.A, b.Apad, b.F, b.Kc = \
+            B, Bp, Ti, To, E, E, Pd, Ha, Hd, A, Apad, self.F, self.Kc
+        b.S1, b.S2, b.Sq = ops.pick_splits(4 * Ha, REC_SPLITS), ops.pick_splits(4 * Hd, REC_SPLITS), ops.pick_splits(A, 2)
+        b.N1pad, b.N2pad = N1pad, N2pad
+        training = sv['training']
+        b.p_att = hp.p_attention_dropout if training else 0.0
+        b.p_dec = hp.p_decoder_dropout if training else 0.0
+        al = 'decoder.attention_layer.'
+        Wc, Wd, v = (P[al + 'location_layer.location_conv.conv.weight'],
+                     P[al + 'location_layer.location_dense.linear_layer.weight'], P[al + 'v.linear_layer.weight'])
+        dims = ops.attn_dims(B, Ti, E, A, self.F, self.Kc)
+        buf = dict(dG1=_f32(To, Bp, 4 * Ha, device=dev), dG2=_f32(To, Bp, 4 * Hd, device=dev),
+                   dctx_hist=_f32(To, B, E, device=dev, zero=False), dpm=_f32(B, Ti, A, device=dev),
+                   acc=_f32(int(lib().gt_attn_acc_elems(dims)), device=dev),
+                   dc1=_f32(Bp, Ha, device=dev), dc2=_f32(Bp, Hd, device=dev), dwcat=_f32(2, 2, B, Ti, device=dev),
+                   dcum_acc=_f32(B, Ti, device=dev), dq_hist=_f32(To, Bp, Apad, device=dev),
+                   dw=_f32(B, Ti, device=dev, zero=False),
+                   partX1=_f32(b.S1, Bp, N1pad, device=dev), partX2=_f32(b.S2, Bp, N2pad, device=dev),
+                   partQ=_f32(b.Sq, Bp, Ha, device=dev))
+        b.memory, b.pm, b.Wc, b.Wd, b.v = ptr(sv['memory']), ptr(sv['pm']), ptr(Wc), ptr(Wd), ptr(v)
+        b.att_keep, b.dec_keep = ptr(sv['att_keep']), ptr(sv['dec_keep'])
+        for k in ('gates1', 'c1', 'gates2', 'c2', 'w_hist', 'cum_hist', 'q_hist'):
+            setattr(b, k, ptr(hist[k]))
+        b.W1Tp, b.W2Tp, b.WqTp, b.dHC, b.dalign = ptr(W1Tp), ptr(W2Tp), ptr(WqTp), ptr(dHC), ptr(dalign_tm)
+        for k in buf:
+            setattr(b, k, ptr(buf[k]))
+        _run('gt_decoder_bwd', b)
+
+        # ---- deferred weight gradients of the decoder (K = To*Bp rows each)
+        dG1, dG2, rows = buf['dG1'], buf['dG2'], To * Bp
+        g1ih, g1hh = G['decoder.attention_rnn.weight_ih'], G['decoder.attention_rnn.weight_hh']
+        g2ih, g2hh = G['decoder.decoder_rnn.weight_ih'], G['decoder.decoder_rnn.weight_hh']
+        ops.linear_dw(dG1, sv['p2'], rows, 4 * Ha, Pd, g1ih, ldc=Pd + E)
+        ops.linear_dw(dG2, hist['hatt'], rows, 4 * Hd, Ha, g2ih, ldc=Ha + E)
+        ops.linear_dw(dG2, hist['HC'], rows, 4 * Hd, E, g2ih, ldx=hc, x_offset=Hd, ldc=Ha + E, c_offset=Ha)
+        if To > 1:
+            r1 = (To - 1) * Bp
+            ops.linear_dw(dG1, hist['HC'], r1, 4 * Ha, E, g1ih, dy_offset=Bp * 4 * Ha, ldx=hc, x_offset=Hd,
+                          ldc=Pd + E, c_offset=Pd)
+            ops.linear_dw(dG1, hist['hatt'], r1, 4 * Ha, Ha, g1hh, dy_offset=Bp * 4 * Ha)
+            ops.linear_dw(dG2, hist['HC'], r1, 4 * Hd, Hd, g2hh, dy_offset=Bp * 4 * Hd, ldx=hc)
+        s1 = ops.col_sums(dG1, rows, 4 * Ha)
+        acc_add(G['decoder.attention_rnn.bias_ih'], s1)
+        acc_add(G['decoder.attention_rnn.bias_hh'], s1)
+        s2 = ops.col_sums(dG2, rows, 4 * Hd)
+        acc_add(G['decoder.decoder_rnn.bias_ih'], s2)
+        acc_add(G['decoder.decoder_rnn.bias_hh'], s2)
+        ops.linear_dw(buf['dq_hist'], hist['hatt'], rows, A, Ha, G[al + 'query_layer.linear_layer.weight'], lddy=Apad)
+        call('gt_attn_acc_reduce', dims, buf['acc'], G[al + 'v.linear_layer.weight'],
+             G[al + 'location_layer.location_dense.linear_layer.weight'],
+             G[al + 'location_layer.location_conv.conv.weight'])
+
+        # ---- prenet backward
+        dp2 = ops.linear_dx(dG1, W1ih, rows, 4 * Ha, Pd, ldw=Pd + E)
+        pk = sv['prenet_keep']
+        call('gt_bias_act_drop_bwd', dp2, sv['p2'], rows, Pd, ACT_RELU, 0, pk[1], 0.5, dp2)
+        ops.linear_dw(dp2, sv['p1'], rows, Pd, Pd, G['decoder.prenet.layers.1.linear_layer.weight'])
+        dp1 = ops.linear_dx(dp2, P['decoder.prenet.layers.1.linear_layer.weight'], rows, Pd, Pd)
+        call('gt_bias_act_drop_bwd', dp1, sv['p1'], rows, Pd, ACT_RELU, 0, pk[0], 0.5, dp1)
+        ops.linear_dw(dp1, sv['x0'], rows, Pd, n_mel, G['decoder.prenet.layers.0.linear_layer.weight'])
+
+        # ---- d(memory) = sum_t w_t^T dctx_t (batched over b) + dpm @ Wmem ;  dWmem = dpm^T memory
+        Wmem = P[al + 'memory_layer.linear_layer.weight']
+        dmem = _f32(B, Ti, E, device=dev, zero=False)
+        sgemm(Operand(hist['w_hist'], RC, ld=B * Ti, offset=B * Ti, batch_stride=Ti),
+              Operand(buf['dctx_hist'], RC, ld=B * E, batch_stride=E), dmem, Ti, E, To, batch=B, c_batch_stride=Ti * E)
+        sgemm(Operand(buf['dpm'], KC, ld=A), Operand(Wmem, RC, ld=E), dmem, B * Ti, E, A, accumulate=True)
+        ops.linear_dw(buf['dpm'], sv['memory'], B * Ti, A, E, G[al + 'memory_layer.linear_layer.weight'])
+
+        col = 2 * H
+        if self.vesus:
+            se = hp.speakers_embedding
+            # d speaker embedding = sum over Ti of dmem[:, :, col:col+se]  (rows = Ti per item)
+            tmp = _f32(Ti, B, se, device=dev, zero=False)
+            check(lib().gt_permute3(ptr(dmem, col), E, Ti * E, 1, Ti, B, se, ptr(tmp), 0, 0, 0, 1.0, ops._stream()),
+                  'gt_permute3')
+            dspk = ops.col_sums(tmp, Ti, B * se).contiguous()
+            call('gt_embedding_bwd', sv['speaker_ids'], dspk, se, B, se, G['speaker_embedding.weight'])
+
+        # ---- BiLSTM backward
+        idx = sv['idx']
+        C = self.enc_dim
+        dhs = _f32(2, Ti * Bp, H, device=dev, zero=False)
+        dm2 = dmem.view(B * Ti, E)
+        call('gt_gather_rows', dm2, E, idx['fwd'], Ti * Bp, H, dhs[0], H, 0)
+        check(lib().gt_gather_rows(ptr(dmem, H), E, ptr(idx['rev']), Ti * Bp, H, ptr(dhs[1]), H, 0, ops._stream()),
+              'gt_gather_rows')
+        Hpad = roundup(H, 16)
+        WhT = torch.stack([pack_rec(P['encoder.lstm.weight_hh_l0' + sfx], Hpad, H, 4 * H, transposed=True)
+                           for sfx in ('', '_reverse')])
+        S = ops.pick_splits(4 * H, REC_SPLITS)
+        a = GtBiLstm()
+        a.B, a.Bp, a.T, a.H, a.S, a.backward, a.Hpad = B, Bp, Ti, H, S, 1, Hpad
+        dG = _f32(2, Ti * Bp, 4 * H, device=dev)
+        dc = _f32(2, Bp, H, device=dev)
+        part = _f32(2, S, Bp, Hpad, device=dev)
+        a.Whp, a.w_zstride, a.active = ptr(WhT), WhT.stride(0), ptr(idx['active'])
+        a.part, a.gates, a.c, a.dhs, a.dG, a.dc = ptr(part), ptr(sv['enc_gates']), ptr(sv['enc_c']), ptr(dhs), ptr(dG), ptr(dc)
+        _run('gt_bilstm_run', a)
+        hs, Xs = sv['enc_hs'], sv['Xs']
+        dXs = _f32(2, Ti * Bp, C, device=dev, zero=False)
+        for d_, sfx in enumerate(('', '_reverse')):
+            ops.linear_dw(dG[d_], Xs[d_], Ti * Bp, 4 * H, C, G['encoder.lstm.weight_ih_l0' + sfx])
+            if Ti > 1:
+                ops.linear_dw(dG[d_], hs[d_], (Ti - 1) * Bp, 4 * H, H, G['encoder.lstm.weight_hh_l0' + sfx],
+                              dy_offset=Bp * 4 * H)
+            bs = ops.col_sums(dG[d_], Ti * Bp, 4 * H)
+            acc_add(G['encoder.lstm.bias_ih_l0' + sfx], bs)
+            acc_add(G['encoder.lstm.bias_hh_l0' + sfx], bs)
+            ops.linear_dx(dG[d_], P['encoder.lstm.weight_ih_l0' + sfx], Ti * Bp, 4 * H, C, out=dXs[d_])
+        dx3 = _f32(B * Ti, C, device=dev, zero=False)
+        call('gt_gather_rows', dXs[0], C, idx['ifwd'], B * Ti, C, dx3, C, 0)
+        call('gt_gather_rows', dXs[1], C, idx['irev'], B * Ti, C, dx3, C, 1)
+
+        # ---- encoder convolutions + embedding
+        demb = self.enc_stack.backward(P, G, dx3, B, Ti, sv['enc_conv'])
+        call('gt_embedding_bwd', sv['text'], demb, hp.symbols_embedding_dim, B * Ti, hp.symbols_embedding_dim,
+             G['embedding.weight'])
+
+
+class DiscriminatorEngine:
+    """Discriminator.forward + adversarial_loss (reference model.py:500-540)."""
+
+    DIL = (1, 2, 2, 2)
+
+    def __init__(self, hp):
+        self.hp = hp
+        self.window, self.n_mel = hp.discriminator_window, hp.n_mel_channels
+
+    def forward(self, P, mel, lengths, keeps, training=True):
+        """mel (B, n_mel, T) cuda; lengths int64 cuda tensor (B).  Returns loss (1,) and saved state."""
+        dev = mel.device
+        B, n_mel, T = mel.shape
+        win = self.window
+        W = T // win + (1 if T % win else 0)
+        cin = win * n_mel
+        x = _f32(B * W, cin, device=dev, zero=False)
+        call('gt_disc_gather_fwd', mel.contiguous(), B, n_mel, T, win, x)
+        sv = dict(B=B, T=T, W=W, layers=[], lengths=lengths)
+        for i in range(4):
+            Wt = P[f'discriminator.{i}.module.0.weight']
+            cout, ci, k = Wt.shape
+            y = ops.conv1d_fwd(x, ops.conv_weight_fwd(Wt), None, B, W, ci, cout, k, self.DIL[i])
+            keep = keeps[i] if (keeps is not None and training) else None
+            call('gt_bias_act_drop_fwd', y, P[f'discriminator.{i}.module.0.bias'], B * W, cout, ACT_TANH, 1, keep, 0.5, y)
+            sv['layers'].append(dict(x=x, y=y, keep=keep))
+            x = y
+        W4 = P['discriminator.4.weight']
+        out = ops.linear(x, W4.view(1, -1), B * W, W4.shape[1], 1, bias=P['discriminator.4.bias'])
+        sv['h4'] = x
+        loss = _f32(1, device=dev, zero=False)
+        call('gt_adv_mean_fwd', out, lengths, B, W, win, loss)
+        sv['out'] = out
+        return loss, sv
+
+    def backward(self, P, G, sv, dloss, scale=1.0, need_dinput=True, need_dparams=True):
+        """dloss: (1,) cuda tensor (upstream gradient) or None for 1.  Returns d mel (B, n_mel, T)."""
+        B, T, W = sv['B'], sv['T'], sv['W']
+        dev = sv['out'].device
+        win, n_mel = self.window, self.n_mel
+        dout = _f32(B * W, 1, device=dev, zero=False)
+        call('gt_adv_mean_bwd', dloss, sv['lengths'], B, W, win, float(scale), dout)
+        W4 = P['discriminator.4.weight']
+        c4 = W4.shape[1]
+        if need_dparams:
+            ops.linear_dw(dout, sv['h4'], B * W, 1, c4, G['discriminator.4.weight'].view(1, -1))
+            acc_add(G['discriminator.4.bias'], ops.col_sums(dout, B * W, 1))
+        dy = ops.linear_dx(dout, W4.view(1, -1), B * W, 1, c4)
+        for i in reversed(range(4)):
+            Wt = P[f'discriminator.{i}.module.0.weight']
+            cout, ci, k = Wt.shape
+            L = sv['layers'][i]
+            dz = _f32(B * W, cout, device=dev, zero=False)
+            call('gt_bias_act_drop_bwd', dy, L['y'], B * W, cout, ACT_TANH, 1, L['keep'], 0.5, dz)
+            if need_dparams:
+                ops.conv1d_dw(dz, L['x'], B, W, ci, cout, k, self.DIL[i], G[f'discriminator.{i}.module.0.weight'])
+                acc_add(G[f'discriminator.{i}.module.0.bias'], ops.col_sums(dz, B * W, cout))
+            if i > 0 or need_dinput:
+                dy = ops.conv1d_dx(dz, ops.conv_weight_bwd(Wt), B, W, ci, cout, k, self.DIL[i])
+        if not need_dinput:
+            return None
+        dmel = _f32(B, n_mel, T, device=dev, zero=False)
+        call('gt_disc_gather_bwd', dy, B, n_mel, T, win, dmel, 0)
+        return dmel

@@ -1,0 +1,283 @@
+"""`model.Tacotron2` / `model.Discriminator` with the reference's Python surface over the HIP engine.
+
+Drop-in for reference model.py:586-723 (Tacotron2) and :500-540 (Discriminator):
+
+* same constructor argument (an HParams object), same sub-module tree, therefore the same
+  `state_dict()` keys and shapes (`decoder.attention_rnn.weight_ih`,
+  `postnet.convolutions.0.0.conv.weight`, `discriminator.0.module.0.weight`, ...) and the same
+  initialisers (layers.py:14-16,35-36,52; model.py:603-605);
+* same calls: `parse_batch(batch)`, `generator(x) -> [mel, mel_postnet, gate, alignments]`,
+  `discriminator.adversarial_loss(mel, lengths)`, `discriminator(x)`, nn.Module protocol.
+
+The sub-modules (nn.Conv1d, nn.LSTMCell, ...) only hold parameters; their forward is never called.
+`forward` is ONE autograd node whose forward/backward run the hand-written HIP kernels through
+the C ABI (engine.py).  There is no PyTorch/CPU fallback: without the extension the call raises.
+"""
+from math import sqrt
+
+import torch
+from torch import nn
+
+from . import ops
+from .engine import DiscriminatorEngine, GeneratorEngine
+from .layers import ConvNorm, DiscConv1d, LinearNorm
+from .utils import to_gpu
+
+
+class DropoutSource:
+    """Counter-based dropout masks / style noise (gt_keep_mask, gt_uniform): (seed, running offset).
+    The oracle reproduces the same stream on the CPU (tests/test_rng.py)."""
+
+    def __init__(self, seed):
+        self.seed, self.offset = int(seed) & 0xFFFFFFFFFFFFFFFF, 0
+
+    def keep(self, shape, p, device):
+        out = torch.empty(shape, dtype=torch.uint8, device=device)
+        ops.call('gt_keep_mask', self.seed, self.offset, float(p), out.numel(), out)
+        self.offset += out.numel()
+        return out
+
+    def uniform(self, shape, device):
+        out = torch.empty(shape, dtype=torch.float32, device=device)
+        ops.call('gt_uniform', self.seed, self.offset, out.numel(), out)
+        self.offset += out.numel()
+        return out
+
+
+def _named_tensors(module):
+    names, tensors = [], []
+    for k, v in module.named_parameters():
+        names.append(k)
+        tensors.append(v)
+    return names, tensors
+
+
+class _GeneratorFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, text, in_lens, mels, out_lens, rng, speaker_ids, emotions, *params):
+        P = dict(zip(module._param_names, (p.detach() for p in params)))
+        P.update({k: v for k, v in module.named_buffers()})
+        outs, sv = module.engine.forward(P, text, in_lens, mels, out_lens, rng, speaker_ids, emotions,
+                                         training=module.training, mask_padding=module.mask_padding)
+        ctx.module, ctx.sv, ctx.P = module, sv, P
+        ctx.needs = [p.requires_grad for p in params]
+        return outs
+
+    @staticmethod
+    def backward(ctx, dmel, dpost, dgate, dalign):
+        module, P = ctx.module, ctx.P
+        G = {k: torch.zeros_like(P[k]) for k in module._param_names}
+        module.engine.backward(P, G, ctx.sv, dmel, dpost, dgate, dalign)
+        grads = tuple(G[k] if need else None for k, need in zip(module._param_names, ctx.needs))
+        return (None,) * 8 + grads
+
+
+class Postnet(nn.Module):
+    def __init__(self, hparams):
+        super().__init__()
+        self.convolutions = nn.ModuleList()
+        n, ch, k = hparams.postnet_n_convolutions, hparams.postnet_embedding_dim, hparams.postnet_kernel_size
+        dims = [hparams.n_mel_channels] + [ch] * (n - 1) + [hparams.n_mel_channels]
+        for i in range(n):
+            self.convolutions.append(nn.Sequential(
+                ConvNorm(dims[i], dims[i + 1], kernel_size=k, stride=1, padding=(k - 1) // 2, dilation=1,
+                         w_init_gain='tanh' if i < n - 1 else 'linear'),
+                nn.BatchNorm1d(dims[i + 1])))
+
+
+class Encoder(nn.Module):
+    def __init__(self, hparams):
+        super().__init__()
+        if hparams.encoder_inputs:
+            raise NotImplementedError('encoder_inputs=True conditioning is outside the accelerated path')
+        dim, k = hparams.encoder_embedding_dim, hparams.encoder_kernel_size
+        self.convolutions = nn.ModuleList([
+            nn.Sequential(ConvNorm(dim, dim, kernel_size=k, stride=1, padding=(k - 1) // 2, dilation=1,
+                                   w_init_gain='relu'), nn.BatchNorm1d(dim))
+            for _ in range(hparams.encoder_n_convolutions)])
+        self.lstm = nn.LSTM(dim, dim // 2, 1, batch_first=True, bidirectional=True)
+
+
+class LocationLayer(nn.Module):
+    def __init__(self, n_filters, kernel_size, attention_dim):
+        super().__init__()
+        self.location_conv = ConvNorm(2, n_filters, kernel_size=kernel_size, padding=(kernel_size - 1) // 2,
+                                      bias=False, stride=1, dilation=1)
+        self.location_dense = LinearNorm(n_filters, attention_dim, bias=False, w_init_gain='tanh')
+
+
+class Attention(nn.Module):
+    def __init__(self, attention_rnn_dim, embedding_dim, attention_dim, n_filters, kernel_size):
+        super().__init__()
+        self.query_layer = LinearNorm(attention_rnn_dim, attention_dim, bias=False, w_init_gain='tanh')
+        self.memory_layer = LinearNorm(embedding_dim, attention_dim, bias=False, w_init_gain='tanh')
+        self.v = LinearNorm(attention_dim, 1, bias=False)
+        self.location_layer = LocationLayer(n_filters, kernel_size, attention_dim)
+        self.score_mask_value = -float('inf')
+
+
+class Prenet(nn.Module):
+    def __init__(self, in_dim, sizes):
+        super().__init__()
+        self.layers = nn.ModuleList([LinearNorm(i, o, bias=False) for i, o in zip([in_dim] + sizes[:-1], sizes)])
+
+
+class Decoder(nn.Module):
+    def __init__(self, hparams):
+        super().__init__()
+        if hparams.n_frames_per_step != 1:
+            raise NotImplementedError('n_frames_per_step must be 1 (as in the reference, hparams.py:71)')
+        noise = hparams.noise_size
+        din = hparams.encoder_embedding_dim + noise
+        if hparams.vesus_path:
+            din += hparams.speakers_embedding + (5 if hparams.use_labels else 0)
+        self.decoder_in_dim = din
+        self.prenet = Prenet(hparams.n_mel_channels, [hparams.prenet_dim, hparams.prenet_dim])
+        self.attention_rnn = nn.LSTMCell(hparams.prenet_dim + din, hparams.attention_rnn_dim)
+        self.attention_layer = Attention(hparams.attention_rnn_dim, din, hparams.attention_dim,
+                                         hparams.attention_location_n_filters,
+                                         hparams.attention_location_kernel_size)
+        self.decoder_rnn = nn.LSTMCell(hparams.attention_rnn_dim + din, hparams.decoder_rnn_dim, 1)
+        self.linear_projection = LinearNorm(hparams.decoder_rnn_dim + din, hparams.n_mel_channels)
+        self.gate_layer = LinearNorm(hparams.decoder_rnn_dim + din, 1, bias=True, w_init_gain='sigmoid')
+
+
+class Tacotron2(nn.Module):
+    def __init__(self, hparams):
+        super().__init__()
+        if not hparams.use_noise:                       # same side effects as reference model.py:589-591
+            hparams.noise_size = 0
+        hparams.use_labels = hparams.use_labels if hparams.vesus_path else False
+        self.hparams = hparams
+        self.mask_padding = hparams.mask_padding
+        self.n_mel_channels = hparams.n_mel_channels
+        self.embedding = nn.Embedding(hparams.n_symbols, hparams.symbols_embedding_dim)
+        val = sqrt(3.0) * sqrt(2.0 / (hparams.n_symbols + hparams.symbols_embedding_dim))
+        self.embedding.weight.data.uniform_(-val, val)
+        self.vesus = bool(hparams.vesus_path)
+        self.use_labels = hparams.use_labels
+        if self.vesus:
+            self.speaker_embedding = nn.Embedding(123, hparams.speakers_embedding)
+            self.speaker_embedding.weight.data.uniform_(-val, val)
+        self.encoder = Encoder(hparams)
+        self.decoder = Decoder(hparams)
+        self.postnet = Postnet(hparams)
+        self.engine = GeneratorEngine(hparams)
+        self._param_names = [k for k, _ in self.named_parameters()]
+        self.dropout_source = DropoutSource(hparams.seed)
+        self.rng_override = None          # tests inject explicit masks / noise here
+
+    def parse_batch(self, batch):
+        """reference model.py:617-630.  Lengths additionally stay on the host (python lists) so the
+        engine never synchronises on them (the reference calls .item()/.cpu() instead)."""
+        text_padded, input_lengths, mel_padded, gate_padded, speaker_ids, emotions, output_lengths = batch
+        self._host_lens = (input_lengths.tolist(), output_lengths.tolist())
+        max_len = int(max(self._host_lens[0]))
+        text_padded = to_gpu(text_padded).long()
+        input_lengths = to_gpu(input_lengths).long()
+        speaker_ids = to_gpu(speaker_ids).long()
+        mel_padded = to_gpu(mel_padded).float()
+        gate_padded = to_gpu(gate_padded).float()
+        emotions = to_gpu(emotions).float()
+        output_lengths = to_gpu(output_lengths).long()
+        return ((text_padded, input_lengths, mel_padded, max_len, speaker_ids, emotions, output_lengths),
+                (mel_padded, gate_padded))
+
+    def draw_rng(self, B, Ti, To, device):
+        """Dropout masks and style noise for one forward, in kernel layout (engine.py docstring)."""
+        hp, src = self.hparams, self.dropout_source
+        Bp = ops.roundup(B, 16)
+        rng = {'prenet_keep': [src.keep((To, Bp, hp.prenet_dim), 0.5, device) for _ in range(2)]}
+        if self.training:
+            dim = hp.encoder_embedding_dim
+            rng['enc_keep'] = [src.keep((B, Ti, dim), 0.5, device) for _ in range(hp.encoder_n_convolutions)]
+            rng['att_keep'] = src.keep((To, Bp, hp.attention_rnn_dim), hp.p_attention_dropout, device)
+            rng['dec_keep'] = src.keep((To, Bp, hp.decoder_rnn_dim), hp.p_decoder_dropout, device)
+            n = hp.postnet_n_convolutions
+            chans = [hp.postnet_embedding_dim] * (n - 1) + [hp.n_mel_channels]
+            rng['post_keep'] = [src.keep((B, To, c), 0.5, device) for c in chans]
+        if hp.noise_size > 0:
+            rng['noise'] = src.uniform((B, hp.noise_size), device)
+        return rng
+
+    def forward(self, inputs):
+        text, text_lengths, mels, max_len, speaker_ids, emotions, output_lengths = inputs
+        host = getattr(self, '_host_lens', None)
+        if host is None or len(host[0]) != text.size(0):
+            host = (text_lengths.tolist(), output_lengths.tolist())
+        in_lens, out_lens = host
+        rng = self.rng_override if self.rng_override is not None else \
+            self.draw_rng(text.size(0), text.size(1), mels.size(2), text.device)
+        params = [p for _, p in self.named_parameters()]
+        outs = _GeneratorFn.apply(self, text.contiguous(), in_lens, mels.contiguous(), out_lens, rng,
+                                  speaker_ids if self.vesus else None,
+                                  emotions.contiguous() if self.use_labels else None, *params)
+        return list(outs)
+
+    def inference(self, *args, **kwargs):
+        raise NotImplementedError('autoregressive inference is a "next" row of the hot-path scope (SURVEY.md 8f-3)')
+
+
+class _AdversarialFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, mel, lengths, keeps, *params):
+        P = dict(zip(module._param_names, (p.detach() for p in params)))
+        loss, sv = module.engine.forward(P, mel.detach(), lengths, keeps, training=module.training)
+        ctx.module, ctx.sv, ctx.P = module, sv, P
+        ctx.need_in = mel.requires_grad
+        ctx.needs = [p.requires_grad for p in params]
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        module, P = ctx.module, ctx.P
+        need_p = any(ctx.needs)
+        G = {k: torch.zeros_like(P[k]) for k in module._param_names} if need_p else None
+        dmel = module.engine.backward(P, G, ctx.sv, dloss.contiguous().view(1), 1.0, need_dinput=ctx.need_in,
+                                      need_dparams=need_p)
+        grads = tuple(G[k] if need else None for k, need in zip(module._param_names, ctx.needs)) if need_p \
+            else (None,) * len(ctx.needs)
+        return (None, dmel, None, None) + grads
+
+
+class Discriminator(nn.Module):
+    def __init__(self, hparams):
+        super().__init__()
+        self.window = hparams.discriminator_window
+        self.in_dim = self.window * hparams.n_mel_channels
+        dd = hparams.discriminator_dim
+        first_hidden = min((int(self.in_dim / dd) + 1) * dd, 1024)
+        self.discriminator = nn.Sequential(
+            DiscConv1d(self.in_dim, first_hidden, 5),
+            DiscConv1d(first_hidden, dd, 5, dilation=2),
+            DiscConv1d(dd, dd, 5, dilation=2),
+            DiscConv1d(dd, hparams.n_mel_channels, 5, dilation=2),
+            nn.Conv1d(hparams.n_mel_channels, 1, 1, bias=True))
+        self.engine = DiscriminatorEngine(hparams)
+        self._param_names = [k for k, _ in self.named_parameters()]
+        self.dropout_source = DropoutSource(hparams.seed + 1)
+        self.rng_override = None
+
+    def _keeps(self, B, T, device):
+        if self.rng_override is not None:
+            return self.rng_override
+        if not self.training:
+            return None
+        W = T // self.window + (1 if T % self.window else 0)
+        chans = [self.discriminator[i].module[0].out_channels for i in range(4)]
+        return [self.dropout_source.keep((B, W, c), 0.5, device) for c in chans]
+
+    def adversarial_loss(self, inputs, target_length):
+        """inputs (B, n_mel, T); reference model.py:529-540."""
+        params = [p for _, p in self.named_parameters()]
+        keeps = self._keeps(inputs.size(0), inputs.size(2), inputs.device)
+        return _AdversarialFn.apply(self, inputs.contiguous(), target_length.contiguous().long(), keeps, *params)
+
+    def forward(self, inputs):
+        """inputs (B, T, n_mel) -> (B, W); reference model.py:514-527 (no gradient through this entry)."""
+        mel = inputs.transpose(1, 2).contiguous()
+        P = {k: v.detach() for k, v in self.named_parameters()}
+        lengths = torch.full((mel.size(0),), mel.size(2), dtype=torch.int64, device=mel.device)
+        _, sv = self.engine.forward(P, mel, lengths, self._keeps(mel.size(0), mel.size(2), mel.device),
+                                    training=self.training)
+        return sv['out'].view(mel.size(0), -1)

@@ -1,0 +1,179 @@
+"""Tensor-level wrappers over the C ABI (include/gantron_hip.h).
+
+Every function takes CUDA (ROCm) fp32 torch tensors, passes raw device pointers + sizes to
+libgantron_hip.so on torch's current stream, and raises GantronHipError on a non-zero status.
+torch is used here for device memory only (allocation, views); all arithmetic is in the HIP
+kernels.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import GtAttnDims, GtGemm, GtOperand, GtSlabs, check, lib
+
+KC, RC, IM2COL_K, IM2COL_R = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t, offset=0):
+    """Device address of element `offset` of tensor t (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr() + offset * t.element_size()
+
+
+def call(name, *args):
+    conv = [a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args]
+    check(getattr(lib(), name)(*conv, _stream()), name)
+
+
+def _require(t, dtype=torch.float32):
+    assert t.is_cuda and t.dtype == dtype and t.is_contiguous(), (t.device, t.dtype, t.is_contiguous())
+    return t
+
+
+class Operand:
+    """Addressing of one GEMM operand (see GtOperand)."""
+
+    def __init__(self, t, mode, ld=0, T=0, C=0, dil=1, pad=0, offset=0, batch_stride=0):
+        self.t, self.mode, self.ld, self.T, self.C = t, mode, ld, T, C
+        self.dil, self.pad, self.offset, self.batch_stride = dil, pad, offset, batch_stride
+
+    def c(self):
+        o = GtOperand()
+        o.p = ptr(self.t, self.offset)
+        o.mode, o.T, o.C, o.dil, o.pad = self.mode, self.T, self.C, self.dil, self.pad
+        o.ld, o.batch_stride = self.ld, self.batch_stride
+        return o
+
+
+def default_split_k(M, N, K, batch=1):
+    """Split the reduction when the output grid alone cannot fill 256 CUs."""
+    tiles = -(-M // 64) * -(-N // 64) * batch
+    if tiles >= 256 or K < 1024:
+        return 1
+    return max(1, min(-(-512 // tiles), K // 256, 64))
+
+
+def sgemm(A, B, C, M, N, K, ldc=None, bias=None, accumulate=False, split_k=1, batch=1,
+          c_batch_stride=0, alpha=1.0, c_offset=0):
+    g = GtGemm()
+    g.A, g.B = A.c(), B.c()
+    g.C = ptr(C, c_offset)
+    g.ldc = N if ldc is None else ldc
+    g.c_batch_stride = c_batch_stride
+    g.bias = ptr(bias)
+    g.M, g.N, g.K, g.batch = M, N, K, batch
+    g.accumulate, g.split_k, g.alpha = int(accumulate), split_k, alpha
+    if split_k > 1 and not accumulate:
+        raise ValueError('split_k > 1 accumulates: zero C and pass accumulate=True')
+    check(lib().gt_sgemm(ctypes.byref(g), _stream()), 'gt_sgemm')
+
+
+def slabs(t, n, stride, ld, offset=0):
+    s = GtSlabs()
+    s.p, s.n, s.slab_stride, s.ld = ptr(t, offset), n, stride, ld
+    return s
+
+
+NO_SLABS = GtSlabs()
+
+
+def attn_dims(B, Ti, E, A, F, Kc):
+    d = GtAttnDims()
+    d.B, d.Ti, d.E, d.A, d.F, d.Kc = B, Ti, E, A, F, Kc
+    return d
+
+
+def roundup(x, m):
+    return -(-x // m) * m
+
+
+def pick_splits(K, want):
+    """Largest split count <= want that leaves no empty K-slab (gt_rec_gemm requirement)."""
+    kb = -(-K // 16)
+    for s in range(min(want, kb), 0, -1):
+        if -(-kb // -(-kb // s)) == s:
+            return s
+    return 1
+
+
+# ---------------------------------------------------------------------------------- layers
+def linear(x, W, M, K, N, bias=None, out=None, ldw=None, w_offset=0, ldx=None, x_offset=0):
+    """out[M,N] = x[M,K] @ W[N,K]^T (+ bias)."""
+    if out is None:
+        out = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    sgemm(Operand(x, KC, ld=ldx or K, offset=x_offset), Operand(W, KC, ld=ldw or K, offset=w_offset), out, M, N, K,
+          bias=bias)
+    return out
+
+
+def linear_dx(dy, W, M, N, K, out=None, ldw=None, w_offset=0, lddy=None, dy_offset=0):
+    """out[M,K] = dy[M,N] @ W[N,K]."""
+    if out is None:
+        out = torch.empty(M, K, device=dy.device, dtype=torch.float32)
+    sgemm(Operand(dy, KC, ld=lddy or N, offset=dy_offset), Operand(W, RC, ld=ldw or K, offset=w_offset), out, M, K, N)
+    return out
+
+
+def linear_dw(dy, x, rows, N, K, dW, lddy=None, dy_offset=0, ldx=None, x_offset=0, ldc=None, c_offset=0):
+    """dW[N,K] += dy[rows,N]^T @ x[rows,K]  (split-K over rows when the output grid is small)."""
+    sk = default_split_k(N, K, rows)
+    sgemm(Operand(dy, RC, ld=lddy or N, offset=dy_offset), Operand(x, RC, ld=ldx or K, offset=x_offset), dW, N, K, rows,
+          ldc=ldc, accumulate=True, split_k=sk, c_offset=c_offset)
+
+
+def col_sums(x, rows, C):
+    """Per-column sums of a (rows, C) matrix -> first C entries of a (2C,) tensor."""
+    out = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+    call('gt_col_stats', x, None, rows, C, out)
+    return out[:C]
+
+
+def conv_weight_fwd(W):
+    """(Cout, Cin, K) -> (Cout, K, Cin): the k-contiguous B operand of the forward implicit GEMM."""
+    co, ci, k = W.shape
+    out = torch.empty(co, k, ci, device=W.device, dtype=torch.float32)
+    call('gt_permute3', W, ci * k, 1, k, co, k, ci, out, 0, 0, 0, 1.0)
+    return out
+
+
+def conv_weight_bwd(W):
+    """(Cout, Cin, K) -> (Cin, K, Cout) with flipped taps: B operand of the input-gradient GEMM."""
+    co, ci, k = W.shape
+    out = torch.empty(ci, k, co, device=W.device, dtype=torch.float32)
+    check(lib().gt_permute3(ptr(W, k - 1), k, -1, ci * k, ci, k, co, out.data_ptr(), 0, 0, 0, 1.0, _stream()),
+          'gt_permute3')
+    return out
+
+
+def conv1d_fwd(x, Wf, bias, B, T, Cin, Cout, K, dil):
+    """Channels-last Conv1d with 'same' padding: x (B*T, Cin) -> (B*T, Cout)."""
+    out = torch.empty(B * T, Cout, device=x.device, dtype=torch.float32)
+    pad = dil * (K - 1) // 2
+    sgemm(Operand(x, IM2COL_K, T=T, C=Cin, dil=dil, pad=pad), Operand(Wf, KC, ld=K * Cin), out, B * T, Cout, K * Cin,
+          bias=bias)
+    return out
+
+
+def conv1d_dx(dy, Wb, B, T, Cin, Cout, K, dil):
+    out = torch.empty(B * T, Cin, device=dy.device, dtype=torch.float32)
+    pad = dil * (K - 1) // 2
+    sgemm(Operand(dy, IM2COL_K, T=T, C=Cout, dil=dil, pad=pad), Operand(Wb, KC, ld=K * Cout), out, B * T, Cin, K * Cout)
+    return out
+
+
+def conv1d_dw(dy, x, B, T, Cin, Cout, K, dil, dW):
+    """dW (Cout, Cin, K) += correlation of dy (B*T, Cout) with x (B*T, Cin)."""
+    pad = dil * (K - 1) // 2
+    tmp = torch.zeros(Cout, K * Cin, device=dy.device, dtype=torch.float32)
+    sk = default_split_k(Cout, K * Cin, B * T)
+    sgemm(Operand(dy, RC, ld=Cout), Operand(x, IM2COL_R, T=T, C=Cin, dil=dil, pad=pad), tmp, Cout, K * Cin, B * T,
+          accumulate=True, split_k=sk)
+    # tmp[co][k][ci] -> dW[co][ci][k]
+    call('gt_permute3', tmp, K * Cin, 1, Cin, Cout, Cin, K, dW, 0, 0, 1, 1.0)

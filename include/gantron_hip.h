@@ -1,0 +1,331 @@
+/*
+ * gantron_hip.h — C ABI of libgantron_hip.so: hand-written HIP kernels (gfx950 / MI355X) for the
+ * GANtron generator+discriminator training step.
+ *
+ * The reference (Brechard/GANtron) has no FFI/plugin layer: its hot path is a chain of stock
+ * PyTorch ops inside nn.Module.forward and autograd.  This library replaces those chains; each
+ * entry cites the reference code it stands in for.  The host side (gantron_amd/ *.py) keeps the
+ * reference's Python API (hparams.HParams, model.Tacotron2, model.Discriminator, ...) and calls
+ * these entries with raw device pointers (tensor.data_ptr()), explicit sizes, explicit dropout
+ * keep-masks (u8, 1 = keep) and the caller's hipStream_t.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative GT_E_* code for invalid arguments, or a
+ *    positive hipError_t; gt_last_error_string() describes the last failure of the calling thread;
+ *  - nothing is allocated, freed or synchronised here: all buffers (outputs, workspaces, saved-for-
+ *    backward state) are owned by the caller; every launch is asynchronous on `stream`;
+ *  - all tensors are fp32 unless stated; activations are "channels-last": (rows = batch*time, C);
+ *  - weights are read in PyTorch layout unless the argument is documented as packed
+ *    (packed copies are produced per call by gt_pack_* into caller-owned scratch).
+ */
+#ifndef GANTRON_HIP_H
+#define GANTRON_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GT_E_ARG   (-1)   /* bad argument / shape */
+#define GT_E_ALIGN (-2)   /* pointer or leading dimension violates an alignment requirement */
+#define GT_E_LIMIT (-3)   /* size exceeds a compiled-in limit */
+
+int gt_version(void);
+const char* gt_last_error_string(void);
+/* sizeof of ABI structs: 0 GtOperand, 1 GtGemm, 2 GtSlabs, 3 GtAttnDims, 4 GtDecoderFwd,
+ * 5 GtDecoderBwd, 6 GtBiLstm (lets a binding verify its layout at load time) */
+int64_t gt_abi_sizeof(int32_t which);
+
+/* ------------------------------------------------------------------------------------------ GEMM
+ * C[m,n] (=|+=) sum_k A(m,k) * B(n,k) (+ bias[n]),   fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * Operand addressing modes (element (r,k) of an operand with rows r and reduction index k):
+ *   GT_OP_KC        p[r*ld + k]                                   (k contiguous)
+ *   GT_OP_RC        p[k*ld + r]                                   (r contiguous)
+ *   GT_OP_IM2COL_K  rows are positions r=(b,t), k=(tap,c):  p[((b*T + t + tap*dil - pad)*C + c)]
+ *   GT_OP_IM2COL_R  rows are r=(tap,c), k is a position (b,t): same address, 0 outside [0,T)
+ * The im2col modes make Conv1d (model.py:117-144,165-178,506-511; layers.py:22-60) and its
+ * input/weight gradients plain GEMMs over channels-last activations.
+ */
+enum { GT_OP_KC = 0, GT_OP_RC = 1, GT_OP_IM2COL_K = 2, GT_OP_IM2COL_R = 3 };
+
+typedef struct GtOperand {
+    const float* p;
+    int32_t mode;
+    int32_t T, C, dil, pad;     /* im2col modes only */
+    int64_t ld;                 /* KC / RC modes */
+    int64_t batch_stride;       /* elements between batches (grid batching) */
+} GtOperand;
+
+typedef struct GtGemm {
+    GtOperand A, B;
+    float* C;
+    int64_t ldc, c_batch_stride;
+    const float* bias;          /* per-n, may be NULL */
+    int32_t M, N, K;
+    int32_t batch;              /* >= 1 */
+    int32_t accumulate;         /* 0: C = ..., 1: C += ... */
+    int32_t split_k;            /* >= 1; > 1 uses fp32 atomics and therefore always accumulates */
+    float alpha;
+} GtGemm;
+
+int gt_sgemm(const GtGemm* g, void* stream);
+
+/* ------------------------------------------------------------------- recurrent (small-M) GEMM
+ * Per-time-step product of the LSTM recurrences (model.py:391-392,406-407 and the BiLSTM of
+ * model.py:207): part[s][m][n] = sum_{k in K-slice s} X[m][k] * W[n][k], m < 16*mtiles <= 64.
+ * W is pre-packed by gt_pack_rec_weight into [N/16][KB][64 lanes][4] (KB = ceil(K/16) 16-wide
+ * k-blocks, zero padded) so that every wave streams 1 KiB lines; X is row-major with
+ * ldx >= 16*KB, rows beyond the batch and columns beyond K must be zero (or finite).
+ * `part` receives `splits` slabs of [16*mtiles][N] spaced part_sstride elements apart; the
+ * consumer (cell kernels) sums them.  nz > 1 runs independent problems (BiLSTM directions).
+ */
+int gt_pack_rec_weight(const float* W, int64_t ldw, int32_t transposed, int32_t N, int32_t n_valid,
+                       int32_t K, float* Wp, void* stream);   /* rows n >= n_valid are zero */
+int64_t gt_rec_weight_elems(int32_t N, int32_t K);
+int gt_rec_gemm(const float* X, int64_t ldx, const float* Wp, float* part, int32_t mtiles,
+                int32_t N, int32_t K, int32_t splits, int64_t part_sstride, int32_t nz,
+                int64_t x_zstride, int64_t w_zstride, int64_t part_zstride, void* stream);
+
+/* ------------------------------------------------------------------------------------ LSTM cell
+ * nn.LSTMCell pointwise part + dropout (model.py:391-394,406-409); gate order i,f,g,o.
+ * gates_pre = sum_s part[s] + pre (pre holds the non-recurrent input projection and both biases).
+ * `active` (per row, may be NULL) implements pack_padded_sequence (model.py:203-210): inactive rows
+ * keep their state and emit zeros.  h (after dropout) is written to up to three destinations.
+ */
+typedef struct GtSlabs { const float* p; int32_t n; int64_t slab_stride; int64_t ld; } GtSlabs;
+
+int gt_lstm_cell_fwd(GtSlabs part, const float* pre, int64_t ld_pre, const float* c_prev,
+                     const float* h_prev, int64_t ld_hprev, const uint8_t* keep, float p_drop,
+                     const int32_t* active, float* gates, float* c_out, float* h_raw,
+                     float* h0, int64_t ld0, float* h1, int64_t ld1, float* h2, int64_t ld2,
+                     int32_t B, int32_t H, void* stream);
+
+/* dh = (sum of up to three slab sources + direct) ; returns pre-activation gate grads + dc_prev. */
+int gt_lstm_cell_bwd(GtSlabs dh_a, GtSlabs dh_b, GtSlabs dh_c, const float* dh_direct,
+                     int64_t ld_direct, const float* dc_next, const float* gates,
+                     const float* c_new, const float* c_prev, const uint8_t* keep, float p_drop,
+                     const int32_t* active, float* dgates, float* dc_prev, float* dh_pass,
+                     int32_t B, int32_t H, void* stream);
+
+/* --------------------------------------------------------------- location-sensitive attention
+ * One decoder step of Attention.forward (model.py:70-91) with LocationLayer (model.py:27-31):
+ *   e[t] = v . tanh(q + Wd conv31([w_prev; w_cum])[t] + pm[t]);  pad -> -inf; w = softmax(e);
+ *   ctx = w @ memory;  w_cum += w.
+ * gt_attn_energies: grid (B, chunks of Ti).  q = sum of `qpart` slabs (query_layer product).
+ * gt_attn_context : softmax over Ti + context; ctx written to up to three destinations.
+ */
+typedef struct GtAttnDims { int32_t B, Ti, E, A, F, Kc; } GtAttnDims;
+
+int gt_attn_energies_fwd(GtAttnDims d, GtSlabs qpart, const float* w_prev, const float* w_cum,
+                         const float* pm, const float* Wc, const float* Wd, const float* v,
+                         const int32_t* lengths, float* q_out, float* energies, void* stream);
+int gt_attn_context_fwd(GtAttnDims d, const float* energies, const float* memory, int64_t ld_mem,
+                        float* w_out, const float* cum_in, float* cum_out,
+                        float* c0, int64_t ld0, float* c1, int64_t ld1, float* c2, int64_t ld2,
+                        void* stream);
+
+/* backward of the two kernels above (recomputes tanh arguments instead of saving them).
+ * context_bwd: dctx = slabs a + slabs b + direct; dw[t'] = memory[b][t'].dctx + carried alignment
+ *   gradients (dwcat_in[0] = d w_prev of step t+1, dcum_acc += dwcat_in[1]; both planes are
+ *   consumed and zeroed) + dw_extern (gradient of the returned alignments).  Also stores dctx
+ *   (for the deferred d memory GEMM) and zeroes this step's dq accumulator.
+ * energies_bwd: softmax backward (needs w and dw over all Ti), then d tanh / dense / conv:
+ *   dq += (atomics), dpm += , dwcat_out += (atomics, [2][B][Ti]), parameter gradients of
+ *   v / location_dense / location_conv accumulate in per-workgroup slabs `acc`. */
+int gt_attn_context_bwd(GtAttnDims d, GtSlabs dctx_a, GtSlabs dctx_b, const float* dctx_direct,
+                        int64_t ld_direct, const float* memory, int64_t ld_mem, float* dwcat_in,
+                        float* dcum_acc, const float* dw_extern, float* dctx_out,
+                        int64_t ld_dctx_out, float* dq_zero, int64_t ld_dq, float* dw_out,
+                        void* stream);
+int gt_attn_energies_bwd(GtAttnDims d, const float* dw, const float* w, const float* q,
+                         const float* w_prev, const float* w_cum, const float* pm, const float* Wc,
+                         const float* Wd, const float* v, float* dq, int64_t ld_dq, float* dpm,
+                         float* dwcat_out, float* acc, void* stream);
+int64_t gt_attn_acc_elems(GtAttnDims d);     /* size of `acc` (dv | dWd | dWc per workgroup) */
+int gt_attn_acc_reduce(GtAttnDims d, const float* acc, float* dv, float* dWd, float* dWc,
+                       void* stream);
+int32_t gt_attn_chunks(int32_t Ti);
+
+/* ------------------------------------------------------------------------- sequential loops
+ * gt_decoder_fwd / gt_decoder_bwd: the teacher-forced decoder loop (Decoder.forward + decode,
+ * model.py:378-454) and its backward-through-time, To steps per call, 7 launches per step.
+ * gt_bilstm_run: the packed encoder BiLSTM (model.py:202-210), both directions, forward or
+ * backward.  Per-step histories use Bp = 16*ceil(B/16) rows per step (pad rows zero) so that they
+ * can be fed to gt_rec_gemm / gt_sgemm directly; keep masks and attention tensors use B rows.
+ */
+typedef struct GtDecoderFwd {
+    int32_t B, Bp, Ti, To, E, ldE, P, Ha, Hd, A, Apad, F, Kc;
+    int32_t S1, S2, Sq;
+    float p_att, p_dec;
+    const float* memory;       /* (B, Ti, ldE) */
+    const float* pm;           /* (B, Ti, A) processed memory */
+    const int32_t* lengths;    /* (B) */
+    const float* pre1;         /* (To, Bp, 4Ha) prenet projection + both biases of attention_rnn */
+    const float* bias2;        /* (4Hd) b_ih + b_hh of decoder_rnn */
+    const float* W1p;          /* packed [4Ha] x [ctx(E) | h_att(Ha)] */
+    const float* Wqp;          /* packed [Apad] x [Ha] */
+    const float* W2p;          /* packed [4Hd] x [h_att(Ha) | ctx(E) | h_dec(Hd)] */
+    const float* Wc; const float* Wd; const float* v;
+    const uint8_t* att_keep;   /* (To, Bp, Ha) or NULL */
+    const uint8_t* dec_keep;   /* (To, Bp, Hd) or NULL */
+    float* X1; int64_t ld1;    /* (Bp, ld1) zero-initialised */
+    float* X2; int64_t ld2;    /* (Bp, ld2) zero-initialised */
+    float* part;               /* slab scratch */
+    float* energies;           /* (B, Ti) */
+    float* gates1; float* c1;  /* (To, Bp, 4Ha), (To+1, Bp, Ha) c1[0] = 0 */
+    float* gates2; float* c2;  /* (To, Bp, 4Hd), (To+1, Bp, Hd) */
+    float* hatt;               /* (To, Bp, Ha) */
+    float* HC;                 /* (To, Bp, Hd+E): [h_dec | ctx] */
+    float* w_hist;             /* (To+1, B, Ti), w_hist[0] = 0 */
+    float* cum_hist;           /* (To+1, B, Ti), cum_hist[0] = 0 */
+    float* q_hist;             /* (To, B, A) */
+} GtDecoderFwd;
+
+typedef struct GtDecoderBwd {
+    int32_t B, Bp, Ti, To, E, ldE, P, Ha, Hd, A, Apad, F, Kc;
+    int32_t S1, S2, Sq;
+    int32_t N1pad, N2pad;      /* roundup16(E+Ha), roundup16(Ha+E+Hd) */
+    float p_att, p_dec;
+    const float* memory; const float* pm;
+    const float* Wc; const float* Wd; const float* v;
+    const uint8_t* att_keep; const uint8_t* dec_keep;
+    const float* gates1; const float* c1; const float* gates2; const float* c2;
+    const float* w_hist; const float* cum_hist; const float* q_hist;
+    const float* W1Tp;         /* packed [N1pad] x [4Ha]  (transpose of the forward operand) */
+    const float* W2Tp;         /* packed [N2pad] x [4Hd] */
+    const float* WqTp;         /* packed [Ha] x [Apad] */
+    const float* dHC;          /* (To, Bp, Hd+E) gradient of the projection input */
+    const float* dalign;       /* (To, B, Ti) gradient of the returned alignments, or NULL */
+    float* dG1; float* dG2;    /* (To, Bp, 4Ha), (To, Bp, 4Hd) pre-activation gate gradients */
+    float* dctx_hist;          /* (To, B, E) */
+    float* dpm;                /* (B, Ti, A) zero-initialised, accumulated */
+    float* acc;                /* gt_attn_acc_elems floats, zero-initialised */
+    float* dc1; float* dc2;    /* (B, H) zero-initialised */
+    float* dwcat;              /* (2, 2, B, Ti) zero-initialised ping-pong */
+    float* dcum_acc;           /* (B, Ti) zero-initialised */
+    float* dq_hist;            /* (To, Bp, Apad) zero-initialised: per-step query gradients */
+    float* dw;                 /* (B, Ti) */
+    float* partX1; float* partX2; float* partQ;
+} GtDecoderBwd;
+
+typedef struct GtBiLstm {
+    int32_t B, Bp, T, H, S, backward;
+    const float* pre;          /* (2, T, Bp, 4H) step-major input projections + biases */
+    const float* Whp;          /* (2) packed [4H] x [H]; for backward packed [Hpad] x [4H] */
+    int64_t w_zstride;
+    const int32_t* active;     /* (T, Bp) 1 while step < length */
+    float* X; int64_t ldx;     /* (2, Bp, ldx) zero-initialised (forward only) */
+    float* part;               /* (2, S, Bp, N) */
+    float* gates;              /* (2, T, Bp, 4H) */
+    float* c;                  /* (2, T+1, Bp, H), c[:,0] = 0 */
+    float* hs;                 /* (2, T, Bp, H) emitted outputs (zero when inactive) */
+    /* backward only */
+    const float* dhs;          /* (2, T, Bp, H) gradient of the emitted outputs */
+    float* dG;                 /* (2, T, Bp, 4H) */
+    float* dc;                 /* (2, Bp, H) zero-initialised */
+    int32_t Hpad;
+} GtBiLstm;
+
+int gt_decoder_fwd(const GtDecoderFwd* a, void* stream);
+int gt_decoder_bwd(const GtDecoderBwd* a, void* stream);
+int gt_bilstm_run(const GtBiLstm* a, void* stream);
+
+/* -------------------------------------------------------------------- elementwise / reductions */
+/* per-column sums over rows: BatchNorm1d batch statistics incl. padding (model.py:123,176) and
+ * bias gradients.  out[0..C) = sum x, out[C..2C) = sum x*y (sum x*x if y is NULL).  Passing
+ * y == x selects the shifted form sum (x-K), sum (x-K)^2 with K = x[0][c] that
+ * gt_bn_act_drop_fwd expects (no cancellation when |mean| >> std). */
+int gt_col_stats(const float* x, const float* y, int64_t rows, int32_t C, float* out2C,
+                 void* stream);
+/* BN(train) -> activation (0 none, 1 relu, 2 tanh) -> dropout; updates running stats.
+ * stats = gt_col_stats output; saves mean/invstd (2C) for backward. */
+int gt_bn_act_drop_fwd(const float* x, const float* stats, int64_t rows, int32_t C,
+                       const float* gamma, const float* beta, float* running_mean,
+                       float* running_var, float momentum, float eps, int32_t act,
+                       const uint8_t* keep, float p_drop, float* y, float* mean_invstd,
+                       int32_t training, void* stream);
+/* backward, two passes: (1) dz = dy*keep*act' and column sums of dz, dz*xhat;
+ * (2) dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)).  dgamma/dbeta += . */
+int gt_bn_act_drop_bwd1(const float* dy, const float* x, const float* mean_invstd,
+                        const float* gamma, const float* beta, int64_t rows, int32_t C,
+                        int32_t act, const uint8_t* keep, float p_drop, float* dz, float* sums2C,
+                        void* stream);
+int gt_bn_act_drop_bwd2(const float* dz, const float* x, const float* mean_invstd,
+                        const float* gamma, const float* sums2C, int64_t rows, int32_t C,
+                        float* dx, float* dgamma, float* dbeta, void* stream);
+/* y = dropout(act(x + bias)); act 0/1/2 as above; order 0: act then dropout (prenet, model.py:104),
+ * order 1: dropout then act (DiscConv1d, layers.py:54-57). */
+int gt_bias_act_drop_fwd(const float* x, const float* bias, int64_t rows, int32_t C, int32_t act,
+                         int32_t order, const uint8_t* keep, float p_drop, float* y, void* stream);
+int gt_bias_act_drop_bwd(const float* dy, const float* y, int64_t rows, int32_t C, int32_t act,
+                         int32_t order, const uint8_t* keep, float p_drop, float* dx, void* stream);
+/* embedding (model.py:648) gather / scatter-add of its gradient */
+int gt_embedding_fwd(const int64_t* ids, const float* table, int64_t n, int32_t D, float* out,
+                     int64_t ld_out, void* stream);
+int gt_embedding_bwd(const int64_t* ids, const float* dout, int64_t ld, int64_t n, int32_t D,
+                     float* dtable, void* stream);
+/* generic strided 3-d permute copy: out[i*o0 + j*o1 + k] (=|+=) alpha * in[i*s0 + j*s1 + k*s2];
+ * o0 = o1 = 0 selects a contiguous output.  Strides may be negative (tap-flipped weights). */
+int gt_permute3(const float* in, int64_t s0, int64_t s1, int64_t s2, int32_t n0, int32_t n1,
+                int32_t n2, float* out, int64_t o0, int64_t o1, int32_t accumulate, float alpha,
+                void* stream);
+/* row gather: out[r] = idx[r] >= 0 ? src[idx[r]] : 0 (C floats per row).  Builds the step-major
+ * views of the packed BiLSTM (pack_padded_sequence / pad_packed_sequence, model.py:203-210). */
+int gt_gather_rows(const float* src, int64_t ld_src, const int32_t* idx, int64_t rows, int32_t C,
+                   float* out, int64_t ld_out, int32_t accumulate, void* stream);
+/* a*x + b*y -> out (any may alias) */
+int gt_axpby(const float* x, float a, const float* y, float b, float* out, int64_t n, void* stream);
+/* out (=|+=) x * (*s) * host_scale with the scalar s read on the device (upstream loss gradients
+ * never visit the host); s may be NULL */
+int gt_scale_dev(const float* x, const float* s, float host_scale, float* out, int64_t n,
+                 int32_t accumulate, void* stream);
+/* padding mask of Tacotron2.parse_output (model.py:632-642), channels-first outputs */
+int gt_mask_outputs(float* mel, float* mel_post, float* gate, const int64_t* out_len, int32_t B,
+                    int32_t n_mel, int32_t To, void* stream);
+/* counter-based dropout keep-mask: keep[i] = u(seed, offset+i) >= p  (shared with the oracle) */
+int gt_keep_mask(uint64_t seed, uint64_t offset, float p, int64_t n, uint8_t* keep, void* stream);
+int gt_uniform(uint64_t seed, uint64_t offset, int64_t n, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------- discriminator
+ * Discriminator.forward input shaping (model.py:523-526): mel (B, n_mel, T) channels-first ->
+ * r (B, W, window*n_mel) channels-last with r[b][w][c] = X'[b].flat[c*W + w]. */
+int gt_disc_gather_fwd(const float* mel, int32_t B, int32_t n_mel, int32_t T, int32_t window,
+                       float* r, void* stream);
+int gt_disc_gather_bwd(const float* dr, int32_t B, int32_t n_mel, int32_t T, int32_t window,
+                       float* dmel, int32_t accumulate, void* stream);
+/* adversarial_loss reduction (model.py:529-540) and its gradient */
+int gt_adv_mean_fwd(const float* out, const int64_t* lengths, int32_t B, int32_t W, int32_t window,
+                    float* loss, void* stream);
+int gt_adv_mean_bwd(const float* dloss, const int64_t* lengths, int32_t B, int32_t W,
+                    int32_t window, float scale, float* dout, void* stream);
+
+/* -------------------------------------------------------------------------------------- losses
+ * Tacotron2Loss (loss_function.py:10-22): sums[0]=MSE(mel), [1]=MSE(mel_post), [2]=BCE(gate);
+ * gradients (unit upstream) written to dmel, dmel_post, dgate. */
+int gt_taco_loss(const float* mel, const float* mel_post, const float* gate, const float* mel_t,
+                 const float* gate_t, int64_t n_mel_elems, int64_t n_gate, float* sums3,
+                 float* dmel, float* dmel_post, float* dgate, void* stream);
+/* guided attention loss (loss_function.py:25-52); align (B, To, Ti); loss += ; dalign = grad */
+int gt_guided_attn_loss(const float* align, const int64_t* in_len, const int64_t* out_len,
+                        int32_t B, int32_t To, int32_t Ti, float* loss, float* dalign,
+                        void* stream);
+
+/* ----------------------------------------------------------------------------------- optimiser
+ * clip_grad_norm_ + Adam with L2 weight decay (train.py:242-243,404-406) over one flat buffer. */
+int gt_sumsq(const float* x, int64_t n, float* out /* += */, void* stream);
+int gt_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, float lr,
+                 float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                 const float* sumsq /* NULL: no clipping */, float max_norm, void* stream);
+
+/* -------------------------------------------------------------------------------------- STFT
+ * TacotronSTFT.mel_spectrogram (layers.py:97-114, stft.py:77-105, audio_processing.py:78-84) */
+int gt_reflect_pad(const float* audio, int32_t B, int64_t n, int32_t pad, float* out, void* stream);
+int gt_stft_magnitude(const float* ft /* rows x 2*cutoff */, int64_t rows, int32_t cutoff,
+                      float* mag, void* stream);
+int gt_log_clamp(const float* x, int64_t n, float clip, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GANTRON_HIP_H */

@@ -1,0 +1,415 @@
+"""Per-kernel checks of libgantron_hip.so on a real MI355X, each against an independent fp32/fp64
+CPU computation (torch CPU ops or the oracle).  All calls go through the C ABI."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from harness import close, u01
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    return torch.device('cuda:0')
+
+
+def g(*shape, seed=0, scale=1.0):
+    gen = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.randn(*shape, generator=gen) * scale
+
+
+# ------------------------------------------------------------------------------------- sgemm
+@pytest.mark.parametrize('M,N,K', [(200, 150, 70), (64, 64, 16), (129, 257, 333), (1, 80, 2048), (515, 1, 33)])
+def test_sgemm_kc_kc(dev, M, N, K):
+    from gantron_amd import ops
+    A, B, bias = g(M, K), g(N, K, seed=1), g(N, seed=2)
+    C = torch.empty(M, N, device=dev)
+    ops.sgemm(ops.Operand(A.to(dev), ops.KC, ld=K), ops.Operand(B.to(dev), ops.KC, ld=K), C, M, N, K, bias=bias.to(dev))
+    close(C, A.double() @ B.double().t() + bias.double(), rtol=1e-5, atol=1e-5, what='sgemm kc/kc')
+
+
+def test_sgemm_modes_accumulate_splitk_batch(dev):
+    from gantron_amd import ops
+    M, N, K = 96, 130, 700
+    A, B = g(M, K), g(N, K, seed=1)
+    ref = A.double() @ B.double().t()
+    # RC/RC: both operands stored reduction-major
+    C = torch.zeros(M, N, device=dev)
+    ops.sgemm(ops.Operand(A.t().contiguous().to(dev), ops.RC, ld=M), ops.Operand(B.t().contiguous().to(dev), ops.RC, ld=N),
+              C, M, N, K)
+    close(C, ref, rtol=1e-5, atol=1e-4, what='rc/rc')
+    # KC/RC and RC/KC
+    C.zero_()
+    ops.sgemm(ops.Operand(A.to(dev), ops.KC, ld=K), ops.Operand(B.t().contiguous().to(dev), ops.RC, ld=N), C, M, N, K)
+    close(C, ref, rtol=1e-5, atol=1e-4, what='kc/rc')
+    C.zero_()
+    ops.sgemm(ops.Operand(A.t().contiguous().to(dev), ops.RC, ld=M), ops.Operand(B.to(dev), ops.KC, ld=K), C, M, N, K)
+    close(C, ref, rtol=1e-5, atol=1e-4, what='rc/kc')
+    # accumulate + split-K on top of existing content, unaligned leading dimension (scalar path)
+    C0 = g(M, N + 3, seed=5)
+    Cd = C0.clone().to(dev)
+    ops.sgemm(ops.Operand(A.to(dev), ops.KC, ld=K), ops.Operand(B.to(dev), ops.KC, ld=K), Cd, M, N, K, ldc=N + 3,
+              accumulate=True, split_k=5, alpha=0.5)
+    want = C0.double()
+    want[:, :N] += 0.5 * ref
+    close(Cd, want, rtol=1e-5, atol=1e-4, what='accumulate split-k')
+    # batched, operands at an element offset
+    nb = 3
+    Ab, Bb = g(nb, M, K, seed=7), g(nb, N, K, seed=8)
+    Cb = torch.empty(nb, M, N, device=dev)
+    Apad = torch.cat((torch.zeros(5), Ab.reshape(-1))).to(dev)
+    ops.sgemm(ops.Operand(Apad, ops.KC, ld=K, offset=5, batch_stride=M * K),
+              ops.Operand(Bb.to(dev), ops.KC, ld=K, batch_stride=N * K), Cb, M, N, K, batch=nb, c_batch_stride=M * N)
+    close(Cb, torch.bmm(Ab.double(), Bb.double().transpose(1, 2)), rtol=1e-5, atol=1e-4, what='batched')
+
+
+@pytest.mark.parametrize('B,T,Cin,Cout,K,dil', [(3, 37, 16, 24, 5, 1), (2, 9, 32, 48, 5, 2), (4, 150, 80, 512, 5, 1)])
+def test_conv1d_fwd_dx_dw(dev, B, T, Cin, Cout, K, dil):
+    from gantron_amd import ops
+    x = g(B, Cin, T).requires_grad_(True)
+    W = g(Cout, Cin, K, seed=1, scale=0.2).requires_grad_(True)
+    bias = g(Cout, seed=2)
+    pad = dil * (K - 1) // 2
+    y = F.conv1d(x.double(), W.double(), bias.double(), padding=pad, dilation=dil)
+    dy = g(B, Cout, T, seed=3)
+    gx, gw = torch.autograd.grad(y, (x, W), dy.double())
+    xcl = x.detach().permute(0, 2, 1).contiguous().view(B * T, Cin).to(dev)
+    Wd = W.detach().to(dev)
+    ycl = ops.conv1d_fwd(xcl, ops.conv_weight_fwd(Wd), bias.to(dev), B, T, Cin, Cout, K, dil)
+    close(ycl.view(B, T, Cout).permute(0, 2, 1), y, rtol=1e-5, atol=1e-4, what='conv fwd')
+    dycl = dy.permute(0, 2, 1).contiguous().view(B * T, Cout).to(dev)
+    dx = ops.conv1d_dx(dycl, ops.conv_weight_bwd(Wd), B, T, Cin, Cout, K, dil)
+    close(dx.view(B, T, Cin).permute(0, 2, 1), gx, rtol=1e-5, atol=1e-4, what='conv dx')
+    dW = torch.zeros(Cout, Cin, K, device=dev)
+    ops.conv1d_dw(dycl, xcl, B, T, Cin, Cout, K, dil, dW)
+    close(dW, gw, rtol=1e-5, atol=1e-4, what='conv dw')
+
+
+# ---------------------------------------------------------------------------- recurrent kernels
+@pytest.mark.parametrize('Bsz,N,K,S', [(64, 256, 512, 4), (8, 64, 96, 3), (33, 128, 100, 2), (64, 4096, 2048, 4)])
+def test_rec_gemm(dev, Bsz, N, K, S):
+    from gantron_amd import ops
+    from gantron_amd.engine import pack_rec
+    Bp, ld = ops.roundup(Bsz, 16), ops.roundup(K, 16) + 16
+    W = g(N, K, scale=0.1)
+    X = torch.zeros(Bp, ld)
+    X[:Bsz, :K] = g(Bsz, K, seed=1)
+    Wp = pack_rec(W.to(dev), N, N, K)
+    S = ops.pick_splits(K, S)
+    part = torch.empty(S, Bp, N, device=dev)
+    ops.call('gt_rec_gemm', X.to(dev), ld, Wp, part, Bp // 16, N, K, S, Bp * N, 1, 0, 0, 0)
+    close(part.sum(0)[:Bsz], X[:Bsz, :K].double() @ W.double().t(), rtol=1e-5, atol=1e-4, what='rec_gemm')
+    # transposed packing: out = X2 @ W (W is K2 x N2 with K2 = N, N2 = K padded to 16)
+    N2 = ops.roundup(K, 16)
+    WTp = pack_rec(W.to(dev), N2, K, N, transposed=True)
+    X2 = torch.zeros(Bp, N)
+    X2[:Bsz] = g(Bsz, N, seed=2)
+    S2 = ops.pick_splits(N, 4)
+    part2 = torch.empty(S2, Bp, N2, device=dev)
+    ops.call('gt_rec_gemm', X2.to(dev), N, WTp, part2, Bp // 16, N2, N, S2, Bp * N2, 1, 0, 0, 0)
+    close(part2.sum(0)[:Bsz, :K], X2[:Bsz].double() @ W.double(), rtol=1e-5, atol=1e-4, what='rec_gemm transposed')
+
+
+def test_lstm_cell_fwd_bwd(dev):
+    from gantron_amd import ops
+    B, H, S, p = 5, 48, 3, 0.1
+    part = g(S, B, 4 * H, scale=0.5)
+    pre = g(B, 4 * H, seed=1, scale=0.5)
+    c_prev = g(B, H, seed=2)
+    keep = (torch.rand(B, H, generator=torch.Generator().manual_seed(3)) >= p)
+    gates_in = (part.sum(0) + pre).double().requires_grad_(True)
+    cp = c_prev.double().requires_grad_(True)
+    i, f, gg, o = gates_in.chunk(4, dim=1)
+    c = torch.sigmoid(f) * cp + torch.sigmoid(i) * torch.tanh(gg)
+    h = torch.sigmoid(o) * torch.tanh(c) * keep.double() / (1 - p)
+    gates = torch.empty(B, 4 * H, device=dev); c_out = torch.empty(B, H, device=dev)
+    h_raw = torch.empty(B, H, device=dev); h0 = torch.zeros(B, H + 7, device=dev)
+    ops.call('gt_lstm_cell_fwd', ops.slabs(part.to(dev), S, B * 4 * H, 4 * H), pre.to(dev), 4 * H, c_prev.to(dev), None, 0,
+             keep.to(torch.uint8).to(dev), p, None, gates, c_out, h_raw, ops.ptr(h0, 3), H + 7, None, 0, None, 0, B, H)
+    close(c_out, c, what='cell c')
+    close(h_raw, h, what='cell h')
+    close(h0[:, 3:3 + H], h, what='cell h strided')
+    dh, dc = g(B, H, seed=4), g(B, H, seed=5)
+    gg_, gc = torch.autograd.grad((h * dh.double()).sum() + (c * dc.double()).sum(), (gates_in, cp))
+    dgates = torch.empty(B, 4 * H, device=dev); dcp = torch.empty(B, H, device=dev)
+    dh_sl = torch.stack((0.25 * dh, 0.75 * dh)).contiguous().to(dev)
+    ops.call('gt_lstm_cell_bwd', ops.slabs(dh_sl, 2, B * H, H), ops.NO_SLABS, ops.NO_SLABS, None, 0, dc.to(dev), gates, c_out,
+             c_prev.to(dev), keep.to(torch.uint8).to(dev), p, None, dgates, dcp, None, B, H)
+    close(dgates, gg_, what='cell dgates')
+    close(dcp, gc, what='cell dc_prev')
+
+
+# ------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize('B,Ti,E,A,Fn,Kc', [(3, 45, 40, 8, 4, 5), (2, 70, 96, 128, 32, 31)])
+def test_attention_step_fwd_bwd(dev, B, Ti, E, A, Fn, Kc):
+    from gantron_amd import ops
+    from gantron_amd._lib import lib
+    from oracle import gantron_ref as R
+    pre = 'decoder.attention_layer.'
+    P = {pre + 'query_layer.linear_layer.weight': g(A, 16, scale=0.3),
+         pre + 'location_layer.location_conv.conv.weight': g(Fn, 2, Kc, seed=1, scale=0.3),
+         pre + 'location_layer.location_dense.linear_layer.weight': g(A, Fn, seed=2, scale=0.3),
+         pre + 'v.linear_layer.weight': g(1, A, seed=3, scale=0.5)}
+    P = {k: v.double().requires_grad_(True) for k, v in P.items()}
+    lens = torch.tensor([Ti, Ti - 7, max(Ti - 20, 3)][:B])
+    memory = g(B, Ti, E, seed=4).double().requires_grad_(True)
+    pm = g(B, Ti, A, seed=5, scale=0.5).double().requires_grad_(True)
+    query = g(B, 16, seed=6).double().requires_grad_(True)
+    w_prev = torch.softmax(g(B, Ti, seed=7), 1).double().requires_grad_(True)
+    w_cum = (torch.softmax(g(B, Ti, seed=8), 1) * 3).double().requires_grad_(True)
+    pad = ~R.length_mask(lens, Ti)
+    ctx, w = R.attention_step(P, query, memory, pm, w_prev, w_cum, pad)
+    q_ref = query @ P[pre + 'query_layer.linear_layer.weight'].t()
+
+    d = ops.attn_dims(B, Ti, E, A, Fn, Kc)
+    f32 = lambda t: t.detach().float().contiguous().to(dev)
+    qd = f32(q_ref)
+    Wc, Wd, v = (f32(P[pre + 'location_layer.location_conv.conv.weight']),
+                 f32(P[pre + 'location_layer.location_dense.linear_layer.weight']), f32(P[pre + 'v.linear_layer.weight']))
+    q_out = torch.empty(B, A, device=dev); en = torch.empty(B, Ti, device=dev)
+    lens32 = lens.to(torch.int32).to(dev)
+    ops.call('gt_attn_energies_fwd', d, ops.slabs(qd, 1, B * A, A), f32(w_prev), f32(w_cum), f32(pm), Wc, Wd, v, lens32, q_out, en)
+    w_out = torch.empty(B, Ti, device=dev); cum_out = torch.empty(B, Ti, device=dev)
+    c0 = torch.empty(B, E, device=dev); c1 = torch.zeros(B, E + 5, device=dev)
+    ops.call('gt_attn_context_fwd', d, en, f32(memory), E, w_out, f32(w_cum), cum_out, c0, E, ops.ptr(c1, 5), E + 5, None, 0)
+    close(w_out, w, rtol=1e-4, atol=1e-6, what='attention weights')
+    close(c0, ctx, rtol=1e-4, atol=1e-5, what='context')
+    close(c1[:, 5:], ctx, rtol=1e-4, atol=1e-5, what='context strided')
+    close(cum_out, w_cum + w, rtol=1e-4, atol=1e-6, what='cumulative')
+
+    # backward: upstream grads on ctx and (externally) on w; carried alignment grads from "step t+1"
+    dctx, dw_ext = g(B, E, seed=9).double(), g(B, Ti, seed=10, scale=0.3).double()
+    carry_prev, carry_cum, cum_acc0 = g(B, Ti, seed=11, scale=0.2), g(B, Ti, seed=12, scale=0.2), g(B, Ti, seed=13, scale=0.2)
+    loss = (ctx * dctx).sum() + (w * (dw_ext + carry_prev.double() + carry_cum.double() + cum_acc0.double())).sum()
+    names = list(P)
+    grads = torch.autograd.grad(loss, [query, memory, pm, w_prev, w_cum] + [P[k] for k in names])
+    gq_in, gmem, gpm, gwp, gwc = grads[:5]
+    gP = dict(zip(names, grads[5:]))
+
+    dwcat_in = torch.stack((carry_prev, carry_cum)).contiguous().to(dev)
+    dcum_acc = cum_acc0.clone().to(dev)
+    dctx_out = torch.empty(B, E, device=dev); dq = torch.full((B, A), 7.0, device=dev); dw = torch.empty(B, Ti, device=dev)
+    half = (0.5 * dctx).float().contiguous().to(dev)
+    ops.call('gt_attn_context_bwd', d, ops.slabs(half, 1, B * E, E), ops.NO_SLABS, half, E, f32(memory), E, dwcat_in, dcum_acc,
+             f32(dw_ext), dctx_out, E, dq, A, dw)
+    close(dctx_out, dctx, what='dctx total')
+    assert float(dwcat_in.abs().max()) == 0.0 and float(dq.abs().max()) == 0.0
+    close(dcum_acc, cum_acc0 + carry_cum, what='dcum_acc')
+    dpm = torch.zeros(B, Ti, A, device=dev); dwcat_out = torch.zeros(2, B, Ti, device=dev)
+    acc = torch.zeros(int(lib().gt_attn_acc_elems(d)), device=dev)
+    ops.call('gt_attn_energies_bwd', d, dw, w_out, q_out, f32(w_prev), f32(w_cum), f32(pm), Wc, Wd, v, dq, A, dpm, dwcat_out, acc)
+    close(dpm, gpm, rtol=2e-3, atol=1e-6, what='dpm')
+    close(dwcat_out[0], gwp, rtol=2e-3, atol=1e-6, what='d w_prev')
+    dv = torch.zeros(1, A, device=dev); dWd = torch.zeros(A, Fn, device=dev); dWc = torch.zeros(Fn, 2, Kc, device=dev)
+    ops.call('gt_attn_acc_reduce', d, acc, dv, dWd, dWc)
+    close(dv, gP[pre + 'v.linear_layer.weight'], rtol=2e-3, atol=1e-6, what='dv')
+    close(dWd, gP[pre + 'location_layer.location_dense.linear_layer.weight'], rtol=2e-3, atol=1e-6, what='dWd')
+    close(dWc, gP[pre + 'location_layer.location_conv.conv.weight'], rtol=2e-3, atol=1e-6, what='dWc')
+    # d memory from the context product: dmem[b,t,:] = w[b,t] * dctx[b,:]
+    close(w_out[:, :, None].cpu().double() * dctx[:, None, :], gmem, rtol=2e-3, atol=1e-6, what='dmemory identity')
+    # d w_cum as seen by the kernel = conv-transpose part only (the loss' direct w_cum terms are zero here)
+    close(dwcat_out[1], gwc, rtol=2e-3, atol=1e-6, what='d w_cum')
+    # dq: gradient w.r.t. the processed query = (d query) projected back is ill-posed; check via q grad directly
+    q2 = q_ref.detach().clone().requires_grad_(True)
+    # recompute energies with q as a leaf
+    cat = torch.stack((w_prev.detach(), w_cum.detach()), dim=1)
+    wconv = P[pre + 'location_layer.location_conv.conv.weight'].detach()
+    loc = F.conv1d(cat, wconv, None, padding=(Kc - 1) // 2).transpose(1, 2) @ \
+        P[pre + 'location_layer.location_dense.linear_layer.weight'].detach().t()
+    e = (torch.tanh(q2[:, None, :] + loc + pm.detach()) @ P[pre + 'v.linear_layer.weight'].detach().t()).squeeze(-1)
+    e = e.masked_fill(pad, -float('inf'))
+    w2 = torch.softmax(e, 1)
+    ctx2 = torch.bmm(w2.unsqueeze(1), memory.detach()).squeeze(1)
+    l2 = (ctx2 * dctx).sum() + (w2 * (dw_ext + carry_prev.double() + carry_cum.double() + cum_acc0.double())).sum()
+    close(dq, torch.autograd.grad(l2, q2)[0], rtol=2e-3, atol=1e-6, what='dq')
+
+
+# ------------------------------------------------------------------------- BN / elementwise
+@pytest.mark.parametrize('rows,C,act', [(300, 24, 1), (1000, 80, 2), (77, 8, 0)])
+def test_bn_act_drop(dev, rows, C, act):
+    from gantron_amd import ops
+    x = (g(rows, C) * 2 + 5).requires_grad_(True)
+    gamma, beta = (1 + 0.1 * g(C, seed=1)).requires_grad_(True), (0.1 * g(C, seed=2)).requires_grad_(True)
+    keep = torch.rand(rows, C, generator=torch.Generator().manual_seed(3)) >= 0.5
+    rm, rv = g(C, seed=4) * 0.1, torch.ones(C) * 0.9
+    xd = x.double()
+    mean, var = xd.mean(0), xd.var(0, unbiased=False)
+    z = (xd - mean) / torch.sqrt(var + 1e-5) * gamma.double() + beta.double()
+    a = torch.relu(z) if act == 1 else (torch.tanh(z) if act == 2 else z)
+    y = a * keep.double() * 2
+    dy = g(rows, C, seed=5)
+    gx, gg, gb = torch.autograd.grad(y, (x, gamma, beta), dy.double())
+    xg = x.detach().to(dev); stats = torch.empty(2 * C, device=dev)
+    ops.call('gt_col_stats', xg, xg, rows, C, stats)
+    yo = torch.empty(rows, C, device=dev); mi = torch.empty(2 * C, device=dev)
+    rmd, rvd = rm.clone().to(dev), rv.clone().to(dev)
+    k8 = keep.to(torch.uint8).to(dev)
+    ops.call('gt_bn_act_drop_fwd', xg, stats, rows, C, gamma.detach().to(dev), beta.detach().to(dev), rmd, rvd, 0.1, 1e-5, act,
+             k8, 0.5, yo, mi, 1)
+    close(yo, y, rtol=1e-4, atol=1e-5, what='bn fwd')
+    close(rmd, 0.9 * rm + 0.1 * mean, rtol=1e-4, atol=1e-6, what='running mean')
+    close(rvd, 0.9 * rv + 0.1 * xd.var(0, unbiased=True), rtol=1e-4, atol=1e-6, what='running var')
+    dz = torch.empty(rows, C, device=dev); sums = torch.empty(2 * C, device=dev)
+    ops.call('gt_bn_act_drop_bwd1', dy.to(dev), xg, mi, gamma.detach().to(dev), beta.detach().to(dev), rows, C, act, k8, 0.5, dz, sums)
+    dx = torch.empty(rows, C, device=dev); dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
+    ops.call('gt_bn_act_drop_bwd2', dz, xg, mi, gamma.detach().to(dev), sums, rows, C, dx, dg, db)
+    close(dx, gx, rtol=1e-3, atol=1e-5, what='bn dx')
+    close(dg, gg, rtol=1e-3, atol=1e-4, what='bn dgamma')
+    close(db, gb, rtol=1e-3, atol=1e-4, what='bn dbeta')
+
+
+def test_elementwise_misc(dev):
+    from gantron_amd import ops
+    # bias + dropout + tanh (DiscConv1d order) and relu + dropout (prenet order), fwd/bwd
+    rows, C = 50, 12
+    x, bias = g(rows, C).requires_grad_(True), g(C, seed=1)
+    keep = torch.rand(rows, C, generator=torch.Generator().manual_seed(2)) >= 0.5
+    dy = g(rows, C, seed=3)
+    y1 = torch.tanh((x.double() + bias.double()) * keep.double() * 2)
+    y0 = torch.relu(x.double()) * keep.double() * 2
+    g1, = torch.autograd.grad(y1, x, dy.double(), retain_graph=True)
+    g0, = torch.autograd.grad(y0, x, dy.double())
+    k8 = keep.to(torch.uint8).to(dev)
+    for order, act, b, yref, gref in ((1, 2, bias.to(dev), y1, g1), (0, 1, None, y0, g0)):
+        yo = torch.empty(rows, C, device=dev)
+        ops.call('gt_bias_act_drop_fwd', x.detach().to(dev), b, rows, C, act, order, k8, 0.5, yo)
+        close(yo, yref, rtol=1e-5, atol=1e-6, what=f'bias_act_drop fwd {order}')
+        dx = torch.empty(rows, C, device=dev)
+        ops.call('gt_bias_act_drop_bwd', dy.to(dev), yo, rows, C, act, order, k8, 0.5, dx)
+        close(dx, gref, rtol=1e-4, atol=1e-6, what=f'bias_act_drop bwd {order}')
+    # embedding gather / scatter-add
+    ids = torch.tensor([[3, 1, 3], [0, 2, 1]])
+    table = g(5, 8)
+    out = torch.empty(6, 8, device=dev)
+    ops.call('gt_embedding_fwd', ids.to(dev), table.to(dev), 6, 8, out, 8)
+    close(out, table[ids.view(-1)], rtol=0, atol=0, what='embedding')
+    dt = torch.zeros(5, 8, device=dev)
+    do = g(6, 8, seed=4)
+    ops.call('gt_embedding_bwd', ids.to(dev), do.to(dev), 8, 6, 8, dt)
+    want = torch.zeros(5, 8).index_add_(0, ids.view(-1), do)
+    close(dt, want, rtol=1e-6, atol=1e-6, what='embedding bwd')
+    # gather rows with -1 and accumulate
+    src = g(7, 6)
+    idx = torch.tensor([2, -1, 6, 0], dtype=torch.int32)
+    o = torch.ones(4, 9, device=dev)
+    ops.call('gt_gather_rows', src.to(dev), 6, idx.to(dev), 4, 6, o, 9, 1)
+    want = torch.ones(4, 9)
+    want[:, :6] += torch.stack([src[2], torch.zeros(6), src[6], src[0]])
+    close(o, want, rtol=0, atol=1e-7, what='gather rows')
+    # mask outputs
+    mel, post, gate = g(2, 4, 6).to(dev), g(2, 4, 6, seed=1).to(dev), g(2, 6, seed=2).to(dev)
+    m0 = mel.clone().cpu()
+    ops.call('gt_mask_outputs', mel, post, gate, torch.tensor([6, 4]).to(dev), 2, 4, 6)
+    m0[1, :, 4:] = 0
+    close(mel, m0, rtol=0, atol=0, what='mask mel')
+    assert float(post[1, :, 4:].abs().max()) == 0 and torch.all(gate[1, 4:] == 1e3) and torch.all(gate[0].cpu() != 1e3)
+
+
+def test_rng_matches_numpy(dev):
+    from gantron_amd import ops
+    n, seed, off = 10000, 1234, 77
+    u = torch.empty(n, device=dev)
+    ops.call('gt_uniform', seed, off, n, u)
+    ref = u01(seed, off, n)
+    assert np.array_equal(u.cpu().numpy(), ref)
+    k = torch.empty(n, dtype=torch.uint8, device=dev)
+    ops.call('gt_keep_mask', seed, off, 0.1, n, k)
+    assert np.array_equal(k.cpu().numpy(), (ref >= np.float32(0.1)).astype(np.uint8))
+    assert 0.88 < k.float().mean().item() < 0.92
+
+
+# --------------------------------------------------------------------- discriminator pieces, losses
+def test_disc_gather_and_adv_mean(dev, golden_dir):
+    import os
+    from gantron_amd import ops
+    from oracle import gantron_ref as R
+    z = np.load(os.path.join(golden_dir, 'ops.npz'))
+    x = torch.from_numpy(z['disc_reshape_in'])                 # (2, 47, 80) frames x mel
+    mel = x.permute(0, 2, 1).contiguous()                       # (B, n_mel, T)
+    r = torch.empty(2 * 3, 1600, device=dev)
+    ops.call('gt_disc_gather_fwd', mel.to(dev), 2, 80, 47, 20, r)
+    want = torch.from_numpy(z['disc_reshape_out'])              # (2, 1600, 3)
+    close(r.view(2, 3, 1600).permute(0, 2, 1), want, rtol=0, atol=0, what='disc gather vs reference fixture')
+    # backward = transpose of the gather
+    for T in (47, 60, 20, 41):
+        B, W = 2, T // 20 + (1 if T % 20 else 0)
+        m = g(B, 80, T).double().requires_grad_(True)
+        rr = R.disc_window_input(m.transpose(1, 2), 20)         # (B, 1600, W)
+        dr = g(B, 1600, W, seed=1).double()
+        gm, = torch.autograd.grad(rr, m, dr)
+        dm = torch.empty(B, 80, T, device=dev)
+        ops.call('gt_disc_gather_bwd', dr.permute(0, 2, 1).float().contiguous().to(dev), B, 80, T, 20, dm, 0)
+        close(dm, gm, rtol=1e-6, atol=1e-6, what=f'disc gather bwd T={T}')
+    outs, lens = torch.from_numpy(z['adv_outs']), torch.from_numpy(z['adv_lens'])
+    loss = torch.empty(1, device=dev)
+    ops.call('gt_adv_mean_fwd', outs.to(dev), lens.to(dev), 7, 3, 20, loss)
+    close(loss, torch.tensor([float(z['adv_batch_loss'])]), rtol=1e-5, atol=1e-6, what='adv mean vs reference fixture')
+    dout = torch.empty(7, 3, device=dev)
+    ops.call('gt_adv_mean_bwd', torch.tensor([2.0]).to(dev), lens.to(dev), 7, 3, 20, 0.5, dout)
+    nb = torch.ceil(lens.double() / 20)
+    want = torch.zeros(7, 3, dtype=torch.double)
+    for b in range(7):
+        want[b, :int(nb[b])] = 1.0 / (7 * nb[b])
+    close(dout, want, rtol=1e-5, atol=1e-7, what='adv mean bwd')
+
+
+def test_losses(dev):
+    from gantron_amd.loss_function import Tacotron2Loss
+    from oracle import gantron_ref as R
+    B, n_mel, To, Ti = 3, 8, 21, 9
+    in_len, out_len = torch.tensor([9, 7, 4]), torch.tensor([21, 15, 11])
+    mel, post = g(B, n_mel, To), g(B, n_mel, To, seed=1)
+    gate = g(B, To, seed=2) * 3
+    align = torch.softmax(g(B, To, Ti, seed=3), dim=2)
+    mel_t, gate_t = g(B, n_mel, To, seed=4), (torch.rand(B, To, generator=torch.Generator().manual_seed(5)) > 0.7).float()
+    leaves = [t.clone().double().requires_grad_(True) for t in (mel, post, gate, align)]
+    ml, gl, al = R.tacotron_loss(leaves, mel_t.double(), gate_t.double(), in_len, out_len)
+    ref_g = torch.autograd.grad(ml + 2 * gl + 10 * al, leaves)
+    dl = [t.to(dev).requires_grad_(True) for t in (mel, post, gate, align)]
+    m2, g2, a2 = Tacotron2Loss()(dl, (mel_t.to(dev), gate_t.to(dev)), in_len.to(dev), out_len.to(dev))
+    close(m2, ml, rtol=1e-5, atol=1e-6, what='mel loss')
+    close(g2, gl, rtol=1e-5, atol=1e-6, what='gate loss')
+    close(a2, al, rtol=1e-4, atol=1e-6, what='attention loss')
+    (m2 + 2 * g2 + 10 * a2).backward()
+    for t, r, name in zip(dl, ref_g, ('dmel', 'dpost', 'dgate', 'dalign')):
+        close(t.grad, r, rtol=1e-4, atol=1e-7, what=name)
+
+
+def test_adam_and_clip(dev):
+    from gantron_amd import ops
+    from oracle import gantron_ref as R
+    n = 5000
+    p0, gr = g(n), g(n, seed=1) * 3
+    P, st = {'w': p0.clone()}, {}
+    grads = {'w': gr.clone()}
+    R.clip_grad_norm(grads, 1.0)
+    R.adam_step(P, grads, st, 1e-3, 1)
+    grads2 = {'w': gr.clone() * 0.5}
+    R.clip_grad_norm(grads2, 1.0)
+    R.adam_step(P, grads2, st, 1e-3, 2)
+    pd, m, v = p0.clone().to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    for step, gsrc in ((1, gr), (2, gr * 0.5)):
+        ss = torch.zeros(1, device=dev)
+        gd = gsrc.to(dev)
+        ops.call('gt_sumsq', gd, n, ss)
+        ops.call('gt_adam_step', pd, gd, m, v, n, 1e-3, 0.9, 0.999, 1e-8, 1e-6, step, ss, 1.0)
+    close(pd, P['w'], rtol=1e-5, atol=1e-6, what='adam')
+
+
+def test_stft_mel(dev, golden_dir):
+    import os
+    from gantron_amd.stft import TacotronSTFT
+    from oracle import gantron_ref as R
+    z = np.load(os.path.join(golden_dir, 'ops.npz'))
+    audio = torch.from_numpy(z['stft_audio'])
+    stft = TacotronSTFT().to(dev)
+    mag = stft.magnitudes(audio.to(dev))
+    close(mag, z['stft_mag'], rtol=1e-4, atol=1e-4, what='stft magnitude vs reference fixture')
+    mel = stft.mel_spectrogram(audio.to(dev))
+    close(mel, R.mel_spectrogram(audio), rtol=1e-4, atol=1e-3, what='mel vs oracle')

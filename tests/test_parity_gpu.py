@@ -1,0 +1,180 @@
+"""Parity of the HIP path with the reference (golden vectors produced by the reference's own
+classes, tests/golden/make_golden.py) and with the CPU oracle on seeded inputs.  The generator step
+and the discriminator step are driven through the reference's Python surface (model.Tacotron2,
+model.Discriminator, loss_function.Tacotron2Loss) exactly as train.py:302-397 does.
+
+Tolerance: the north star asks for mel outputs within 1e-3 relative (fp32); outputs and losses are
+checked at 1e-3, gradients at 2e-3 of each tensor's max-abs plus a 2e-6 floor (conv biases that
+feed a BatchNorm have mathematically zero gradient: both sides hold ~1e-7 rounding noise there)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import common
+from harness import close, kernel_disc_keep, kernel_rng
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    return torch.device('cuda:0')
+
+
+def run_pair_hip(hp, g_state, d_state, batch, mask_seed, dev, vesus=False):
+    """One G step + one D step through the module API; returns outputs, losses, grads, buffers."""
+    from gantron_amd.loss_function import Tacotron2Loss
+    from gantron_amd.model import Discriminator, Tacotron2
+    G, D = Tacotron2(hp).to(dev).train(), Discriminator(hp).to(dev).train()
+    G.load_state_dict(g_state)
+    D.load_state_dict(d_state)
+    text, il, mel, gate, spk, emo, ol = batch
+    B, Ti, To = text.shape[0], text.shape[1], mel.shape[2]
+    stream = common.MaskStream(mask_seed)
+    rng = common.draw_generator_rng(stream, hp, B, Ti, To)
+    G.rng_override = kernel_rng(rng, B, dev)
+    D.rng_override = kernel_disc_keep(common.draw_disc_keep(stream, hp, B, To), dev)
+    crit = Tacotron2Loss()
+    for p in D.parameters():
+        p.requires_grad = False
+    G.zero_grad()
+    x, y = G.parse_batch(batch)
+    y_pred = G(x)
+    mel_loss, gate_loss, attn_loss = crit(y_pred, y, x[1], x[-1])
+    adv = D.adversarial_loss(y_pred[1], x[-1])
+    total = mel_loss + gate_loss + adv + 10 * attn_loss
+    total.backward()
+    res = dict(out=dict(zip(('mel', 'mel_post', 'gate', 'align'), [t.detach().cpu() for t in y_pred])),
+               g_loss=dict(mel=mel_loss, gate=gate_loss, attn=attn_loss, adv=adv, total=total),
+               g_grad={k: p.grad.detach().cpu() for k, p in G.named_parameters()},
+               buffers={k: v.detach().cpu() for k, v in G.state_dict().items()
+                        if k.endswith(('running_mean', 'running_var'))})
+    res['g_loss'] = {k: v.detach().cpu() for k, v in res['g_loss'].items()}
+    fake = y_pred[1].detach()
+    for p in D.parameters():
+        p.requires_grad = True
+    D.zero_grad()
+    D.rng_override = kernel_disc_keep(common.draw_disc_keep(stream, hp, B, To), dev)
+    real_loss = 1 * D.adversarial_loss(x[2], x[-1])
+    D.rng_override = kernel_disc_keep(common.draw_disc_keep(stream, hp, B, To), dev)
+    fake_loss = -1 * D.adversarial_loss(fake, x[-1])
+    d_loss = (real_loss + fake_loss) / 2
+    d_loss.backward()
+    res['d_loss'] = dict(real=real_loss.detach().cpu(), fake=fake_loss.detach().cpu(), total=d_loss.detach().cpu())
+    res['d_grad'] = {k: p.grad.detach().cpu() for k, p in D.named_parameters()}
+    return res
+
+
+def test_tiny_pair_matches_reference_golden(dev, golden_dir):
+    from gantron_amd.hparams import HParams
+    z = np.load(os.path.join(golden_dir, 'tiny_pair.npz'))
+    hp = HParams(str(z['hparams']))
+    batch = common.synthetic_batch(hp, z['in_lens'].tolist(), z['out_lens'].tolist(), seed=int(z['batch_seed']))
+    res = run_pair_hip(hp, common.unpack_dict(z, 'g_state_before'), common.unpack_dict(z, 'd_state'), batch,
+                       int(z['mask_seed']), dev)
+    for k, v in common.unpack_dict(z, 'out').items():
+        close(res['out'][k], v, rtol=1e-3, atol=1e-5, what=f'out.{k}')
+    for k, v in common.unpack_dict(z, 'g_loss').items():
+        close(res['g_loss'][k], v, rtol=1e-3, atol=1e-6, what=f'g_loss.{k}')
+    for k, v in common.unpack_dict(z, 'g_buffers_after').items():
+        close(res['buffers'][k], v, rtol=1e-3, atol=1e-6, what=f'buffer.{k}')
+    bad = []
+    for k, v in common.unpack_dict(z, 'g_grad').items():
+        try:
+            close(res['g_grad'][k], v, rtol=2e-3, atol=2e-6, what=f'g_grad.{k}')
+        except AssertionError as e:
+            bad.append(str(e))
+    for k, v in common.unpack_dict(z, 'd_loss').items():
+        close(res['d_loss'][k], v, rtol=1e-3, atol=1e-6, what=f'd_loss.{k}')
+    for k, v in common.unpack_dict(z, 'd_grad').items():
+        try:
+            close(res['d_grad'][k], v, rtol=2e-3, atol=2e-6, what=f'd_grad.{k}')
+        except AssertionError as e:
+            bad.append(str(e))
+    assert not bad, '\n'.join(bad)
+
+
+@pytest.mark.parametrize('name', ['full_pair_summary.npz', 'vesus_pair_summary.npz'])
+def test_full_size_matches_reference_summaries(dev, golden_dir, name):
+    """Full hparams (E=1024 vanilla / E=1093 VESUS labels+noise), B=2: closed-form weights; the
+    reference's outputs and gradients are pinned by L2 norms and sparse probes."""
+    from gantron_amd.hparams import HParams
+    z = np.load(os.path.join(golden_dir, name))
+    hp = HParams(str(z['hparams']))
+    vesus = bool(z['vesus'])
+    shapes_g = {k[len('shape_g/'):]: tuple(z[k]) for k in z.files if k.startswith('shape_g/')}
+    shapes_d = {k[len('shape_d/'):]: tuple(z[k]) for k in z.files if k.startswith('shape_d/')}
+    gs = common.closed_form_weights(shapes_g, int(z['weight_seed']))
+    ds = common.closed_form_weights(shapes_d, int(z['weight_seed']) + 1)
+    batch = common.synthetic_batch(hp, z['in_lens'].tolist(), z['out_lens'].tolist(), seed=int(z['batch_seed']),
+                                   vesus=vesus)
+    res = run_pair_hip(hp, gs, ds, batch, int(z['mask_seed']), dev, vesus=vesus)
+    got = dict(out=res['out'], g_grad=res['g_grad'], d_grad=res['d_grad'], g_buffers_after=res['buffers'])
+    bad = []
+    for key, tensors in got.items():
+        for tname, t in tensors.items():
+            pre = f'{key}/{tname}/'
+            if pre + 'l2' not in z.files:
+                continue
+            s = common.summarize(t)
+            scale = float(z[pre + 'absmax']) + 1e-12
+            if abs(s['l2'] - float(z[pre + 'l2'])) > 2e-3 * float(z[pre + 'l2']) + 1e-5:
+                bad.append(f'{pre} l2 {s["l2"]:.6e} vs {float(z[pre + "l2"]):.6e}')
+            perr = np.abs(s['probe_val'] - z[pre + 'probe_val']).max()
+            if perr > 2e-3 * scale + 2e-6:
+                bad.append(f'{pre} probe err {perr:.3e} vs scale {scale:.3e}')
+    for k in ('mel', 'gate', 'attn', 'adv', 'total'):
+        close(res['g_loss'][k], z[f'g_loss/{k}'], rtol=1e-3, atol=1e-6, what=f'g_loss.{k}')
+    for k in ('real', 'fake', 'total'):
+        close(res['d_loss'][k], z[f'd_loss/{k}'], rtol=1e-3, atol=1e-6, what=f'd_loss.{k}')
+    assert not bad, '\n'.join(bad)
+
+
+def test_midsize_against_oracle(dev):
+    """B=5 (padded to 16 rows), ragged lengths, To not a multiple of the discriminator window:
+    HIP path vs the CPU oracle on identical seeded inputs and masks."""
+    from gantron_amd.hparams import HParams
+    from oracle import gantron_ref as R
+    hp = HParams('use_labels=False,use_noise=True,n_mel_channels=16,encoder_embedding_dim=32,symbols_embedding_dim=32,'
+                 'attention_rnn_dim=64,decoder_rnn_dim=64,prenet_dim=16,attention_dim=32,attention_location_n_filters=8,'
+                 'attention_location_kernel_size=9,postnet_embedding_dim=32,noise_size=32,discriminator_dim=32,'
+                 'discriminator_window=6')
+    in_lens, out_lens = [40, 33, 33, 20, 9], [57, 70, 41, 25, 13]
+    batch = common.synthetic_batch(hp, in_lens, out_lens, seed=5)
+    Gp, Dp = R.init_params(hp, seed=3)
+    for k in list(Gp):
+        if k.endswith('running_var'):
+            Gp[k.replace('running_var', 'num_batches_tracked')] = torch.zeros((), dtype=torch.long)
+    res = run_pair_hip(hp, Gp, Dp, batch, 77, dev)
+    text, il, mel, gate, spk, emo, ol = batch
+    stream = common.MaskStream(77)
+    B, Ti, To = len(in_lens), max(in_lens), max(out_lens)
+    rng = common.draw_generator_rng(stream, hp, B, Ti, To)
+    rng['disc_keep'] = common.draw_disc_keep(stream, hp, B, To)
+    Gp = {k: v for k, v in Gp.items() if not k.endswith('num_batches_tracked')}
+    out, losses, grads, new_stats = R.generator_step_grads(Gp, Dp, (text, il, mel, gate, ol), rng, hp)
+    for name, t in zip(('mel', 'mel_post', 'gate', 'align'), out):
+        close(res['out'][name], t, rtol=1e-3, atol=1e-5, what=f'out.{name}')
+    for k, v in losses.items():
+        close(res['g_loss'][k], v, rtol=1e-3, atol=1e-6, what=f'g_loss.{k}')
+    bad = []
+    for k, v in grads.items():
+        try:
+            close(res['g_grad'][k], v, rtol=2e-3, atol=2e-6, what=f'g_grad.{k}')
+        except AssertionError as e:
+            bad.append(str(e))
+    keep_real = common.draw_disc_keep(stream, hp, B, To)
+    keep_fake = common.draw_disc_keep(stream, hp, B, To)
+    dl, dg = R.discriminator_step_grads(Dp, mel, ol, out[1], ol, keep_real, keep_fake, hp)
+    for k, v in dl.items():
+        close(res['d_loss'][k], v, rtol=1e-3, atol=1e-6, what=f'd_loss.{k}')
+    for k, v in dg.items():
+        try:
+            close(res['d_grad'][k], v, rtol=2e-3, atol=2e-6, what=f'd_grad.{k}')
+        except AssertionError as e:
+            bad.append(str(e))
+    assert not bad, '\n'.join(bad)
