@@ -130,7 +130,8 @@ def test_lstm_cell_fwd_bwd(dev):
     h = torch.sigmoid(o) * torch.tanh(c) * keep.double() / (1 - p)
     gates = torch.empty(B, 4 * H, device=dev); c_out = torch.empty(B, H, device=dev)
     h_raw = torch.empty(B, H, device=dev); h0 = torch.zeros(B, H + 7, device=dev)
-    ops.call('gt_lstm_cell_fwd', ops.slabs(part.to(dev), S, B * 4 * H, 4 * H), pre.to(dev), 4 * H, c_prev.to(dev), None, 0,
+    part_d = part.to(dev)     # slabs()/ptr() keep raw addresses only: the tensor must outlive the call
+    ops.call('gt_lstm_cell_fwd', ops.slabs(part_d, S, B * 4 * H, 4 * H), pre.to(dev), 4 * H, c_prev.to(dev), None, 0,
              keep.to(torch.uint8).to(dev), p, None, gates, c_out, h_raw, ops.ptr(h0, 3), H + 7, None, 0, None, 0, B, H)
     close(c_out, c, what='cell c')
     close(h_raw, h, what='cell h')
@@ -368,8 +369,8 @@ def test_losses(dev):
     gate = g(B, To, seed=2) * 3
     align = torch.softmax(g(B, To, Ti, seed=3), dim=2)
     mel_t, gate_t = g(B, n_mel, To, seed=4), (torch.rand(B, To, generator=torch.Generator().manual_seed(5)) > 0.7).float()
-    leaves = [t.clone().double().requires_grad_(True) for t in (mel, post, gate, align)]
-    ml, gl, al = R.tacotron_loss(leaves, mel_t.double(), gate_t.double(), in_len, out_len)
+    leaves = [t.clone().requires_grad_(True) for t in (mel, post, gate, align)]
+    ml, gl, al = R.tacotron_loss(leaves, mel_t, gate_t, in_len, out_len)
     ref_g = torch.autograd.grad(ml + 2 * gl + 10 * al, leaves)
     dl = [t.to(dev).requires_grad_(True) for t in (mel, post, gate, align)]
     m2, g2, a2 = Tacotron2Loss()(dl, (mel_t.to(dev), gate_t.to(dev)), in_len.to(dev), out_len.to(dev))
