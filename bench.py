@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""Headline benchmark: mel-frames/sec over a (generator step + discriminator step) pair, vanilla
+GANtron (use_labels=False, use_noise=True), LJSpeech-shaped synthetic batch, fp32.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pair: the body of the reference's generator step (train.py:361-423: parse_batch,
+G forward, Tacotron2Loss incl. guided attention, adversarial loss through the frozen D, backward,
+clip, Adam) followed by the body of its discriminator step (train.py:302-360) on the same batch
+with the cached generator output.  Inputs are resident on the device before the timed region.
+Multi-GPU: one process per GPU, each with its own batch (weak scaling), flat-buffer gradient
+all-reduce over RCCL after every backward.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HPARAMS = 'use_labels=False,use_noise=True'
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32
+HBM_PEAK_GBS = 8000.0
+FAMILIES = ['rec_gemm', 'sgemm', 'attn_energies_fwd', 'attn_context_fwd', 'attn_context_bwd', 'attn_energies_bwd',
+            'lstm_cell_fwd', 'lstm_cell_bwd']
+KERNEL_OF = {'rec_gemm': 'rec_gemm_kernel', 'sgemm': 'sgemm_kernel', 'attn_energies_fwd': 'attn_energies_fwd_kernel',
+             'attn_context_fwd': 'attn_context_fwd_kernel', 'attn_context_bwd': 'attn_context_bwd_kernel',
+             'attn_energies_bwd': 'attn_energies_bwd_kernel', 'lstm_cell_fwd': 'lstm_cell_fwd_kernel',
+             'lstm_cell_bwd': 'lstm_cell_bwd_kernel'}
+MFMA_BOUND = {'rec_gemm', 'sgemm'}
+
+
+def ljspeech_shaped_batch(hp, B, seed, fixed=False):
+    """Ti ~ round(clip(N(100,33),12,187)), To = clip(round(5.66 Ti + N(0,25)),96,870),
+    sorted by Ti descending; ids uniform [1,147]; mel ~ N(-5.5,2.2) clipped to [-11.52, 2]."""
+    rs = np.random.default_rng(seed)
+    if fixed:
+        ti = np.full(B, 150)
+        to = np.full(B, 800)
+    else:
+        ti = np.rint(np.clip(rs.normal(100, 33, B), 12, 187)).astype(int)
+        to = np.clip(np.rint(5.66 * ti + rs.normal(0, 25, B)), 96, 870).astype(int)
+    order = np.argsort(-ti, kind='stable')
+    ti, to = ti[order], to[order]
+    Ti, To = int(ti.max()), int(to.max())
+    text = torch.zeros(B, Ti, dtype=torch.long)
+    mel = torch.zeros(B, hp.n_mel_channels, To)
+    gate = torch.zeros(B, To)
+    for b in range(B):
+        text[b, :ti[b]] = torch.from_numpy(rs.integers(1, hp.n_symbols, ti[b]))
+        m = np.clip(rs.normal(-5.5, 2.2, (hp.n_mel_channels, to[b])), -11.52, 2.0)
+        mel[b, :, :to[b]] = torch.from_numpy(m).float()
+        gate[b, to[b] - 1:] = 1
+    return (text, torch.from_numpy(ti).long(), mel, gate, torch.zeros(B), torch.zeros(B, 5),
+            torch.from_numpy(to).long())
+
+
+def pair_flops(hp, in_lens, out_lens):
+    """Algorithmic FLOPs of one G+D pair on the padded shapes."""
+    B, Ti, To = len(in_lens), max(in_lens), max(out_lens)
+    E = hp.encoder_embedding_dim + (hp.noise_size if hp.use_noise else 0)
+    enc = 3932160 * B * Ti + 1572864 * sum(in_lens)
+    dec = B * To * (22317056 + 7232 * Ti) + 128 * E * B * Ti + 86016 * B * (To + 1)
+    post = 4341760 * B * To
+    W = To // 20 + (1 if To % 20 else 0)
+    disc = 12329040 * B * W
+    g = 2 * (3 * (enc + dec + post) + 2 * disc)
+    d = 2 * (3 * 2 * disc)
+    return g + d
+
+
+def host_threads():
+    """CPU threads this process may really use: the affinity mask, capped at the 16-core share a
+    one-GPU box grants (os.cpu_count() reports the whole host and would oversubscribe)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+def log(msg):
+    print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The CPU oracle (oracle/gantron_ref.py, a restatement of the reference pinned by its golden
+    vectors) timed on the host cores for one G+D pair of a bounded LJSpeech-shaped sample."""
+    from gantron_amd.hparams import HParams
+    from oracle import gantron_ref as R
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    import common
+    hp = HParams(HPARAMS)
+    B = 8
+    batch = ljspeech_shaped_batch(hp, B, seed=99)
+    text, il, mel, gate, _, _, ol = batch
+    # bound the sample: clip to at most 200 frames / 50 characters per item
+    ol = torch.clamp(ol, max=200)
+    il = torch.clamp(il, max=50)
+    text, mel, gate = text[:, :int(il.max())], mel[:, :, :int(ol.max())].contiguous(), gate[:, :int(ol.max())].contiguous()
+    for b in range(B):
+        gate[b, int(ol[b]) - 1:] = 1
+        mel[b, :, int(ol[b]):] = 0
+        text[b, int(il[b]):] = 0
+    Ti, To = text.shape[1], mel.shape[2]
+    torch.set_num_threads(host_threads())
+    Gp, Dp = R.init_params(hp, seed=1)
+    stream = common.MaskStream(5)
+    rng = common.draw_generator_rng(stream, hp, B, Ti, To)
+    rng['disc_keep'] = common.draw_disc_keep(stream, hp, B, To)
+    kr, kf = common.draw_disc_keep(stream, hp, B, To), common.draw_disc_keep(stream, hp, B, To)
+
+    def pair():
+        out, _, grads, _ = R.generator_step_grads(Gp, Dp, (text, il, mel, gate, ol), rng, hp)
+        R.clip_grad_norm(grads, 1.0)
+        R.discriminator_step_grads(Dp, mel, ol, out[1], ol, kr, kf, hp)
+    t0 = time.perf_counter()
+    pair()
+    first = time.perf_counter() - t0
+    log(f'cpu baseline: first pair {first:.2f} s on {torch.get_num_threads()} threads')
+    reps = max(1, min(3, int(seconds_budget / max(first, 1e-3)) - 1))
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        pair()
+        times.append(time.perf_counter() - t0)
+    t = float(np.median(times)) if times else first
+    frames = int(ol.sum())
+    return dict(value=frames / t, unit='mel-frames/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'oracle/gantron_ref.py G+D pair, B={B}, Ti<={Ti}, To<={To} ({frames} valid frames), '
+                       f'{t:.2f} s per pair, median of {max(len(times), 1)}')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=64)
+    ap.add_argument('--fixed-shape', action='store_true', help='nominal Ti=150, To=800 for every item')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP extension has no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    import torch.distributed as dist
+    from gantron_amd import _lib
+    from gantron_amd.distributed import apply_gradient_allreduce
+    from gantron_amd.hparams import HParams
+    from gantron_amd.loss_function import Tacotron2Loss
+    from gantron_amd.model import Discriminator, Tacotron2
+    from gantron_amd.optim import FlatAdam
+    from gantron_amd.train_steps import discriminator_step, generator_step
+
+    hp = HParams(HPARAMS + f',batch_size={args.batch}')
+    if world > 1:
+        hp.distributed_run = True
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', init_method='env://', world_size=world, rank=rank)
+    torch.manual_seed(hp.seed)
+    G, D = Tacotron2(hp).to(dev).train(), Discriminator(hp).to(dev).train()
+    g_opt = FlatAdam(G, lr=hp.g_learning_rate, weight_decay=hp.weight_decay)
+    d_opt = FlatAdam(D, lr=hp.d_learning_rate, weight_decay=hp.weight_decay)
+    if world > 1:
+        G, D = apply_gradient_allreduce(G), apply_gradient_allreduce(D)
+    crit = Tacotron2Loss()
+    batch = ljspeech_shaped_batch(hp, args.batch, seed=1234 + rank, fixed=args.fixed_shape)
+    # lengths stay on the host, as they are when a DataLoader produces the batch (no per-step D2H sync)
+    batch = tuple(t if i in (1, 6) else t.to(dev) for i, t in enumerate(batch))
+    in_lens, out_lens = batch[1].tolist(), batch[6].tolist()
+    frames = sum(out_lens)
+
+    def pair(it):
+        _, generated = generator_step(G, D, g_opt, crit, batch, hp, iteration=it)
+        discriminator_step(G, D, d_opt, batch, generated, hp)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log(f'setup done: B={args.batch} Ti={max(in_lens)} To={max(out_lens)} frames={frames}')
+    for i in range(args.warmup):
+        pair(i)
+        torch.cuda.synchronize()
+        log(f'warmup pair {i} done')
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        pair(args.warmup + i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    log(f'timed region: {elapsed:.3f} s for {args.steps} pairs')
+    if world > 1:
+        t = torch.tensor([elapsed, float(frames)], device=dev, dtype=torch.float64)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed, total_frames = float(tmax[0]), float(t[1])
+    else:
+        total_frames = float(frames)
+
+    # ---- roofline of the dominant kernel family: one extra pair with HIP events around every launch
+    roof = None
+    cpu = None
+    if rank == 0:
+        lib = _lib.lib()
+        torch.cuda.synchronize()
+        lib.gt_prof_begin()
+        pair(args.warmup + args.steps)
+        out = (ctypes.c_double * 32)()
+        _lib.check(lib.gt_prof_end(out), 'gt_prof_end')
+        log('profiled pair done')
+        fam = [dict(name=FAMILIES[f], launches=int(out[4 * f]), ms=out[4 * f + 1], flops=out[4 * f + 2],
+                    bytes=out[4 * f + 3]) for f in range(8)]
+        dom = max(fam, key=lambda r: r['ms'])
+        avg_ms = dom['ms'] / max(dom['launches'], 1)
+        if dom['name'] in MFMA_BOUND:
+            ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12 if dom['ms'] > 0 else 0.0
+            roof = dict(bound='mfma', achieved=ach, peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
+                        frac=ach / FP32_MFMA_PEAK_TFLOPS, traffic=None)
+        else:
+            ach = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9 if dom['ms'] > 0 else 0.0
+            roof = dict(bound='hbm', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s', frac=ach / HBM_PEAK_GBS, traffic=None)
+        roof.update(kernel=KERNEL_OF[dom['name']], launches_per_pair=dom['launches'], avg_launch_us=avg_ms * 1e3,
+                    families={r['name']: dict(launches=r['launches'], ms=round(r['ms'], 3),
+                                              tflops=round(r['flops'] / max(r['ms'], 1e-9) / 1e9, 2),
+                                              gbs=round(r['bytes'] / max(r['ms'], 1e-9) / 1e6, 1)) for r in fam})
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline()
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        Ti, To = max(in_lens), max(out_lens)
+        ms = elapsed / args.steps * 1e3
+        fl = pair_flops(hp, in_lens, out_lens)
+        line = dict(metric='mel-frames/sec (gen+disc step) LJSpeech bs=64', value=total_frames * args.steps / elapsed,
+                    unit='mel-frames/s', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms,
+                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                    config=dict(workload='Vanilla GANtron (use_labels=False,use_noise=True) LJSpeech-shaped batch=%d fp32, '
+                                         'G step + D step pair incl. clip+Adam' % args.batch,
+                                per_gpu_batch=args.batch, global_batch=args.batch * world, Ti_max=Ti, To_max=To,
+                                valid_frames_per_rank=frames, padded_frames_per_rank=args.batch * To,
+                                parallelism='dp%d' % world, pair_tflop=fl / 1e12,
+                                pair_mfma_frac=fl / (elapsed / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS),
+                    roofline=roof, cpu_baseline=cpu)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -27,3 +27,61 @@ extern "C" int64_t gt_abi_sizeof(int32_t which) {
         default: return -1;
     }
 }
+
+// ------------------------------------------------------------------ per-launch event timing
+#include <vector>
+bool g_gt_prof_on = false;
+namespace {
+struct ProfRec { int fam; double flops, bytes; hipEvent_t e0, e1; };
+std::vector<ProfRec> g_recs;
+std::vector<hipEvent_t> g_pool;
+size_t g_pool_next = 0;
+hipEvent_t next_event() {
+    if (g_pool_next == g_pool.size()) {
+        hipEvent_t e;
+        hipEventCreate(&e);
+        g_pool.push_back(e);
+    }
+    return g_pool[g_pool_next++];
+}
+}  // namespace
+
+void gt_prof_mark(int family, double flops, double bytes, hipStream_t st, bool begin) {
+    if (begin) {
+        ProfRec r;
+        r.fam = family; r.flops = flops; r.bytes = bytes;
+        r.e0 = next_event(); r.e1 = next_event();
+        hipEventRecord(r.e0, st);
+        g_recs.push_back(r);
+    } else if (!g_recs.empty()) {
+        hipEventRecord(g_recs.back().e1, st);
+    }
+}
+
+extern "C" int gt_prof_begin(void) {
+    g_recs.clear();
+    g_pool_next = 0;
+    g_gt_prof_on = true;
+    return 0;
+}
+
+// Stops recording, waits for the recorded events and fills per-family totals:
+// out[f*4+0] = launches, +1 = total ms, +2 = total flops, +3 = total bytes  (f < GT_FAM_COUNT)
+extern "C" int gt_prof_end(double* out) {
+    g_gt_prof_on = false;
+    GT_REQUIRE(out != nullptr, GT_E_ARG, "gt_prof_end: NULL");
+    for (int i = 0; i < GT_FAM_COUNT * 4; ++i) out[i] = 0.0;
+    for (auto& r : g_recs) {
+        hipError_t e = hipEventSynchronize(r.e1);
+        GT_REQUIRE(e == hipSuccess, (int)e, "gt_prof_end: event sync failed");
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, r.e0, r.e1);
+        GT_REQUIRE(e == hipSuccess, (int)e, "gt_prof_end: elapsed failed");
+        out[r.fam * 4 + 0] += 1.0;
+        out[r.fam * 4 + 1] += ms;
+        out[r.fam * 4 + 2] += r.flops;
+        out[r.fam * 4 + 3] += r.bytes;
+    }
+    g_recs.clear();
+    return 0;
+}

@@ -341,6 +341,8 @@ extern "C" int gt_attn_energies_fwd(GtAttnDims d, GtSlabs qpart, const float* w_
     if (rc) return rc;
     GT_REQUIRE(qpart.p && w_prev && w_cum && pm && Wc && Wd && v && energies, GT_E_ARG, "gt_attn_energies_fwd: NULL pointer");
     dim3 grid(cdiv(d.Ti, CT), d.B);
+    GtProfScope prof(GT_FAM_ATTN_E_FWD, 2.0 * d.B * d.Ti * (double)(d.F * 2 * d.Kc + d.A * d.F + 2 * d.A),
+                     4.0 * d.B * d.Ti * (d.A + 3.0), (hipStream_t)stream);
     hipLaunchKernelGGL(attn_energies_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, d, qpart, w_prev, w_cum, pm,
                        Wc, Wd, v, lengths, q_out, energies);
     GT_LAUNCH_CHECK();
@@ -355,6 +357,8 @@ extern "C" int gt_attn_context_fwd(GtAttnDims d, const float* energies, const fl
     GT_REQUIRE(energies && memory && w_out && ld_mem >= d.E, GT_E_ARG, "gt_attn_context_fwd: bad argument");
     GT_REQUIRE(cum_out == nullptr || cum_in != nullptr, GT_E_ARG, "gt_attn_context_fwd: cum_in missing");
     dim3 grid(cdiv(d.E, 256), d.B);
+    GtProfScope prof(GT_FAM_ATTN_C_FWD, 2.0 * d.B * d.Ti * (double)d.E, 4.0 * d.B * ((double)d.Ti * d.E + 3.0 * d.E + 4.0 * d.Ti),
+                     (hipStream_t)stream);
     hipLaunchKernelGGL(attn_context_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, d, energies, memory,
                        (long)ld_mem, w_out, cum_in, cum_out, c0, (long)ld0, c1, (long)ld1, c2, (long)ld2);
     GT_LAUNCH_CHECK();
@@ -370,6 +374,8 @@ extern "C" int gt_attn_context_bwd(GtAttnDims d, GtSlabs dctx_a, GtSlabs dctx_b,
     GT_REQUIRE(memory && dw_out && ld_mem >= d.E, GT_E_ARG, "gt_attn_context_bwd: bad argument");
     GT_REQUIRE((size_t)d.E * 4 <= 64 * 1024, GT_E_LIMIT, "gt_attn_context_bwd: E too large for LDS");
     dim3 grid(cdiv(d.Ti, CT), d.B);
+    GtProfScope prof(GT_FAM_ATTN_C_BWD, 2.0 * d.B * d.Ti * (double)d.E, 4.0 * d.B * ((double)d.Ti * d.E + 4.0 * d.E + 6.0 * d.Ti),
+                     (hipStream_t)stream);
     hipLaunchKernelGGL(attn_context_bwd_kernel, grid, dim3(256), (size_t)d.E * 4, (hipStream_t)stream, d, dctx_a,
                        dctx_b, dctx_direct, (long)ld_direct, memory, (long)ld_mem, dwcat_in, dcum_acc, dw_extern,
                        dctx_out, (long)ld_dctx_out, dq_zero, (long)ld_dq, dw_out);
@@ -386,6 +392,8 @@ extern "C" int gt_attn_energies_bwd(GtAttnDims d, const float* dw, const float* 
     GT_REQUIRE(dw && w && q && w_prev && w_cum && pm && Wc && Wd && v && dq && dpm && dwcat_out && acc, GT_E_ARG,
                "gt_attn_energies_bwd: NULL pointer");
     dim3 grid(cdiv(d.Ti, CT), d.B);
+    GtProfScope prof(GT_FAM_ATTN_E_BWD, 2.0 * d.B * d.Ti * (double)(3 * d.F * 2 * d.Kc + 3 * d.A * d.F + 4 * d.A),
+                     4.0 * d.B * d.Ti * (3.0 * d.A + 6.0), (hipStream_t)stream);
     hipLaunchKernelGGL(attn_energies_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, d, dw, w, q, w_prev, w_cum,
                        pm, Wc, Wd, v, dq, (long)ld_dq, dpm, dwcat_out, acc);
     GT_LAUNCH_CHECK();

@@ -31,6 +31,19 @@ void gt_set_error(const char* fmt, ...);
 
 __host__ __device__ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+// ---- optional per-launch timing (HIP events on the launch stream), enabled by gt_prof_begin()
+enum { GT_FAM_REC_GEMM = 0, GT_FAM_SGEMM = 1, GT_FAM_ATTN_E_FWD = 2, GT_FAM_ATTN_C_FWD = 3, GT_FAM_ATTN_C_BWD = 4,
+       GT_FAM_ATTN_E_BWD = 5, GT_FAM_CELL_FWD = 6, GT_FAM_CELL_BWD = 7, GT_FAM_COUNT = 8 };
+extern bool g_gt_prof_on;
+void gt_prof_mark(int family, double flops, double bytes, hipStream_t st, bool begin);
+struct GtProfScope {
+    int fam; hipStream_t st; bool on;
+    GtProfScope(int family, double flops, double bytes, hipStream_t s) : fam(family), st(s), on(g_gt_prof_on) {
+        if (on) gt_prof_mark(fam, flops, bytes, st, true);
+    }
+    ~GtProfScope() { if (on) gt_prof_mark(fam, 0, 0, st, false); }
+};
+
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }

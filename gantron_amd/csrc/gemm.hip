@@ -297,6 +297,8 @@ extern "C" int gt_sgemm(const GtGemm* g, void* stream) {
     d.split_k = cdiv(g->K, d.k_per_split);   // drop empty splits
     hipStream_t st = (hipStream_t)stream;
 
+    GtProfScope prof(GT_FAM_SGEMM, 2.0 * g->M * (double)g->N * g->K * g->batch,
+                     4.0 * g->batch * ((double)g->M * g->K + (double)g->N * g->K + (double)g->M * g->N), st);
     const long tiles128 = (long)cdiv(g->M, 128) * cdiv(g->N, 128) * g->batch * d.split_k;
     const bool big = tiles128 >= 192 && g->M > 64 && g->N > 64;
     const long gz = (long)g->batch * d.split_k;

@@ -214,6 +214,8 @@ extern "C" int gt_rec_gemm(const float* X, int64_t ldx, const float* Wp, float* 
     GT_REQUIRE(ns == splits, GT_E_ARG, "gt_rec_gemm: splits=%d leaves empty slabs for K=%d (use <= %d)", splits, K, ns);
     dim3 grid(cdiv(N, 64), splits, nz);
     hipStream_t st = (hipStream_t)stream;
+    GtProfScope prof(GT_FAM_REC_GEMM, 2.0 * 16 * mtiles * (double)N * K * nz,
+                     4.0 * nz * ((double)N * K + 16.0 * mtiles * K + 16.0 * mtiles * N * splits), st);
 #define GT_REC(MT)                                                                                    \
     hipLaunchKernelGGL((rec_gemm_kernel<MT>), grid, dim3(256), 0, st, X, (long)ldx, Wp, part, N, KB, \
                        KBS, (long)x_zstride, (long)w_zstride, (long)part_zstride, (long)part_sstride)
@@ -240,6 +242,7 @@ extern "C" int gt_lstm_cell_fwd(GtSlabs part, const float* pre, int64_t ld_pre, 
     a.keep = keep; a.scale = 1.0f / (1.0f - p_drop); a.active = active; a.gates = gates; a.c_out = c_out;
     a.h_raw = h_raw; a.h0 = h0; a.ld0 = ld0; a.h1 = h1; a.ld1 = ld1; a.h2 = h2; a.ld2 = ld2; a.B = B; a.H = H;
     const long n = (long)B * H;
+    GtProfScope prof(GT_FAM_CELL_FWD, 0.0, 4.0 * n * (4.0 * part.n + 4 + 1 + 4 + 1 + 3), (hipStream_t)stream);
     hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, a);
     GT_LAUNCH_CHECK();
     return 0;
@@ -256,6 +259,7 @@ extern "C" int gt_lstm_cell_bwd(GtSlabs dh_a, GtSlabs dh_b, GtSlabs dh_c, const 
     a.gates = gates; a.c_new = c_new; a.c_prev = c_prev; a.keep = keep; a.scale = 1.0f / (1.0f - p_drop);
     a.active = active; a.dgates = dgates; a.dc_prev = dc_prev; a.dh_pass = dh_pass; a.B = B; a.H = H;
     const long n = (long)B * H;
+    GtProfScope prof(GT_FAM_CELL_BWD, 0.0, 4.0 * n * (dh_a.n + dh_b.n + dh_c.n + 1 + 1 + 4 + 2 + 4 + 1), (hipStream_t)stream);
     hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, a);
     GT_LAUNCH_CHECK();
     return 0;

@@ -37,6 +37,15 @@ const char* gt_last_error_string(void);
  * 5 GtDecoderBwd, 6 GtBiLstm (lets a binding verify its layout at load time) */
 int64_t gt_abi_sizeof(int32_t which);
 
+/* Optional per-launch timing with HIP events recorded on the launch stream (bench.py's roofline
+ * leg).  Between gt_prof_begin() and gt_prof_end() every launch of a profiled kernel family is
+ * bracketed by two events; gt_prof_end waits for them and fills, per family f (0 rec_gemm,
+ * 1 sgemm, 2 attn_energies_fwd, 3 attn_context_fwd, 4 attn_context_bwd, 5 attn_energies_bwd,
+ * 6 lstm_cell_fwd, 7 lstm_cell_bwd): out[4f] launches, out[4f+1] total ms, out[4f+2] algorithmic
+ * flops, out[4f+3] algorithmic bytes.  `out` is a HOST array of 32 doubles.  Not thread-safe. */
+int gt_prof_begin(void);
+int gt_prof_end(double* out);
+
 /* ------------------------------------------------------------------------------------------ GEMM
  * C[m,n] (=|+=) sum_k A(m,k) * B(n,k) (+ bias[n]),   fp32 MFMA (v_mfma_f32_32x32x2_f32).
  * Operand addressing modes (element (r,k) of an operand with rows r and reduction index k):
