@@ -7,7 +7,17 @@
 // The backward kernels recompute the tanh arguments (the reference's autograd saves a
 // (B,Ti,128) tensor per step: 3.9 GB over 800 steps) and accumulate the location-layer parameter
 // gradients in per-workgroup slabs (no atomics) that gt_attn_acc_reduce folds after the loop.
+#include <stdlib.h>
 #include "common.h"
+
+// matrix-core versions for the reference's default dimensions (attention_mfma.hip)
+void gt_launch_attn_energies_fwd_mfma(GtAttnDims d, GtSlabs qpart, const float* w_prev, const float* w_cum,
+                                      const float* pm, const float* Wc, const float* Wd, const float* v,
+                                      const int* lengths, float* q_out, float* energies, hipStream_t st);
+void gt_launch_attn_energies_bwd_mfma(GtAttnDims d, const float* dw, const float* w, const float* q,
+                                      const float* w_prev, const float* w_cum, const float* pm, const float* Wc,
+                                      const float* Wd, const float* v, float* dq, long ld_dq, float* dpm,
+                                      float* dwcat_out, float* acc, hipStream_t st);
 
 namespace {
 
@@ -22,20 +32,30 @@ constexpr int LDS_A = MAXA + 1;    // [CT][A] scratch row stride
 constexpr int MAX_TI = 2048;
 
 struct Shared {
+    alignas(16) float locf[CT * LDL];     // 16-byte aligned rows: read with ds_read_b128
+    alignas(16) float dlocf[CT * LDL];
+    alignas(16) float buf[CT * LDS_A];    // fwd: v*tanh ; bwd: ds
     float q[MAXA];
     float v[MAXA];
     float wc[MAXF * 2 * MAXK];
     float wd[MAXA * LDW];
-    float win[2][WINW + 1];
-    float locf[CT * LDL];
-    float buf[CT * LDS_A];      // fwd: v*tanh ; bwd: ds
-    float dlocf[CT * LDL];
+    float win[2][WINW + 2];
     float de[CT];
     float dvs[MAXA];
     float red[16];
 };
 
-__device__ __forceinline__ void load_weights(Shared& S, const GtAttnDims& d, const float* Wc, const float* Wd,
+// Compile-time copies of the attention dimensions (0 = take the runtime value): with constants the
+// inner loops unroll and their LDS reads are issued in batches instead of one exposed read per MAC.
+template <int CA, int CF, int CK>
+struct Dims {
+    int A, F, Kc, Ti, B;
+    __device__ __forceinline__ explicit Dims(const GtAttnDims& d)
+        : A(CA ? CA : d.A), F(CF ? CF : d.F), Kc(CK ? CK : d.Kc), Ti(d.Ti), B(d.B) {}
+};
+
+template <class D>
+__device__ __forceinline__ void load_weights(Shared& S, const D& d, const float* Wc, const float* Wd,
                                              const float* v) {
     for (int i = threadIdx.x; i < d.F * 2 * d.Kc; i += blockDim.x) S.wc[i] = Wc[i];
     for (int i = threadIdx.x; i < d.A * d.F; i += blockDim.x) {
@@ -45,7 +65,8 @@ __device__ __forceinline__ void load_weights(Shared& S, const GtAttnDims& d, con
     for (int i = threadIdx.x; i < d.A; i += blockDim.x) S.v[i] = v[i];
 }
 
-__device__ __forceinline__ void load_window(Shared& S, const GtAttnDims& d, const float* w_prev, const float* w_cum,
+template <class D>
+__device__ __forceinline__ void load_window(Shared& S, const D& d, const float* w_prev, const float* w_cum,
                                             int b, int t0) {
     const int pad = (d.Kc - 1) / 2;
     const int ww = CT + d.Kc - 1;
@@ -58,34 +79,65 @@ __device__ __forceinline__ void load_window(Shared& S, const GtAttnDims& d, cons
 }
 
 // locf[tl][f] = sum_{c,k} Wc[f][c][k] * win[c][tl+k]
-__device__ __forceinline__ void location_conv(Shared& S, const GtAttnDims& d) {
+template <class D>
+__device__ __forceinline__ void location_conv(Shared& S, const D& d) {
     for (int o = threadIdx.x; o < CT * d.F; o += blockDim.x) {
         const int tl = o / d.F, f = o - tl * d.F;
-        float acc = 0.f;
-        for (int c = 0; c < 2; ++c) {
-            const float* wrow = &S.wc[(f * 2 + c) * d.Kc];
-            const float* x = &S.win[c][tl];
-            for (int k = 0; k < d.Kc; ++k) acc += wrow[k] * x[k];
+        float acc0 = 0.f, acc1 = 0.f;
+        const float* w0 = &S.wc[(f * 2 + 0) * d.Kc];
+        const float* w1 = &S.wc[(f * 2 + 1) * d.Kc];
+        const float* x0 = &S.win[0][tl];
+        const float* x1 = &S.win[1][tl];
+#pragma unroll
+        for (int k = 0; k < d.Kc; ++k) {
+            acc0 += w0[k] * x0[k];
+            acc1 += w1[k] * x1[k];
         }
-        S.locf[tl * LDL + f] = acc;
+        S.locf[tl * LDL + f] = acc0 + acc1;
     }
 }
 
-// tanh argument for (tl, dd): q + Wd . locf[tl] + pm
-__device__ __forceinline__ float dense_arg(const Shared& S, const GtAttnDims& d, int tl, int dd, float pmv) {
-    float s = S.q[dd] + pmv;
-    const float* wrow = &S.wd[dd * LDW];
-    const float* l = &S.locf[tl * LDL];
-    for (int f = 0; f < d.F; ++f) s += wrow[f] * l[f];
-    return s;
+// Wd row of this thread's attention channel in registers (zero beyond F)
+template <class D>
+__device__ __forceinline__ void load_wrow(const Shared& S, const D& d, int dd, float (&wrow)[MAXF]) {
+#pragma unroll
+    for (int f = 0; f < MAXF; ++f) wrow[f] = (f < d.F) ? S.wd[dd * LDW + f] : 0.f;
 }
 
-__global__ __launch_bounds__(256) void attn_energies_fwd_kernel(GtAttnDims d, GtSlabs qpart, const float* w_prev,
+// sum_f wrow[f] * locf[tl][f] with 16-byte LDS reads (locf rows are zero padded to MAXF)
+__device__ __forceinline__ float dense_dot(const Shared& S, int tl, const float (&wrow)[MAXF]) {
+    const float4* l = reinterpret_cast<const float4*>(&S.locf[tl * LDL]);
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int f4 = 0; f4 < MAXF / 4; ++f4) {
+        const float4 v = l[f4];
+        s0 += wrow[4 * f4 + 0] * v.x;
+        s1 += wrow[4 * f4 + 1] * v.y;
+        s0 += wrow[4 * f4 + 2] * v.z;
+        s1 += wrow[4 * f4 + 3] * v.w;
+    }
+    return s0 + s1;
+}
+
+__device__ __forceinline__ void zero_locf(Shared& S) {
+    for (int i = threadIdx.x; i < CT * LDL; i += blockDim.x) { S.locf[i] = 0.f; S.dlocf[i] = 0.f; }
+}
+
+// NIT = CT / (256 / A): positions handled by each thread (attention_dim 128 -> 16)
+template <int NIT, int CA, int CF, int CK>
+__global__ __launch_bounds__(256) void attn_energies_fwd_kernel(GtAttnDims dims, GtSlabs qpart, const float* w_prev,
                                                                 const float* w_cum, const float* pm, const float* Wc,
                                                                 const float* Wd, const float* v, const int* lengths,
                                                                 float* q_out, float* energies) {
     __shared__ Shared S;
+    const Dims<CA, CF, CK> d(dims);
     const int b = blockIdx.y, t0 = blockIdx.x * CT;
+    const int G = CT / NIT;
+    const int dd = threadIdx.x % d.A, g = threadIdx.x / d.A;
+    // first long-latency global load issued before the LDS set-up; later ones one iteration ahead
+    const float* pm_b = pm + (long)b * d.Ti * d.A + dd;
+    float pm_next = (t0 + g < d.Ti) ? pm_b[(long)(t0 + g) * d.A] : 0.f;
+    zero_locf(S);
     load_weights(S, d, Wc, Wd, v);
     for (int i = threadIdx.x; i < d.A; i += blockDim.x) {
         const float qv = slab_sum(qpart.p, qpart.n, qpart.slab_stride, (long)b * qpart.ld + i);
@@ -96,38 +148,37 @@ __global__ __launch_bounds__(256) void attn_energies_fwd_kernel(GtAttnDims d, Gt
     __syncthreads();
     location_conv(S, d);
     __syncthreads();
-    const int G = blockDim.x / d.A;
-    const int dd = threadIdx.x % d.A, g = threadIdx.x / d.A;
-    if (g < G) {
-        for (int tl = g; tl < CT; tl += G) {
-            const int t = t0 + tl;
-            float val = 0.f;
-            if (t < d.Ti) {
-                const float s = dense_arg(S, d, tl, dd, pm[((long)b * d.Ti + t) * d.A + dd]);
-                val = S.v[dd] * tanhf(s);
-            }
-            S.buf[tl * LDS_A + dd] = val;
-        }
+    float wrow[MAXF];
+    load_wrow(S, d, dd, wrow);
+    const float qd = S.q[dd], vd = S.v[dd];
+#pragma unroll 2
+    for (int i = 0; i < NIT; ++i) {
+        const int tl = g + G * i;
+        const float pm_cur = pm_next;
+        const int tn = t0 + tl + G;
+        pm_next = (i + 1 < NIT && tn < d.Ti) ? pm_b[(long)tn * d.A] : 0.f;
+        const float sarg = qd + pm_cur + dense_dot(S, tl, wrow);
+        S.buf[tl * LDS_A + dd] = (t0 + tl < d.Ti) ? vd * tanhf(sarg) : 0.f;
     }
     __syncthreads();
-    if (threadIdx.x < CT) {
-        const int t = t0 + threadIdx.x;
-        if (t < d.Ti) {
-            float e = 0.f;
-            for (int i = 0; i < d.A; ++i) e += S.buf[threadIdx.x * LDS_A + i];
+    // reduce over the attention channels: 8 lanes per position
+    {
+        const int tl = threadIdx.x >> 3, part = threadIdx.x & 7;
+        float e = 0.f;
+        for (int i = part; i < d.A; i += 8) e += S.buf[tl * LDS_A + i];
+        e += __shfl_xor(e, 4, 64);
+        e += __shfl_xor(e, 2, 64);
+        e += __shfl_xor(e, 1, 64);
+        const int t = t0 + tl;
+        if (part == 0 && t < d.Ti) {
             if (lengths != nullptr && t >= lengths[b]) e = -INFINITY;
             energies[(long)b * d.Ti + t] = e;
         }
     }
 }
 
-__global__ __launch_bounds__(256) void attn_context_fwd_kernel(GtAttnDims d, const float* energies, const float* memory,
-                                                               long ld_mem, float* w_out, const float* cum_in,
-                                                               float* cum_out, float* c0, long ld0, float* c1, long ld1,
-                                                               float* c2, long ld2) {
-    __shared__ float w[MAX_TI];
-    __shared__ float red[16];
-    const int b = blockIdx.y;
+// softmax over Ti (block-wide) into LDS; returns nothing, w[] holds the normalised weights
+__device__ __forceinline__ void softmax_row(const GtAttnDims& d, const float* energies, int b, float* w, float* red) {
     float mx = -INFINITY;
     for (int t = threadIdx.x; t < d.Ti; t += blockDim.x) {
         const float e = energies[(long)b * d.Ti + t];
@@ -143,17 +194,58 @@ __global__ __launch_bounds__(256) void attn_context_fwd_kernel(GtAttnDims d, con
     }
     sum = block_sum(sum, red);
     const float inv = 1.0f / sum;
-    for (int t = threadIdx.x; t < d.Ti; t += blockDim.x) {
-        const float wv = w[t] * inv;
-        w[t] = wv;
-        if (blockIdx.x == 0) {
-            w_out[(long)b * d.Ti + t] = wv;
-            if (cum_out != nullptr) cum_out[(long)b * d.Ti + t] = cum_in[(long)b * d.Ti + t] + wv;
+    for (int t = threadIdx.x; t < d.Ti; t += blockDim.x) w[t] *= inv;
+    __syncthreads();
+}
+
+// grid (256-column chunks of E, B).  VEC: E, ld_mem multiples of 4 and 16-byte aligned memory: every
+// wave streams float4 columns of a quarter of the rows (4 rows in flight), partial sums fold through LDS.
+template <bool VEC>
+__global__ __launch_bounds__(256) void attn_context_fwd_kernel(GtAttnDims d, const float* energies, const float* memory,
+                                                               long ld_mem, float* w_out, const float* cum_in,
+                                                               float* cum_out, float* c0, long ld0, float* c1, long ld1,
+                                                               float* c2, long ld2) {
+    __shared__ float w[MAX_TI];
+    __shared__ float red[16];
+    __shared__ __attribute__((aligned(16))) float psum[4][256];
+    const int b = blockIdx.y;
+    softmax_row(d, energies, b, w, red);
+    if (blockIdx.x == 0) {
+        for (int t = threadIdx.x; t < d.Ti; t += blockDim.x) {
+            w_out[(long)b * d.Ti + t] = w[t];
+            if (cum_out != nullptr) cum_out[(long)b * d.Ti + t] = cum_in[(long)b * d.Ti + t] + w[t];
         }
     }
-    __syncthreads();
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col < d.E) {
+    float c = 0.f;
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (VEC) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int col4 = blockIdx.x * 256 + 4 * lane;
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+        if (col4 < d.E) {
+            const float* m = memory + (long)b * d.Ti * ld_mem + col4;
+            int t = wave;
+            for (; t + 12 < d.Ti; t += 16) {
+                const float4 m0 = *reinterpret_cast<const float4*>(m + (long)t * ld_mem);
+                const float4 m1 = *reinterpret_cast<const float4*>(m + (long)(t + 4) * ld_mem);
+                const float4 m2 = *reinterpret_cast<const float4*>(m + (long)(t + 8) * ld_mem);
+                const float4 m3 = *reinterpret_cast<const float4*>(m + (long)(t + 12) * ld_mem);
+                const float w0 = w[t], w1 = w[t + 4], w2 = w[t + 8], w3 = w[t + 12];
+                a0.x += w0 * m0.x; a0.y += w0 * m0.y; a0.z += w0 * m0.z; a0.w += w0 * m0.w;
+                a1.x += w1 * m1.x; a1.y += w1 * m1.y; a1.z += w1 * m1.z; a1.w += w1 * m1.w;
+                a0.x += w2 * m2.x; a0.y += w2 * m2.y; a0.z += w2 * m2.z; a0.w += w2 * m2.w;
+                a1.x += w3 * m3.x; a1.y += w3 * m3.y; a1.z += w3 * m3.z; a1.w += w3 * m3.w;
+            }
+            for (; t < d.Ti; t += 4) {
+                const float4 m0 = *reinterpret_cast<const float4*>(m + (long)t * ld_mem);
+                const float w0 = w[t];
+                a0.x += w0 * m0.x; a0.y += w0 * m0.y; a0.z += w0 * m0.z; a0.w += w0 * m0.w;
+            }
+        }
+        *reinterpret_cast<float4*>(&psum[wave][4 * lane]) = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+        __syncthreads();
+        c = (psum[0][threadIdx.x] + psum[1][threadIdx.x]) + (psum[2][threadIdx.x] + psum[3][threadIdx.x]);
+    } else if (col < d.E) {
         const float* m = memory + (long)b * d.Ti * ld_mem + col;
         float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
         int t = 0;
@@ -164,7 +256,9 @@ __global__ __launch_bounds__(256) void attn_context_fwd_kernel(GtAttnDims d, con
             acc3 += w[t + 3] * m[(long)(t + 3) * ld_mem];
         }
         for (; t < d.Ti; ++t) acc0 += w[t] * m[(long)t * ld_mem];
-        const float c = (acc0 + acc1) + (acc2 + acc3);
+        c = (acc0 + acc1) + (acc2 + acc3);
+    }
+    if (col < d.E) {
         if (c0 != nullptr) c0[(long)b * ld0 + col] = c;
         if (c1 != nullptr) c1[(long)b * ld1 + col] = c;
         if (c2 != nullptr) c2[(long)b * ld2 + col] = c;
@@ -172,12 +266,14 @@ __global__ __launch_bounds__(256) void attn_context_fwd_kernel(GtAttnDims d, con
 }
 
 // grid (chunks of CT positions, B).  dw[t'] = memory[b][t'] . dctx + carried alignment gradients.
+template <bool VEC>
 __global__ __launch_bounds__(256) void attn_context_bwd_kernel(GtAttnDims d, GtSlabs da, GtSlabs db,
                                                                const float* dctx_direct, long ld_direct,
                                                                const float* memory, long ld_mem, float* dwcat_in,
                                                                float* dcum_acc, const float* dw_extern, float* dctx_out,
                                                                long ld_dctx_out, float* dq_zero, long ld_dq, float* dw_out) {
-    extern __shared__ float dctx[];   // E floats
+    extern __shared__ __attribute__((aligned(16))) float dctx[];   // E floats
+    __shared__ float dots[CT];
     const int b = blockIdx.y, t0 = blockIdx.x * CT;
     for (int e = threadIdx.x; e < d.E; e += blockDim.x) {
         float g = 0.f;
@@ -190,39 +286,75 @@ __global__ __launch_bounds__(256) void attn_context_bwd_kernel(GtAttnDims d, GtS
     if (blockIdx.x == 0 && dq_zero != nullptr)
         for (int i = threadIdx.x; i < d.A; i += blockDim.x) dq_zero[(long)b * ld_dq + i] = 0.f;
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int tl = wave; tl < CT; tl += nw) {
-        const int t = t0 + tl;
-        if (t >= d.Ti) break;
-        const float* m = memory + ((long)b * d.Ti + t) * ld_mem;
-        float acc = 0.f;
-        for (int e = lane; e < d.E; e += 64) acc += m[e] * dctx[e];
-        acc = wave_sum(acc);
-        if (lane == 0) {
-            const long i = (long)b * d.Ti + t;
-            const long plane = (long)d.B * d.Ti;
-            float carried = 0.f;
-            if (dwcat_in != nullptr) {
-                const float cum = dcum_acc[i] + dwcat_in[plane + i];
-                dcum_acc[i] = cum;
-                carried = dwcat_in[i] + cum;
-                dwcat_in[i] = 0.f;
-                dwcat_in[plane + i] = 0.f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* mb = memory + (long)b * d.Ti * ld_mem;
+    if (VEC) {
+        // wave w owns rows t0 + w + 4*i (i < 8); 4 rows in flight per pass
+        const int e4n = d.E / 4;
+        const float4* dc4 = reinterpret_cast<const float4*>(dctx);
+        for (int pass = 0; pass < 2; ++pass) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            int trow[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) trow[r] = min(t0 + wave + 4 * (4 * pass + r), d.Ti - 1);
+            for (int e4 = lane; e4 < e4n; e4 += 64) {
+                const float4 dc = dc4[e4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float4 m = *reinterpret_cast<const float4*>(mb + (long)trow[r] * ld_mem + 4 * e4);
+                    acc[r] += m.x * dc.x + m.y * dc.y + m.z * dc.z + m.w * dc.w;
+                }
             }
-            if (dw_extern != nullptr) carried += dw_extern[i];
-            dw_out[i] = acc + carried;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = wave_sum(acc[r]);
+                if (lane == 0) dots[wave + 4 * (4 * pass + r)] = v;
+            }
         }
+    } else {
+        for (int tl = wave; tl < CT; tl += 4) {
+            const int t = min(t0 + tl, d.Ti - 1);
+            const float* m = mb + (long)t * ld_mem;
+            float acc = 0.f;
+            for (int e = lane; e < d.E; e += 64) acc += m[e] * dctx[e];
+            acc = wave_sum(acc);
+            if (lane == 0) dots[tl] = acc;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < CT && t0 + threadIdx.x < d.Ti) {
+        const long i = (long)b * d.Ti + t0 + threadIdx.x;
+        const long plane = (long)d.B * d.Ti;
+        float carried = 0.f;
+        if (dwcat_in != nullptr) {
+            const float cum = dcum_acc[i] + dwcat_in[plane + i];
+            dcum_acc[i] = cum;
+            carried = dwcat_in[i] + cum;
+            dwcat_in[i] = 0.f;
+            dwcat_in[plane + i] = 0.f;
+        }
+        if (dw_extern != nullptr) carried += dw_extern[i];
+        dw_out[i] = dots[threadIdx.x] + carried;
     }
 }
 
 // grid (chunks, B).  Energies backward for CT positions; see file header.
-__global__ __launch_bounds__(256) void attn_energies_bwd_kernel(GtAttnDims d, const float* dw, const float* w,
+template <int NIT, int CA, int CF, int CK>
+__global__ __launch_bounds__(256) void attn_energies_bwd_kernel(GtAttnDims dims, const float* dw, const float* w,
                                                                 const float* q, const float* w_prev, const float* w_cum,
                                                                 const float* pm, const float* Wc, const float* Wd,
                                                                 const float* v, float* dq, long ld_dq, float* dpm, float* dwcat_out,
                                                                 float* acc) {
     __shared__ Shared S;
+    const Dims<CA, CF, CK> d(dims);
     const int b = blockIdx.y, t0 = blockIdx.x * CT;
+    const int G = CT / NIT;
+    const int dd = threadIdx.x % d.A, g = threadIdx.x / d.A;
+    // first long-latency global loads issued before the LDS set-up; later ones one iteration ahead
+    const long row0 = (long)b * d.Ti * d.A + dd;
+    float pm_next = 0.f, dpm_next = 0.f;
+    if (t0 + g < d.Ti) { pm_next = pm[row0 + (long)(t0 + g) * d.A]; dpm_next = dpm[row0 + (long)(t0 + g) * d.A]; }
+    zero_locf(S);
     load_weights(S, d, Wc, Wd, v);
     for (int i = threadIdx.x; i < d.A; i += blockDim.x) S.q[i] = q[(long)b * d.A + i];
     load_window(S, d, w_prev, w_cum, b, t0);
@@ -238,72 +370,153 @@ __global__ __launch_bounds__(256) void attn_energies_bwd_kernel(GtAttnDims d, co
     location_conv(S, d);
     __syncthreads();
 
-    float* acc_wg = acc + ((long)b * gridDim.x + blockIdx.x) * (d.A + d.A * d.F + d.F * 2 * d.Kc);
-    const int G = blockDim.x / d.A;
-    const int dd = threadIdx.x % d.A, g = threadIdx.x / d.A;
+    const int per_wg = d.A + d.A * d.F + d.F * 2 * d.Kc;
+    float* acc_wg = acc + ((long)b * gridDim.x + blockIdx.x) * per_wg;
+    float wrow[MAXF], dwd[MAXF];
+    load_wrow(S, d, dd, wrow);
+#pragma unroll
+    for (int f = 0; f < MAXF; ++f) dwd[f] = 0.f;
+    const float qd = S.q[dd], vd = S.v[dd];
     float dq_acc = 0.f, dv_acc = 0.f;
-    if (g < G) {
-        for (int tl = g; tl < CT; tl += G) {
-            const int t = t0 + tl;
-            float ds = 0.f;
-            if (t < d.Ti) {
-                const long pi = ((long)b * d.Ti + t) * d.A + dd;
-                const float u = tanhf(dense_arg(S, d, tl, dd, pm[pi]));
-                const float de = S.de[tl];
-                ds = de * S.v[dd] * (1.f - u * u);
-                dv_acc += de * u;
-                dq_acc += ds;
-                dpm[pi] += ds;
-            }
-            S.buf[tl * LDS_A + dd] = ds;
+#pragma unroll 2
+    for (int i = 0; i < NIT; ++i) {
+        const int tl = g + G * i;
+        const float pm_cur = pm_next, dpm_cur = dpm_next;
+        const int tn = t0 + tl + G;
+        if (i + 1 < NIT && tn < d.Ti) { pm_next = pm[row0 + (long)tn * d.A]; dpm_next = dpm[row0 + (long)tn * d.A]; }
+        const float4* l = reinterpret_cast<const float4*>(&S.locf[tl * LDL]);
+        float4 lv[MAXF / 4];
+#pragma unroll
+        for (int f4 = 0; f4 < MAXF / 4; ++f4) lv[f4] = l[f4];
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int f4 = 0; f4 < MAXF / 4; ++f4) {
+            s0 += wrow[4 * f4 + 0] * lv[f4].x; s1 += wrow[4 * f4 + 1] * lv[f4].y;
+            s0 += wrow[4 * f4 + 2] * lv[f4].z; s1 += wrow[4 * f4 + 3] * lv[f4].w;
         }
-        atomicAdd(&dq[(long)b * ld_dq + dd], dq_acc);
+        float ds = 0.f;
+        if (t0 + tl < d.Ti) {
+            const float u = tanhf(qd + pm_cur + s0 + s1);
+            const float de = S.de[tl];
+            ds = de * vd * (1.f - u * u);
+            dv_acc += de * u;
+            dq_acc += ds;
+            dpm[row0 + (long)(t0 + tl) * d.A] = dpm_cur + ds;
+        }
+        // dWd[dd][f] += ds * locf[tl][f]
+#pragma unroll
+        for (int f4 = 0; f4 < MAXF / 4; ++f4) {
+            dwd[4 * f4 + 0] += ds * lv[f4].x; dwd[4 * f4 + 1] += ds * lv[f4].y;
+            dwd[4 * f4 + 2] += ds * lv[f4].z; dwd[4 * f4 + 3] += ds * lv[f4].w;
+        }
+        S.buf[tl * LDS_A + dd] = ds;
     }
-    __syncthreads();
-    // dv: fold the G groups through LDS
+    atomicAdd(&dq[(long)b * ld_dq + dd], dq_acc);
     if (threadIdx.x < d.A) S.dvs[threadIdx.x] = 0.f;
-    __syncthreads();
-    if (g < G) atomicAdd(&S.dvs[dd], dv_acc);
-    __syncthreads();
-    if (threadIdx.x < d.A) acc_wg[threadIdx.x] += S.dvs[threadIdx.x];
+    __syncthreads();                                   // ds complete in S.buf, dvs zeroed
+    atomicAdd(&S.dvs[dd], dv_acc);
 
-    // dlocf[tl][f] = sum_d ds[tl][d] * Wd[d][f]
-    for (int o = threadIdx.x; o < CT * d.F; o += blockDim.x) {
-        const int tl = o / d.F, f = o - tl * d.F;
-        float a = 0.f;
-        for (int i = 0; i < d.A; ++i) a += S.buf[tl * LDS_A + i] * S.wd[i * LDW + f];
-        S.dlocf[tl * LDL + f] = a;
+    // dlocf[tl][f] = sum_d ds[tl][d] * Wd[d][f]: thread -> (f, 4 positions tl = tq + 8*j)
+    {
+        const int f = threadIdx.x % MAXF, tq = threadIdx.x / MAXF;      // tq in [0, 8)
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (f < d.F) {
+#pragma unroll 8
+            for (int i = 0; i < d.A; ++i) {
+                const float wv = S.wd[i * LDW + f];
+                a0 += S.buf[(tq + 0) * LDS_A + i] * wv;
+                a1 += S.buf[(tq + 8) * LDS_A + i] * wv;
+                a2 += S.buf[(tq + 16) * LDS_A + i] * wv;
+                a3 += S.buf[(tq + 24) * LDS_A + i] * wv;
+            }
+            S.dlocf[(tq + 0) * LDL + f] = a0;
+            S.dlocf[(tq + 8) * LDL + f] = a1;
+            S.dlocf[(tq + 16) * LDL + f] = a2;
+            S.dlocf[(tq + 24) * LDL + f] = a3;
+        }
     }
-    // dWd[d][f] += sum_tl ds[tl][d] * locf[tl][f]
+    __syncthreads();                                   // dlocf + dvs complete; S.buf free for reuse
+    // fold the G partial dWd rows through LDS (S.buf as [G][A][F] needs G*A*F <= CT*LDS_A: 256*32 vs 32*129)
     float* acc_wd = acc_wg + d.A;
-    for (int o = threadIdx.x; o < d.A * d.F; o += blockDim.x) {
-        const int i = o / d.F, f = o - i * d.F;
-        float a = 0.f;
-        for (int tl = 0; tl < CT; ++tl) a += S.buf[tl * LDS_A + i] * S.locf[tl * LDL + f];
-        acc_wd[o] += a;
+    for (int gg = 0; gg < G; ++gg) {
+        if (g == gg) {
+#pragma unroll
+            for (int f = 0; f < MAXF; ++f) {
+                float* slot = &S.wd[dd * LDW + f];      // Wd no longer needed: reuse as the dWd accumulator
+                *slot = (gg == 0 ? 0.f : *slot) + dwd[f];
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
+    // batched read-modify-write of this workgroup's slab: loads first, then adds and stores
+    {
+        const int nwd = d.A * d.F;
+        float old[(MAXA * MAXF) / 256];
+#pragma unroll
+        for (int i = 0; i < (MAXA * MAXF) / 256; ++i) {
+            const int o = threadIdx.x + 256 * i;
+            old[i] = (o < nwd) ? acc_wd[o] : 0.f;
+        }
+        const float dv_old = (threadIdx.x < d.A) ? acc_wg[threadIdx.x] : 0.f;
+#pragma unroll
+        for (int i = 0; i < (MAXA * MAXF) / 256; ++i) {
+            const int o = threadIdx.x + 256 * i;
+            if (o < nwd) acc_wd[o] = old[i] + S.wd[(o / d.F) * LDW + (o % d.F)];
+        }
+        if (threadIdx.x < d.A) acc_wg[threadIdx.x] = dv_old + S.dvs[threadIdx.x];
+    }
     // dWc[f][c][k] += sum_tl dlocf[tl][f] * win[c][tl+k]
     float* acc_wc = acc_wg + d.A + d.A * d.F;
-    for (int o = threadIdx.x; o < d.F * 2 * d.Kc; o += blockDim.x) {
-        const int f = o / (2 * d.Kc), r = o - f * 2 * d.Kc, c = r / d.Kc, k = r - c * d.Kc;
-        float a = 0.f;
-        for (int tl = 0; tl < CT; ++tl) a += S.dlocf[tl * LDL + f] * S.win[c][tl + k];
-        acc_wc[o] += a;
+    {
+        constexpr int NWC = (MAXF * 2 * MAXK + 255) / 256;
+        const int nwc = d.F * 2 * d.Kc;
+        float old[NWC], val[NWC];
+#pragma unroll
+        for (int i = 0; i < NWC; ++i) {
+            const int o = threadIdx.x + 256 * i;
+            old[i] = (o < nwc) ? acc_wc[o] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NWC; ++i) {
+            const int o = threadIdx.x + 256 * i;
+            float a = 0.f;
+            if (o < nwc) {
+                const int f = o / (2 * d.Kc), r = o - f * 2 * d.Kc, c = r / d.Kc, k = r - c * d.Kc;
+#pragma unroll
+                for (int tl = 0; tl < CT; ++tl) a += S.dlocf[tl * LDL + f] * S.win[c][tl + k];
+            }
+            val[i] = a;
+        }
+#pragma unroll
+        for (int i = 0; i < NWC; ++i) {
+            const int o = threadIdx.x + 256 * i;
+            if (o < nwc) acc_wc[o] = old[i] + val[i];
+        }
     }
     // d[w_prev; w_cum][p] = sum_{f,k} dlocf[p-k][f] * Wc[f][c][k]   (transposed conv over the window)
     const int pad = (d.Kc - 1) / 2, ww = CT + d.Kc - 1;
-    for (int o = threadIdx.x; o < 2 * ww; o += blockDim.x) {
-        const int c = o / ww, p = o - c * ww;
-        const int t = t0 + p - pad;
-        if (t < 0 || t >= d.Ti) continue;
+    {
+        // 2 lanes per output (split the filter range), 2*ww <= 124 outputs -> 248 threads busy
+        const int o = threadIdx.x >> 1, half = threadIdx.x & 1;
         float a = 0.f;
-        for (int k = 0; k < d.Kc; ++k) {
-            const int tl = p - k;
-            if (tl < 0 || tl >= CT) continue;
-            for (int f = 0; f < d.F; ++f) a += S.dlocf[tl * LDL + f] * S.wc[(f * 2 + c) * d.Kc + k];
+        int t = -1, c = 0;
+        if (o < 2 * ww) {
+            c = o / ww;
+            const int p = o - c * ww;
+            t = t0 + p - pad;
+            if (t >= 0 && t < d.Ti) {
+                const int fh = (d.F + 1) / 2;
+                const int f0 = half * fh, f1 = min(d.F, f0 + fh);
+                for (int k = 0; k < d.Kc; ++k) {
+                    const int tl = p - k;
+                    if (tl < 0 || tl >= CT) continue;
+                    for (int f = f0; f < f1; ++f) a += S.dlocf[tl * LDL + f] * S.wc[(f * 2 + c) * d.Kc + k];
+                }
+            }
         }
-        atomicAdd(&dwcat_out[(long)c * d.B * d.Ti + (long)b * d.Ti + t], a);
+        a += __shfl_xor(a, 1, 64);
+        if (half == 0 && o < 2 * ww && t >= 0 && t < d.Ti)
+            atomicAdd(&dwcat_out[(long)c * d.B * d.Ti + (long)b * d.Ti + t], a);
     }
 }
 
@@ -320,7 +533,7 @@ __global__ void attn_acc_reduce_kernel(const float* acc, int nwg, int per, int A
 
 int check_dims(const GtAttnDims& d, const char* who) {
     GT_REQUIRE(d.B > 0 && d.Ti > 0 && d.Ti <= MAX_TI && d.E > 0, GT_E_ARG, "%s: bad B/Ti/E (%d,%d,%d)", who, d.B, d.Ti, d.E);
-    GT_REQUIRE(d.A > 0 && d.A <= MAXA && 256 % d.A == 0, GT_E_LIMIT, "%s: attention_dim %d must divide 256 and be <= %d", who, d.A, MAXA);
+    GT_REQUIRE(d.A >= 8 && d.A <= MAXA && 256 % d.A == 0, GT_E_LIMIT, "%s: attention_dim %d must be a power of two in [8, %d]", who, d.A, MAXA);
     GT_REQUIRE(d.F > 0 && d.F <= MAXF && d.Kc > 0 && d.Kc <= MAXK && (d.Kc & 1), GT_E_LIMIT,
                "%s: location filters %d (<=%d) / kernel %d (odd, <=%d)", who, d.F, MAXF, d.Kc, MAXK);
     return 0;
@@ -343,8 +556,24 @@ extern "C" int gt_attn_energies_fwd(GtAttnDims d, GtSlabs qpart, const float* w_
     dim3 grid(cdiv(d.Ti, CT), d.B);
     GtProfScope prof(GT_FAM_ATTN_E_FWD, 2.0 * d.B * d.Ti * (double)(d.F * 2 * d.Kc + d.A * d.F + 2 * d.A),
                      4.0 * d.B * d.Ti * (d.A + 3.0), (hipStream_t)stream);
-    hipLaunchKernelGGL(attn_energies_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, d, qpart, w_prev, w_cum, pm,
-                       Wc, Wd, v, lengths, q_out, energies);
+#define GT_EF(NIT, CA, CF, CK)                                                                                   \
+    hipLaunchKernelGGL((attn_energies_fwd_kernel<NIT, CA, CF, CK>), grid, dim3(256), 0, (hipStream_t)stream, d,  \
+                       qpart, w_prev, w_cum, pm, Wc, Wd, v, lengths, q_out, energies)
+    if (d.A == 128 && d.F == 32 && d.Kc == 31 && !getenv("GANTRON_ATTN_VALU")) {
+        gt_launch_attn_energies_fwd_mfma(d, qpart, w_prev, w_cum, pm, Wc, Wd, v, lengths, q_out, energies,
+                                         (hipStream_t)stream);      // the reference's default hparams
+    } else if (d.A == 128 && d.F == 32 && d.Kc == 31) {
+        GT_EF(16, 128, 32, 31);
+    } else {
+        switch (CT / (256 / d.A)) {
+            case 1: GT_EF(1, 0, 0, 0); break;
+            case 2: GT_EF(2, 0, 0, 0); break;
+            case 4: GT_EF(4, 0, 0, 0); break;
+            case 8: GT_EF(8, 0, 0, 0); break;
+            default: GT_EF(16, 0, 0, 0); break;
+        }
+    }
+#undef GT_EF
     GT_LAUNCH_CHECK();
     return 0;
 }
@@ -359,8 +588,13 @@ extern "C" int gt_attn_context_fwd(GtAttnDims d, const float* energies, const fl
     dim3 grid(cdiv(d.E, 256), d.B);
     GtProfScope prof(GT_FAM_ATTN_C_FWD, 2.0 * d.B * d.Ti * (double)d.E, 4.0 * d.B * ((double)d.Ti * d.E + 3.0 * d.E + 4.0 * d.Ti),
                      (hipStream_t)stream);
-    hipLaunchKernelGGL(attn_context_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, d, energies, memory,
-                       (long)ld_mem, w_out, cum_in, cum_out, c0, (long)ld0, c1, (long)ld1, c2, (long)ld2);
+    const bool vec = (d.E % 4 == 0) && (ld_mem % 4 == 0) && aligned16(memory);
+    if (vec)
+        hipLaunchKernelGGL((attn_context_fwd_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, d, energies, memory,
+                           (long)ld_mem, w_out, cum_in, cum_out, c0, (long)ld0, c1, (long)ld1, c2, (long)ld2);
+    else
+        hipLaunchKernelGGL((attn_context_fwd_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, d, energies, memory,
+                           (long)ld_mem, w_out, cum_in, cum_out, c0, (long)ld0, c1, (long)ld1, c2, (long)ld2);
     GT_LAUNCH_CHECK();
     return 0;
 }
@@ -376,9 +610,15 @@ extern "C" int gt_attn_context_bwd(GtAttnDims d, GtSlabs dctx_a, GtSlabs dctx_b,
     dim3 grid(cdiv(d.Ti, CT), d.B);
     GtProfScope prof(GT_FAM_ATTN_C_BWD, 2.0 * d.B * d.Ti * (double)d.E, 4.0 * d.B * ((double)d.Ti * d.E + 4.0 * d.E + 6.0 * d.Ti),
                      (hipStream_t)stream);
-    hipLaunchKernelGGL(attn_context_bwd_kernel, grid, dim3(256), (size_t)d.E * 4, (hipStream_t)stream, d, dctx_a,
-                       dctx_b, dctx_direct, (long)ld_direct, memory, (long)ld_mem, dwcat_in, dcum_acc, dw_extern,
-                       dctx_out, (long)ld_dctx_out, dq_zero, (long)ld_dq, dw_out);
+    const bool vec = (d.E % 4 == 0) && (ld_mem % 4 == 0) && aligned16(memory);
+    if (vec)
+        hipLaunchKernelGGL((attn_context_bwd_kernel<true>), grid, dim3(256), (size_t)d.E * 4, (hipStream_t)stream, d,
+                           dctx_a, dctx_b, dctx_direct, (long)ld_direct, memory, (long)ld_mem, dwcat_in, dcum_acc,
+                           dw_extern, dctx_out, (long)ld_dctx_out, dq_zero, (long)ld_dq, dw_out);
+    else
+        hipLaunchKernelGGL((attn_context_bwd_kernel<false>), grid, dim3(256), (size_t)d.E * 4, (hipStream_t)stream, d,
+                           dctx_a, dctx_b, dctx_direct, (long)ld_direct, memory, (long)ld_mem, dwcat_in, dcum_acc,
+                           dw_extern, dctx_out, (long)ld_dctx_out, dq_zero, (long)ld_dq, dw_out);
     GT_LAUNCH_CHECK();
     return 0;
 }
@@ -394,8 +634,24 @@ extern "C" int gt_attn_energies_bwd(GtAttnDims d, const float* dw, const float* 
     dim3 grid(cdiv(d.Ti, CT), d.B);
     GtProfScope prof(GT_FAM_ATTN_E_BWD, 2.0 * d.B * d.Ti * (double)(3 * d.F * 2 * d.Kc + 3 * d.A * d.F + 4 * d.A),
                      4.0 * d.B * d.Ti * (3.0 * d.A + 6.0), (hipStream_t)stream);
-    hipLaunchKernelGGL(attn_energies_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, d, dw, w, q, w_prev, w_cum,
-                       pm, Wc, Wd, v, dq, (long)ld_dq, dpm, dwcat_out, acc);
+#define GT_EB(NIT, CA, CF, CK)                                                                                   \
+    hipLaunchKernelGGL((attn_energies_bwd_kernel<NIT, CA, CF, CK>), grid, dim3(256), 0, (hipStream_t)stream, d,  \
+                       dw, w, q, w_prev, w_cum, pm, Wc, Wd, v, dq, (long)ld_dq, dpm, dwcat_out, acc)
+    if (d.A == 128 && d.F == 32 && d.Kc == 31 && !getenv("GANTRON_ATTN_VALU")) {
+        gt_launch_attn_energies_bwd_mfma(d, dw, w, q, w_prev, w_cum, pm, Wc, Wd, v, dq, (long)ld_dq, dpm, dwcat_out, acc,
+                                         (hipStream_t)stream);
+    } else if (d.A == 128 && d.F == 32 && d.Kc == 31) {
+        GT_EB(16, 128, 32, 31);
+    } else {
+        switch (CT / (256 / d.A)) {
+            case 1: GT_EB(1, 0, 0, 0); break;
+            case 2: GT_EB(2, 0, 0, 0); break;
+            case 4: GT_EB(4, 0, 0, 0); break;
+            case 8: GT_EB(8, 0, 0, 0); break;
+            default: GT_EB(16, 0, 0, 0); break;
+        }
+    }
+#undef GT_EB
     GT_LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,382 @@
+// Location-sensitive attention energies, forward and backward, for the reference's default
+// dimensions (attention_dim 128, 32 location filters, kernel 31) on the matrix cores.
+//
+// Per workgroup (batch row b, 32 encoder positions) every contraction of the step is a small GEMM
+// on v_mfma_f32_16x16x4_f32 (exact fp32, same rate as the fp32 VALU peak but ~1000x fewer LDS
+// operand reads than a scalar MAC loop, which is what bounded the VALU version):
+//   G1 conv   : locf[32 x 32]   = im2col(window)[32 x 62] . Wc^T[62 x 32]
+//   G2 dense  : s[32 x 128]     = locf[32 x 32] . Wd^T[32 x 128]          (+ q + pm, tanh, .v)
+//   G3        : dlocf[32 x 32]  = ds[32 x 128] . Wd[128 x 32]
+//   G4        : dWd[128 x 32]   = ds^T[128 x 32] . locf[32 x 32]
+//   G5        : dWc[32 x 62]    = dlocf^T[32 x 32] . im2col(window)[32 x 62]
+//   G6        : g[32 x 62]      = dlocf[32 x 32] . Wc[32 x 62]   (then d window = diagonal sums of g)
+// Operand fragments are read from LDS as float4 along k where the operand is k-contiguous (the four
+// MFMAs of a 16-wide k-step then take elements j=0..3, i.e. k = 16*s + 4*(lane>>4) + j for BOTH
+// operands) and as four ds_read_b32 otherwise; row strides are chosen so that every such read is
+// bank-conflict free (see the LD* constants).
+#include "common.h"
+
+namespace {
+
+constexpr int CT = 32, A = 128, F = 32, KC = 31, KK = 2 * KC;   // KK = 62 (c,k) pairs
+constexpr int LDC = 68;    // Wc rows [f][kk], zero padded to 64 (+4: 4*68 % 32 == 16)
+constexpr int LDD = 36;    // Wd rows [d][f]
+constexpr int LDL = 36;    // locf / dlocf rows [tl][f]
+constexpr int LDS_ = 132;  // ds rows [tl][d]
+constexpr int LDG = 66;    // g rows [tl][kk]
+constexpr int WL = 64;     // window row length (32 + 30 used)
+
+struct SharedM {
+    alignas(16) float wc[F * LDC];
+    alignas(16) float wd[A * LDD];
+    alignas(16) float locf[CT * LDL];
+    alignas(16) float dlocf[CT * LDL];
+    alignas(16) float ds[CT * LDS_];
+    alignas(16) float g[CT * LDG];
+    float win[2][WL];
+    float q[A];
+    float v[A];
+    float de[CT];
+    float epart[4][CT];
+    float red[16];
+};
+
+__device__ __forceinline__ f32x4 mfma4(const float4& a, const float4& b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, c, 0, 0, 0);
+    return c;
+}
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// four strided scalars as one fragment
+__device__ __forceinline__ float4 ld4s(const float* p, int stride) {
+    return make_float4(p[0], p[stride], p[2 * stride], p[3 * stride]);
+}
+
+__device__ __forceinline__ void stage_common(SharedM& S, const GtAttnDims& d, const float* Wc, const float* Wd,
+                                             const float* v, const float* w_prev, const float* w_cum, int b, int t0) {
+    for (int i = threadIdx.x; i < F * LDC; i += 256) {
+        const int f = i / LDC, kk = i - f * LDC;
+        S.wc[i] = kk < KK ? Wc[f * KK + kk] : 0.f;
+    }
+    for (int i = threadIdx.x; i < A * F; i += 256) S.wd[(i >> 5) * LDD + (i & 31)] = Wd[i];
+    if (threadIdx.x < A) S.v[threadIdx.x] = v[threadIdx.x];
+    if (threadIdx.x < 2 * WL) {
+        const int c = threadIdx.x / WL, p = threadIdx.x - c * WL;
+        const int t = t0 + p - (KC - 1) / 2;
+        const float* src = c == 0 ? w_prev : w_cum;
+        S.win[c][p] = (p < CT + KC - 1 && t >= 0 && t < d.Ti) ? src[(long)b * d.Ti + t] : 0.f;
+    }
+}
+
+// im2col element (tl, kk) of the window; kk >= 62 is multiplied by zero weights
+__device__ __forceinline__ float im2col(const SharedM& S, int tl, int kk) {
+    kk = min(kk, KK - 1);
+    const int c = kk >= KC ? 1 : 0;
+    return S.win[c][tl + kk - c * KC];
+}
+
+// G1: wave w computes the 16x16 tile (mt = w>>1, nt = w&1) of locf and stores it to LDS.
+__device__ __forceinline__ void conv_tile(SharedM& S, int wave, int lane) {
+    const int mt = wave >> 1, nt = wave & 1;
+    const int r = lane & 15, kq = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const int k0 = 16 * s4 + 4 * kq;
+        const float4 a = make_float4(im2col(S, 16 * mt + r, k0), im2col(S, 16 * mt + r, k0 + 1),
+                                     im2col(S, 16 * mt + r, k0 + 2), im2col(S, 16 * mt + r, k0 + 3));
+        const float4 bb = ld4(&S.wc[(16 * nt + r) * LDC + k0]);
+        acc = mfma4(a, bb, acc);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) S.locf[(16 * mt + 4 * kq + e) * LDL + 16 * nt + r] = acc[e];
+}
+
+// G2: wave w owns attention channels [32w, 32w+32): tiles (mt, nl) -> acc[mt][nl]
+__device__ __forceinline__ void dense_tiles(const SharedM& S, int wave, int lane, f32x4 (&acc)[2][2]) {
+    const int r = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nl = 0; nl < 2; ++nl) acc[mt][nl] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s4 = 0; s4 < 2; ++s4) {
+        const int k0 = 16 * s4 + 4 * kq;
+        float4 a[2], bb[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) a[mt] = ld4(&S.locf[(16 * mt + r) * LDL + k0]);
+#pragma unroll
+        for (int nl = 0; nl < 2; ++nl) bb[nl] = ld4(&S.wd[(32 * wave + 16 * nl + r) * LDD + k0]);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nl = 0; nl < 2; ++nl) acc[mt][nl] = mfma4(a[mt], bb[nl], acc[mt][nl]);
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_energies_fwd_mfma(GtAttnDims d, GtSlabs qpart, const float* w_prev,
+                                                              const float* w_cum, const float* pm, const float* Wc,
+                                                              const float* Wd, const float* v, const int* lengths,
+                                                              float* q_out, float* energies) {
+    __shared__ SharedM S;
+    const int b = blockIdx.y, t0 = blockIdx.x * CT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    // processed-memory values in accumulator layout, issued before anything else
+    float pmv[2][2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nl = 0; nl < 2; ++nl)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int t = t0 + 16 * mt + 4 * kq + e;
+                pmv[mt][nl][e] = t < d.Ti ? pm[((long)b * d.Ti + t) * A + 32 * wave + 16 * nl + r] : 0.f;
+            }
+    stage_common(S, d, Wc, Wd, v, w_prev, w_cum, b, t0);
+    if (threadIdx.x < A) {
+        const float qv = slab_sum(qpart.p, qpart.n, qpart.slab_stride, (long)b * qpart.ld + threadIdx.x);
+        S.q[threadIdx.x] = qv;
+        if (blockIdx.x == 0 && q_out != nullptr) q_out[(long)b * A + threadIdx.x] = qv;
+    }
+    __syncthreads();
+    conv_tile(S, wave, lane);
+    __syncthreads();
+    f32x4 acc[2][2];
+    dense_tiles(S, wave, lane, acc);
+    // epilogue: e[tl] += sum_d v[d] * tanh(s + q[d] + pm)
+    float ep[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float sum = 0.f;
+#pragma unroll
+            for (int nl = 0; nl < 2; ++nl) {
+                const int dd = 32 * wave + 16 * nl + r;
+                sum += S.v[dd] * tanhf(acc[mt][nl][e] + S.q[dd] + pmv[mt][nl][e]);
+            }
+            sum += __shfl_xor(sum, 1, 64);
+            sum += __shfl_xor(sum, 2, 64);
+            sum += __shfl_xor(sum, 4, 64);
+            sum += __shfl_xor(sum, 8, 64);
+            ep[mt][e] = sum;
+        }
+    if (r == 0) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) S.epart[wave][16 * mt + 4 * kq + e] = ep[mt][e];
+    }
+    __syncthreads();
+    if (threadIdx.x < CT) {
+        const int t = t0 + threadIdx.x;
+        if (t < d.Ti) {
+            float e = (S.epart[0][threadIdx.x] + S.epart[1][threadIdx.x]) + (S.epart[2][threadIdx.x] + S.epart[3][threadIdx.x]);
+            if (lengths != nullptr && t >= lengths[b]) e = -INFINITY;
+            energies[(long)b * d.Ti + t] = e;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_energies_bwd_mfma(GtAttnDims d, const float* dw, const float* w,
+                                                              const float* q, const float* w_prev, const float* w_cum,
+                                                              const float* pm, const float* Wc, const float* Wd,
+                                                              const float* v, float* dq, long ld_dq, float* dpm,
+                                                              float* dwcat_out, float* acc_slabs) {
+    __shared__ SharedM S;
+    const int b = blockIdx.y, t0 = blockIdx.x * CT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    constexpr int PER = A + A * F + F * KK;
+    float* acc_wg = acc_slabs + ((long)b * gridDim.x + blockIdx.x) * PER;
+    // long-latency global loads first: pm and the dpm accumulator in accumulator layout
+    float pmv[2][2][4], dpmv[2][2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nl = 0; nl < 2; ++nl)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int t = t0 + 16 * mt + 4 * kq + e;
+                const long pi = ((long)b * d.Ti + t) * A + 32 * wave + 16 * nl + r;
+                pmv[mt][nl][e] = t < d.Ti ? pm[pi] : 0.f;
+                dpmv[mt][nl][e] = t < d.Ti ? dpm[pi] : 0.f;
+            }
+    stage_common(S, d, Wc, Wd, v, w_prev, w_cum, b, t0);
+    if (threadIdx.x < A) S.q[threadIdx.x] = q[(long)b * A + threadIdx.x];
+    // softmax backward: de = w * (dw - sum_t w*dw)
+    float part = 0.f;
+    for (int t = threadIdx.x; t < d.Ti; t += 256) part += w[(long)b * d.Ti + t] * dw[(long)b * d.Ti + t];
+    const float dot = block_sum(part, S.red);
+    if (threadIdx.x < CT) {
+        const int t = t0 + threadIdx.x;
+        S.de[threadIdx.x] = (t < d.Ti) ? w[(long)b * d.Ti + t] * (dw[(long)b * d.Ti + t] - dot) : 0.f;
+    }
+    __syncthreads();
+    conv_tile(S, wave, lane);
+    __syncthreads();
+    f32x4 acc[2][2];
+    dense_tiles(S, wave, lane, acc);
+    // ds = de * v * (1 - u^2); dq, dv column sums; dpm += ds; ds -> LDS
+    float dqs[2] = {0.f, 0.f}, dvs[2] = {0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nl = 0; nl < 2; ++nl) {
+            const int dd = 32 * wave + 16 * nl + r;
+            const float qd = S.q[dd], vd = S.v[dd];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int tl = 16 * mt + 4 * kq + e;
+                float dsv = 0.f;
+                if (t0 + tl < d.Ti) {
+                    const float u = tanhf(acc[mt][nl][e] + qd + pmv[mt][nl][e]);
+                    const float de = S.de[tl];
+                    dsv = de * vd * (1.f - u * u);
+                    dvs[nl] += de * u;
+                    dqs[nl] += dsv;
+                    dpm[((long)b * d.Ti + t0 + tl) * A + dd] = dpmv[mt][nl][e] + dsv;
+                }
+                S.ds[tl * LDS_ + dd] = dsv;
+            }
+        }
+#pragma unroll
+    for (int nl = 0; nl < 2; ++nl) {
+        dqs[nl] += __shfl_xor(dqs[nl], 16, 64);
+        dqs[nl] += __shfl_xor(dqs[nl], 32, 64);
+        dvs[nl] += __shfl_xor(dvs[nl], 16, 64);
+        dvs[nl] += __shfl_xor(dvs[nl], 32, 64);
+        if (kq == 0) {
+            const int dd = 32 * wave + 16 * nl + r;
+            atomicAdd(&dq[(long)b * ld_dq + dd], dqs[nl]);
+            acc_wg[dd] += dvs[nl];
+        }
+    }
+    __syncthreads();                                   // ds complete
+
+    // G3: dlocf tile (mt = wave>>1, nt = wave&1) = ds[32x128] . Wd[128x32]
+    {
+        const int mt = wave >> 1, nt = wave & 1;
+        f32x4 c3 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s4 = 0; s4 < 8; ++s4) {
+            const int k0 = 16 * s4 + 4 * kq;
+            const float4 a = ld4(&S.ds[(16 * mt + r) * LDS_ + k0]);
+            const float4 bb = ld4s(&S.wd[k0 * LDD + 16 * nt + r], LDD);
+            c3 = mfma4(a, bb, c3);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) S.dlocf[(16 * mt + 4 * kq + e) * LDL + 16 * nt + r] = c3[e];
+    }
+    // G4: dWd rows [32w, 32w+32) x 32 filters = ds^T . locf ; read-modify-write of this workgroup's slab
+    {
+        float* acc_wd = acc_wg + A;
+        f32x4 c4[2][2];
+        float old[2][2][4];
+#pragma unroll
+        for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                c4[ml][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    old[ml][nt][e] = acc_wd[(32 * wave + 16 * ml + 4 * kq + e) * F + 16 * nt + r];
+            }
+#pragma unroll
+        for (int s4 = 0; s4 < 2; ++s4) {
+            const int k0 = 16 * s4 + 4 * kq;     // tl
+            float4 a[2], bb[2];
+#pragma unroll
+            for (int ml = 0; ml < 2; ++ml) a[ml] = ld4s(&S.ds[k0 * LDS_ + 32 * wave + 16 * ml + r], LDS_);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) bb[nt] = ld4s(&S.locf[k0 * LDL + 16 * nt + r], LDL);
+#pragma unroll
+            for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) c4[ml][nt] = mfma4(a[ml], bb[nt], c4[ml][nt]);
+        }
+#pragma unroll
+        for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc_wd[(32 * wave + 16 * ml + 4 * kq + e) * F + 16 * nt + r] = old[ml][nt][e] + c4[ml][nt][e];
+    }
+    __syncthreads();                                   // dlocf complete
+    // G5: dWc[f][kk] += dlocf^T . im2col ; wave w: filter tile mt = w>>1, kk tiles nt in {2*(w&1), 2*(w&1)+1}
+    // G6: g[tl][kk]  = dlocf . Wc       ; same tile assignment (rows = tl)
+    {
+        float* acc_wc = acc_wg + A + A * F;
+        const int mt = wave >> 1;
+        f32x4 c5[2], c6[2];
+        float old[2][4];
+#pragma unroll
+        for (int nl = 0; nl < 2; ++nl) {
+            c5[nl] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            c6[nl] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int kk = 16 * (2 * (wave & 1) + nl) + r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) old[nl][e] = kk < KK ? acc_wc[(16 * mt + 4 * kq + e) * KK + kk] : 0.f;
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 2; ++s4) {
+            const int k0 = 16 * s4 + 4 * kq;
+            const float4 a5 = ld4s(&S.dlocf[k0 * LDL + 16 * mt + r], LDL);        // A[row=f][k=tl]
+            const float4 a6 = ld4(&S.dlocf[(16 * mt + r) * LDL + k0]);            // A[row=tl][k=f]
+#pragma unroll
+            for (int nl = 0; nl < 2; ++nl) {
+                const int kk = 16 * (2 * (wave & 1) + nl) + r;
+                const float4 b5 = make_float4(im2col(S, k0, kk), im2col(S, k0 + 1, kk), im2col(S, k0 + 2, kk),
+                                              im2col(S, k0 + 3, kk));            // B[k=tl][col=kk]
+                const float4 b6 = ld4s(&S.wc[k0 * LDC + kk], LDC);               // B[k=f][col=kk]
+                c5[nl] = mfma4(a5, b5, c5[nl]);
+                c6[nl] = mfma4(a6, b6, c6[nl]);
+            }
+        }
+#pragma unroll
+        for (int nl = 0; nl < 2; ++nl) {
+            const int kk = 16 * (2 * (wave & 1) + nl) + r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (kk < KK) acc_wc[(16 * mt + 4 * kq + e) * KK + kk] = old[nl][e] + c5[nl][e];
+                S.g[(16 * mt + 4 * kq + e) * LDG + kk] = c6[nl][e];
+            }
+        }
+    }
+    __syncthreads();                                   // g complete
+    // d[w_prev; w_cum][p] = sum_k g[p-k][(c,k)]  (p = window position, t = t0 + p - 15)
+    if (threadIdx.x < 2 * (CT + KC - 1)) {
+        const int c = threadIdx.x / (CT + KC - 1), p = threadIdx.x - c * (CT + KC - 1);
+        const int t = t0 + p - (KC - 1) / 2;
+        if (t >= 0 && t < d.Ti) {
+            float a = 0.f;
+            const int klo = max(0, p - (CT - 1)), khi = min(KC - 1, p);
+            for (int k = klo; k <= khi; ++k) a += S.g[(p - k) * LDG + c * KC + k];
+            atomicAdd(&dwcat_out[(long)c * d.B * d.Ti + (long)b * d.Ti + t], a);
+        }
+    }
+}
+
+}  // namespace
+
+// entry points used by attention.hip when the dimensions match (128, 32, 31)
+void gt_launch_attn_energies_fwd_mfma(GtAttnDims d, GtSlabs qpart, const float* w_prev, const float* w_cum,
+                                      const float* pm, const float* Wc, const float* Wd, const float* v,
+                                      const int* lengths, float* q_out, float* energies, hipStream_t st) {
+    dim3 grid(cdiv(d.Ti, CT), d.B);
+    hipLaunchKernelGGL(attn_energies_fwd_mfma, grid, dim3(256), 0, st, d, qpart, w_prev, w_cum, pm, Wc, Wd, v, lengths,
+                       q_out, energies);
+}
+
+void gt_launch_attn_energies_bwd_mfma(GtAttnDims d, const float* dw, const float* w, const float* q,
+                                      const float* w_prev, const float* w_cum, const float* pm, const float* Wc,
+                                      const float* Wd, const float* v, float* dq, long ld_dq, float* dpm,
+                                      float* dwcat_out, float* acc, hipStream_t st) {
+    dim3 grid(cdiv(d.Ti, CT), d.B);
+    hipLaunchKernelGGL(attn_energies_bwd_mfma, grid, dim3(256), 0, st, d, dw, w, q, w_prev, w_cum, pm, Wc, Wd, v, dq,
+                       ld_dq, dpm, dwcat_out, acc);
+}

@@ -35,41 +35,103 @@ __global__ __launch_bounds__(256) void pack_rec_weight_kernel(const float* W, lo
     }
 }
 
+// Activation chunks (MT*16 rows x 128 k) are staged through LDS once per workgroup with fully
+// coalesced 512-byte row segments and shared by the four waves (each wave owns 16 gate columns), so
+// a workgroup reads every activation element from L2 exactly once; the next chunk's global loads are
+// issued into registers before the current chunk's MFMAs.  The wave's weight fragments (1 KiB per
+// 16-wide k-block, lane-linear) stream straight into VGPRs, one chunk ahead.
+constexpr int REC_CK = 8;                 // k-blocks (of 16) per LDS chunk
+constexpr int REC_LD = REC_CK * 16 + 4;   // padded LDS row: conflict-free ds_read_b128 / ds_write_b128
+
+template <int MT>
+struct RecChunk {                         // per-thread registers of one activation chunk
+    static constexpr int NV = MT * 16 * REC_CK * 16 / 4 / 256;   // float4 per thread (MT=4: 8)
+    float4 v[NV];
+    __device__ __forceinline__ void load(const float* X, long ldx, int kb, int kb1, int tid) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f / (REC_CK * 4), c4 = f % (REC_CK * 4);
+            const int kblk = kb + (c4 >> 2);
+            v[i] = (kblk < kb1) ? *reinterpret_cast<const float4*>(X + (long)row * ldx + (long)kb * 16 + 4 * c4)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __device__ __forceinline__ void store(float* S, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f / (REC_CK * 4), c4 = f % (REC_CK * 4);
+            *reinterpret_cast<float4*>(&S[row * REC_LD + 4 * c4]) = v[i];
+        }
+    }
+};
+
+struct RecW {                             // weight fragments of one chunk
+    float4 w[REC_CK];
+    __device__ __forceinline__ void load(const float4* wp, int kb, int kb1) {
+#pragma unroll
+        for (int u = 0; u < REC_CK; ++u) w[u] = (kb + u < kb1) ? wp[u * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+};
+
 template <int MT>
 __global__ __launch_bounds__(256) void rec_gemm_kernel(const float* __restrict__ X, long ldx,
                                                        const float* __restrict__ Wp,
                                                        float* __restrict__ part, int N, int KB, int KBS,
                                                        long xz, long wz, long pz, long ps) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nb = blockIdx.x * 4 + wave;
-    if (nb * 16 >= N) return;
-    const int s = blockIdx.y;
+    __shared__ __attribute__((aligned(16))) float Xs[MT * 16 * REC_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = blockIdx.y, z = blockIdx.z;
     const int kb0 = s * KBS;
     const int kb1 = min(KB, kb0 + KBS);
-    const int z = blockIdx.z;
+    int nb = blockIdx.x * 4 + wave;
+    const bool active = nb * 16 < N;      // inactive waves still help staging and join the barriers
+    if (!active) nb = 0;
     const float4* wp = reinterpret_cast<const float4*>(Wp + (long)z * wz) + ((long)nb * KB + kb0) * 64 + lane;
-    const float* xp = X + (long)z * xz + (long)(lane & 15) * ldx + (long)kb0 * 16 + 4 * (lane >> 4);
+    const float* Xz = X + (long)z * xz;
 
     f32x4 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll 4
-    for (int kb = kb0; kb < kb1; ++kb) {
-        const float4 b = *wp;
-        float4 a[MT];
+    RecChunk<MT> xc;
+    RecW wa, wb;
+    xc.load(Xz, ldx, kb0, kb1, tid);
+    wa.load(wp, kb0, kb1);
+    const float* xs = Xs + (lane & 15) * REC_LD + 4 * (lane >> 4);
+    // one chunk: publish the staged activations, prefetch the next chunk (activations + weights),
+    // run the chunk's MFMAs.  `cur`/`nxt` are bound statically (two calls per loop trip) so that the
+    // register arrays are never indexed at run time.
+    auto chunk = [&](const RecW& cur, RecW& nxt, int kb) __attribute__((always_inline)) {
+        xc.store(Xs, tid);
+        __syncthreads();
+        const int kn = kb + REC_CK;
+        if (kn < kb1) xc.load(Xz, ldx, kn, kb1, tid);
+        nxt.load(wp + (long)REC_CK * 64, kn, kb1);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float4*>(xp + (long)mt * 16 * ldx);
-        wp += 64;
-        xp += 16;
+        for (int u = 0; u < REC_CK; ++u) {
+            float4 a[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b.x, acc[mt], 0, 0, 0);
-            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b.y, acc[mt], 0, 0, 0);
-            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, b.z, acc[mt], 0, 0, 0);
-            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b.w, acc[mt], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float4*>(xs + mt * 16 * REC_LD + u * 16);
+            const float4 b = cur.w[u];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b.x, acc[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b.y, acc[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, b.z, acc[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b.w, acc[mt], 0, 0, 0);
         }
+        __syncthreads();
+        wp += (long)REC_CK * 64;
+    };
+    for (int kb = kb0; kb < kb1; kb += 2 * REC_CK) {
+        chunk(wa, wb, kb);
+        if (kb + REC_CK < kb1) chunk(wb, wa, kb + REC_CK);
     }
+    if (!active) return;
     // C/D map of the 16x16 MFMA: n = lane&15, m = 4*(lane>>4) + reg
     float* out = part + (long)z * pz + (long)s * ps + nb * 16 + (lane & 15);
 #pragma unroll
@@ -90,44 +152,85 @@ struct CellFwd {
     int B, H;
 };
 
+// V = hidden units per thread (4: float4 accesses when every pointer / leading dimension allows it)
+template <int V>
 __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(CellFwd a) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)a.B * a.H) return;
-    const int b = (int)(idx / a.H), j = (int)(idx - (long)b * a.H);
+    const long vid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int HV = a.H / V;
+    if (vid >= (long)a.B * HV) return;
+    const int b = (int)(vid / HV), j = (int)(vid - (long)b * HV) * V;
+    const long idx = (long)b * a.H + j;
     const bool act = (a.active == nullptr) || (a.active[b] != 0);
-    float gi[4];
+    float gi[4][V];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        float v = (a.pre != nullptr) ? a.pre[(long)b * a.ld_pre + q * a.H + j] : 0.f;
-        v += slab_sum(a.part.p, a.part.n, a.part.slab_stride, (long)b * a.part.ld + q * a.H + j);
-        gi[q] = v;
+        const long po = (long)b * a.part.ld + q * a.H + j;
+#pragma unroll
+        for (int e = 0; e < V; ++e) gi[q][e] = 0.f;
+        if (a.pre != nullptr) {
+            if (V == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(a.pre + (long)b * a.ld_pre + q * a.H + j);
+                gi[q][0] = t.x; gi[q][1 % V] = t.y; gi[q][2 % V] = t.z; gi[q][3 % V] = t.w;
+            } else {
+                gi[q][0] = a.pre[(long)b * a.ld_pre + q * a.H + j];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {                 // all slab loads of a gate are issued together
+            if (s < a.part.n) {
+                const float* p = a.part.p + (long)s * a.part.slab_stride + po;
+                if (V == 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(p);
+                    gi[q][0] += t.x; gi[q][1 % V] += t.y; gi[q][2 % V] += t.z; gi[q][3 % V] += t.w;
+                } else {
+                    gi[q][0] += p[0];
+                }
+            }
+        }
     }
-    const float i = sigmoidf_(gi[0]), f = sigmoidf_(gi[1]), g = tanhf(gi[2]), o = sigmoidf_(gi[3]);
-    const float cp = a.c_prev[idx];
-    float c = f * cp + i * g;
-    float h = o * tanhf(c);
-    float hout;
-    if (act) {
-        hout = h;
-        if (a.keep != nullptr) hout = h * (a.keep[idx] ? a.scale : 0.f);
+    float cp[V], cn[V], hout[V], hcarry[V], gv[4][V];
+    unsigned char kp[V];
+    if (V == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(a.c_prev + idx);
+        cp[0] = t.x; cp[1 % V] = t.y; cp[2 % V] = t.z; cp[3 % V] = t.w;
+        if (a.keep != nullptr) {
+            const uchar4 k = *reinterpret_cast<const uchar4*>(a.keep + idx);
+            kp[0] = k.x; kp[1 % V] = k.y; kp[2 % V] = k.z; kp[3 % V] = k.w;
+        }
     } else {
-        // packed-sequence semantics: state passes through, the emitted output is zero
-        c = cp;
-        hout = 0.f;
+        cp[0] = a.c_prev[idx];
+        if (a.keep != nullptr) kp[0] = a.keep[idx];
     }
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        const float i = sigmoidf_(gi[0][e]), f = sigmoidf_(gi[1][e]), g = tanhf(gi[2][e]), o = sigmoidf_(gi[3][e]);
+        gv[0][e] = i; gv[1][e] = f; gv[2][e] = g; gv[3][e] = o;
+        float c = f * cp[e] + i * g;
+        const float h = o * tanhf(c);
+        if (act) {
+            hout[e] = (a.keep != nullptr) ? h * (kp[e] ? a.scale : 0.f) : h;
+            hcarry[e] = hout[e];
+        } else {
+            // packed-sequence semantics: state passes through, the emitted output is zero
+            c = cp[e];
+            hout[e] = 0.f;
+            hcarry[e] = (a.h_prev != nullptr) ? a.h_prev[(long)b * a.ld_hprev + j + e] : 0.f;
+        }
+        cn[e] = c;
+    }
+    auto put = [&](float* base, long off, const float (&vals)[V]) __attribute__((always_inline)) {
+        if (V == 4) *reinterpret_cast<float4*>(base + off) = make_float4(vals[0], vals[1 % V], vals[2 % V], vals[3 % V]);
+        else base[off] = vals[0];
+    };
     if (a.gates != nullptr) {
-        a.gates[(long)b * 4 * a.H + 0 * a.H + j] = i;
-        a.gates[(long)b * 4 * a.H + 1 * a.H + j] = f;
-        a.gates[(long)b * 4 * a.H + 2 * a.H + j] = g;
-        a.gates[(long)b * 4 * a.H + 3 * a.H + j] = o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) put(a.gates, (long)b * 4 * a.H + q * a.H + j, gv[q]);
     }
-    a.c_out[idx] = c;
-    // value carried to the next step: for inactive rows the previous hidden state
-    const float hcarry = act ? hout : (a.h_prev != nullptr ? a.h_prev[(long)b * a.ld_hprev + j] : 0.f);
-    if (a.h_raw != nullptr) a.h_raw[idx] = hout;          // emitted output (zero when inactive)
-    if (a.h0 != nullptr) a.h0[(long)b * a.ld0 + j] = hcarry;
-    if (a.h1 != nullptr) a.h1[(long)b * a.ld1 + j] = hcarry;
-    if (a.h2 != nullptr) a.h2[(long)b * a.ld2 + j] = hcarry;
+    put(a.c_out, idx, cn);
+    if (a.h_raw != nullptr) put(a.h_raw, idx, hout);          // emitted output (zero when inactive)
+    if (a.h0 != nullptr) put(a.h0, (long)b * a.ld0 + j, hcarry);
+    if (a.h1 != nullptr) put(a.h1, (long)b * a.ld1 + j, hcarry);
+    if (a.h2 != nullptr) put(a.h2, (long)b * a.ld2 + j, hcarry);
 }
 
 struct CellBwd {
@@ -141,41 +244,92 @@ struct CellBwd {
     int B, H;
 };
 
+template <int V>
+__device__ __forceinline__ void vload(const float* p, float (&o)[V]) {
+    if (V == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        o[0] = t.x; o[1 % V] = t.y; o[2 % V] = t.z; o[3 % V] = t.w;
+    } else {
+        o[0] = p[0];
+    }
+}
+template <int V>
+__device__ __forceinline__ void vstore(float* p, const float (&o)[V]) {
+    if (V == 4) *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1 % V], o[2 % V], o[3 % V]);
+    else p[0] = o[0];
+}
+template <int V>
+__device__ __forceinline__ void slab_acc(const GtSlabs& sl, long off, float (&o)[V]) {
+    if (sl.p == nullptr) return;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        if (s < sl.n) {
+            float t[V];
+            vload<V>(sl.p + (long)s * sl.slab_stride + off, t);
+#pragma unroll
+            for (int e = 0; e < V; ++e) o[e] += t[e];
+        }
+    }
+}
+
+template <int V>
 __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(CellBwd a) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)a.B * a.H) return;
-    const int b = (int)(idx / a.H), j = (int)(idx - (long)b * a.H);
+    const long vid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int HV = a.H / V;
+    if (vid >= (long)a.B * HV) return;
+    const int b = (int)(vid / HV), j = (int)(vid - (long)b * HV) * V;
+    const long idx = (long)b * a.H + j;
     // dh_carry: gradient w.r.t. the hidden state carried into later steps (slab sources),
     // dh_out  : gradient w.r.t. the emitted output of this step (direct source).
-    float dh_carry = 0.f;
-    if (a.da.p != nullptr) dh_carry += slab_sum(a.da.p, a.da.n, a.da.slab_stride, (long)b * a.da.ld + j);
-    if (a.db.p != nullptr) dh_carry += slab_sum(a.db.p, a.db.n, a.db.slab_stride, (long)b * a.db.ld + j);
-    if (a.dc.p != nullptr) dh_carry += slab_sum(a.dc.p, a.dc.n, a.dc.slab_stride, (long)b * a.dc.ld + j);
-    const float dh_out = (a.dh_direct != nullptr) ? a.dh_direct[(long)b * a.ld_direct + j] : 0.f;
-    const float dcn = (a.dc_next != nullptr) ? a.dc_next[idx] : 0.f;
+    float dh_carry[V], dh_out[V], dcn[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { dh_carry[e] = 0.f; dh_out[e] = 0.f; dcn[e] = 0.f; }
+    slab_acc<V>(a.da, (long)b * a.da.ld + j, dh_carry);
+    slab_acc<V>(a.db, (long)b * a.db.ld + j, dh_carry);
+    slab_acc<V>(a.dc, (long)b * a.dc.ld + j, dh_carry);
+    if (a.dh_direct != nullptr) vload<V>(a.dh_direct + (long)b * a.ld_direct + j, dh_out);
+    if (a.dc_next != nullptr) vload<V>(a.dc_next + idx, dcn);
     const bool act = (a.active == nullptr) || (a.active[b] != 0);
-    float* dg = a.dgates + (long)b * 4 * a.H;
+    float* dg = a.dgates + (long)b * 4 * a.H + j;
+    float dgi[V], dgf[V], dgg[V], dgo[V], dcp[V], dpass[V];
     if (!act) {
         // inactive packed-sequence row: state passed through untouched, output was zero
-        dg[0 * a.H + j] = 0.f; dg[1 * a.H + j] = 0.f; dg[2 * a.H + j] = 0.f; dg[3 * a.H + j] = 0.f;
-        a.dc_prev[idx] = dcn;
-        if (a.dh_pass != nullptr) a.dh_pass[idx] = dh_carry;
-        return;
+#pragma unroll
+        for (int e = 0; e < V; ++e) { dgi[e] = dgf[e] = dgg[e] = dgo[e] = 0.f; dcp[e] = dcn[e]; dpass[e] = dh_carry[e]; }
+    } else {
+        float gi[V], gf[V], gg[V], go[V], cn[V], cp[V];
+        const float* gt = a.gates + (long)b * 4 * a.H + j;
+        vload<V>(gt, gi); vload<V>(gt + a.H, gf); vload<V>(gt + 2 * a.H, gg); vload<V>(gt + 3 * a.H, go);
+        vload<V>(a.c_new + idx, cn);
+        vload<V>(a.c_prev + idx, cp);
+        unsigned char kp[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) kp[e] = 1;
+        if (a.keep != nullptr) {
+            if (V == 4) {
+                const uchar4 k = *reinterpret_cast<const uchar4*>(a.keep + idx);
+                kp[0] = k.x; kp[1 % V] = k.y; kp[2 % V] = k.z; kp[3 % V] = k.w;
+            } else {
+                kp[0] = a.keep[idx];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float dh = dh_carry[e] + dh_out[e];
+            if (a.keep != nullptr) dh *= (kp[e] ? a.scale : 0.f);
+            const float tc = tanhf(cn[e]);
+            const float dcell = dcn[e] + dh * go[e] * (1.f - tc * tc);
+            dgi[e] = dcell * gg[e] * gi[e] * (1.f - gi[e]);
+            dgf[e] = dcell * cp[e] * gf[e] * (1.f - gf[e]);
+            dgg[e] = dcell * gi[e] * (1.f - gg[e] * gg[e]);
+            dgo[e] = dh * tc * go[e] * (1.f - go[e]);
+            dcp[e] = dcell * gf[e];
+            dpass[e] = 0.f;
+        }
     }
-    float dh = dh_carry + dh_out;
-    if (a.keep != nullptr) dh *= (a.keep[idx] ? a.scale : 0.f);
-    const float* gt = a.gates + (long)b * 4 * a.H;
-    const float i = gt[0 * a.H + j], f = gt[1 * a.H + j], g = gt[2 * a.H + j], o = gt[3 * a.H + j];
-    const float tc = tanhf(a.c_new[idx]);
-    const float cp = a.c_prev[idx];
-    const float d_o = dh * tc;
-    const float dcell = dcn + dh * o * (1.f - tc * tc);
-    dg[0 * a.H + j] = dcell * g * i * (1.f - i);
-    dg[1 * a.H + j] = dcell * cp * f * (1.f - f);
-    dg[2 * a.H + j] = dcell * i * (1.f - g * g);
-    dg[3 * a.H + j] = d_o * o * (1.f - o);
-    a.dc_prev[idx] = dcell * f;
-    if (a.dh_pass != nullptr) a.dh_pass[idx] = 0.f;
+    vstore<V>(dg, dgi); vstore<V>(dg + a.H, dgf); vstore<V>(dg + 2 * a.H, dgg); vstore<V>(dg + 3 * a.H, dgo);
+    vstore<V>(a.dc_prev + idx, dcp);
+    if (a.dh_pass != nullptr) vstore<V>(a.dh_pass + idx, dpass);
 }
 
 }  // namespace
@@ -237,13 +391,21 @@ extern "C" int gt_lstm_cell_fwd(GtSlabs part, const float* pre, int64_t ld_pre, 
                                 int32_t H, void* stream) {
     GT_REQUIRE(part.p && c_prev && c_out && B > 0 && H > 0 && part.n >= 1, GT_E_ARG, "gt_lstm_cell_fwd: bad argument");
     GT_REQUIRE(p_drop >= 0.f && p_drop < 1.f, GT_E_ARG, "gt_lstm_cell_fwd: p_drop");
+    GT_REQUIRE(part.n <= 16, GT_E_LIMIT, "gt_lstm_cell_fwd: at most 16 slabs");
     CellFwd a;
     a.part = part; a.pre = pre; a.ld_pre = ld_pre; a.c_prev = c_prev; a.h_prev = h_prev; a.ld_hprev = ld_hprev;
     a.keep = keep; a.scale = 1.0f / (1.0f - p_drop); a.active = active; a.gates = gates; a.c_out = c_out;
     a.h_raw = h_raw; a.h0 = h0; a.ld0 = ld0; a.h1 = h1; a.ld1 = ld1; a.h2 = h2; a.ld2 = ld2; a.B = B; a.H = H;
     const long n = (long)B * H;
     GtProfScope prof(GT_FAM_CELL_FWD, 0.0, 4.0 * n * (4.0 * part.n + 4 + 1 + 4 + 1 + 3), (hipStream_t)stream);
-    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    auto ok4 = [](const void* p, int64_t ld) { return p == nullptr || (aligned16(p) && ld % 4 == 0); };
+    const bool vec = H % 4 == 0 && ok4(part.p, part.ld) && part.slab_stride % 4 == 0 && ok4(pre, ld_pre) && aligned16(c_prev) &&
+                     (keep == nullptr || (((uintptr_t)keep) & 3) == 0) && ok4(gates, 0) && aligned16(c_out) && ok4(h_raw, 0) &&
+                     ok4(h0, ld0) && ok4(h1, ld1) && ok4(h2, ld2);
+    if (vec)
+        hipLaunchKernelGGL((lstm_cell_fwd_kernel<4>), dim3((unsigned)cdiv64(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((lstm_cell_fwd_kernel<1>), dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, a);
     GT_LAUNCH_CHECK();
     return 0;
 }
@@ -260,7 +422,16 @@ extern "C" int gt_lstm_cell_bwd(GtSlabs dh_a, GtSlabs dh_b, GtSlabs dh_c, const 
     a.active = active; a.dgates = dgates; a.dc_prev = dc_prev; a.dh_pass = dh_pass; a.B = B; a.H = H;
     const long n = (long)B * H;
     GtProfScope prof(GT_FAM_CELL_BWD, 0.0, 4.0 * n * (dh_a.n + dh_b.n + dh_c.n + 1 + 1 + 4 + 2 + 4 + 1), (hipStream_t)stream);
-    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    auto ok4 = [](const void* p, int64_t ld) { return p == nullptr || (aligned16(p) && ld % 4 == 0); };
+    auto sl4 = [&](const GtSlabs& sl) { return sl.p == nullptr || (aligned16(sl.p) && sl.ld % 4 == 0 && sl.slab_stride % 4 == 0); };
+    const bool vec = H % 4 == 0 && sl4(dh_a) && sl4(dh_b) && sl4(dh_c) && ok4(dh_direct, ld_direct) && ok4(dc_next, 0) &&
+                     aligned16(gates) && aligned16(c_new) && aligned16(c_prev) && (keep == nullptr || (((uintptr_t)keep) & 3) == 0) &&
+                     aligned16(dgates) && aligned16(dc_prev) && ok4(dh_pass, 0);
+    GT_REQUIRE(dh_a.n <= 16 && dh_b.n <= 16 && dh_c.n <= 16, GT_E_LIMIT, "gt_lstm_cell_bwd: at most 16 slabs per source");
+    if (vec)
+        hipLaunchKernelGGL((lstm_cell_bwd_kernel<4>), dim3((unsigned)cdiv64(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((lstm_cell_bwd_kernel<1>), dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, a);
     GT_LAUNCH_CHECK();
     return 0;
 }

@@ -23,7 +23,8 @@ from .ops import (ACT_NONE, ACT_RELU, ACT_TANH, IM2COL_K, IM2COL_R, KC, RC, Oper
 from ._lib import GtBiLstm, GtDecoderBwd, GtDecoderFwd, check, lib
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
-REC_SPLITS = 4          # K-splits of the per-step recurrent GEMMs: (4H/64) x 4 workgroups per launch
+import os as _os
+REC_SPLITS = int(_os.environ.get("GANTRON_REC_SPLITS", "4"))   # K-splits of the per-step recurrent GEMMs
 
 
 def _f32(*shape, device, zero=True):
@@ -39,6 +40,13 @@ def acc_add(dst, src):
     """dst += src through the axpby kernel (dst, src contiguous, same numel)."""
     assert dst.is_contiguous() and src.is_contiguous() and dst.numel() == src.numel()
     call('gt_axpby', dst, 1.0, src, 1.0, dst, dst.numel())
+
+
+def rec_splits(N, K):
+    """K-splits of a per-step recurrent GEMM: enough that (N/64) x splits covers the 256 CUs, not more
+    (every extra slab is 4*Bp*N bytes the cell kernel has to read back)."""
+    want = max(REC_SPLITS, -(-256 // max(N // 64, 1)))
+    return ops.pick_splits(K, min(want, 16))
 
 
 def pack_rec(W2d, N, n_valid, K, transposed=False):
@@ -248,7 +256,7 @@ class GeneratorEngine:
         d = GtDecoderFwd()
         d.B, d.Bp, d.Ti, d.To, d.E, d.ldE, d.P, d.Ha, d.Hd, d.A, d.Apad, d.F, d.Kc = \
             B, Bp, Ti, To, E, E, Pd, Ha, Hd, A, Apad, self.F, self.Kc
-        d.S1, d.S2, d.Sq = ops.pick_splits(K1, REC_SPLITS), ops.pick_splits(K2, REC_SPLITS), ops.pick_splits(Ha, 16)
+        d.S1, d.S2, d.Sq = rec_splits(4 * Ha, K1), rec_splits(4 * Hd, K2), ops.pick_splits(Ha, 16)
         d.p_att = hp.p_attention_dropout if training else 0.0
         d.p_dec = hp.p_decoder_dropout if training else 0.0
         keep_t = dict(W1p=pack_rec(W1cat, 4 * Ha, 4 * Ha, K1), W2p=pack_rec(W2cat, 4 * Hd, 4 * Hd, K2),
@@ -369,7 +377,7 @@ class GeneratorEngine:
         b = GtDecoderBwd()
         b.B, b.Bp, b.Ti, b.To, b.E, b.ldE, b.P, b.Ha, b.Hd, b.A, b.Apad, b.F, b.Kc = \
             B, Bp, Ti, To, E, E, Pd, Ha, Hd, A, Apad, self.F, self.Kc
-        b.S1, b.S2, b.Sq = ops.pick_splits(4 * Ha, REC_SPLITS), ops.pick_splits(4 * Hd, REC_SPLITS), ops.pick_splits(A, 2)
+        b.S1, b.S2, b.Sq = rec_splits(N1pad, 4 * Ha), rec_splits(N2pad, 4 * Hd), ops.pick_splits(A, 2)
         b.N1pad, b.N2pad = N1pad, N2pad
         training = sv['training']
         b.p_att = hp.p_attention_dropout if training else 0.0
