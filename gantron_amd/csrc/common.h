@@ -89,7 +89,7 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 }
 
 // Counter-based uniform in [0,1): a 64-bit mix (splitmix64 finaliser) of (seed, counter); the
-// oracle/tests implement the identical integer recipe in numpy (tests/test_rng.py).
+// tests implement the identical integer recipe in numpy (tests/harness.py:u01).
 __host__ __device__ __forceinline__ uint32_t gt_hash32(uint64_t seed, uint64_t ctr) {
     uint64_t z = seed + 0x9E3779B97F4A7C15ull * (ctr + 1);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;

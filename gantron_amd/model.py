@@ -26,7 +26,7 @@ from .utils import to_gpu
 
 class DropoutSource:
     """Counter-based dropout masks / style noise (gt_keep_mask, gt_uniform): (seed, running offset).
-    The oracle reproduces the same stream on the CPU (tests/test_rng.py)."""
+    tests reproduce the same stream on the CPU (tests/harness.py:u01)."""
 
     def __init__(self, seed):
         self.seed, self.offset = int(seed) & 0xFFFFFFFFFFFFFFFF, 0
