@@ -16,8 +16,8 @@ void gt_launch_attn_energies_fwd_mfma(GtAttnDims d, GtSlabs qpart, const float* 
                                       const int* lengths, float* q_out, float* energies, hipStream_t st);
 void gt_launch_attn_energies_bwd_mfma(GtAttnDims d, const float* dw, const float* w, const float* q,
                                       const float* w_prev, const float* w_cum, const float* pm, const float* Wc,
-                                      const float* Wd, const float* v, float* dq, long ld_dq, float* dpm,
-                                      float* dwcat_out, float* acc, hipStream_t st);
+                                      const float* Wd, const float* v, const int* lengths, float* dq, long ld_dq,
+                                      float* dpm, float* dwcat_out, float* acc, hipStream_t st);
 
 namespace {
 
@@ -132,6 +132,10 @@ __global__ __launch_bounds__(256) void attn_energies_fwd_kernel(GtAttnDims dims,
     __shared__ Shared S;
     const Dims<CA, CF, CK> d(dims);
     const int b = blockIdx.y, t0 = blockIdx.x * CT;
+    if (lengths != nullptr && t0 >= lengths[b]) {      // chunk entirely in the padding: energies are -inf
+        if (threadIdx.x < CT && t0 + threadIdx.x < d.Ti) energies[(long)b * d.Ti + t0 + threadIdx.x] = -INFINITY;
+        return;
+    }
     const int G = CT / NIT;
     const int dd = threadIdx.x % d.A, g = threadIdx.x / d.A;
     // first long-latency global load issued before the LDS set-up; later ones one iteration ahead
@@ -202,9 +206,9 @@ __device__ __forceinline__ void softmax_row(const GtAttnDims& d, const float* en
 // wave streams float4 columns of a quarter of the rows (4 rows in flight), partial sums fold through LDS.
 template <bool VEC>
 __global__ __launch_bounds__(256) void attn_context_fwd_kernel(GtAttnDims d, const float* energies, const float* memory,
-                                                               long ld_mem, float* w_out, const float* cum_in,
-                                                               float* cum_out, float* c0, long ld0, float* c1, long ld1,
-                                                               float* c2, long ld2) {
+                                                               long ld_mem, const int* lengths, float* w_out,
+                                                               const float* cum_in, float* cum_out, float* c0, long ld0,
+                                                               float* c1, long ld1, float* c2, long ld2) {
     __shared__ float w[MAX_TI];
     __shared__ float red[16];
     __shared__ __attribute__((aligned(16))) float psum[4][256];
@@ -218,6 +222,8 @@ __global__ __launch_bounds__(256) void attn_context_fwd_kernel(GtAttnDims d, con
     }
     float c = 0.f;
     const int col = blockIdx.x * 256 + threadIdx.x;
+    // rows beyond the memory length have weight exactly 0 (energy -inf): never read them
+    const int Tv = lengths != nullptr ? min(lengths[b], d.Ti) : d.Ti;
     if (VEC) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int col4 = blockIdx.x * 256 + 4 * lane;
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(256) void attn_context_fwd_kernel(GtAttnDims d, con
         if (col4 < d.E) {
             const float* m = memory + (long)b * d.Ti * ld_mem + col4;
             int t = wave;
-            for (; t + 12 < d.Ti; t += 16) {
+            for (; t + 12 < Tv; t += 16) {
                 const float4 m0 = *reinterpret_cast<const float4*>(m + (long)t * ld_mem);
                 const float4 m1 = *reinterpret_cast<const float4*>(m + (long)(t + 4) * ld_mem);
                 const float4 m2 = *reinterpret_cast<const float4*>(m + (long)(t + 8) * ld_mem);
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(256) void attn_context_fwd_kernel(GtAttnDims d, con
                 a0.x += w2 * m2.x; a0.y += w2 * m2.y; a0.z += w2 * m2.z; a0.w += w2 * m2.w;
                 a1.x += w3 * m3.x; a1.y += w3 * m3.y; a1.z += w3 * m3.z; a1.w += w3 * m3.w;
             }
-            for (; t < d.Ti; t += 4) {
+            for (; t < Tv; t += 4) {
                 const float4 m0 = *reinterpret_cast<const float4*>(m + (long)t * ld_mem);
                 const float w0 = w[t];
                 a0.x += w0 * m0.x; a0.y += w0 * m0.y; a0.z += w0 * m0.z; a0.w += w0 * m0.w;
@@ -249,13 +255,13 @@ __global__ __launch_bounds__(256) void attn_context_fwd_kernel(GtAttnDims d, con
         const float* m = memory + (long)b * d.Ti * ld_mem + col;
         float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
         int t = 0;
-        for (; t + 3 < d.Ti; t += 4) {
+        for (; t + 3 < Tv; t += 4) {
             acc0 += w[t] * m[(long)t * ld_mem];
             acc1 += w[t + 1] * m[(long)(t + 1) * ld_mem];
             acc2 += w[t + 2] * m[(long)(t + 2) * ld_mem];
             acc3 += w[t + 3] * m[(long)(t + 3) * ld_mem];
         }
-        for (; t < d.Ti; ++t) acc0 += w[t] * m[(long)t * ld_mem];
+        for (; t < Tv; ++t) acc0 += w[t] * m[(long)t * ld_mem];
         c = (acc0 + acc1) + (acc2 + acc3);
     }
     if (col < d.E) {
@@ -269,12 +275,24 @@ __global__ __launch_bounds__(256) void attn_context_fwd_kernel(GtAttnDims d, con
 template <bool VEC>
 __global__ __launch_bounds__(256) void attn_context_bwd_kernel(GtAttnDims d, GtSlabs da, GtSlabs db,
                                                                const float* dctx_direct, long ld_direct,
-                                                               const float* memory, long ld_mem, float* dwcat_in,
-                                                               float* dcum_acc, const float* dw_extern, float* dctx_out,
-                                                               long ld_dctx_out, float* dq_zero, long ld_dq, float* dw_out) {
+                                                               const float* memory, long ld_mem, const int* lengths,
+                                                               float* dwcat_in, float* dcum_acc, const float* dw_extern,
+                                                               float* dctx_out, long ld_dctx_out, float* dq_zero, long ld_dq,
+                                                               float* dw_out) {
     extern __shared__ __attribute__((aligned(16))) float dctx[];   // E floats
     __shared__ float dots[CT];
     const int b = blockIdx.y, t0 = blockIdx.x * CT;
+    // padded positions carry weight 0: their dw never reaches an energy gradient, so it is set to 0
+    // and neither the upstream context gradient nor their memory rows are read
+    const int Tv = lengths != nullptr ? min(lengths[b], d.Ti) : d.Ti;
+    if (t0 >= Tv) {
+        if (threadIdx.x < CT && t0 + threadIdx.x < d.Ti) {
+            const long i = (long)b * d.Ti + t0 + threadIdx.x;
+            if (dwcat_in != nullptr) { dwcat_in[i] = 0.f; dwcat_in[(long)d.B * d.Ti + i] = 0.f; }
+            dw_out[i] = 0.f;
+        }
+        return;
+    }
     for (int e = threadIdx.x; e < d.E; e += blockDim.x) {
         float g = 0.f;
         if (da.p != nullptr) g += slab_sum(da.p, da.n, da.slab_stride, (long)b * da.ld + e);
@@ -296,7 +314,7 @@ __global__ __launch_bounds__(256) void attn_context_bwd_kernel(GtAttnDims d, GtS
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
             int trow[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) trow[r] = min(t0 + wave + 4 * (4 * pass + r), d.Ti - 1);
+            for (int r = 0; r < 4; ++r) trow[r] = min(t0 + wave + 4 * (4 * pass + r), Tv - 1);
             for (int e4 = lane; e4 < e4n; e4 += 64) {
                 const float4 dc = dc4[e4];
 #pragma unroll
@@ -313,7 +331,7 @@ __global__ __launch_bounds__(256) void attn_context_bwd_kernel(GtAttnDims d, GtS
         }
     } else {
         for (int tl = wave; tl < CT; tl += 4) {
-            const int t = min(t0 + tl, d.Ti - 1);
+            const int t = min(t0 + tl, Tv - 1);
             const float* m = mb + (long)t * ld_mem;
             float acc = 0.f;
             for (int e = lane; e < d.E; e += 64) acc += m[e] * dctx[e];
@@ -334,7 +352,7 @@ __global__ __launch_bounds__(256) void attn_context_bwd_kernel(GtAttnDims d, GtS
             dwcat_in[plane + i] = 0.f;
         }
         if (dw_extern != nullptr) carried += dw_extern[i];
-        dw_out[i] = dots[threadIdx.x] + carried;
+        dw_out[i] = (t0 + (int)threadIdx.x < Tv) ? dots[threadIdx.x] + carried : 0.f;
     }
 }
 
@@ -343,11 +361,12 @@ template <int NIT, int CA, int CF, int CK>
 __global__ __launch_bounds__(256) void attn_energies_bwd_kernel(GtAttnDims dims, const float* dw, const float* w,
                                                                 const float* q, const float* w_prev, const float* w_cum,
                                                                 const float* pm, const float* Wc, const float* Wd,
-                                                                const float* v, float* dq, long ld_dq, float* dpm, float* dwcat_out,
-                                                                float* acc) {
+                                                                const float* v, const int* lengths, float* dq, long ld_dq,
+                                                                float* dpm, float* dwcat_out, float* acc) {
     __shared__ Shared S;
     const Dims<CA, CF, CK> d(dims);
     const int b = blockIdx.y, t0 = blockIdx.x * CT;
+    if (lengths != nullptr && t0 >= lengths[b]) return;      // all-padding chunk: every gradient is zero
     const int G = CT / NIT;
     const int dd = threadIdx.x % d.A, g = threadIdx.x / d.A;
     // first long-latency global loads issued before the LDS set-up; later ones one iteration ahead
@@ -579,7 +598,7 @@ extern "C" int gt_attn_energies_fwd(GtAttnDims d, GtSlabs qpart, const float* w_
 }
 
 extern "C" int gt_attn_context_fwd(GtAttnDims d, const float* energies, const float* memory, int64_t ld_mem,
-                                   float* w_out, const float* cum_in, float* cum_out, float* c0, int64_t ld0,
+                                   const int32_t* lengths, float* w_out, const float* cum_in, float* cum_out, float* c0, int64_t ld0,
                                    float* c1, int64_t ld1, float* c2, int64_t ld2, void* stream) {
     int rc = check_dims(d, "gt_attn_context_fwd");
     if (rc) return rc;
@@ -591,17 +610,17 @@ extern "C" int gt_attn_context_fwd(GtAttnDims d, const float* energies, const fl
     const bool vec = (d.E % 4 == 0) && (ld_mem % 4 == 0) && aligned16(memory);
     if (vec)
         hipLaunchKernelGGL((attn_context_fwd_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, d, energies, memory,
-                           (long)ld_mem, w_out, cum_in, cum_out, c0, (long)ld0, c1, (long)ld1, c2, (long)ld2);
+                           (long)ld_mem, lengths, w_out, cum_in, cum_out, c0, (long)ld0, c1, (long)ld1, c2, (long)ld2);
     else
         hipLaunchKernelGGL((attn_context_fwd_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, d, energies, memory,
-                           (long)ld_mem, w_out, cum_in, cum_out, c0, (long)ld0, c1, (long)ld1, c2, (long)ld2);
+                           (long)ld_mem, lengths, w_out, cum_in, cum_out, c0, (long)ld0, c1, (long)ld1, c2, (long)ld2);
     GT_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int gt_attn_context_bwd(GtAttnDims d, GtSlabs dctx_a, GtSlabs dctx_b, const float* dctx_direct,
-                                     int64_t ld_direct, const float* memory, int64_t ld_mem, float* dwcat_in,
-                                     float* dcum_acc, const float* dw_extern, float* dctx_out, int64_t ld_dctx_out,
+                                     int64_t ld_direct, const float* memory, int64_t ld_mem, const int32_t* lengths,
+                                     float* dwcat_in, float* dcum_acc, const float* dw_extern, float* dctx_out, int64_t ld_dctx_out,
                                      float* dq_zero, int64_t ld_dq, float* dw_out, void* stream) {
     int rc = check_dims(d, "gt_attn_context_bwd");
     if (rc) return rc;
@@ -613,11 +632,11 @@ extern "C" int gt_attn_context_bwd(GtAttnDims d, GtSlabs dctx_a, GtSlabs dctx_b,
     const bool vec = (d.E % 4 == 0) && (ld_mem % 4 == 0) && aligned16(memory);
     if (vec)
         hipLaunchKernelGGL((attn_context_bwd_kernel<true>), grid, dim3(256), (size_t)d.E * 4, (hipStream_t)stream, d,
-                           dctx_a, dctx_b, dctx_direct, (long)ld_direct, memory, (long)ld_mem, dwcat_in, dcum_acc,
+                           dctx_a, dctx_b, dctx_direct, (long)ld_direct, memory, (long)ld_mem, lengths, dwcat_in, dcum_acc,
                            dw_extern, dctx_out, (long)ld_dctx_out, dq_zero, (long)ld_dq, dw_out);
     else
         hipLaunchKernelGGL((attn_context_bwd_kernel<false>), grid, dim3(256), (size_t)d.E * 4, (hipStream_t)stream, d,
-                           dctx_a, dctx_b, dctx_direct, (long)ld_direct, memory, (long)ld_mem, dwcat_in, dcum_acc,
+                           dctx_a, dctx_b, dctx_direct, (long)ld_direct, memory, (long)ld_mem, lengths, dwcat_in, dcum_acc,
                            dw_extern, dctx_out, (long)ld_dctx_out, dq_zero, (long)ld_dq, dw_out);
     GT_LAUNCH_CHECK();
     return 0;
@@ -625,8 +644,8 @@ extern "C" int gt_attn_context_bwd(GtAttnDims d, GtSlabs dctx_a, GtSlabs dctx_b,
 
 extern "C" int gt_attn_energies_bwd(GtAttnDims d, const float* dw, const float* w, const float* q,
                                       const float* w_prev, const float* w_cum, const float* pm, const float* Wc,
-                                      const float* Wd, const float* v, float* dq, int64_t ld_dq, float* dpm,
-                                      float* dwcat_out, float* acc, void* stream) {
+                                      const float* Wd, const float* v, const int32_t* lengths, float* dq, int64_t ld_dq,
+                                      float* dpm, float* dwcat_out, float* acc, void* stream) {
     int rc = check_dims(d, "gt_attn_energies_bwd");
     if (rc) return rc;
     GT_REQUIRE(dw && w && q && w_prev && w_cum && pm && Wc && Wd && v && dq && dpm && dwcat_out && acc, GT_E_ARG,
@@ -636,9 +655,9 @@ extern "C" int gt_attn_energies_bwd(GtAttnDims d, const float* dw, const float* 
                      4.0 * d.B * d.Ti * (3.0 * d.A + 6.0), (hipStream_t)stream);
 #define GT_EB(NIT, CA, CF, CK)                                                                                   \
     hipLaunchKernelGGL((attn_energies_bwd_kernel<NIT, CA, CF, CK>), grid, dim3(256), 0, (hipStream_t)stream, d,  \
-                       dw, w, q, w_prev, w_cum, pm, Wc, Wd, v, dq, (long)ld_dq, dpm, dwcat_out, acc)
+                       dw, w, q, w_prev, w_cum, pm, Wc, Wd, v, lengths, dq, (long)ld_dq, dpm, dwcat_out, acc)
     if (d.A == 128 && d.F == 32 && d.Kc == 31 && !getenv("GANTRON_ATTN_VALU")) {
-        gt_launch_attn_energies_bwd_mfma(d, dw, w, q, w_prev, w_cum, pm, Wc, Wd, v, dq, (long)ld_dq, dpm, dwcat_out, acc,
+        gt_launch_attn_energies_bwd_mfma(d, dw, w, q, w_prev, w_cum, pm, Wc, Wd, v, lengths, dq, (long)ld_dq, dpm, dwcat_out, acc,
                                          (hipStream_t)stream);
     } else if (d.A == 128 && d.F == 32 && d.Kc == 31) {
         GT_EB(16, 128, 32, 31);

@@ -122,6 +122,10 @@ __global__ __launch_bounds__(256) void attn_energies_fwd_mfma(GtAttnDims d, GtSl
                                                               float* q_out, float* energies) {
     __shared__ SharedM S;
     const int b = blockIdx.y, t0 = blockIdx.x * CT;
+    if (lengths != nullptr && t0 >= lengths[b]) {      // chunk entirely in the padding: energies are -inf
+        if (threadIdx.x < CT && t0 + threadIdx.x < d.Ti) energies[(long)b * d.Ti + t0 + threadIdx.x] = -INFINITY;
+        return;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, kq = lane >> 4;
     // processed-memory values in accumulator layout, issued before anything else
@@ -184,10 +188,11 @@ __global__ __launch_bounds__(256) void attn_energies_fwd_mfma(GtAttnDims d, GtSl
 __global__ __launch_bounds__(256) void attn_energies_bwd_mfma(GtAttnDims d, const float* dw, const float* w,
                                                               const float* q, const float* w_prev, const float* w_cum,
                                                               const float* pm, const float* Wc, const float* Wd,
-                                                              const float* v, float* dq, long ld_dq, float* dpm,
-                                                              float* dwcat_out, float* acc_slabs) {
+                                                              const float* v, const int* lengths, float* dq, long ld_dq,
+                                                              float* dpm, float* dwcat_out, float* acc_slabs) {
     __shared__ SharedM S;
     const int b = blockIdx.y, t0 = blockIdx.x * CT;
+    if (lengths != nullptr && t0 >= lengths[b]) return;      // all-padding chunk: every gradient is zero
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, kq = lane >> 4;
     constexpr int PER = A + A * F + F * KK;
@@ -374,9 +379,9 @@ void gt_launch_attn_energies_fwd_mfma(GtAttnDims d, GtSlabs qpart, const float* 
 
 void gt_launch_attn_energies_bwd_mfma(GtAttnDims d, const float* dw, const float* w, const float* q,
                                       const float* w_prev, const float* w_cum, const float* pm, const float* Wc,
-                                      const float* Wd, const float* v, float* dq, long ld_dq, float* dpm,
-                                      float* dwcat_out, float* acc, hipStream_t st) {
+                                      const float* Wd, const float* v, const int* lengths, float* dq, long ld_dq,
+                                      float* dpm, float* dwcat_out, float* acc, hipStream_t st) {
     dim3 grid(cdiv(d.Ti, CT), d.B);
-    hipLaunchKernelGGL(attn_energies_bwd_mfma, grid, dim3(256), 0, st, d, dw, w, q, w_prev, w_cum, pm, Wc, Wd, v, dq,
-                       ld_dq, dpm, dwcat_out, acc);
+    hipLaunchKernelGGL(attn_energies_bwd_mfma, grid, dim3(256), 0, st, d, dw, w, q, w_prev, w_cum, pm, Wc, Wd, v, lengths,
+                       dq, ld_dq, dpm, dwcat_out, acc);
 }

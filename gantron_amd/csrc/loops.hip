@@ -8,6 +8,7 @@
 // mel/gate projection of all steps (reads HC), every weight gradient (dW = dGates^T . inputs with
 // K = To*B) and d(memory) (batched W^T . dctx).  Inside the loop only the recurrent products
 // ([ctx|h] . W) remain, as weight-streaming small-M MFMA kernels (recurrent.hip).
+#include <vector>
 #include "common.h"
 
 extern "C" {
@@ -23,44 +24,111 @@ static inline GtSlabs slabs(const float* p, int n, int64_t stride, int64_t ld) {
 }
 static const GtSlabs kNoSlabs = {nullptr, 0, 0, 0};
 
+// ---- two-chain pipelining -----------------------------------------------------------------------
+// A decoder step is two dependent chains: the attention chain (attention LSTM, query, energies,
+// softmax+context) and the decoder-LSTM chain.  Forward, the attention chain of step t+1 depends only
+// on the attention chain of step t, so the decoder LSTM of step t runs concurrently with it on an
+// auxiliary stream; backward the roles swap (the decoder-LSTM chain leads).  Every kernel of the loop
+// is latency-bound at ~1 wave per SIMD, so two kernels in flight fill each other's bubbles.
+// Hand-offs use a ring of `ring` buffers (X2 forward, partX2 backward) and HIP events.
+static hipStream_t g_aux_stream = nullptr;
+static std::vector<hipEvent_t> g_loop_events;
+
+static int aux_stream(hipStream_t* out) {
+    if (g_aux_stream == nullptr) {
+        hipError_t e = hipStreamCreateWithFlags(&g_aux_stream, hipStreamNonBlocking);
+        GT_REQUIRE(e == hipSuccess, (int)e, "decoder loop: cannot create the auxiliary stream");
+    }
+    *out = g_aux_stream;
+    return 0;
+}
+static int loop_event(size_t i, hipEvent_t* out) {
+    while (g_loop_events.size() <= i) {
+        hipEvent_t ev;
+        hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        GT_REQUIRE(e == hipSuccess, (int)e, "decoder loop: cannot create an event");
+        g_loop_events.push_back(ev);
+    }
+    *out = g_loop_events[i];
+    return 0;
+}
+#define GT_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e__ = (call);                                                                  \
+        GT_REQUIRE(e__ == hipSuccess, (int)e__, "%s failed: %s", #call, hipGetErrorString(e__)); \
+    } while (0)
+
 int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
     GT_REQUIRE(a != nullptr, GT_E_ARG, "gt_decoder_fwd: NULL");
     GT_REQUIRE(a->B > 0 && a->Bp >= a->B && a->Bp % 16 == 0 && a->Bp <= 64, GT_E_LIMIT,
                "gt_decoder_fwd: batch %d (padded %d) must fit 64 rows per call", a->B, a->Bp);
     GT_REQUIRE(a->To > 0 && a->Ti > 0 && a->Ha % 16 == 0 && a->Hd % 16 == 0 && a->Apad % 16 == 0, GT_E_ARG,
                "gt_decoder_fwd: bad dims");
+    GT_REQUIRE(a->ring >= 1 && a->ring <= 8 && (a->ring == 1 || a->part2 != nullptr), GT_E_ARG, "gt_decoder_fwd: ring/part2");
     const int mt = a->Bp / 16;
     const int N1 = 4 * a->Ha, N2 = 4 * a->Hd;
     const int K1 = a->E + a->Ha, K2 = a->Ha + a->E + a->Hd;
     const int64_t hc_ld = a->Hd + a->E;
     GtAttnDims d; d.B = a->B; d.Ti = a->Ti; d.E = a->E; d.A = a->A; d.F = a->F; d.Kc = a->Kc;
     const int64_t BT = (int64_t)a->B * a->Ti;
+    const int R = a->ring;
+    const bool two = R > 1;
+    hipStream_t sA = (hipStream_t)stream, sB = sA;
+    float* partB = two ? a->part2 : a->part;
+    hipEvent_t ev;
+    if (two) {
+        GT_TRY(aux_stream(&sB));
+        GT_TRY(loop_event(0, &ev));
+        GT_HIP(hipEventRecord(ev, sA));
+        GT_HIP(hipStreamWaitEvent(sB, ev, 0));
+    }
+    // events: [1 .. R+1] attention chain done (ring), [R+2 .. 2R+2] decoder chain done (ring)
+    auto evA = [&](int t, hipEvent_t* e) { return loop_event(1 + (size_t)(t % (R + 1)), e); };
+    auto evB = [&](int t, hipEvent_t* e) { return loop_event(2 + R + (size_t)(t % (R + 1)), e); };
     for (int t = 0; t < a->To; ++t) {
         const uint8_t* k1 = a->att_keep ? a->att_keep + (int64_t)t * a->Bp * a->Ha : nullptr;
         const uint8_t* k2 = a->dec_keep ? a->dec_keep + (int64_t)t * a->Bp * a->Hd : nullptr;
         float* hc_t = a->HC + (int64_t)t * a->Bp * hc_ld;
-        // attention LSTM: [ctx_{t-1} | h_att_{t-1}] . W1r + pre1[t]
-        GT_TRY(gt_rec_gemm(a->X1, a->ld1, a->W1p, a->part, mt, N1, K1, a->S1, (int64_t)a->Bp * N1, 1, 0, 0, 0, stream));
+        float* X2t = a->X2 + (int64_t)(t % R) * a->Bp * a->ld2;
+        float* X2n = a->X2 + (int64_t)((t + 1) % R) * a->Bp * a->ld2;
+        // ---- attention chain (stream A)
+        GT_TRY(gt_rec_gemm(a->X1, a->ld1, a->W1p, a->part, mt, N1, K1, a->S1, (int64_t)a->Bp * N1, 1, 0, 0, 0, sA));
+        if (two && t >= R) {     // X2 ring slot t%R was last read by the decoder chain of step t-R
+            GT_TRY(evB(t - R, &ev));
+            GT_HIP(hipStreamWaitEvent(sA, ev, 0));
+        }
         GT_TRY(gt_lstm_cell_fwd(slabs(a->part, a->S1, (int64_t)a->Bp * N1, N1), a->pre1 + (int64_t)t * a->Bp * N1, N1,
                                 a->c1 + (int64_t)t * a->Bp * a->Ha, nullptr, 0, k1, a->p_att, nullptr,
                                 a->gates1 + (int64_t)t * a->Bp * N1, a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha,
-                                a->hatt + (int64_t)t * a->Bp * a->Ha, a->X1 + a->E, a->ld1, a->X2, a->ld2, nullptr, 0,
-                                a->B, a->Ha, stream));
-        // query projection, energies, softmax + context
-        GT_TRY(gt_rec_gemm(a->X2, a->ld2, a->Wqp, a->part, mt, a->Apad, a->Ha, a->Sq, (int64_t)a->Bp * a->Apad, 1, 0, 0,
-                           0, stream));
+                                a->hatt + (int64_t)t * a->Bp * a->Ha, a->X1 + a->E, a->ld1, X2t, a->ld2, nullptr, 0,
+                                a->B, a->Ha, sA));
+        GT_TRY(gt_rec_gemm(X2t, a->ld2, a->Wqp, a->part, mt, a->Apad, a->Ha, a->Sq, (int64_t)a->Bp * a->Apad, 1, 0, 0,
+                           0, sA));
         GT_TRY(gt_attn_energies_fwd(d, slabs(a->part, a->Sq, (int64_t)a->Bp * a->Apad, a->Apad),
                                     a->w_hist + (int64_t)t * BT, a->cum_hist + (int64_t)t * BT, a->pm, a->Wc, a->Wd, a->v,
-                                    a->lengths, a->q_hist + (int64_t)t * a->B * a->A, a->energies, stream));
-        GT_TRY(gt_attn_context_fwd(d, a->energies, a->memory, a->ldE, a->w_hist + (int64_t)(t + 1) * BT,
+                                    a->lengths, a->q_hist + (int64_t)t * a->B * a->A, a->energies, sA));
+        GT_TRY(gt_attn_context_fwd(d, a->energies, a->memory, a->ldE, a->lengths, a->w_hist + (int64_t)(t + 1) * BT,
                                    a->cum_hist + (int64_t)t * BT, a->cum_hist + (int64_t)(t + 1) * BT, a->X1, a->ld1,
-                                   a->X2 + a->Ha, a->ld2, hc_t + a->Hd, hc_ld, stream));
-        // decoder LSTM: [h_att_t | ctx_t | h_dec_{t-1}] . W2 + bias
-        GT_TRY(gt_rec_gemm(a->X2, a->ld2, a->W2p, a->part, mt, N2, K2, a->S2, (int64_t)a->Bp * N2, 1, 0, 0, 0, stream));
-        GT_TRY(gt_lstm_cell_fwd(slabs(a->part, a->S2, (int64_t)a->Bp * N2, N2), a->bias2, 0,
+                                   X2t + a->Ha, a->ld2, hc_t + a->Hd, hc_ld, sA));
+        if (two) {
+            GT_TRY(evA(t, &ev));
+            GT_HIP(hipEventRecord(ev, sA));
+            GT_HIP(hipStreamWaitEvent(sB, ev, 0));
+        }
+        // ---- decoder LSTM chain (stream B): [h_att_t | ctx_t | h_dec_{t-1}] . W2 + bias
+        GT_TRY(gt_rec_gemm(X2t, a->ld2, a->W2p, partB, mt, N2, K2, a->S2, (int64_t)a->Bp * N2, 1, 0, 0, 0, sB));
+        GT_TRY(gt_lstm_cell_fwd(slabs(partB, a->S2, (int64_t)a->Bp * N2, N2), a->bias2, 0,
                                 a->c2 + (int64_t)t * a->Bp * a->Hd, nullptr, 0, k2, a->p_dec, nullptr,
                                 a->gates2 + (int64_t)t * a->Bp * N2, a->c2 + (int64_t)(t + 1) * a->Bp * a->Hd, nullptr,
-                                a->X2 + a->Ha + a->E, a->ld2, hc_t, hc_ld, nullptr, 0, a->B, a->Hd, stream));
+                                X2n + a->Ha + a->E, a->ld2, hc_t, hc_ld, nullptr, 0, a->B, a->Hd, sB));
+        if (two) {
+            GT_TRY(evB(t, &ev));
+            GT_HIP(hipEventRecord(ev, sB));
+        }
+    }
+    if (two) {      // join: everything issued on the auxiliary stream is ordered before later work on `stream`
+        GT_TRY(evB(a->To - 1, &ev));
+        GT_HIP(hipStreamWaitEvent(sA, ev, 0));
     }
     return 0;
 }
@@ -68,12 +136,26 @@ int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
 int gt_decoder_bwd(const GtDecoderBwd* a, void* stream) {
     GT_REQUIRE(a != nullptr, GT_E_ARG, "gt_decoder_bwd: NULL");
     GT_REQUIRE(a->B > 0 && a->Bp >= a->B && a->Bp % 16 == 0 && a->Bp <= 64, GT_E_LIMIT, "gt_decoder_bwd: batch");
+    GT_REQUIRE(a->ring >= 1 && a->ring <= 8, GT_E_ARG, "gt_decoder_bwd: ring");
     const int mt = a->Bp / 16;
     const int N1 = 4 * a->Ha, N2 = 4 * a->Hd;
     const int64_t hc_ld = a->Hd + a->E;
     GtAttnDims d; d.B = a->B; d.Ti = a->Ti; d.E = a->E; d.A = a->A; d.F = a->F; d.Kc = a->Kc;
     const int64_t BT = (int64_t)a->B * a->Ti;
     const int64_t sX1 = (int64_t)a->Bp * a->N1pad, sX2 = (int64_t)a->Bp * a->N2pad, sQ = (int64_t)a->Bp * a->Ha;
+    const int R = a->ring;
+    const bool two = R > 1;
+    hipStream_t sA = (hipStream_t)stream, sB = sA;
+    hipEvent_t ev;
+    if (two) {
+        GT_TRY(aux_stream(&sB));
+        GT_TRY(loop_event(0, &ev));
+        GT_HIP(hipEventRecord(ev, sA));
+        GT_HIP(hipStreamWaitEvent(sB, ev, 0));
+    }
+    auto evA = [&](int t, hipEvent_t* e) { return loop_event(1 + (size_t)(t % (R + 1)), e); };
+    auto evB = [&](int t, hipEvent_t* e) { return loop_event(2 + R + (size_t)(t % (R + 1)), e); };
+    auto ringX2 = [&](int t) { return a->partX2 + (int64_t)(t % R) * a->S2 * sX2; };
     for (int t = a->To - 1; t >= 0; --t) {
         const bool last = (t == a->To - 1);
         const uint8_t* k1 = a->att_keep ? a->att_keep + (int64_t)t * a->Bp * a->Ha : nullptr;
@@ -82,32 +164,47 @@ int gt_decoder_bwd(const GtDecoderBwd* a, void* stream) {
         float* dG2_t = a->dG2 + (int64_t)t * a->Bp * N2;
         float* dG1_t = a->dG1 + (int64_t)t * a->Bp * N1;
         float* dq_t = a->dq_hist + (int64_t)t * a->Bp * a->Apad;
-        // decoder LSTM cell: dh = projection grad + recurrent grad from step t+1
-        GT_TRY(gt_lstm_cell_bwd(last ? kNoSlabs : slabs(a->partX2 + a->Ha + a->E, a->S2, sX2, a->N2pad), kNoSlabs,
+        float* pX2 = ringX2(t);
+        const float* pX2next = ringX2(t + 1);
+        // ---- decoder LSTM chain (stream B, leads): dh = projection grad + recurrent grad from step t+1
+        GT_TRY(gt_lstm_cell_bwd(last ? kNoSlabs : slabs(pX2next + a->Ha + a->E, a->S2, sX2, a->N2pad), kNoSlabs,
                                 kNoSlabs, dhc_t, hc_ld, a->dc2, a->gates2 + (int64_t)t * a->Bp * N2,
                                 a->c2 + (int64_t)(t + 1) * a->Bp * a->Hd, a->c2 + (int64_t)t * a->Bp * a->Hd, k2,
-                                a->p_dec, nullptr, dG2_t, a->dc2, nullptr, a->B, a->Hd, stream));
-        GT_TRY(gt_rec_gemm(dG2_t, N2, a->W2Tp, a->partX2, mt, a->N2pad, N2, a->S2, sX2, 1, 0, 0, 0, stream));
-        // attention backward
+                                a->p_dec, nullptr, dG2_t, a->dc2, nullptr, a->B, a->Hd, sB));
+        if (two && t + R <= a->To - 1) {   // ring slot t%R was last read by the attention chain of step t+R
+            GT_TRY(evA(t + R, &ev));
+            GT_HIP(hipStreamWaitEvent(sB, ev, 0));
+        }
+        GT_TRY(gt_rec_gemm(dG2_t, N2, a->W2Tp, pX2, mt, a->N2pad, N2, a->S2, sX2, 1, 0, 0, 0, sB));
+        if (two) {
+            GT_TRY(evB(t, &ev));
+            GT_HIP(hipEventRecord(ev, sB));
+            GT_HIP(hipStreamWaitEvent(sA, ev, 0));
+        }
+        // ---- attention chain (stream A)
         float* dwcat_in = a->dwcat + (int64_t)((t + 1) & 1) * 2 * BT;
         float* dwcat_out = a->dwcat + (int64_t)(t & 1) * 2 * BT;
-        GT_TRY(gt_attn_context_bwd(d, slabs(a->partX2 + a->Ha, a->S2, sX2, a->N2pad),
+        GT_TRY(gt_attn_context_bwd(d, slabs(pX2 + a->Ha, a->S2, sX2, a->N2pad),
                                    last ? kNoSlabs : slabs(a->partX1, a->S1, sX1, a->N1pad), dhc_t + a->Hd, hc_ld,
-                                   a->memory, a->ldE, dwcat_in, a->dcum_acc,
+                                   a->memory, a->ldE, a->lengths, dwcat_in, a->dcum_acc,
                                    a->dalign ? a->dalign + (int64_t)t * BT : nullptr,
-                                   a->dctx_hist + (int64_t)t * a->B * a->E, a->E, dq_t, a->Apad, a->dw, stream));
+                                   a->dctx_hist + (int64_t)t * a->B * a->E, a->E, dq_t, a->Apad, a->dw, sA));
         GT_TRY(gt_attn_energies_bwd(d, a->dw, a->w_hist + (int64_t)(t + 1) * BT, a->q_hist + (int64_t)t * a->B * a->A,
                                     a->w_hist + (int64_t)t * BT, a->cum_hist + (int64_t)t * BT, a->pm, a->Wc, a->Wd, a->v,
-                                    dq_t, a->Apad, a->dpm, dwcat_out, a->acc, stream));
-        GT_TRY(gt_rec_gemm(dq_t, a->Apad, a->WqTp, a->partQ, mt, a->Ha, a->A, a->Sq, sQ, 1, 0, 0, 0, stream));
+                                    a->lengths, dq_t, a->Apad, a->dpm, dwcat_out, a->acc, sA));
+        GT_TRY(gt_rec_gemm(dq_t, a->Apad, a->WqTp, a->partQ, mt, a->Ha, a->A, a->Sq, sQ, 1, 0, 0, 0, sA));
         // attention LSTM cell: dh = d(h_att as decoder-LSTM input) + d(query) + recurrent grad from t+1
-        GT_TRY(gt_lstm_cell_bwd(slabs(a->partX2, a->S2, sX2, a->N2pad), slabs(a->partQ, a->Sq, sQ, a->Ha),
+        GT_TRY(gt_lstm_cell_bwd(slabs(pX2, a->S2, sX2, a->N2pad), slabs(a->partQ, a->Sq, sQ, a->Ha),
                                 last ? kNoSlabs : slabs(a->partX1 + a->E, a->S1, sX1, a->N1pad), nullptr, 0, a->dc1,
                                 a->gates1 + (int64_t)t * a->Bp * N1, a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha,
                                 a->c1 + (int64_t)t * a->Bp * a->Ha, k1, a->p_att, nullptr, dG1_t, a->dc1, nullptr, a->B,
-                                a->Ha, stream));
+                                a->Ha, sA));
+        if (two) {
+            GT_TRY(evA(t, &ev));
+            GT_HIP(hipEventRecord(ev, sA));
+        }
         if (t > 0)
-            GT_TRY(gt_rec_gemm(dG1_t, N1, a->W1Tp, a->partX1, mt, a->N1pad, N1, a->S1, sX1, 1, 0, 0, 0, stream));
+            GT_TRY(gt_rec_gemm(dG1_t, N1, a->W1Tp, a->partX1, mt, a->N1pad, N1, a->S1, sX1, 1, 0, 0, 0, sA));
     }
     return 0;
 }

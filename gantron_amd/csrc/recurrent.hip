@@ -403,7 +403,7 @@ extern "C" int gt_lstm_cell_fwd(GtSlabs part, const float* pre, int64_t ld_pre, 
                      (keep == nullptr || (((uintptr_t)keep) & 3) == 0) && ok4(gates, 0) && aligned16(c_out) && ok4(h_raw, 0) &&
                      ok4(h0, ld0) && ok4(h1, ld1) && ok4(h2, ld2);
     if (vec)
-        hipLaunchKernelGGL((lstm_cell_fwd_kernel<4>), dim3((unsigned)cdiv64(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((lstm_cell_fwd_kernel<4>), dim3((unsigned)cdiv64(n / 4, 64)), dim3(64), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL((lstm_cell_fwd_kernel<1>), dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, a);
     GT_LAUNCH_CHECK();
@@ -429,7 +429,7 @@ extern "C" int gt_lstm_cell_bwd(GtSlabs dh_a, GtSlabs dh_b, GtSlabs dh_c, const 
                      aligned16(dgates) && aligned16(dc_prev) && ok4(dh_pass, 0);
     GT_REQUIRE(dh_a.n <= 16 && dh_b.n <= 16 && dh_c.n <= 16, GT_E_LIMIT, "gt_lstm_cell_bwd: at most 16 slabs per source");
     if (vec)
-        hipLaunchKernelGGL((lstm_cell_bwd_kernel<4>), dim3((unsigned)cdiv64(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((lstm_cell_bwd_kernel<4>), dim3((unsigned)cdiv64(n / 4, 64)), dim3(64), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL((lstm_cell_bwd_kernel<1>), dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, a);
     GT_LAUNCH_CHECK();

@@ -24,7 +24,8 @@ from ._lib import GtBiLstm, GtDecoderBwd, GtDecoderFwd, check, lib
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 import os as _os
-REC_SPLITS = int(_os.environ.get("GANTRON_REC_SPLITS", "4"))   # K-splits of the per-step recurrent GEMMs
+REC_SPLITS = int(_os.environ.get("GANTRON_REC_SPLITS", "4"))
+DEC_RING = int(_os.environ.get("GANTRON_DEC_RING", "4"))     # 1 = single stream; >1 = two-chain pipelining   # K-splits of the per-step recurrent GEMMs
 
 
 def _f32(*shape, device, zero=True):
@@ -263,8 +264,9 @@ class GeneratorEngine:
                       Wqp=pack_rec(P['decoder.attention_layer.query_layer.linear_layer.weight'], Apad, A, Ha))
         lens32 = torch.tensor(in_lens, dtype=torch.int32, device=dev)
         ld1, ld2 = roundup(K1, 16), roundup(K2, 16)
-        ws = dict(X1=_f32(Bp, ld1, device=dev), X2=_f32(Bp, ld2, device=dev),
+        ws = dict(X1=_f32(Bp, ld1, device=dev), X2=_f32(DEC_RING, Bp, ld2, device=dev),
                   part=_f32(max(d.S1 * Bp * 4 * Ha, d.S2 * Bp * 4 * Hd, d.Sq * Bp * Apad), device=dev, zero=False),
+                  part2=_f32(d.S2 * Bp * 4 * Hd, device=dev, zero=False),
                   energies=_f32(B, Ti, device=dev, zero=False))
         hist = dict(gates1=_f32(To, Bp, 4 * Ha, device=dev), c1=_f32(To + 1, Bp, Ha, device=dev),
                     gates2=_f32(To, Bp, 4 * Hd, device=dev), c2=_f32(To + 1, Bp, Hd, device=dev),
@@ -281,6 +283,7 @@ class GeneratorEngine:
         dec_keep = rng.get('dec_keep') if training else None
         d.att_keep, d.dec_keep = ptr(att_keep), ptr(dec_keep)
         d.X1, d.ld1, d.X2, d.ld2, d.part, d.energies = ptr(ws['X1']), ld1, ptr(ws['X2']), ld2, ptr(ws['part']), ptr(ws['energies'])
+        d.part2, d.ring = ptr(ws['part2']), DEC_RING
         for k in ('gates1', 'c1', 'gates2', 'c2', 'hatt', 'HC', 'w_hist', 'cum_hist', 'q_hist'):
             setattr(d, k, ptr(hist[k]))
         _run('gt_decoder_fwd', d)
@@ -392,15 +395,17 @@ class GeneratorEngine:
                    dc1=_f32(Bp, Ha, device=dev), dc2=_f32(Bp, Hd, device=dev), dwcat=_f32(2, 2, B, Ti, device=dev),
                    dcum_acc=_f32(B, Ti, device=dev), dq_hist=_f32(To, Bp, Apad, device=dev),
                    dw=_f32(B, Ti, device=dev, zero=False),
-                   partX1=_f32(b.S1, Bp, N1pad, device=dev), partX2=_f32(b.S2, Bp, N2pad, device=dev),
+                   partX1=_f32(b.S1, Bp, N1pad, device=dev), partX2=_f32(DEC_RING, b.S2, Bp, N2pad, device=dev),
                    partQ=_f32(b.Sq, Bp, Ha, device=dev))
         b.memory, b.pm, b.Wc, b.Wd, b.v = ptr(sv['memory']), ptr(sv['pm']), ptr(Wc), ptr(Wd), ptr(v)
+        b.lengths = ptr(sv['lens32'])
         b.att_keep, b.dec_keep = ptr(sv['att_keep']), ptr(sv['dec_keep'])
         for k in ('gates1', 'c1', 'gates2', 'c2', 'w_hist', 'cum_hist', 'q_hist'):
             setattr(b, k, ptr(hist[k]))
         b.W1Tp, b.W2Tp, b.WqTp, b.dHC, b.dalign = ptr(W1Tp), ptr(W2Tp), ptr(WqTp), ptr(dHC), ptr(dalign_tm)
         for k in buf:
             setattr(b, k, ptr(buf[k]))
+        b.ring = DEC_RING
         _run('gt_decoder_bwd', b)
 
         # ---- deferred weight gradients of the decoder (K = To*Bp rows each)

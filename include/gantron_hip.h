@@ -123,6 +123,8 @@ int gt_lstm_cell_bwd(GtSlabs dh_a, GtSlabs dh_b, GtSlabs dh_c, const float* dh_d
  *   ctx = w @ memory;  w_cum += w.
  * gt_attn_energies: grid (B, chunks of Ti).  q = sum of `qpart` slabs (query_layer product).
  * gt_attn_context : softmax over Ti + context; ctx written to up to three destinations.
+ * `lengths` (may be NULL) lets every attention kernel skip the padded tail of a memory row: those
+ * positions have weight exactly 0 and zero gradient, so results are unchanged.
  */
 typedef struct GtAttnDims { int32_t B, Ti, E, A, F, Kc; } GtAttnDims;
 
@@ -130,7 +132,7 @@ int gt_attn_energies_fwd(GtAttnDims d, GtSlabs qpart, const float* w_prev, const
                          const float* pm, const float* Wc, const float* Wd, const float* v,
                          const int32_t* lengths, float* q_out, float* energies, void* stream);
 int gt_attn_context_fwd(GtAttnDims d, const float* energies, const float* memory, int64_t ld_mem,
-                        float* w_out, const float* cum_in, float* cum_out,
+                        const int32_t* lengths, float* w_out, const float* cum_in, float* cum_out,
                         float* c0, int64_t ld0, float* c1, int64_t ld1, float* c2, int64_t ld2,
                         void* stream);
 
@@ -143,14 +145,14 @@ int gt_attn_context_fwd(GtAttnDims d, const float* energies, const float* memory
  *   dq += (atomics), dpm += , dwcat_out += (atomics, [2][B][Ti]), parameter gradients of
  *   v / location_dense / location_conv accumulate in per-workgroup slabs `acc`. */
 int gt_attn_context_bwd(GtAttnDims d, GtSlabs dctx_a, GtSlabs dctx_b, const float* dctx_direct,
-                        int64_t ld_direct, const float* memory, int64_t ld_mem, float* dwcat_in,
-                        float* dcum_acc, const float* dw_extern, float* dctx_out,
+                        int64_t ld_direct, const float* memory, int64_t ld_mem,
+                        const int32_t* lengths, float* dwcat_in, float* dcum_acc, const float* dw_extern, float* dctx_out,
                         int64_t ld_dctx_out, float* dq_zero, int64_t ld_dq, float* dw_out,
                         void* stream);
 int gt_attn_energies_bwd(GtAttnDims d, const float* dw, const float* w, const float* q,
                          const float* w_prev, const float* w_cum, const float* pm, const float* Wc,
-                         const float* Wd, const float* v, float* dq, int64_t ld_dq, float* dpm,
-                         float* dwcat_out, float* acc, void* stream);
+                         const float* Wd, const float* v, const int32_t* lengths, float* dq,
+                         int64_t ld_dq, float* dpm, float* dwcat_out, float* acc, void* stream);
 int64_t gt_attn_acc_elems(GtAttnDims d);     /* size of `acc` (dv | dWd | dWc per workgroup) */
 int gt_attn_acc_reduce(GtAttnDims d, const float* acc, float* dv, float* dWd, float* dWc,
                        void* stream);
@@ -179,8 +181,10 @@ typedef struct GtDecoderFwd {
     const uint8_t* att_keep;   /* (To, Bp, Ha) or NULL */
     const uint8_t* dec_keep;   /* (To, Bp, Hd) or NULL */
     float* X1; int64_t ld1;    /* (Bp, ld1) zero-initialised */
-    float* X2; int64_t ld2;    /* (Bp, ld2) zero-initialised */
-    float* part;               /* slab scratch */
+    float* X2; int64_t ld2;    /* (ring, Bp, ld2) zero-initialised */
+    float* part;               /* slab scratch of the attention chain */
+    float* part2;              /* slab scratch of the decoder-LSTM chain (ring > 1) */
+    int32_t ring;              /* 1: one stream; 2..8: two-chain pipelining over a ring of X2 buffers */
     float* energies;           /* (B, Ti) */
     float* gates1; float* c1;  /* (To, Bp, 4Ha), (To+1, Bp, Ha) c1[0] = 0 */
     float* gates2; float* c2;  /* (To, Bp, 4Hd), (To+1, Bp, Hd) */
@@ -197,6 +201,7 @@ typedef struct GtDecoderBwd {
     int32_t N1pad, N2pad;      /* roundup16(E+Ha), roundup16(Ha+E+Hd) */
     float p_att, p_dec;
     const float* memory; const float* pm;
+    const int32_t* lengths;    /* (B) memory lengths */
     const float* Wc; const float* Wd; const float* v;
     const uint8_t* att_keep; const uint8_t* dec_keep;
     const float* gates1; const float* c1; const float* gates2; const float* c2;
@@ -215,7 +220,8 @@ typedef struct GtDecoderBwd {
     float* dcum_acc;           /* (B, Ti) zero-initialised */
     float* dq_hist;            /* (To, Bp, Apad) zero-initialised: per-step query gradients */
     float* dw;                 /* (B, Ti) */
-    float* partX1; float* partX2; float* partQ;
+    float* partX1; float* partX2; float* partQ;   /* partX2: (ring, S2, Bp, N2pad) */
+    int32_t ring;              /* as in GtDecoderFwd */
 } GtDecoderBwd;
 
 typedef struct GtBiLstm {

@@ -178,7 +178,7 @@ def test_attention_step_fwd_bwd(dev, B, Ti, E, A, Fn, Kc):
     ops.call('gt_attn_energies_fwd', d, ops.slabs(qd, 1, B * A, A), f32(w_prev), f32(w_cum), f32(pm), Wc, Wd, v, lens32, q_out, en)
     w_out = torch.empty(B, Ti, device=dev); cum_out = torch.empty(B, Ti, device=dev)
     c0 = torch.empty(B, E, device=dev); c1 = torch.zeros(B, E + 5, device=dev)
-    ops.call('gt_attn_context_fwd', d, en, f32(memory), E, w_out, f32(w_cum), cum_out, c0, E, ops.ptr(c1, 5), E + 5, None, 0)
+    ops.call('gt_attn_context_fwd', d, en, f32(memory), E, lens32, w_out, f32(w_cum), cum_out, c0, E, ops.ptr(c1, 5), E + 5, None, 0)
     close(w_out, w, rtol=1e-4, atol=1e-6, what='attention weights')
     close(c0, ctx, rtol=1e-4, atol=1e-5, what='context')
     close(c1[:, 5:], ctx, rtol=1e-4, atol=1e-5, what='context strided')
@@ -197,14 +197,15 @@ def test_attention_step_fwd_bwd(dev, B, Ti, E, A, Fn, Kc):
     dcum_acc = cum_acc0.clone().to(dev)
     dctx_out = torch.empty(B, E, device=dev); dq = torch.full((B, A), 7.0, device=dev); dw = torch.empty(B, Ti, device=dev)
     half = (0.5 * dctx).float().contiguous().to(dev)
-    ops.call('gt_attn_context_bwd', d, ops.slabs(half, 1, B * E, E), ops.NO_SLABS, half, E, f32(memory), E, dwcat_in, dcum_acc,
+    ops.call('gt_attn_context_bwd', d, ops.slabs(half, 1, B * E, E), ops.NO_SLABS, half, E, f32(memory), E, lens32, dwcat_in, dcum_acc,
              f32(dw_ext), dctx_out, E, dq, A, dw)
     close(dctx_out, dctx, what='dctx total')
     assert float(dwcat_in.abs().max()) == 0.0 and float(dq.abs().max()) == 0.0
-    close(dcum_acc, cum_acc0 + carry_cum, what='dcum_acc')
+    valid = R.length_mask(lens, Ti)          # padded positions carry no gradient: their bookkeeping is skipped
+    close(dcum_acc.cpu() * valid, (cum_acc0 + carry_cum) * valid, what='dcum_acc')
     dpm = torch.zeros(B, Ti, A, device=dev); dwcat_out = torch.zeros(2, B, Ti, device=dev)
     acc = torch.zeros(int(lib().gt_attn_acc_elems(d)), device=dev)
-    ops.call('gt_attn_energies_bwd', d, dw, w_out, q_out, f32(w_prev), f32(w_cum), f32(pm), Wc, Wd, v, dq, A, dpm, dwcat_out, acc)
+    ops.call('gt_attn_energies_bwd', d, dw, w_out, q_out, f32(w_prev), f32(w_cum), f32(pm), Wc, Wd, v, lens32, dq, A, dpm, dwcat_out, acc)
     close(dpm, gpm, rtol=2e-3, atol=1e-6, what='dpm')
     close(dwcat_out[0], gwp, rtol=2e-3, atol=1e-6, what='d w_prev')
     dv = torch.zeros(1, A, device=dev); dWd = torch.zeros(A, Fn, device=dev); dWc = torch.zeros(Fn, 2, Kc, device=dev)

@@ -76,12 +76,12 @@ q_out = torch.empty(B, A, device=dev); en = torch.empty(B, Ti, device=dev)
 timeit('attn_energies_fwd', lambda: ops.call('gt_attn_energies_fwd', d, ops.slabs(qpart, 16, Bp * A, A), w_prev, w_cum, pm, Wc, Wd, v, lens, q_out, en))
 w_out = torch.empty(B, Ti, device=dev); cum_out = torch.empty(B, Ti, device=dev)
 c0 = torch.empty(Bp, 2048, device=dev); c1 = torch.empty(Bp, 3072, device=dev); c2 = torch.empty(Bp, 2048, device=dev)
-timeit('attn_context_fwd', lambda: ops.call('gt_attn_context_fwd', d, en, memory, E, w_out, w_cum, cum_out, c0, 2048, c1, 3072, c2, 2048),
+timeit('attn_context_fwd', lambda: ops.call('gt_attn_context_fwd', d, en, memory, E, lens, w_out, w_cum, cum_out, c0, 2048, c1, 3072, c2, 2048),
        bytes_=4.0 * B * Ti * E)
 dsa = torch.randn(4, Bp, 3072, device=dev); dsb = torch.randn(4, Bp, 2048, device=dev); dhc = torch.randn(Bp, 2048, device=dev)
 dwcat = torch.zeros(2, 2, B, Ti, device=dev); dcum = torch.zeros(B, Ti, device=dev); dctx_out = torch.empty(B, E, device=dev)
 dq = torch.zeros(Bp, A, device=dev); dw = torch.empty(B, Ti, device=dev)
 timeit('attn_context_bwd', lambda: ops.call('gt_attn_context_bwd', d, ops.slabs(dsa, 4, Bp * 3072, 3072, 1024), ops.slabs(dsb, 4, Bp * 2048, 2048),
-                                             ops.ptr(dhc, 1024), 2048, memory, E, dwcat[0], dcum, None, dctx_out, E, dq, A, dw), bytes_=4.0 * B * Ti * E)
+                                             ops.ptr(dhc, 1024), 2048, memory, E, lens, dwcat[0], dcum, None, dctx_out, E, dq, A, dw), bytes_=4.0 * B * Ti * E)
 dpm = torch.zeros(B, Ti, A, device=dev); acc = torch.zeros(int(lib().gt_attn_acc_elems(d)), device=dev)
-timeit('attn_energies_bwd', lambda: ops.call('gt_attn_energies_bwd', d, dw, w_out, q_out, w_prev, w_cum, pm, Wc, Wd, v, dq, A, dpm, dwcat[1], acc))
+timeit('attn_energies_bwd', lambda: ops.call('gt_attn_energies_bwd', d, dw, w_out, q_out, w_prev, w_cum, pm, Wc, Wd, v, lens, dq, A, dpm, dwcat[1], acc))
