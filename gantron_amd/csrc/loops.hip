@@ -156,7 +156,9 @@ int gt_decoder_bwd(const GtDecoderBwd* a, void* stream) {
     auto evA = [&](int t, hipEvent_t* e) { return loop_event(1 + (size_t)(t % (R + 1)), e); };
     auto evB = [&](int t, hipEvent_t* e) { return loop_event(2 + R + (size_t)(t % (R + 1)), e); };
     auto ringX2 = [&](int t) { return a->partX2 + (int64_t)(t % R) * a->S2 * sX2; };
-    for (int t = a->To - 1; t >= 0; --t) {
+    const int t_hi = (a->t_hi >= a->t_lo && a->t_hi < a->To) ? a->t_hi : a->To - 1;
+    const int t_lo = (a->t_hi >= a->t_lo && a->t_lo >= 0 && a->t_hi < a->To) ? a->t_lo : 0;
+    for (int t = t_hi; t >= t_lo; --t) {
         const bool last = (t == a->To - 1);
         const uint8_t* k1 = a->att_keep ? a->att_keep + (int64_t)t * a->Bp * a->Ha : nullptr;
         const uint8_t* k2 = a->dec_keep ? a->dec_keep + (int64_t)t * a->Bp * a->Hd : nullptr;

@@ -25,6 +25,7 @@ from ._lib import GtBiLstm, GtDecoderBwd, GtDecoderFwd, check, lib
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 import os as _os
 REC_SPLITS = int(_os.environ.get("GANTRON_REC_SPLITS", "4"))
+BWD_CHUNKS = int(_os.environ.get("GANTRON_BWD_CHUNKS", "6"))
 DEC_RING = int(_os.environ.get("GANTRON_DEC_RING", "4"))     # 1 = single stream; >1 = two-chain pipelining   # K-splits of the per-step recurrent GEMMs
 
 
@@ -35,6 +36,36 @@ def _f32(*shape, device, zero=True):
 def _run(name, struct):
     import ctypes
     check(getattr(lib(), name)(ctypes.byref(struct), ops._stream()), name)
+
+
+class LeafStream:
+    """Side stream for weight-gradient GEMMs.  They are leaves of the backward graph (nothing on the
+    critical path consumes them), so they run concurrently with the latency-bound recurrent loops and
+    fill the CUs those leave idle.  Inputs produced on the main stream are kept alive until join()."""
+
+    def __init__(self):
+        self.stream = None
+        self.keep = []
+        self.enabled = _os.environ.get('GANTRON_LEAF_STREAM', '1') != '0'
+
+    def run(self, fn, *tensors):
+        if not self.enabled:
+            fn()
+            return
+        if self.stream is None:
+            self.stream = torch.cuda.Stream()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        self.keep.extend(tensors)
+        with torch.cuda.stream(self.stream):
+            fn()
+
+    def join(self):
+        if self.stream is not None and self.enabled:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        self.keep.clear()
+
+
+LEAF = LeafStream()
 
 
 def acc_add(dst, src):
@@ -103,8 +134,11 @@ class ConvBNStack:
             call('gt_bn_act_drop_bwd2', dz, s['y'], s['mi'], P[bn + '.weight'], sums, rows, cout, dconv,
                  G[bn + '.weight'], G[bn + '.bias'])
             x_in = first_input_override if (i == 0 and first_input_override is not None) else s['x']
-            ops.conv1d_dw(dconv, x_in, B, T, cin, cout, k, 1, G[f'{self.prefix}.{i}.0.conv.weight'])
-            acc_add(G[f'{self.prefix}.{i}.0.conv.bias'], ops.col_sums(dconv, rows, cout))
+
+            def leaf(dconv=dconv, x_in=x_in, cin=cin, cout=cout, k=k, i=i):
+                ops.conv1d_dw(dconv, x_in, B, T, cin, cout, k, 1, G[f'{self.prefix}.{i}.0.conv.weight'])
+                acc_add(G[f'{self.prefix}.{i}.0.conv.bias'], ops.col_sums(dconv, rows, cout))
+            LEAF.run(leaf, dconv, x_in)
             if i > 0 or need_dx:
                 dy = ops.conv1d_dx(dconv, ops.conv_weight_bwd(W), B, T, cin, cout, k, 1)
         return dy
@@ -353,13 +387,15 @@ class GeneratorEngine:
         if dgate is not None:
             check(lib().gt_permute3(ptr(dgate.contiguous()), 1, To, 0, To, B, 1, ptr(dout, n_mel), Bp * nout, nout, 0, 1.0,
                                     ops._stream()), 'gt_permute3')
-        dWpg = _f32(nout, hc, device=dev)
-        ops.linear_dw(dout, hist['HC'], To * Bp, nout, hc, dWpg)
-        acc_add(G['decoder.linear_projection.linear_layer.weight'], dWpg[:n_mel])
-        acc_add(G['decoder.gate_layer.linear_layer.weight'], dWpg[n_mel:])
-        bsum = ops.col_sums(dout, To * Bp, nout)
-        acc_add(G['decoder.linear_projection.linear_layer.bias'], bsum[:n_mel])
-        acc_add(G['decoder.gate_layer.linear_layer.bias'], bsum[n_mel:])
+        def leaf_proj():
+            dWpg = _f32(nout, hc, device=dev)
+            ops.linear_dw(dout, hist['HC'], To * Bp, nout, hc, dWpg)
+            acc_add(G['decoder.linear_projection.linear_layer.weight'], dWpg[:n_mel])
+            acc_add(G['decoder.gate_layer.linear_layer.weight'], dWpg[n_mel:])
+            bsum = ops.col_sums(dout, To * Bp, nout)
+            acc_add(G['decoder.linear_projection.linear_layer.bias'], bsum[:n_mel])
+            acc_add(G['decoder.gate_layer.linear_layer.bias'], bsum[n_mel:])
+        LEAF.run(leaf_proj, dout)
         dHC = ops.linear_dx(dout, sv['Wpg'], To * Bp, nout, hc)
 
         # ---- decoder loop backward
@@ -406,40 +442,55 @@ class GeneratorEngine:
         for k in buf:
             setattr(b, k, ptr(buf[k]))
         b.ring = DEC_RING
-        _run('gt_decoder_bwd', b)
-
-        # ---- deferred weight gradients of the decoder (K = To*Bp rows each)
-        dG1, dG2, rows = buf['dG1'], buf['dG2'], To * Bp
+        dG1, dG2 = buf['dG1'], buf['dG2']
         g1ih, g1hh = G['decoder.attention_rnn.weight_ih'], G['decoder.attention_rnn.weight_hh']
         g2ih, g2hh = G['decoder.decoder_rnn.weight_ih'], G['decoder.decoder_rnn.weight_hh']
-        ops.linear_dw(dG1, sv['p2'], rows, 4 * Ha, Pd, g1ih, ldc=Pd + E)
-        ops.linear_dw(dG2, hist['hatt'], rows, 4 * Hd, Ha, g2ih, ldc=Ha + E)
-        ops.linear_dw(dG2, hist['HC'], rows, 4 * Hd, E, g2ih, ldx=hc, x_offset=Hd, ldc=Ha + E, c_offset=Ha)
-        if To > 1:
-            r1 = (To - 1) * Bp
-            ops.linear_dw(dG1, hist['HC'], r1, 4 * Ha, E, g1ih, dy_offset=Bp * 4 * Ha, ldx=hc, x_offset=Hd,
-                          ldc=Pd + E, c_offset=Pd)
-            ops.linear_dw(dG1, hist['hatt'], r1, 4 * Ha, Ha, g1hh, dy_offset=Bp * 4 * Ha)
-            ops.linear_dw(dG2, hist['HC'], r1, 4 * Hd, Hd, g2hh, dy_offset=Bp * 4 * Hd, ldx=hc)
-        s1 = ops.col_sums(dG1, rows, 4 * Ha)
-        acc_add(G['decoder.attention_rnn.bias_ih'], s1)
-        acc_add(G['decoder.attention_rnn.bias_hh'], s1)
-        s2 = ops.col_sums(dG2, rows, 4 * Hd)
-        acc_add(G['decoder.decoder_rnn.bias_ih'], s2)
-        acc_add(G['decoder.decoder_rnn.bias_hh'], s2)
-        ops.linear_dw(buf['dq_hist'], hist['hatt'], rows, A, Ha, G[al + 'query_layer.linear_layer.weight'], lddy=Apad)
-        call('gt_attn_acc_reduce', dims, buf['acc'], G[al + 'v.linear_layer.weight'],
-             G[al + 'location_layer.location_dense.linear_layer.weight'],
-             G[al + 'location_layer.location_conv.conv.weight'])
+
+        def leaf_decoder(lo, hi):
+            """Weight gradients contributed by decoder steps lo..hi (dW = dGates^T . inputs, K = rows)."""
+            n, o = (hi - lo + 1) * Bp, lo * Bp
+            ops.linear_dw(dG1, sv['p2'], n, 4 * Ha, Pd, g1ih, dy_offset=o * 4 * Ha, x_offset=o * Pd, ldc=Pd + E)
+            ops.linear_dw(dG2, hist['hatt'], n, 4 * Hd, Ha, g2ih, dy_offset=o * 4 * Hd, x_offset=o * Ha, ldc=Ha + E)
+            ops.linear_dw(dG2, hist['HC'], n, 4 * Hd, E, g2ih, dy_offset=o * 4 * Hd, ldx=hc, x_offset=o * hc + Hd,
+                          ldc=Ha + E, c_offset=Ha)
+            l1 = max(lo, 1)                      # pairs (t, t-1): gradients of the recurrent inputs
+            if hi >= l1:
+                n1, o1, p1_ = (hi - l1 + 1) * Bp, l1 * Bp, (l1 - 1) * Bp
+                ops.linear_dw(dG1, hist['HC'], n1, 4 * Ha, E, g1ih, dy_offset=o1 * 4 * Ha, ldx=hc,
+                              x_offset=p1_ * hc + Hd, ldc=Pd + E, c_offset=Pd)
+                ops.linear_dw(dG1, hist['hatt'], n1, 4 * Ha, Ha, g1hh, dy_offset=o1 * 4 * Ha, x_offset=p1_ * Ha)
+                ops.linear_dw(dG2, hist['HC'], n1, 4 * Hd, Hd, g2hh, dy_offset=o1 * 4 * Hd, ldx=hc, x_offset=p1_ * hc)
+            s1 = ops.col_sums(dG1[lo:hi + 1], n, 4 * Ha)
+            acc_add(G['decoder.attention_rnn.bias_ih'], s1)
+            acc_add(G['decoder.attention_rnn.bias_hh'], s1)
+            s2 = ops.col_sums(dG2[lo:hi + 1], n, 4 * Hd)
+            acc_add(G['decoder.decoder_rnn.bias_ih'], s2)
+            acc_add(G['decoder.decoder_rnn.bias_hh'], s2)
+            ops.linear_dw(buf['dq_hist'], hist['hatt'], n, A, Ha, G[al + 'query_layer.linear_layer.weight'], lddy=Apad,
+                          dy_offset=o * Apad, x_offset=o * Ha)
+
+        # the loop is issued in chunks; the weight-gradient GEMMs of a finished chunk run on the leaf stream
+        # while the (latency-bound) loop continues with earlier steps
+        n_chunks = max(1, min(BWD_CHUNKS, To // 32))
+        bounds = [round(i * To / n_chunks) for i in range(n_chunks + 1)]
+        for ci in reversed(range(n_chunks)):
+            lo, hi = bounds[ci], bounds[ci + 1] - 1
+            b.t_hi, b.t_lo = hi, lo
+            _run('gt_decoder_bwd', b)
+            LEAF.run(lambda lo=lo, hi=hi: leaf_decoder(lo, hi), dHC)
+        LEAF.run(lambda: call('gt_attn_acc_reduce', dims, buf['acc'], G[al + 'v.linear_layer.weight'],
+                              G[al + 'location_layer.location_dense.linear_layer.weight'],
+                              G[al + 'location_layer.location_conv.conv.weight']), buf['acc'])
+        rows = To * Bp
 
         # ---- prenet backward
         dp2 = ops.linear_dx(dG1, W1ih, rows, 4 * Ha, Pd, ldw=Pd + E)
         pk = sv['prenet_keep']
         call('gt_bias_act_drop_bwd', dp2, sv['p2'], rows, Pd, ACT_RELU, 0, pk[1], 0.5, dp2)
-        ops.linear_dw(dp2, sv['p1'], rows, Pd, Pd, G['decoder.prenet.layers.1.linear_layer.weight'])
+        LEAF.run(lambda: ops.linear_dw(dp2, sv['p1'], rows, Pd, Pd, G['decoder.prenet.layers.1.linear_layer.weight']), dp2)
         dp1 = ops.linear_dx(dp2, P['decoder.prenet.layers.1.linear_layer.weight'], rows, Pd, Pd)
         call('gt_bias_act_drop_bwd', dp1, sv['p1'], rows, Pd, ACT_RELU, 0, pk[0], 0.5, dp1)
-        ops.linear_dw(dp1, sv['x0'], rows, Pd, n_mel, G['decoder.prenet.layers.0.linear_layer.weight'])
+        LEAF.run(lambda: ops.linear_dw(dp1, sv['x0'], rows, Pd, n_mel, G['decoder.prenet.layers.0.linear_layer.weight']), dp1)
 
         # ---- d(memory) = sum_t w_t^T dctx_t (batched over b) + dpm @ Wmem ;  dWmem = dpm^T memory
         Wmem = P[al + 'memory_layer.linear_layer.weight']
@@ -447,7 +498,7 @@ class GeneratorEngine:
         sgemm(Operand(hist['w_hist'], RC, ld=B * Ti, offset=B * Ti, batch_stride=Ti),
               Operand(buf['dctx_hist'], RC, ld=B * E, batch_stride=E), dmem, Ti, E, To, batch=B, c_batch_stride=Ti * E)
         sgemm(Operand(buf['dpm'], KC, ld=A), Operand(Wmem, RC, ld=E), dmem, B * Ti, E, A, accumulate=True)
-        ops.linear_dw(buf['dpm'], sv['memory'], B * Ti, A, E, G[al + 'memory_layer.linear_layer.weight'])
+        LEAF.run(lambda: ops.linear_dw(buf['dpm'], sv['memory'], B * Ti, A, E, G[al + 'memory_layer.linear_layer.weight']), buf['dpm'])
 
         col = 2 * H
         if self.vesus:
@@ -498,6 +549,7 @@ class GeneratorEngine:
         demb = self.enc_stack.backward(P, G, dx3, B, Ti, sv['enc_conv'])
         call('gt_embedding_bwd', sv['text'], demb, hp.symbols_embedding_dim, B * Ti, hp.symbols_embedding_dim,
              G['embedding.weight'])
+        LEAF.join()
 
 
 class DiscriminatorEngine:

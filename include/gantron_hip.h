@@ -222,6 +222,8 @@ typedef struct GtDecoderBwd {
     float* dw;                 /* (B, Ti) */
     float* partX1; float* partX2; float* partQ;   /* partX2: (ring, S2, Bp, N2pad) */
     int32_t ring;              /* as in GtDecoderFwd */
+    int32_t t_hi, t_lo;        /* steps t_hi..t_lo (descending) of this call; t_hi < t_lo = all steps.  State
+                                  persists in the buffers, so a loop may be issued in several calls. */
 } GtDecoderBwd;
 
 typedef struct GtBiLstm {
