@@ -166,15 +166,19 @@ def main():
     from gantron_amd.train_steps import discriminator_step, generator_step
 
     hp = HParams(HPARAMS + f',batch_size={args.batch}')
-    if world > 1:
+    # GANTRON_FORCE_DIST=1 exercises the RCCL gradient-averaging path on a single rank (1-GPU boxes)
+    use_dist = world > 1 or os.environ.get('GANTRON_FORCE_DIST') == '1'
+    if use_dist:
         hp.distributed_run = True
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', init_method='env://', world_size=world, rank=rank)
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', init_method='env://', world_size=world, rank=rank,
+                                device_id=dev)
     torch.manual_seed(hp.seed)
     G, D = Tacotron2(hp).to(dev).train(), Discriminator(hp).to(dev).train()
     g_opt = FlatAdam(G, lr=hp.g_learning_rate, weight_decay=hp.weight_decay)
     d_opt = FlatAdam(D, lr=hp.d_learning_rate, weight_decay=hp.weight_decay)
-    if world > 1:
+    if use_dist:
         G, D = apply_gradient_allreduce(G), apply_gradient_allreduce(D)
     crit = Tacotron2Loss()
     batch = ljspeech_shaped_batch(hp, args.batch, seed=1234 + rank, fixed=args.fixed_shape)
@@ -188,7 +192,7 @@ def main():
         discriminator_step(G, D, d_opt, batch, generated, hp)
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -241,7 +245,7 @@ def main():
                                               gbs=round(r['bytes'] / max(r['ms'], 1e-9) / 1e6, 1)) for r in fam})
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()
-    if world > 1:
+    if use_dist:
         dist.barrier()
 
     if rank == 0:
@@ -259,7 +263,7 @@ def main():
                                 pair_mfma_frac=fl / (elapsed / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS),
                     roofline=roof, cpu_baseline=cpu)
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

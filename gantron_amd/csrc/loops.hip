@@ -36,7 +36,11 @@ static std::vector<hipEvent_t> g_loop_events;
 
 static int aux_stream(hipStream_t* out) {
     if (g_aux_stream == nullptr) {
-        hipError_t e = hipStreamCreateWithFlags(&g_aux_stream, hipStreamNonBlocking);
+        // highest priority: the loop kernels are the critical path, the weight-gradient GEMMs that
+        // share the device (leaf stream, normal priority) should only fill what they leave idle
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);
+        hipError_t e = hipStreamCreateWithPriority(&g_aux_stream, hipStreamNonBlocking, hi);
         GT_REQUIRE(e == hipSuccess, (int)e, "decoder loop: cannot create the auxiliary stream");
     }
     *out = g_aux_stream;

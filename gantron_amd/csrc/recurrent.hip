@@ -8,6 +8,7 @@
 // v_mfma_f32_16x16x4_f32 (4 independent accumulators = 4 row tiles keep the pipe at issue rate).
 // K is split over blockIdx.y into partial slabs that the pointwise cell kernel sums, so a step
 // occupies (N/64) x splits workgroups with no atomics and no inter-workgroup hand-off.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -36,21 +37,26 @@ __global__ __launch_bounds__(256) void pack_rec_weight_kernel(const float* W, lo
 }
 
 // Activation chunks (MT*16 rows x 128 k) are staged through LDS once per workgroup with fully
-// coalesced 512-byte row segments and shared by the four waves (each wave owns 16 gate columns), so
-// a workgroup reads every activation element from L2 exactly once; the next chunk's global loads are
-// issued into registers before the current chunk's MFMAs.  The wave's weight fragments (1 KiB per
-// 16-wide k-block, lane-linear) stream straight into VGPRs, one chunk ahead.
+// coalesced 512-byte row segments and shared by all waves; the next chunk's global loads are issued
+// into registers before the current chunk's MFMAs.  A workgroup has 8 waves = 2 per SIMD: wave w owns
+// gate columns [16*(w&3), +16) of the workgroup's 64 and the k-blocks of half (w>>2) of every chunk, so
+// two waves interleave on each matrix pipe (one's LDS/VMEM waits hide under the other's MFMAs; a single
+// wave per SIMD reached only ~60 % of the MFMA rate) and 64 KiB of weight loads are in flight per CU.
+// The two K-halves are folded through LDS at the end.  The wave's weight fragments (1 KiB per 16-wide
+// k-block, lane-linear) stream straight into VGPRs, one chunk ahead.
 constexpr int REC_CK = 8;                 // k-blocks (of 16) per LDS chunk
+constexpr int REC_HK = REC_CK / 2;        // k-blocks per wave per chunk
 constexpr int REC_LD = REC_CK * 16 + 4;   // padded LDS row: conflict-free ds_read_b128 / ds_write_b128
+constexpr int REC_THREADS = 512;
 
 template <int MT>
 struct RecChunk {                         // per-thread registers of one activation chunk
-    static constexpr int NV = MT * 16 * REC_CK * 16 / 4 / 256;   // float4 per thread (MT=4: 8)
-    float4 v[NV];
+    static constexpr int NV = MT * 16 * REC_CK * 16 / 4 / REC_THREADS;   // float4 per thread (MT=4: 4)
+    float4 v[NV > 0 ? NV : 1];
     __device__ __forceinline__ void load(const float* X, long ldx, int kb, int kb1, int tid) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int f = tid + 256 * i;
+            const int f = tid + REC_THREADS * i;
             const int row = f / (REC_CK * 4), c4 = f % (REC_CK * 4);
             const int kblk = kb + (c4 >> 2);
             v[i] = (kblk < kb1) ? *reinterpret_cast<const float4*>(X + (long)row * ldx + (long)kb * 16 + 4 * c4)
@@ -60,35 +66,39 @@ struct RecChunk {                         // per-thread registers of one activat
     __device__ __forceinline__ void store(float* S, int tid) const {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int f = tid + 256 * i;
+            const int f = tid + REC_THREADS * i;
             const int row = f / (REC_CK * 4), c4 = f % (REC_CK * 4);
             *reinterpret_cast<float4*>(&S[row * REC_LD + 4 * c4]) = v[i];
         }
     }
 };
 
-struct RecW {                             // weight fragments of one chunk
-    float4 w[REC_CK];
+struct RecW {                             // weight fragments of this wave's half of one chunk
+    float4 w[REC_HK];
     __device__ __forceinline__ void load(const float4* wp, int kb, int kb1) {
 #pragma unroll
-        for (int u = 0; u < REC_CK; ++u) w[u] = (kb + u < kb1) ? wp[u * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < REC_HK; ++u) w[u] = (kb + u < kb1) ? wp[u * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 };
 
-template <int MT>
-__global__ __launch_bounds__(256) void rec_gemm_kernel(const float* __restrict__ X, long ldx,
-                                                       const float* __restrict__ Wp,
-                                                       float* __restrict__ part, int N, int KB, int KBS,
-                                                       long xz, long wz, long pz, long ps) {
+// DBG (diagnostics, GANTRON_REC_DEBUG): bit 0 = no weight loads, bit 1 = no MFMAs, bit 2 = no activation staging
+template <int MT, int DBG = 0>
+__global__ __launch_bounds__(REC_THREADS) void rec_gemm_kernel(const float* __restrict__ X, long ldx,
+                                                               const float* __restrict__ Wp,
+                                                               float* __restrict__ part, int N, int KB, int KBS,
+                                                               long xz, long wz, long pz, long ps) {
+    static_assert(MT == 4 || MT == 2 || MT == 1 || MT == 3, "row tiles");
     __shared__ __attribute__((aligned(16))) float Xs[MT * 16 * REC_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = wave >> 2;
     const int s = blockIdx.y, z = blockIdx.z;
     const int kb0 = s * KBS;
     const int kb1 = min(KB, kb0 + KBS);
-    int nb = blockIdx.x * 4 + wave;
+    int nb = blockIdx.x * 4 + (wave & 3);
     const bool active = nb * 16 < N;      // inactive waves still help staging and join the barriers
     if (!active) nb = 0;
-    const float4* wp = reinterpret_cast<const float4*>(Wp + (long)z * wz) + ((long)nb * KB + kb0) * 64 + lane;
+    // this wave's k-blocks of chunk c: kb0 + 8c + 4*half + {0..3}
+    const float4* wp = reinterpret_cast<const float4*>(Wp + (long)z * wz) + ((long)nb * KB + kb0 + REC_HK * half) * 64 + lane;
     const float* Xz = X + (long)z * xz;
 
     f32x4 acc[MT];
@@ -97,24 +107,48 @@ __global__ __launch_bounds__(256) void rec_gemm_kernel(const float* __restrict__
 
     RecChunk<MT> xc;
     RecW wa, wb;
-    xc.load(Xz, ldx, kb0, kb1, tid);
-    wa.load(wp, kb0, kb1);
-    const float* xs = Xs + (lane & 15) * REC_LD + 4 * (lane >> 4);
+    // staging needs MT*16 rows x 32 float4 = MT*512 float4: with MT < 4 only part of the threads take part
+    constexpr int STAGE_THREADS = (RecChunk<MT>::NV > 0) ? REC_THREADS : MT * 128;
+    const bool stager = RecChunk<MT>::NV > 0 || tid < STAGE_THREADS;
+    auto xload = [&](int kb) __attribute__((always_inline)) {
+        if (RecChunk<MT>::NV > 0) { xc.load(Xz, ldx, kb, kb1, tid); return; }
+        if (stager) {
+            const int row = tid / (REC_CK * 4), c4 = tid % (REC_CK * 4);
+            xc.v[0] = (kb + (c4 >> 2) < kb1) ? *reinterpret_cast<const float4*>(Xz + (long)row * ldx + (long)kb * 16 + 4 * c4)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto xstore = [&]() __attribute__((always_inline)) {
+        if (RecChunk<MT>::NV > 0) { xc.store(Xs, tid); return; }
+        if (stager) {
+            const int row = tid / (REC_CK * 4), c4 = tid % (REC_CK * 4);
+            *reinterpret_cast<float4*>(&Xs[row * REC_LD + 4 * c4]) = xc.v[0];
+        }
+    };
+    xload(kb0);
+    wa.load(wp, kb0 + REC_HK * half, kb1);
+    if (DBG & 1) wb = wa;
+    const float* xs = Xs + (lane & 15) * REC_LD + 4 * (lane >> 4) + REC_HK * half * 16;
     // one chunk: publish the staged activations, prefetch the next chunk (activations + weights),
     // run the chunk's MFMAs.  `cur`/`nxt` are bound statically (two calls per loop trip) so that the
     // register arrays are never indexed at run time.
     auto chunk = [&](const RecW& cur, RecW& nxt, int kb) __attribute__((always_inline)) {
-        xc.store(Xs, tid);
+        if (!(DBG & 4) || kb == kb0) xstore();
         __syncthreads();
         const int kn = kb + REC_CK;
-        if (kn < kb1) xc.load(Xz, ldx, kn, kb1, tid);
-        nxt.load(wp + (long)REC_CK * 64, kn, kb1);
+        if (!(DBG & 4) && kn < kb1) xload(kn);
+        if (!(DBG & 1)) nxt.load(wp + (long)REC_CK * 64, kn + REC_HK * half, kb1);
 #pragma unroll
-        for (int u = 0; u < REC_CK; ++u) {
+        for (int u = 0; u < REC_HK; ++u) {
             float4 a[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float4*>(xs + mt * 16 * REC_LD + u * 16);
             const float4 b = cur.w[u];
+            if (DBG & 2) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) { acc[mt][0] += a[mt].x * b.x; acc[mt][1] += a[mt].y * b.y; acc[mt][2] += a[mt].z * b.z; acc[mt][3] += a[mt].w * b.w; }
+                continue;
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b.x, acc[mt], 0, 0, 0);
 #pragma unroll
@@ -131,13 +165,23 @@ __global__ __launch_bounds__(256) void rec_gemm_kernel(const float* __restrict__
         chunk(wa, wb, kb);
         if (kb + REC_CK < kb1) chunk(wb, wa, kb + REC_CK);
     }
-    if (!active) return;
+    // fold the two K-halves through LDS (Xs is free after the last barrier): [wave&3][mt][reg][lane]
+    float* red = Xs;
+    if (half == 1) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(((wave & 3) * MT + mt) * 4 + r) * 64 + lane] = acc[mt][r];
+    }
+    __syncthreads();
+    if (half == 1 || !active) return;
     // C/D map of the 16x16 MFMA: n = lane&15, m = 4*(lane>>4) + reg
     float* out = part + (long)z * pz + (long)s * ps + nb * 16 + (lane & 15);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[(long)(mt * 16 + 4 * (lane >> 4) + r) * N] = acc[mt][r];
+        for (int r = 0; r < 4; ++r)
+            out[(long)(mt * 16 + 4 * (lane >> 4) + r) * N] = acc[mt][r] + red[(((wave & 3) * MT + mt) * 4 + r) * 64 + lane];
 }
 
 struct CellFwd {
@@ -370,9 +414,30 @@ extern "C" int gt_rec_gemm(const float* X, int64_t ldx, const float* Wp, float* 
     hipStream_t st = (hipStream_t)stream;
     GtProfScope prof(GT_FAM_REC_GEMM, 2.0 * 16 * mtiles * (double)N * K * nz,
                      4.0 * nz * ((double)N * K + 16.0 * mtiles * K + 16.0 * mtiles * N * splits), st);
+    // reserve enough LDS that at most ONE workgroup fits a CU: the grid is sized to the CU count and
+    // two co-resident workgroups would serialise on one CU's matrix pipes while another CU idles
+    static const int lds_pad = getenv("GANTRON_REC_LDS_PAD") ? atoi(getenv("GANTRON_REC_LDS_PAD")) : 0;
 #define GT_REC(MT)                                                                                    \
-    hipLaunchKernelGGL((rec_gemm_kernel<MT>), grid, dim3(256), 0, st, X, (long)ldx, Wp, part, N, KB, \
+    hipLaunchKernelGGL((rec_gemm_kernel<MT>), grid, dim3(REC_THREADS), lds_pad, st, X, (long)ldx, Wp, part, N, KB, \
                        KBS, (long)x_zstride, (long)w_zstride, (long)part_zstride, (long)part_sstride)
+    static const int dbg = getenv("GANTRON_REC_DEBUG") ? atoi(getenv("GANTRON_REC_DEBUG")) : 0;
+    if (dbg && mtiles == 4) {   // diagnostic variants (wrong results by construction)
+#define GT_RECD(D)                                                                                       \
+    hipLaunchKernelGGL((rec_gemm_kernel<4, D>), grid, dim3(REC_THREADS), lds_pad, st, X, (long)ldx, Wp, part, N, KB,  \
+                       KBS, (long)x_zstride, (long)w_zstride, (long)part_zstride, (long)part_sstride)
+        switch (dbg) {
+            case 1: GT_RECD(1); break;
+            case 2: GT_RECD(2); break;
+            case 3: GT_RECD(3); break;
+            case 4: GT_RECD(4); break;
+            case 5: GT_RECD(5); break;
+            case 6: GT_RECD(6); break;
+            default: GT_RECD(7); break;
+        }
+#undef GT_RECD
+        GT_LAUNCH_CHECK();
+        return 0;
+    }
     switch (mtiles) {
         case 1: GT_REC(1); break;
         case 2: GT_REC(2); break;

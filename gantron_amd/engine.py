@@ -25,6 +25,8 @@ from ._lib import GtBiLstm, GtDecoderBwd, GtDecoderFwd, check, lib
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 import os as _os
 REC_SPLITS = int(_os.environ.get("GANTRON_REC_SPLITS", "4"))
+HIGH_PRIORITY_BACKWARD = _os.environ.get('GANTRON_HIGH_PRIO', '0') != '0'   # measured: no gain on MI355X
+_HIGH_STREAM = None
 BWD_CHUNKS = int(_os.environ.get("GANTRON_BWD_CHUNKS", "6"))
 DEC_RING = int(_os.environ.get("GANTRON_DEC_RING", "4"))     # 1 = single stream; >1 = two-chain pipelining   # K-splits of the per-step recurrent GEMMs
 
@@ -36,6 +38,35 @@ def _f32(*shape, device, zero=True):
 def _run(name, struct):
     import ctypes
     check(getattr(lib(), name)(ctypes.byref(struct), ops._stream()), name)
+
+
+class PhaseTimer:
+    """Optional wall-clock phase breakdown (GANTRON_PHASE_TIMING=1): synchronises at every mark, so it
+    serialises the streams -- a development aid, never on in a measured run."""
+
+    def __init__(self):
+        self.on = _os.environ.get('GANTRON_PHASE_TIMING', '0') == '1'
+        self.t = None
+        self.acc = {}
+
+    def mark(self, name):
+        if not self.on:
+            return
+        import time
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        if self.t is not None and name is not None:
+            self.acc[name] = self.acc.get(name, 0.0) + (now - self.t) * 1e3
+        self.t = now
+
+    def report(self):
+        if self.on and self.acc:
+            import sys
+            print('[phases ms] ' + '  '.join(f'{k}={v:.1f}' for k, v in self.acc.items()), file=sys.stderr, flush=True)
+            self.acc = {}
+
+
+PHASES = PhaseTimer()
 
 
 class LeafStream:
@@ -53,7 +84,7 @@ class LeafStream:
             fn()
             return
         if self.stream is None:
-            self.stream = torch.cuda.Stream()
+            self.stream = torch.cuda.Stream(priority=torch.cuda.Stream.priority_range()[0])
         self.stream.wait_stream(torch.cuda.current_stream())
         self.keep.extend(tensors)
         with torch.cuda.stream(self.stream):
@@ -198,6 +229,7 @@ class GeneratorEngine:
         sv = dict(B=B, Bp=Bp, Ti=Ti, To=To, in_lens=list(in_lens), out_lens=list(out_lens), training=training,
                   text=text)
 
+        PHASES.mark(None)
         # ---- embedding + encoder convolutions (channels-last rows = (b, t))
         x = _f32(B * Ti, hp.symbols_embedding_dim, device=dev, zero=False)
         call('gt_embedding_fwd', text, P['embedding.weight'], B * Ti, hp.symbols_embedding_dim, x,
@@ -206,6 +238,7 @@ class GeneratorEngine:
         x = self.enc_stack.forward(P, x, B, Ti, rng.get('enc_keep'), training, sv['enc_conv'])
         sv['enc_x3'] = x
 
+        PHASES.mark('f.enc_conv')
         # ---- packed BiLSTM, step-major
         fwd_i, rev_i, ifwd, irev, active = self.step_major_index(in_lens, Ti, Bp)
         idx = {k: v.to(dev) for k, v in dict(fwd=fwd_i, rev=rev_i, ifwd=ifwd, irev=irev, active=active).items()}
@@ -236,6 +269,7 @@ class GeneratorEngine:
         _run('gt_bilstm_run', a)
         sv.update(Xs=Xs, enc_gates=gates, enc_c=cst, enc_hs=hs)
 
+        PHASES.mark('f.bilstm')
         # ---- decoder memory = [encoder outputs | speaker | labels | style noise]
         memory = _f32(B, Ti, E, device=dev)
         mem2 = memory.view(B * Ti, E)
@@ -320,7 +354,9 @@ class GeneratorEngine:
         d.part2, d.ring = ptr(ws['part2']), DEC_RING
         for k in ('gates1', 'c1', 'gates2', 'c2', 'hatt', 'HC', 'w_hist', 'cum_hist', 'q_hist'):
             setattr(d, k, ptr(hist[k]))
+        PHASES.mark('f.pre_loop')
         _run('gt_decoder_fwd', d)
+        PHASES.mark('f.dec_loop')
         sv.update(hist=hist, pre1=pre1, lens32=lens32, att_keep=att_keep, dec_keep=dec_keep,
                   prenet_keep=pk)
 
@@ -343,6 +379,7 @@ class GeneratorEngine:
                                 ops._stream()), 'gt_permute3')
         sv['Wpg'] = Wpg
 
+        PHASES.mark('f.proj')
         # ---- PostNet + residual + padding mask
         sv['post_conv'] = []
         post_cl = self.post_stack.forward(P, mel_cl, B, To, rng.get('post_keep'), training, sv['post_conv'])
@@ -356,12 +393,27 @@ class GeneratorEngine:
             mel_cl_masked = _f32(B * To, n_mel, device=dev, zero=False)
             call('gt_permute3', mel, n_mel * To, 1, To, B, To, n_mel, mel_cl_masked, 0, 0, 0, 1.0)
             sv['mel_cl_masked'] = mel_cl_masked
+        PHASES.mark('f.postnet')
         return (mel, mel_post, gate, align), sv
 
     # ------------------------------------------------------------------------------ backward
     def backward(self, P, G, sv, dmel, dmel_post, dgate, dalign):
         """Accumulate parameter gradients into G (dict name -> tensor).  d* are gradients of the four
-        outputs (any may be None)."""
+        outputs (any may be None).  Runs on a high-priority stream so that the latency-bound loop kernels
+        win the CUs over the weight-gradient GEMMs of the (normal-priority) leaf stream."""
+        if HIGH_PRIORITY_BACKWARD:
+            global _HIGH_STREAM
+            if _HIGH_STREAM is None:
+                _HIGH_STREAM = torch.cuda.Stream(priority=torch.cuda.Stream.priority_range()[1])
+            outer = torch.cuda.current_stream()
+            _HIGH_STREAM.wait_stream(outer)
+            with torch.cuda.stream(_HIGH_STREAM):
+                self._backward(P, G, sv, dmel, dmel_post, dgate, dalign)
+            outer.wait_stream(_HIGH_STREAM)
+        else:
+            self._backward(P, G, sv, dmel, dmel_post, dgate, dalign)
+
+    def _backward(self, P, G, sv, dmel, dmel_post, dgate, dalign):
         hp = self.hp
         B, Bp, Ti, To = sv['B'], sv['Bp'], sv['Ti'], sv['To']
         n_mel, H, E, A, Pd, Ha, Hd = self.n_mel, self.H, self.E, self.A, self.P, self.Ha, self.Hd
@@ -369,6 +421,7 @@ class GeneratorEngine:
         hist = sv['hist']
         hc, nout = Hd + E, n_mel + 1
 
+        PHASES.mark(None)
         # ---- PostNet backward (channels-last)
         dmel_cl = _f32(B * To, n_mel, device=dev)
         if dmel is not None:
@@ -381,6 +434,7 @@ class GeneratorEngine:
                                           first_input_override=sv.get('mel_cl_masked'))
             call('gt_axpby', dmel_cl, 1.0, dx, 1.0, dmel_cl, B * To * n_mel)
 
+        PHASES.mark('b.postnet')
         # ---- projection backward: gradient w.r.t. [h_dec | ctx] of every step
         dout = _f32(To, Bp, nout, device=dev)
         call('gt_permute3', dmel_cl, n_mel, To * n_mel, 1, To, B, n_mel, dout, Bp * nout, nout, 0, 1.0)
@@ -469,6 +523,7 @@ class GeneratorEngine:
             ops.linear_dw(buf['dq_hist'], hist['hatt'], n, A, Ha, G[al + 'query_layer.linear_layer.weight'], lddy=Apad,
                           dy_offset=o * Apad, x_offset=o * Ha)
 
+        PHASES.mark('b.pre_loop')
         # the loop is issued in chunks; the weight-gradient GEMMs of a finished chunk run on the leaf stream
         # while the (latency-bound) loop continues with earlier steps
         n_chunks = max(1, min(BWD_CHUNKS, To // 32))
@@ -482,6 +537,7 @@ class GeneratorEngine:
                               G[al + 'location_layer.location_dense.linear_layer.weight'],
                               G[al + 'location_layer.location_conv.conv.weight']), buf['acc'])
         rows = To * Bp
+        PHASES.mark('b.dec_loop+dW')
 
         # ---- prenet backward
         dp2 = ops.linear_dx(dG1, W1ih, rows, 4 * Ha, Pd, ldw=Pd + E)
@@ -510,6 +566,7 @@ class GeneratorEngine:
             dspk = ops.col_sums(tmp, Ti, B * se).contiguous()
             call('gt_embedding_bwd', sv['speaker_ids'], dspk, se, B, se, G['speaker_embedding.weight'])
 
+        PHASES.mark('b.prenet_dmem')
         # ---- BiLSTM backward
         idx = sv['idx']
         C = self.enc_dim
@@ -545,11 +602,14 @@ class GeneratorEngine:
         call('gt_gather_rows', dXs[0], C, idx['ifwd'], B * Ti, C, dx3, C, 0)
         call('gt_gather_rows', dXs[1], C, idx['irev'], B * Ti, C, dx3, C, 1)
 
+        PHASES.mark('b.bilstm')
         # ---- encoder convolutions + embedding
         demb = self.enc_stack.backward(P, G, dx3, B, Ti, sv['enc_conv'])
         call('gt_embedding_bwd', sv['text'], demb, hp.symbols_embedding_dim, B * Ti, hp.symbols_embedding_dim,
              G['embedding.weight'])
         LEAF.join()
+        PHASES.mark('b.enc_conv')
+        PHASES.report()
 
 
 class DiscriminatorEngine:
