@@ -24,6 +24,15 @@ static inline GtSlabs slabs(const float* p, int n, int64_t stride, int64_t ld) {
 }
 static const GtSlabs kNoSlabs = {nullptr, 0, 0, 0};
 
+// Recurrent product for Bp activation rows: up to 64 rows are one launch with Bp/16 row tiles; larger
+// batches (Bp a multiple of 64) use blockIdx.z over 64-row blocks that share the packed weights.
+static int rec_rows(const float* X, int64_t ldx, const float* Wp, float* part, int Bp, int N, int K, int S,
+                    void* stream) {
+    if (Bp <= 64) return gt_rec_gemm(X, ldx, Wp, part, Bp / 16, N, K, S, (int64_t)Bp * N, 1, 0, 0, 0, stream);
+    return gt_rec_gemm(X, ldx, Wp, part, 4, N, K, S, (int64_t)Bp * N, Bp / 64, 64 * ldx, 0, (int64_t)64 * N, stream);
+}
+static bool rows_ok(int B, int Bp) { return B > 0 && Bp >= B && ((Bp <= 64 && Bp % 16 == 0) || Bp % 64 == 0); }
+
 // ---- two-chain pipelining -----------------------------------------------------------------------
 // A decoder step is two dependent chains: the attention chain (attention LSTM, query, energies,
 // softmax+context) and the decoder-LSTM chain.  Forward, the attention chain of step t+1 depends only
@@ -64,12 +73,11 @@ static int loop_event(size_t i, hipEvent_t* out) {
 
 int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
     GT_REQUIRE(a != nullptr, GT_E_ARG, "gt_decoder_fwd: NULL");
-    GT_REQUIRE(a->B > 0 && a->Bp >= a->B && a->Bp % 16 == 0 && a->Bp <= 64, GT_E_LIMIT,
-               "gt_decoder_fwd: batch %d (padded %d) must fit 64 rows per call", a->B, a->Bp);
+    GT_REQUIRE(rows_ok(a->B, a->Bp), GT_E_LIMIT,
+               "gt_decoder_fwd: batch %d must be padded to a multiple of 16 (<= 64) or of 64 (got %d)", a->B, a->Bp);
     GT_REQUIRE(a->To > 0 && a->Ti > 0 && a->Ha % 16 == 0 && a->Hd % 16 == 0 && a->Apad % 16 == 0, GT_E_ARG,
                "gt_decoder_fwd: bad dims");
     GT_REQUIRE(a->ring >= 1 && a->ring <= 8 && (a->ring == 1 || a->part2 != nullptr), GT_E_ARG, "gt_decoder_fwd: ring/part2");
-    const int mt = a->Bp / 16;
     const int N1 = 4 * a->Ha, N2 = 4 * a->Hd;
     const int K1 = a->E + a->Ha, K2 = a->Ha + a->E + a->Hd;
     const int64_t hc_ld = a->Hd + a->E;
@@ -96,7 +104,7 @@ int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
         float* X2t = a->X2 + (int64_t)(t % R) * a->Bp * a->ld2;
         float* X2n = a->X2 + (int64_t)((t + 1) % R) * a->Bp * a->ld2;
         // ---- attention chain (stream A)
-        GT_TRY(gt_rec_gemm(a->X1, a->ld1, a->W1p, a->part, mt, N1, K1, a->S1, (int64_t)a->Bp * N1, 1, 0, 0, 0, sA));
+        GT_TRY(rec_rows(a->X1, a->ld1, a->W1p, a->part, a->Bp, N1, K1, a->S1, sA));
         if (two && t >= R) {     // X2 ring slot t%R was last read by the decoder chain of step t-R
             GT_TRY(evB(t - R, &ev));
             GT_HIP(hipStreamWaitEvent(sA, ev, 0));
@@ -106,8 +114,7 @@ int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
                                 a->gates1 + (int64_t)t * a->Bp * N1, a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha,
                                 a->hatt + (int64_t)t * a->Bp * a->Ha, a->X1 + a->E, a->ld1, X2t, a->ld2, nullptr, 0,
                                 a->B, a->Ha, sA));
-        GT_TRY(gt_rec_gemm(X2t, a->ld2, a->Wqp, a->part, mt, a->Apad, a->Ha, a->Sq, (int64_t)a->Bp * a->Apad, 1, 0, 0,
-                           0, sA));
+        GT_TRY(rec_rows(X2t, a->ld2, a->Wqp, a->part, a->Bp, a->Apad, a->Ha, a->Sq, sA));
         GT_TRY(gt_attn_energies_fwd(d, slabs(a->part, a->Sq, (int64_t)a->Bp * a->Apad, a->Apad),
                                     a->w_hist + (int64_t)t * BT, a->cum_hist + (int64_t)t * BT, a->pm, a->Wc, a->Wd, a->v,
                                     a->lengths, a->q_hist + (int64_t)t * a->B * a->A, a->energies, sA));
@@ -120,7 +127,7 @@ int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
             GT_HIP(hipStreamWaitEvent(sB, ev, 0));
         }
         // ---- decoder LSTM chain (stream B): [h_att_t | ctx_t | h_dec_{t-1}] . W2 + bias
-        GT_TRY(gt_rec_gemm(X2t, a->ld2, a->W2p, partB, mt, N2, K2, a->S2, (int64_t)a->Bp * N2, 1, 0, 0, 0, sB));
+        GT_TRY(rec_rows(X2t, a->ld2, a->W2p, partB, a->Bp, N2, K2, a->S2, sB));
         GT_TRY(gt_lstm_cell_fwd(slabs(partB, a->S2, (int64_t)a->Bp * N2, N2), a->bias2, 0,
                                 a->c2 + (int64_t)t * a->Bp * a->Hd, nullptr, 0, k2, a->p_dec, nullptr,
                                 a->gates2 + (int64_t)t * a->Bp * N2, a->c2 + (int64_t)(t + 1) * a->Bp * a->Hd, nullptr,
@@ -139,9 +146,8 @@ int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
 
 int gt_decoder_bwd(const GtDecoderBwd* a, void* stream) {
     GT_REQUIRE(a != nullptr, GT_E_ARG, "gt_decoder_bwd: NULL");
-    GT_REQUIRE(a->B > 0 && a->Bp >= a->B && a->Bp % 16 == 0 && a->Bp <= 64, GT_E_LIMIT, "gt_decoder_bwd: batch");
+    GT_REQUIRE(rows_ok(a->B, a->Bp), GT_E_LIMIT, "gt_decoder_bwd: batch padding");
     GT_REQUIRE(a->ring >= 1 && a->ring <= 8, GT_E_ARG, "gt_decoder_bwd: ring");
-    const int mt = a->Bp / 16;
     const int N1 = 4 * a->Ha, N2 = 4 * a->Hd;
     const int64_t hc_ld = a->Hd + a->E;
     GtAttnDims d; d.B = a->B; d.Ti = a->Ti; d.E = a->E; d.A = a->A; d.F = a->F; d.Kc = a->Kc;
@@ -181,7 +187,7 @@ int gt_decoder_bwd(const GtDecoderBwd* a, void* stream) {
             GT_TRY(evA(t + R, &ev));
             GT_HIP(hipStreamWaitEvent(sB, ev, 0));
         }
-        GT_TRY(gt_rec_gemm(dG2_t, N2, a->W2Tp, pX2, mt, a->N2pad, N2, a->S2, sX2, 1, 0, 0, 0, sB));
+        GT_TRY(rec_rows(dG2_t, N2, a->W2Tp, pX2, a->Bp, a->N2pad, N2, a->S2, sB));
         if (two) {
             GT_TRY(evB(t, &ev));
             GT_HIP(hipEventRecord(ev, sB));
@@ -198,7 +204,7 @@ int gt_decoder_bwd(const GtDecoderBwd* a, void* stream) {
         GT_TRY(gt_attn_energies_bwd(d, a->dw, a->w_hist + (int64_t)(t + 1) * BT, a->q_hist + (int64_t)t * a->B * a->A,
                                     a->w_hist + (int64_t)t * BT, a->cum_hist + (int64_t)t * BT, a->pm, a->Wc, a->Wd, a->v,
                                     a->lengths, dq_t, a->Apad, a->dpm, dwcat_out, a->acc, sA));
-        GT_TRY(gt_rec_gemm(dq_t, a->Apad, a->WqTp, a->partQ, mt, a->Ha, a->A, a->Sq, sQ, 1, 0, 0, 0, sA));
+        GT_TRY(rec_rows(dq_t, a->Apad, a->WqTp, a->partQ, a->Bp, a->Ha, a->A, a->Sq, sA));
         // attention LSTM cell: dh = d(h_att as decoder-LSTM input) + d(query) + recurrent grad from t+1
         GT_TRY(gt_lstm_cell_bwd(slabs(pX2, a->S2, sX2, a->N2pad), slabs(a->partQ, a->Sq, sQ, a->Ha),
                                 last ? kNoSlabs : slabs(a->partX1 + a->E, a->S1, sX1, a->N1pad), nullptr, 0, a->dc1,
@@ -210,23 +216,25 @@ int gt_decoder_bwd(const GtDecoderBwd* a, void* stream) {
             GT_HIP(hipEventRecord(ev, sA));
         }
         if (t > 0)
-            GT_TRY(gt_rec_gemm(dG1_t, N1, a->W1Tp, a->partX1, mt, a->N1pad, N1, a->S1, sX1, 1, 0, 0, 0, sA));
+            GT_TRY(rec_rows(dG1_t, N1, a->W1Tp, a->partX1, a->Bp, a->N1pad, N1, a->S1, sA));
     }
     return 0;
 }
 
 int gt_bilstm_run(const GtBiLstm* a, void* stream) {
     GT_REQUIRE(a != nullptr, GT_E_ARG, "gt_bilstm_run: NULL");
-    GT_REQUIRE(a->B > 0 && a->Bp >= a->B && a->Bp % 16 == 0 && a->Bp <= 64 && a->H % 4 == 0 && a->T > 0, GT_E_LIMIT,
+    GT_REQUIRE(rows_ok(a->B, a->Bp) && a->H % 4 == 0 && a->T > 0, GT_E_LIMIT,
                "gt_bilstm_run: bad dims B=%d Bp=%d H=%d T=%d", a->B, a->Bp, a->H, a->T);
-    const int mt = a->Bp / 16;
+    const int mt = a->Bp <= 64 ? a->Bp / 16 : 4;
+    const int nblk = a->Bp <= 64 ? 1 : a->Bp / 64;      // 64-row blocks (extra launches for big batches)
     const int N = 4 * a->H;
     const int64_t TB = (int64_t)a->T * a->Bp;
     if (!a->backward) {
         const int64_t pz = (int64_t)a->S * a->Bp * N;
         for (int s = 0; s < a->T; ++s) {
-            GT_TRY(gt_rec_gemm(a->X, a->ldx, a->Whp, a->part, mt, N, a->H, a->S, (int64_t)a->Bp * N, 2,
-                               (int64_t)a->Bp * a->ldx, a->w_zstride, pz, stream));
+            for (int rb = 0; rb < nblk; ++rb)
+                GT_TRY(gt_rec_gemm(a->X + (int64_t)rb * 64 * a->ldx, a->ldx, a->Whp, a->part + (int64_t)rb * 64 * N, mt, N,
+                                   a->H, a->S, (int64_t)a->Bp * N, 2, (int64_t)a->Bp * a->ldx, a->w_zstride, pz, stream));
             for (int dir = 0; dir < 2; ++dir) {
                 float* X = a->X + (int64_t)dir * a->Bp * a->ldx;
                 GT_TRY(gt_lstm_cell_fwd(slabs(a->part + dir * pz, a->S, (int64_t)a->Bp * N, N),
@@ -253,8 +261,10 @@ int gt_bilstm_run(const GtBiLstm* a, void* stream) {
                                         a->dc + (int64_t)dir * a->Bp * a->H, nullptr, a->Bp, a->H, stream));
             }
             if (s > 0)
-                GT_TRY(gt_rec_gemm(a->dG + (int64_t)s * a->Bp * N, N, a->Whp, a->part, mt, a->Hpad, N, a->S,
-                                   (int64_t)a->Bp * a->Hpad, 2, TB * N, a->w_zstride, pz, stream));
+                for (int rb = 0; rb < nblk; ++rb)
+                    GT_TRY(gt_rec_gemm(a->dG + ((int64_t)s * a->Bp + rb * 64) * N, N, a->Whp,
+                                       a->part + (int64_t)rb * 64 * a->Hpad, mt, a->Hpad, N, a->S,
+                                       (int64_t)a->Bp * a->Hpad, 2, TB * N, a->w_zstride, pz, stream));
         }
     }
     return 0;

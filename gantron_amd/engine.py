@@ -223,8 +223,7 @@ class GeneratorEngine:
         hp, dev = self.hp, text.device
         B, Ti = text.shape
         To = mels.shape[2]
-        Bp = roundup(B, 16)
-        assert Bp <= 64, 'one call handles at most 64 utterances'
+        Bp = roundup(B, 16) if B <= 64 else roundup(B, 64)      # rows per decoder step (pad rows stay zero)
         n_mel, H, E, A = self.n_mel, self.H, self.E, self.A
         sv = dict(B=B, Bp=Bp, Ti=Ti, To=To, in_lens=list(in_lens), out_lens=list(out_lens), training=training,
                   text=text)

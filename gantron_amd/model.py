@@ -186,7 +186,7 @@ class Tacotron2(nn.Module):
     def draw_rng(self, B, Ti, To, device):
         """Dropout masks and style noise for one forward, in kernel layout (engine.py docstring)."""
         hp, src = self.hparams, self.dropout_source
-        Bp = ops.roundup(B, 16)
+        Bp = ops.roundup(B, 16) if B <= 64 else ops.roundup(B, 64)
         rng = {'prenet_keep': [src.keep((To, Bp, hp.prenet_dim), 0.5, device) for _ in range(2)]}
         if self.training:
             dim = hp.encoder_embedding_dim

@@ -29,7 +29,7 @@ def pad_rows(t, Bp):
 
 def kernel_rng(rng, B, device):
     """Oracle-layout rng dict (tests/golden/common.draw_generator_rng) -> engine layout on `device`."""
-    Bp = roundup(B, 16)
+    Bp = roundup(B, 16) if B <= 64 else roundup(B, 64)
     u8 = lambda t: t.to(torch.uint8).contiguous().to(device)
     out = {}
     if rng.get('enc_keep') is not None:

@@ -134,9 +134,11 @@ def test_full_size_matches_reference_summaries(dev, golden_dir, name):
     assert not bad, '\n'.join(bad)
 
 
-def test_midsize_against_oracle(dev):
-    """B=5 (padded to 16 rows), ragged lengths, To not a multiple of the discriminator window:
-    HIP path vs the CPU oracle on identical seeded inputs and masks."""
+@pytest.mark.parametrize('case', ['ragged5', 'batch70'])
+def test_midsize_against_oracle(dev, case):
+    """B=5 (padded to 16 rows) with ragged lengths and To not a multiple of the discriminator window, and
+    B=70 (> 64 rows: two 64-row blocks per recurrent launch): HIP path vs the CPU oracle on identical
+    seeded inputs and masks."""
     from gantron_amd.hparams import HParams
     from oracle import gantron_ref as R
     hp = HParams('use_labels=False,use_noise=True,n_mel_channels=16,encoder_embedding_dim=32,symbols_embedding_dim=32,'
@@ -144,6 +146,10 @@ def test_midsize_against_oracle(dev):
                  'attention_location_kernel_size=9,postnet_embedding_dim=32,noise_size=32,discriminator_dim=32,'
                  'discriminator_window=6')
     in_lens, out_lens = [40, 33, 33, 20, 9], [57, 70, 41, 25, 13]
+    if case == 'batch70':
+        g = torch.Generator().manual_seed(3)
+        in_lens = sorted(torch.randint(3, 15, (70,), generator=g).tolist(), reverse=True)
+        out_lens = torch.randint(6, 23, (70,), generator=g).tolist()
     batch = common.synthetic_batch(hp, in_lens, out_lens, seed=5)
     Gp, Dp = R.init_params(hp, seed=3)
     for k in list(Gp):
