@@ -35,6 +35,7 @@ KERNEL_OF = {'rec_gemm': 'rec_gemm_kernel', 'sgemm': 'sgemm_kernel', 'attn_energ
              'attn_energies_bwd': 'attn_energies_bwd_kernel', 'lstm_cell_fwd': 'lstm_cell_fwd_kernel',
              'lstm_cell_bwd': 'lstm_cell_bwd_kernel'}
 MFMA_BOUND = {'rec_gemm', 'sgemm'}
+PROF_STRIDE = 64
 
 
 def ljspeech_shaped_batch(hp, B, seed, fixed=False):
@@ -202,11 +203,21 @@ def main():
         torch.cuda.synchronize()
         log(f'warmup pair {i} done')
     sync()
+    # roofline leg: every PROF_STRIDE-th launch of each kernel family is bracketed by two HIP events on its
+    # launch stream DURING the timed region (a sparse sample keeps the perturbation below 1 %)
+    lib = _lib.lib()
+    null_us = ctypes.c_double(0.0)
+    _lib.check(lib.gt_prof_calibrate(200, ctypes.byref(null_us), torch.cuda.current_stream().cuda_stream),
+               'gt_prof_calibrate')
+    sync()
+    lib.gt_prof_begin_sampled(PROF_STRIDE)
     t0 = time.perf_counter()
     for i in range(args.steps):
         pair(args.warmup + i)
     sync()
     elapsed = time.perf_counter() - t0
+    prof_out = (ctypes.c_double * 32)()
+    _lib.check(lib.gt_prof_end(prof_out), 'gt_prof_end')
     log(f'timed region: {elapsed:.3f} s for {args.steps} pairs')
     if world > 1:
         t = torch.tensor([elapsed, float(frames)], device=dev, dtype=torch.float64)
@@ -217,18 +228,15 @@ def main():
     else:
         total_frames = float(frames)
 
-    # ---- roofline of the dominant kernel family: one extra pair with HIP events around every launch
+    # ---- roofline of the dominant kernel family from the sampled brackets of the timed region
     roof = None
     cpu = None
     if rank == 0:
-        lib = _lib.lib()
-        torch.cuda.synchronize()
-        lib.gt_prof_begin()
-        pair(args.warmup + args.steps)
-        out = (ctypes.c_double * 32)()
-        _lib.check(lib.gt_prof_end(out), 'gt_prof_end')
-        log('profiled pair done')
-        fam = [dict(name=FAMILIES[f], launches=int(out[4 * f]), ms=out[4 * f + 1], flops=out[4 * f + 2],
+        out = prof_out
+        null_ms = null_us.value * 1e-3          # event-bracket time of an empty kernel (launch latency)
+        # every bracket = kernel execution + the launch latency an empty kernel also shows: subtract it
+        fam = [dict(name=FAMILIES[f], launches=int(out[4 * f]),
+                    ms=max(out[4 * f + 1] - null_ms * out[4 * f], 1e-9) if out[4 * f] else 0.0, flops=out[4 * f + 2],
                     bytes=out[4 * f + 3]) for f in range(8)]
         dom = max(fam, key=lambda r: r['ms'])
         avg_ms = dom['ms'] / max(dom['launches'], 1)
@@ -239,7 +247,9 @@ def main():
         else:
             ach = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9 if dom['ms'] > 0 else 0.0
             roof = dict(bound='hbm', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s', frac=ach / HBM_PEAK_GBS, traffic=None)
-        roof.update(kernel=KERNEL_OF[dom['name']], launches_per_pair=dom['launches'], avg_launch_us=avg_ms * 1e3,
+        roof.update(kernel=KERNEL_OF[dom['name']], sampled_launches=dom['launches'], sample_stride=PROF_STRIDE,
+                    avg_launch_us=avg_ms * 1e3,
+                    event_bracket_null_us=null_us.value,
                     families={r['name']: dict(launches=r['launches'], ms=round(r['ms'], 3),
                                               tflops=round(r['flops'] / max(r['ms'], 1e-9) / 1e9, 2),
                                               gbs=round(r['bytes'] / max(r['ms'], 1e-9) / 1e6, 1)) for r in fam})

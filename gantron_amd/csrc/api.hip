@@ -58,9 +58,19 @@ void gt_prof_mark(int family, double flops, double bytes, hipStream_t st, bool b
     }
 }
 
-extern "C" int gt_prof_begin(void) {
+static int g_prof_stride = 1;
+static long g_prof_count[GT_FAM_COUNT];
+
+bool gt_prof_sample(int family) { return (g_prof_count[family]++ % g_prof_stride) == 0; }
+
+extern "C" int gt_prof_begin(void) { return gt_prof_begin_sampled(1); }
+
+extern "C" int gt_prof_begin_sampled(int32_t stride) {
+    GT_REQUIRE(stride >= 1, GT_E_ARG, "gt_prof_begin_sampled: stride");
     g_recs.clear();
     g_pool_next = 0;
+    g_prof_stride = stride;
+    for (int i = 0; i < GT_FAM_COUNT; ++i) g_prof_count[i] = 0;
     g_gt_prof_on = true;
     return 0;
 }
@@ -83,5 +93,32 @@ extern "C" int gt_prof_end(double* out) {
         out[r.fam * 4 + 3] += r.bytes;
     }
     g_recs.clear();
+    return 0;
+}
+
+// Bracket overhead of the event pair itself: events around an EMPTY kernel measure the launch latency
+// that every bracketed launch includes on top of its execution time.  bench.py subtracts it.
+__global__ void gt_null_kernel() {}
+
+extern "C" int gt_prof_calibrate(int32_t n, double* out_us, void* stream) {
+    GT_REQUIRE(n > 0 && out_us != nullptr, GT_E_ARG, "gt_prof_calibrate: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<hipEvent_t> ev(2 * (size_t)n);
+    for (auto& e : ev) hipEventCreate(&e);
+    for (int i = 0; i < n; ++i) {
+        hipEventRecord(ev[2 * i], st);
+        hipLaunchKernelGGL(gt_null_kernel, dim3(256), dim3(256), 0, st);
+        hipEventRecord(ev[2 * i + 1], st);
+    }
+    hipError_t e = hipStreamSynchronize(st);
+    GT_REQUIRE(e == hipSuccess, (int)e, "gt_prof_calibrate: sync failed");
+    double tot = 0.0;
+    for (int i = 0; i < n; ++i) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
+        tot += ms;
+    }
+    for (auto& x : ev) hipEventDestroy(x);
+    *out_us = tot * 1e3 / n;
     return 0;
 }

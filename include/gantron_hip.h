@@ -44,7 +44,11 @@ int64_t gt_abi_sizeof(int32_t which);
  * 6 lstm_cell_fwd, 7 lstm_cell_bwd): out[4f] launches, out[4f+1] total ms, out[4f+2] algorithmic
  * flops, out[4f+3] algorithmic bytes.  `out` is a HOST array of 32 doubles.  Not thread-safe. */
 int gt_prof_begin(void);
+int gt_prof_begin_sampled(int32_t stride);   /* bracket only every stride-th launch of each family */
 int gt_prof_end(double* out);
+/* average event-bracket time (us) of an EMPTY kernel on `stream`: the launch latency every bracket
+ * includes on top of the kernel's execution time (HOST pointer out_us) */
+int gt_prof_calibrate(int32_t n, double* out_us, void* stream);
 
 /* ------------------------------------------------------------------------------------------ GEMM
  * C[m,n] (=|+=) sum_k A(m,k) * B(n,k) (+ bias[n]),   fp32 MFMA (v_mfma_f32_32x32x2_f32).
