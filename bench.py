@@ -247,6 +247,16 @@ def main():
         else:
             ach = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9 if dom['ms'] > 0 else 0.0
             roof = dict(bound='hbm', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s', frac=ach / HBM_PEAK_GBS, traffic=None)
+        # HBM traffic per launch from the committed PMC passes of this same command (tools/pmc_traffic.py);
+        # PMC counters cannot be read from inside the process, so the figure is the latest profiled one
+        try:
+            import glob
+            pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))[-1]))
+            roof['traffic'] = pmc['kernels'][KERNEL_OF[dom['name']]]['hbm_bytes_per_launch']
+            roof['traffic_source'] = 'profiles/ PMC passes (FETCH_SIZE x2 + WRITE_SIZE), bytes per launch'
+            roof['algorithmic_bytes_per_launch'] = dom['bytes'] / max(dom['launches'], 1)
+        except (IndexError, KeyError, OSError, ValueError):
+            pass
         roof.update(kernel=KERNEL_OF[dom['name']], sampled_launches=dom['launches'], sample_stride=PROF_STRIDE,
                     avg_launch_us=avg_ms * 1e3,
                     event_bracket_null_us=null_us.value,

@@ -150,3 +150,24 @@ def test_bench_helpers():
     fixed = bench.ljspeech_shaped_batch(hp, 64, seed=0, fixed=True)
     fl = bench.pair_flops(hp, fixed[1].tolist(), fixed[6].tolist())
     assert abs(fl / 1e12 - 9.38) < 0.05          # 9.38 TFLOP per pair at B=64, 150/800
+
+
+def test_flat_adam_state_dict_uses_torch_adam_layout():
+    """Checkpoints written by the reference hold torch.optim.Adam state dicts (train.py:158-166)."""
+    from gantron_amd.optim import FlatAdam
+    m = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    ref = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-6)
+    m(torch.randn(4, 5)).sum().backward()
+    ref.step()
+    opt = FlatAdam(m, lr=5e-4, weight_decay=1e-6)
+    opt.load_state_dict(ref.state_dict())
+    assert opt.step_count == 1 and opt.param_groups[0]['lr'] == 1e-3
+    sd = opt.state_dict()
+    rsd = ref.state_dict()
+    assert sd['param_groups'][0]['params'] == rsd['param_groups'][0]['params']
+    for i, st in rsd['state'].items():
+        assert torch.allclose(sd['state'][i]['exp_avg'], st['exp_avg'])
+        assert torch.allclose(sd['state'][i]['exp_avg_sq'], st['exp_avg_sq'])
+        assert float(sd['state'][i]['step']) == float(st['step'])
+    ref2 = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-6)
+    ref2.load_state_dict(sd)                     # and back: the reference's optimizer accepts our dict
