@@ -1,0 +1,174 @@
+"""Integration checks on a real MI355X: evaluation-mode forward, a few optimizer steps against the
+oracle (loss-curve and parameter agreement), and the reference-compatible train loop end to end
+(schedule, checkpoint write / resume) on a small synthetic dataset."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import common
+from harness import close, kernel_disc_keep, kernel_rng
+
+pytestmark = pytest.mark.gpu
+
+MID = ('use_labels=False,use_noise=True,n_mel_channels=16,encoder_embedding_dim=32,symbols_embedding_dim=32,'
+       'attention_rnn_dim=64,decoder_rnn_dim=64,prenet_dim=16,attention_dim=32,attention_location_n_filters=8,'
+       'attention_location_kernel_size=9,postnet_embedding_dim=32,noise_size=32,discriminator_dim=32,'
+       'discriminator_window=6')
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    return torch.device('cuda:0')
+
+
+def _with_counters(Gp):
+    out = dict(Gp)
+    for k in list(Gp):
+        if k.endswith('running_var'):
+            out[k.replace('running_var', 'num_batches_tracked')] = torch.zeros((), dtype=torch.long)
+    return out
+
+
+def test_eval_mode_forward_matches_oracle(dev):
+    """model.eval(): BatchNorm uses running statistics, dropout is off everywhere except the Prenet
+    (reference model.py:104: training=True hard-coded), exactly what validate() runs (train.py:172-183)."""
+    from gantron_amd.hparams import HParams
+    from gantron_amd.model import Tacotron2
+    from oracle import gantron_ref as R
+    hp = HParams(MID)
+    in_lens, out_lens = [21, 18, 7], [30, 41, 12]
+    batch = common.synthetic_batch(hp, in_lens, out_lens, seed=9)
+    Gp, _ = R.init_params(hp, seed=4)
+    g = torch.Generator().manual_seed(1)
+    for k in Gp:                                   # non-trivial running statistics
+        if k.endswith('running_mean'):
+            Gp[k] = torch.randn(Gp[k].shape, generator=g) * 0.1
+        if k.endswith('running_var'):
+            Gp[k] = torch.rand(Gp[k].shape, generator=g) + 0.5
+    G = Tacotron2(hp).to(dev).eval()
+    G.load_state_dict(_with_counters(Gp))
+    stream = common.MaskStream(3)
+    rng = common.draw_generator_rng(stream, hp, 3, max(in_lens), max(out_lens))
+    G.rng_override = kernel_rng(rng, 3, dev)
+    with torch.no_grad():
+        x, _ = G.parse_batch(batch)
+        got = G(x)
+    text, il, mel, gate, spk, emo, ol = batch
+    want = R.generator_forward(Gp, text, il, mel, ol, rng, training=False)
+    for name, a, b in zip(('mel', 'mel_post', 'gate', 'align'), got, want):
+        close(a, b, rtol=1e-3, atol=1e-5, what=f'eval {name}')
+    for k, v in G.state_dict().items():            # evaluation must not touch the running statistics
+        if k.endswith(('running_mean', 'running_var')):
+            close(v, Gp[k], rtol=0, atol=0, what=k)
+
+
+def test_three_optimizer_steps_track_the_oracle(dev):
+    """G,D,G schedule with Adam + clipping: losses of every step and the final parameters agree with the
+    oracle driven by the same masks (train.py:361-423, 302-360)."""
+    from gantron_amd.hparams import HParams
+    from gantron_amd.loss_function import Tacotron2Loss
+    from gantron_amd.model import Discriminator, Tacotron2
+    from gantron_amd.optim import FlatAdam
+    from gantron_amd.train_steps import discriminator_step, generator_step
+    from oracle import gantron_ref as R
+    hp = HParams(MID)
+    in_lens, out_lens = [17, 12, 12, 5], [26, 33, 19, 8]
+    batch = common.synthetic_batch(hp, in_lens, out_lens, seed=2)
+    text, il, mel, gate, spk, emo, ol = batch
+    B, Ti, To = 4, max(in_lens), max(out_lens)
+    Gp, Dp = R.init_params(hp, seed=8)
+    G, D = Tacotron2(hp).to(dev).train(), Discriminator(hp).to(dev).train()
+    G.load_state_dict(_with_counters(Gp))
+    D.load_state_dict(Dp)
+    g_opt = FlatAdam(G, lr=hp.g_learning_rate, weight_decay=hp.weight_decay)
+    d_opt = FlatAdam(D, lr=hp.d_learning_rate, weight_decay=hp.weight_decay)
+    crit = Tacotron2Loss()
+    stream_h, stream_o = common.MaskStream(21), common.MaskStream(21)
+    g_state, d_state = {}, {}
+    Go, Do = dict(Gp), dict(Dp)
+    g_step = d_step = 0
+    fake_h = fake_o = None
+    for it, kind in enumerate(('G', 'D', 'G')):
+        if kind == 'G':
+            rng = common.draw_generator_rng(stream_h, hp, B, Ti, To)
+            dk = common.draw_disc_keep(stream_h, hp, B, To)
+            G.rng_override, D.rng_override = kernel_rng(rng, B, dev), kernel_disc_keep(dk, dev)
+            losses, fake_h = generator_step(G, D, g_opt, crit, batch, hp, iteration=it)
+            rng_o = common.draw_generator_rng(stream_o, hp, B, Ti, To)
+            rng_o['disc_keep'] = common.draw_disc_keep(stream_o, hp, B, To)
+            out, lo, grads, new_stats = R.generator_step_grads(Go, Do, (text, il, mel, gate, ol), rng_o, hp)
+            R.clip_grad_norm(grads, hp.grad_clip_thresh)
+            g_step += 1
+            R.adam_step(Go, grads, g_state, hp.g_learning_rate, g_step, wd=hp.weight_decay)
+            Go.update(new_stats)
+            fake_o = out[1]
+            close(losses['total'], lo['total'], rtol=2e-3, atol=1e-5, what=f'step {it} G loss')
+        else:
+            kr, kf = common.draw_disc_keep(stream_h, hp, B, To), common.draw_disc_keep(stream_h, hp, B, To)
+            # adversarial_loss is called twice per discriminator step: real masks first, then fake masks
+            masks = [kernel_disc_keep(kr, dev), kernel_disc_keep(kf, dev)]
+            orig = D._keeps
+            D._keeps = lambda *a, **k: masks.pop(0)
+            losses = discriminator_step(G, D, d_opt, batch, fake_h, hp)
+            D._keeps = orig
+            kr_o, kf_o = common.draw_disc_keep(stream_o, hp, B, To), common.draw_disc_keep(stream_o, hp, B, To)
+            lo, grads = R.discriminator_step_grads(Do, mel, ol, fake_o, ol, kr_o, kf_o, hp)
+            d_step += 1
+            R.adam_step(Do, grads, d_state, hp.d_learning_rate, d_step, wd=hp.weight_decay)
+            close(losses['total'], lo['total'], rtol=2e-3, atol=1e-5, what=f'step {it} D loss')
+    bad = []
+    for k, p in G.named_parameters():
+        if k.endswith('.0.conv.bias'):
+            # a conv bias in front of a BatchNorm has a mathematically zero gradient; both sides hold ~1e-7 of
+            # rounding noise there, which Adam turns into +-lr steps of arbitrary sign: not comparable
+            continue
+        try:
+            close(p, Go[k], rtol=5e-3, atol=2e-5, what=f'G param {k}')
+        except AssertionError as e:
+            bad.append(str(e))
+    for k, p in D.named_parameters():
+        try:
+            close(p, Do[k], rtol=5e-3, atol=2e-5, what=f'D param {k}')
+        except AssertionError as e:
+            bad.append(str(e))
+    assert not bad, '\n'.join(bad)
+
+
+def test_train_loop_end_to_end(dev, tmp_path):
+    """gantron_amd.train.train() on precomputed mels: schedule runs, a checkpoint with the reference's
+    dict schema is written, and training resumes from it."""
+    from gantron_amd import train as T
+    from gantron_amd.hparams import HParams
+    rs = np.random.default_rng(0)
+    wavs = tmp_path / 'mels'
+    wavs.mkdir()
+    lines = []
+    for i in range(12):
+        n = int(rs.integers(12, 30))
+        np.save(wavs / f'u{i}.npy', np.clip(rs.normal(-5.5, 2.2, (16, n)), -11.5, 2).astype(np.float32))
+        words = ' '.join(rs.choice(['alpha', 'beta', 'gamma', 'delta', 'tau'], size=int(rs.integers(2, 5))))
+        lines.append(f'u{i}.npy|{words}.')
+    flist = tmp_path / 'train.txt'
+    flist.write_text('\n'.join(lines) + '\n')
+    hp = HParams(MID + ',batch_size=4,iters_per_checkpoint=6,disc_warmp_up=8,attn_steps=4,epochs=100,load_mel_from_disk=True')
+    hp.training_files = [str(flist), str(flist)]
+    hp.validation_files = [str(flist), str(flist)]
+    hp.iterations = 12
+    out = tmp_path / 'out'
+    T.train(str(out), None, False, 1, 0, 'g', hp, str(wavs) + '/')
+    ckpts = sorted(os.listdir(out))
+    assert ckpts, 'no checkpoint written'
+    ck = torch.load(out / ckpts[-1], map_location='cpu')
+    assert set(ck) == {'iteration', 'state_dict', 'g_optimizer', 'g_learning_rate', 'd_optimizer', 'd_learning_rate'}
+    assert 'decoder.attention_rnn.weight_ih' in ck['state_dict'] and not any(k.startswith('discriminator') for k in ck['state_dict'])
+    assert all(torch.isfinite(v).all() for v in ck['state_dict'].values() if v.dtype.is_floating_point)
+    hp2 = HParams(MID + ',batch_size=4,iters_per_checkpoint=100,disc_warmp_up=8,attn_steps=4,epochs=100,load_mel_from_disk=True')
+    hp2.training_files, hp2.validation_files = hp.training_files, hp.validation_files
+    hp2.iterations = ck['iteration'] + 3
+    out2 = tmp_path / 'out2'
+    T.train(str(out2), str(out / ckpts[-1]), False, 1, 0, 'g', hp2, str(wavs) + '/')
+    assert os.listdir(out2)
