@@ -107,3 +107,16 @@ __host__ __device__ __forceinline__ uint32_t gt_hash32(uint64_t seed, uint64_t c
 __host__ __device__ __forceinline__ float gt_u01(uint64_t seed, uint64_t ctr) {
     return (float)(gt_hash32(seed, ctr) >> 8) * (1.0f / 16777216.0f);
 }
+
+// Library-internal variants of gt_lstm_cell_fwd / gt_lstm_cell_bwd (recurrent.hip): nz = 2 runs two
+// independent problems in one launch (the two BiLSTM directions, loops.hip); z holds the element offsets of
+// the second problem's buffers: fwd {part, pre, c, h_prev, gates, h_raw, h0}, bwd {slabs, dh_direct, dc,
+// gates, c, dgates}.
+int gt_cell_fwd_z(GtSlabs part, const float* pre, int64_t ld_pre, const float* c_prev, const float* h_prev,
+                  int64_t ld_hprev, const uint8_t* keep, float p_drop, const int32_t* active, float* gates, float* c_out,
+                  float* h_raw, float* h0, int64_t ld0, float* h1, int64_t ld1, float* h2, int64_t ld2, int32_t B, int32_t H,
+                  int nz, const int64_t* z, void* stream);
+int gt_cell_bwd_z(GtSlabs dh_a, GtSlabs dh_b, GtSlabs dh_c, const float* dh_direct, int64_t ld_direct,
+                  const float* dc_next, const float* gates, const float* c_new, const float* c_prev, const uint8_t* keep,
+                  float p_drop, const int32_t* active, float* dgates, float* dc_prev, float* dh_pass, int32_t B, int32_t H,
+                  int nz, const int64_t* z, void* stream);

@@ -48,7 +48,7 @@ static int aux_stream(hipStream_t* out) {
         // highest priority: the loop kernels are the critical path, the weight-gradient GEMMs that
         // share the device (leaf stream, normal priority) should only fill what they leave idle
         int lo = 0, hi = 0;
-        hipDeviceGetStreamPriorityRange(&lo, &hi);
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         hipError_t e = hipStreamCreateWithPriority(&g_aux_stream, hipStreamNonBlocking, hi);
         GT_REQUIRE(e == hipSuccess, (int)e, "decoder loop: cannot create the auxiliary stream");
     }
@@ -235,31 +235,25 @@ int gt_bilstm_run(const GtBiLstm* a, void* stream) {
             for (int rb = 0; rb < nblk; ++rb)
                 GT_TRY(gt_rec_gemm(a->X + (int64_t)rb * 64 * a->ldx, a->ldx, a->Whp, a->part + (int64_t)rb * 64 * N, mt, N,
                                    a->H, a->S, (int64_t)a->Bp * N, 2, (int64_t)a->Bp * a->ldx, a->w_zstride, pz, stream));
-            for (int dir = 0; dir < 2; ++dir) {
-                float* X = a->X + (int64_t)dir * a->Bp * a->ldx;
-                GT_TRY(gt_lstm_cell_fwd(slabs(a->part + dir * pz, a->S, (int64_t)a->Bp * N, N),
-                                        a->pre + ((int64_t)dir * TB + (int64_t)s * a->Bp) * N, N,
-                                        a->c + ((int64_t)dir * (a->T + 1) + s) * a->Bp * a->H, X, a->ldx, nullptr, 0.f,
-                                        a->active + (int64_t)s * a->Bp, a->gates + ((int64_t)dir * TB + (int64_t)s * a->Bp) * N,
-                                        a->c + ((int64_t)dir * (a->T + 1) + s + 1) * a->Bp * a->H,
-                                        a->hs + ((int64_t)dir * TB + (int64_t)s * a->Bp) * a->H, X, a->ldx, nullptr, 0,
-                                        nullptr, 0, a->Bp, a->H, stream));
-            }
+            // both directions in one launch: blockIdx.y = direction, per-pointer element offsets
+            const int64_t zf[7] = {pz, TB * N, (int64_t)(a->T + 1) * a->Bp * a->H, (int64_t)a->Bp * a->ldx, TB * N,
+                                   TB * a->H, (int64_t)a->Bp * a->ldx};
+            GT_TRY(gt_cell_fwd_z(slabs(a->part, a->S, (int64_t)a->Bp * N, N), a->pre + (int64_t)s * a->Bp * N, N,
+                                 a->c + (int64_t)s * a->Bp * a->H, a->X, a->ldx, nullptr, 0.f,
+                                 a->active + (int64_t)s * a->Bp, a->gates + (int64_t)s * a->Bp * N,
+                                 a->c + (int64_t)(s + 1) * a->Bp * a->H, a->hs + (int64_t)s * a->Bp * a->H, a->X, a->ldx,
+                                 nullptr, 0, nullptr, 0, a->Bp, a->H, 2, zf, stream));
         }
     } else {
         GT_REQUIRE(a->Hpad % 16 == 0 && a->Hpad >= a->H, GT_E_ARG, "gt_bilstm_run: Hpad");
         const int64_t pz = (int64_t)a->S * a->Bp * a->Hpad;
         for (int s = a->T - 1; s >= 0; --s) {
-            for (int dir = 0; dir < 2; ++dir) {
-                GT_TRY(gt_lstm_cell_bwd(s == a->T - 1 ? kNoSlabs : slabs(a->part + dir * pz, a->S, (int64_t)a->Bp * a->Hpad, a->Hpad),
-                                        kNoSlabs, kNoSlabs, a->dhs + ((int64_t)dir * TB + (int64_t)s * a->Bp) * a->H, a->H,
-                                        a->dc + (int64_t)dir * a->Bp * a->H,
-                                        a->gates + ((int64_t)dir * TB + (int64_t)s * a->Bp) * N,
-                                        a->c + ((int64_t)dir * (a->T + 1) + s + 1) * a->Bp * a->H,
-                                        a->c + ((int64_t)dir * (a->T + 1) + s) * a->Bp * a->H, nullptr, 0.f,
-                                        a->active + (int64_t)s * a->Bp, a->dG + ((int64_t)dir * TB + (int64_t)s * a->Bp) * N,
-                                        a->dc + (int64_t)dir * a->Bp * a->H, nullptr, a->Bp, a->H, stream));
-            }
+            const int64_t zb[6] = {pz, TB * a->H, (int64_t)a->Bp * a->H, TB * N, (int64_t)(a->T + 1) * a->Bp * a->H, TB * N};
+            GT_TRY(gt_cell_bwd_z(s == a->T - 1 ? kNoSlabs : slabs(a->part, a->S, (int64_t)a->Bp * a->Hpad, a->Hpad),
+                                 kNoSlabs, kNoSlabs, a->dhs + (int64_t)s * a->Bp * a->H, a->H, a->dc,
+                                 a->gates + (int64_t)s * a->Bp * N, a->c + (int64_t)(s + 1) * a->Bp * a->H,
+                                 a->c + (int64_t)s * a->Bp * a->H, nullptr, 0.f, a->active + (int64_t)s * a->Bp,
+                                 a->dG + (int64_t)s * a->Bp * N, a->dc, nullptr, a->Bp, a->H, 2, zb, stream));
             if (s > 0)
                 for (int rb = 0; rb < nblk; ++rb)
                     GT_TRY(gt_rec_gemm(a->dG + ((int64_t)s * a->Bp + rb * 64) * N, N, a->Whp,

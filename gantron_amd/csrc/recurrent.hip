@@ -194,11 +194,22 @@ struct CellFwd {
     float* gates; float* c_out; float* h_raw;
     float* h0; long ld0; float* h1; long ld1; float* h2; long ld2;
     int B, H;
+    // blockIdx.y = 1 (second BiLSTM direction): element offsets added to the pointers above
+    long z_part, z_pre, z_c, z_hprev, z_gates, z_hraw, z_h0;
 };
 
 // V = hidden units per thread (4: float4 accesses when every pointer / leading dimension allows it)
 template <int V>
 __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(CellFwd a) {
+    if (blockIdx.y != 0) {
+        a.part.p += a.z_part;
+        if (a.pre) a.pre += a.z_pre;
+        a.c_prev += a.z_c; a.c_out += a.z_c;
+        if (a.h_prev) a.h_prev += a.z_hprev;
+        if (a.gates) a.gates += a.z_gates;
+        if (a.h_raw) a.h_raw += a.z_hraw;
+        if (a.h0) a.h0 += a.z_h0;
+    }
     const long vid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int HV = a.H / V;
     if (vid >= (long)a.B * HV) return;
@@ -286,6 +297,7 @@ struct CellBwd {
     const int* active;
     float* dgates; float* dc_prev; float* dh_pass;
     int B, H;
+    long z_da, z_direct, z_dc, z_gates, z_c, z_dgates;     // blockIdx.y = 1: second BiLSTM direction
 };
 
 template <int V>
@@ -318,6 +330,14 @@ __device__ __forceinline__ void slab_acc(const GtSlabs& sl, long off, float (&o)
 
 template <int V>
 __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(CellBwd a) {
+    if (blockIdx.y != 0) {
+        if (a.da.p) a.da.p += a.z_da;
+        if (a.dh_direct) a.dh_direct += a.z_direct;
+        if (a.dc_next) a.dc_next += a.z_dc;
+        a.dc_prev += a.z_dc;
+        a.gates += a.z_gates; a.c_new += a.z_c; a.c_prev += a.z_c;
+        a.dgates += a.z_dgates;
+    }
     const long vid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int HV = a.H / V;
     if (vid >= (long)a.B * HV) return;
@@ -449,28 +469,71 @@ extern "C" int gt_rec_gemm(const float* X, int64_t ldx, const float* Wp, float* 
     return 0;
 }
 
+int gt_cell_fwd_z(GtSlabs part, const float* pre, int64_t ld_pre, const float* c_prev, const float* h_prev,
+                  int64_t ld_hprev, const uint8_t* keep, float p_drop, const int32_t* active, float* gates, float* c_out,
+                  float* h_raw, float* h0, int64_t ld0, float* h1, int64_t ld1, float* h2, int64_t ld2, int32_t B, int32_t H,
+                  int nz, const int64_t* z, void* stream) {
+    GT_REQUIRE(part.p && c_prev && c_out && B > 0 && H > 0 && part.n >= 1, GT_E_ARG, "gt_lstm_cell_fwd: bad argument");
+    GT_REQUIRE(p_drop >= 0.f && p_drop < 1.f, GT_E_ARG, "gt_lstm_cell_fwd: p_drop");
+    GT_REQUIRE(part.n <= 16, GT_E_LIMIT, "gt_lstm_cell_fwd: at most 16 slabs");
+    GT_REQUIRE(nz == 1 || (nz == 2 && z != nullptr && keep == nullptr && h1 == nullptr && h2 == nullptr), GT_E_ARG,
+               "gt_lstm_cell_fwd: paired launch takes offsets, no dropout and one h destination");
+    CellFwd a;
+    a.part = part; a.pre = pre; a.ld_pre = ld_pre; a.c_prev = c_prev; a.h_prev = h_prev; a.ld_hprev = ld_hprev;
+    a.keep = keep; a.scale = 1.0f / (1.0f - p_drop); a.active = active; a.gates = gates; a.c_out = c_out;
+    a.h_raw = h_raw; a.h0 = h0; a.ld0 = ld0; a.h1 = h1; a.ld1 = ld1; a.h2 = h2; a.ld2 = ld2; a.B = B; a.H = H;
+    a.z_part = z ? z[0] : 0; a.z_pre = z ? z[1] : 0; a.z_c = z ? z[2] : 0; a.z_hprev = z ? z[3] : 0;
+    a.z_gates = z ? z[4] : 0; a.z_hraw = z ? z[5] : 0; a.z_h0 = z ? z[6] : 0;
+    const long n = (long)B * H;
+    GtProfScope prof(GT_FAM_CELL_FWD, 0.0, nz * 4.0 * n * (4.0 * part.n + 4 + 1 + 4 + 1 + 3), (hipStream_t)stream);
+    auto ok4 = [](const void* p, int64_t ld) { return p == nullptr || (aligned16(p) && ld % 4 == 0); };
+    const bool vec = H % 4 == 0 && ok4(part.p, part.ld) && part.slab_stride % 4 == 0 && ok4(pre, ld_pre) && aligned16(c_prev) &&
+                     (keep == nullptr || (((uintptr_t)keep) & 3) == 0) && ok4(gates, 0) && aligned16(c_out) && ok4(h_raw, 0) &&
+                     ok4(h0, ld0) && ok4(h1, ld1) && ok4(h2, ld2) &&
+                     (a.z_part | a.z_pre | a.z_c | a.z_hprev | a.z_gates | a.z_hraw | a.z_h0) % 4 == 0;
+    if (vec)
+        hipLaunchKernelGGL((lstm_cell_fwd_kernel<4>), dim3((unsigned)cdiv64(n / 4, 64), nz), dim3(64), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((lstm_cell_fwd_kernel<1>), dim3((unsigned)cdiv64(n, 256), nz), dim3(256), 0, (hipStream_t)stream, a);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int gt_lstm_cell_fwd(GtSlabs part, const float* pre, int64_t ld_pre, const float* c_prev,
                                 const float* h_prev, int64_t ld_hprev, const uint8_t* keep, float p_drop,
                                 const int32_t* active, float* gates, float* c_out, float* h_raw, float* h0,
                                 int64_t ld0, float* h1, int64_t ld1, float* h2, int64_t ld2, int32_t B,
                                 int32_t H, void* stream) {
-    GT_REQUIRE(part.p && c_prev && c_out && B > 0 && H > 0 && part.n >= 1, GT_E_ARG, "gt_lstm_cell_fwd: bad argument");
-    GT_REQUIRE(p_drop >= 0.f && p_drop < 1.f, GT_E_ARG, "gt_lstm_cell_fwd: p_drop");
-    GT_REQUIRE(part.n <= 16, GT_E_LIMIT, "gt_lstm_cell_fwd: at most 16 slabs");
-    CellFwd a;
-    a.part = part; a.pre = pre; a.ld_pre = ld_pre; a.c_prev = c_prev; a.h_prev = h_prev; a.ld_hprev = ld_hprev;
-    a.keep = keep; a.scale = 1.0f / (1.0f - p_drop); a.active = active; a.gates = gates; a.c_out = c_out;
-    a.h_raw = h_raw; a.h0 = h0; a.ld0 = ld0; a.h1 = h1; a.ld1 = ld1; a.h2 = h2; a.ld2 = ld2; a.B = B; a.H = H;
+    return gt_cell_fwd_z(part, pre, ld_pre, c_prev, h_prev, ld_hprev, keep, p_drop, active, gates, c_out, h_raw, h0, ld0,
+                         h1, ld1, h2, ld2, B, H, 1, nullptr, stream);
+}
+
+int gt_cell_bwd_z(GtSlabs dh_a, GtSlabs dh_b, GtSlabs dh_c, const float* dh_direct, int64_t ld_direct,
+                  const float* dc_next, const float* gates, const float* c_new, const float* c_prev, const uint8_t* keep,
+                  float p_drop, const int32_t* active, float* dgates, float* dc_prev, float* dh_pass, int32_t B, int32_t H,
+                  int nz, const int64_t* z, void* stream) {
+    GT_REQUIRE(gates && c_new && c_prev && dgates && dc_prev && B > 0 && H > 0, GT_E_ARG, "gt_lstm_cell_bwd: bad argument");
+    GT_REQUIRE(dh_a.n <= 16 && dh_b.n <= 16 && dh_c.n <= 16, GT_E_LIMIT, "gt_lstm_cell_bwd: at most 16 slabs per source");
+    GT_REQUIRE(nz == 1 || (nz == 2 && z != nullptr && keep == nullptr && dh_b.p == nullptr && dh_c.p == nullptr &&
+                           dh_pass == nullptr), GT_E_ARG, "gt_lstm_cell_bwd: paired launch takes offsets and one slab source");
+    CellBwd a;
+    a.da = dh_a; a.db = dh_b; a.dc = dh_c; a.dh_direct = dh_direct; a.ld_direct = ld_direct; a.dc_next = dc_next;
+    a.gates = gates; a.c_new = c_new; a.c_prev = c_prev; a.keep = keep; a.scale = 1.0f / (1.0f - p_drop);
+    a.active = active; a.dgates = dgates; a.dc_prev = dc_prev; a.dh_pass = dh_pass; a.B = B; a.H = H;
+    a.z_da = z ? z[0] : 0; a.z_direct = z ? z[1] : 0; a.z_dc = z ? z[2] : 0; a.z_gates = z ? z[3] : 0;
+    a.z_c = z ? z[4] : 0; a.z_dgates = z ? z[5] : 0;
     const long n = (long)B * H;
-    GtProfScope prof(GT_FAM_CELL_FWD, 0.0, 4.0 * n * (4.0 * part.n + 4 + 1 + 4 + 1 + 3), (hipStream_t)stream);
+    GtProfScope prof(GT_FAM_CELL_BWD, 0.0, nz * 4.0 * n * (dh_a.n + dh_b.n + dh_c.n + 1 + 1 + 4 + 2 + 4 + 1), (hipStream_t)stream);
     auto ok4 = [](const void* p, int64_t ld) { return p == nullptr || (aligned16(p) && ld % 4 == 0); };
-    const bool vec = H % 4 == 0 && ok4(part.p, part.ld) && part.slab_stride % 4 == 0 && ok4(pre, ld_pre) && aligned16(c_prev) &&
-                     (keep == nullptr || (((uintptr_t)keep) & 3) == 0) && ok4(gates, 0) && aligned16(c_out) && ok4(h_raw, 0) &&
-                     ok4(h0, ld0) && ok4(h1, ld1) && ok4(h2, ld2);
+    auto sl4 = [&](const GtSlabs& sl) { return sl.p == nullptr || (aligned16(sl.p) && sl.ld % 4 == 0 && sl.slab_stride % 4 == 0); };
+    const bool vec = H % 4 == 0 && sl4(dh_a) && sl4(dh_b) && sl4(dh_c) && ok4(dh_direct, ld_direct) && ok4(dc_next, 0) &&
+                     aligned16(gates) && aligned16(c_new) && aligned16(c_prev) && (keep == nullptr || (((uintptr_t)keep) & 3) == 0) &&
+                     aligned16(dgates) && aligned16(dc_prev) && ok4(dh_pass, 0) &&
+                     (a.z_da | a.z_direct | a.z_dc | a.z_gates | a.z_c | a.z_dgates) % 4 == 0;
     if (vec)
-        hipLaunchKernelGGL((lstm_cell_fwd_kernel<4>), dim3((unsigned)cdiv64(n / 4, 64)), dim3(64), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((lstm_cell_bwd_kernel<4>), dim3((unsigned)cdiv64(n / 4, 64), nz), dim3(64), 0, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL((lstm_cell_fwd_kernel<1>), dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((lstm_cell_bwd_kernel<1>), dim3((unsigned)cdiv64(n, 256), nz), dim3(256), 0, (hipStream_t)stream, a);
     GT_LAUNCH_CHECK();
     return 0;
 }
@@ -480,23 +543,6 @@ extern "C" int gt_lstm_cell_bwd(GtSlabs dh_a, GtSlabs dh_b, GtSlabs dh_c, const 
                                 const float* c_prev, const uint8_t* keep, float p_drop, const int32_t* active,
                                 float* dgates, float* dc_prev, float* dh_pass, int32_t B, int32_t H,
                                 void* stream) {
-    GT_REQUIRE(gates && c_new && c_prev && dgates && dc_prev && B > 0 && H > 0, GT_E_ARG, "gt_lstm_cell_bwd: bad argument");
-    CellBwd a;
-    a.da = dh_a; a.db = dh_b; a.dc = dh_c; a.dh_direct = dh_direct; a.ld_direct = ld_direct; a.dc_next = dc_next;
-    a.gates = gates; a.c_new = c_new; a.c_prev = c_prev; a.keep = keep; a.scale = 1.0f / (1.0f - p_drop);
-    a.active = active; a.dgates = dgates; a.dc_prev = dc_prev; a.dh_pass = dh_pass; a.B = B; a.H = H;
-    const long n = (long)B * H;
-    GtProfScope prof(GT_FAM_CELL_BWD, 0.0, 4.0 * n * (dh_a.n + dh_b.n + dh_c.n + 1 + 1 + 4 + 2 + 4 + 1), (hipStream_t)stream);
-    auto ok4 = [](const void* p, int64_t ld) { return p == nullptr || (aligned16(p) && ld % 4 == 0); };
-    auto sl4 = [&](const GtSlabs& sl) { return sl.p == nullptr || (aligned16(sl.p) && sl.ld % 4 == 0 && sl.slab_stride % 4 == 0); };
-    const bool vec = H % 4 == 0 && sl4(dh_a) && sl4(dh_b) && sl4(dh_c) && ok4(dh_direct, ld_direct) && ok4(dc_next, 0) &&
-                     aligned16(gates) && aligned16(c_new) && aligned16(c_prev) && (keep == nullptr || (((uintptr_t)keep) & 3) == 0) &&
-                     aligned16(dgates) && aligned16(dc_prev) && ok4(dh_pass, 0);
-    GT_REQUIRE(dh_a.n <= 16 && dh_b.n <= 16 && dh_c.n <= 16, GT_E_LIMIT, "gt_lstm_cell_bwd: at most 16 slabs per source");
-    if (vec)
-        hipLaunchKernelGGL((lstm_cell_bwd_kernel<4>), dim3((unsigned)cdiv64(n / 4, 64)), dim3(64), 0, (hipStream_t)stream, a);
-    else
-        hipLaunchKernelGGL((lstm_cell_bwd_kernel<1>), dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, a);
-    GT_LAUNCH_CHECK();
-    return 0;
+    return gt_cell_bwd_z(dh_a, dh_b, dh_c, dh_direct, ld_direct, dc_next, gates, c_new, c_prev, keep, p_drop, active,
+                         dgates, dc_prev, dh_pass, B, H, 1, nullptr, stream);
 }

@@ -109,7 +109,8 @@ def rec_splits(N, K):
     """K-splits of a per-step recurrent GEMM: enough that (N/64) x splits covers the 256 CUs, not more
     (every extra slab is 4*Bp*N bytes the cell kernel has to read back)."""
     want = max(REC_SPLITS, -(-256 // max(N // 64, 1)))
-    return ops.pick_splits(K, min(want, 16))
+    want = min(want, 16, max(1, -(-K // 16) // 8))      # at least one 8-block LDS chunk of K per workgroup
+    return ops.pick_splits(K, want)
 
 
 def pack_rec(W2d, N, n_valid, K, transposed=False):
@@ -255,7 +256,7 @@ class GeneratorEngine:
             Whp.append(pack_rec(P['encoder.lstm.weight_hh_l0' + sfx], 4 * H, 4 * H, H))
         Whp = torch.stack(Whp)
         ldx = roundup(H, 16)
-        S = ops.pick_splits(H, REC_SPLITS)
+        S = rec_splits(4 * H, H)
         a = GtBiLstm()
         a.B, a.Bp, a.T, a.H, a.S, a.backward = B, Bp, Ti, H, S, 0
         gates = _f32(2, Ti, Bp, 4 * H, device=dev, zero=False)
@@ -577,7 +578,7 @@ class GeneratorEngine:
         Hpad = roundup(H, 16)
         WhT = torch.stack([pack_rec(P['encoder.lstm.weight_hh_l0' + sfx], Hpad, H, 4 * H, transposed=True)
                            for sfx in ('', '_reverse')])
-        S = ops.pick_splits(4 * H, REC_SPLITS)
+        S = rec_splits(Hpad, 4 * H)
         a = GtBiLstm()
         a.B, a.Bp, a.T, a.H, a.S, a.backward, a.Hpad = B, Bp, Ti, H, S, 1, Hpad
         dG = _f32(2, Ti * Bp, 4 * H, device=dev)
