@@ -91,6 +91,20 @@ def log(msg):
     print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
 
 
+def cpu_sample_batch(hp, B=8):
+    """The bounded CPU-baseline sample: an LJSpeech-shaped batch clipped to <= 200 frames / 50 characters
+    per item (also timed against the real reference in the build container, tests/golden/time_reference.py)."""
+    text, il, mel, gate, _, _, ol = ljspeech_shaped_batch(hp, B, seed=99)
+    ol = torch.clamp(ol, max=200)
+    il = torch.clamp(il, max=50)
+    text, mel, gate = text[:, :int(il.max())], mel[:, :, :int(ol.max())].contiguous(), gate[:, :int(ol.max())].contiguous()
+    for b in range(B):
+        gate[b, int(ol[b]) - 1:] = 1
+        mel[b, :, int(ol[b]):] = 0
+        text[b, int(il[b]):] = 0
+    return text.contiguous(), il, mel, gate, ol
+
+
 def cpu_baseline(seconds_budget=20.0):
     """The CPU oracle (oracle/gantron_ref.py, a restatement of the reference pinned by its golden
     vectors) timed on the host cores for one G+D pair of a bounded LJSpeech-shaped sample."""
@@ -100,16 +114,7 @@ def cpu_baseline(seconds_budget=20.0):
     import common
     hp = HParams(HPARAMS)
     B = 8
-    batch = ljspeech_shaped_batch(hp, B, seed=99)
-    text, il, mel, gate, _, _, ol = batch
-    # bound the sample: clip to at most 200 frames / 50 characters per item
-    ol = torch.clamp(ol, max=200)
-    il = torch.clamp(il, max=50)
-    text, mel, gate = text[:, :int(il.max())], mel[:, :, :int(ol.max())].contiguous(), gate[:, :int(ol.max())].contiguous()
-    for b in range(B):
-        gate[b, int(ol[b]) - 1:] = 1
-        mel[b, :, int(ol[b]):] = 0
-        text[b, int(il[b]):] = 0
+    text, il, mel, gate, ol = cpu_sample_batch(hp, B)
     Ti, To = text.shape[1], mel.shape[2]
     torch.set_num_threads(host_threads())
     Gp, Dp = R.init_params(hp, seed=1)

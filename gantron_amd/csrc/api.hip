@@ -24,6 +24,7 @@ extern "C" int64_t gt_abi_sizeof(int32_t which) {
         case 4: return sizeof(GtDecoderFwd);
         case 5: return sizeof(GtDecoderBwd);
         case 6: return sizeof(GtBiLstm);
+        case 7: return sizeof(GtDecoderInfer);
         default: return -1;
     }
 }

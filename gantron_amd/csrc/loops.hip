@@ -144,6 +144,81 @@ int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
     return 0;
 }
 
+// ---- free-running decode (Decoder.inference, model.py:456-497) ------------------------------------
+__global__ void gate_stop_kernel(const float* gate, int64_t ld, int B, float threshold, int t, int* stop_step) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float s = 1.f / (1.f + __expf(-gate[(int64_t)b * ld]));
+    if (s > threshold) atomicMin(stop_step + b, t);
+}
+
+static GtOperand kc(const float* p, int64_t ld) {
+    GtOperand o; o.p = p; o.mode = GT_OP_KC; o.T = o.C = o.dil = o.pad = 0; o.ld = ld; o.batch_stride = 0; return o;
+}
+static int small_linear(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
+                        int M, int N, int K, void* stream) {
+    GtGemm g; g.A = kc(X, ldx); g.B = kc(W, ldw); g.C = Y; g.ldc = ldy; g.c_batch_stride = 0; g.bias = bias;
+    g.M = M; g.N = N; g.K = K; g.batch = 1; g.accumulate = 0; g.split_k = 1; g.alpha = 1.f;
+    return gt_sgemm(&g, stream);
+}
+
+int gt_decoder_infer(const GtDecoderInfer* q, void* stream) {
+    GT_REQUIRE(q != nullptr, GT_E_ARG, "gt_decoder_infer: NULL");
+    const GtDecoderFwd* a = &q->step;
+    GT_REQUIRE(rows_ok(a->B, a->Bp), GT_E_LIMIT, "gt_decoder_infer: batch %d must be padded to 16/64 rows (got %d)", a->B, a->Bp);
+    GT_REQUIRE(a->To > 0 && a->Ti > 0 && a->Ha % 16 == 0 && a->Hd % 16 == 0 && a->Apad % 16 == 0 && q->n_mel > 0, GT_E_ARG,
+               "gt_decoder_infer: bad dims");
+    GT_REQUIRE(a->att_keep == nullptr && a->dec_keep == nullptr && a->ring == 1, GT_E_ARG,
+               "gt_decoder_infer: evaluation mode only (no LSTM dropout, one stream)");
+    GT_REQUIRE(q->t_lo >= 0 && q->t_lo <= q->t_hi && q->t_hi <= a->To, GT_E_ARG, "gt_decoder_infer: step range [%d,%d) of %d",
+               q->t_lo, q->t_hi, a->To);
+    GT_REQUIRE(q->W0 && q->W1 && q->W1x && q->bias1 && q->keep0 && q->keep1 && q->Wpg && q->bpg && q->p1 && q->p2 && q->frames &&
+               q->stop_step && a->pre1, GT_E_ARG, "gt_decoder_infer: NULL pointer");
+    const int N1 = 4 * a->Ha, N2 = 4 * a->Hd, P = a->P, nout = q->n_mel + 1;
+    const int K1 = a->E + a->Ha, K2 = a->Ha + a->E + a->Hd;
+    const int64_t hc_ld = a->Hd + a->E;
+    GtAttnDims d; d.B = a->B; d.Ti = a->Ti; d.E = a->E; d.A = a->A; d.F = a->F; d.Kc = a->Kc;
+    const int64_t BT = (int64_t)a->B * a->Ti;
+    float* pre1 = const_cast<float*>(a->pre1);
+    hipStream_t s = (hipStream_t)stream;
+    for (int t = q->t_lo; t < q->t_hi; ++t) {
+        const float* frame = q->frames + (int64_t)t * a->Bp * nout;
+        float* out_t = q->frames + (int64_t)(t + 1) * a->Bp * nout;
+        float* hc_t = a->HC + (int64_t)t * a->Bp * hc_ld;
+        // Prenet on the previous frame, then its share of the attention-LSTM gate pre-activations
+        GT_TRY(small_linear(frame, nout, q->W0, q->n_mel, nullptr, q->p1, P, a->Bp, P, q->n_mel, stream));
+        GT_TRY(gt_bias_act_drop_fwd(q->p1, nullptr, a->Bp, P, 1, 0, q->keep0 + (int64_t)t * a->Bp * P, 0.5f, q->p1, stream));
+        GT_TRY(small_linear(q->p1, P, q->W1, P, nullptr, q->p2, P, a->Bp, P, P, stream));
+        GT_TRY(gt_bias_act_drop_fwd(q->p2, nullptr, a->Bp, P, 1, 0, q->keep1 + (int64_t)t * a->Bp * P, 0.5f, q->p2, stream));
+        GT_TRY(small_linear(q->p2, P, q->W1x, q->ldw1x, q->bias1, pre1, N1, a->Bp, N1, P, stream));
+        // decode step (same sequence as gt_decoder_fwd, single stream, single X2 buffer)
+        GT_TRY(rec_rows(a->X1, a->ld1, a->W1p, a->part, a->Bp, N1, K1, a->S1, s));
+        GT_TRY(gt_lstm_cell_fwd(slabs(a->part, a->S1, (int64_t)a->Bp * N1, N1), pre1, N1,
+                                a->c1 + (int64_t)t * a->Bp * a->Ha, nullptr, 0, nullptr, 0.f, nullptr,
+                                a->gates1 + (int64_t)t * a->Bp * N1, a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha,
+                                a->hatt + (int64_t)t * a->Bp * a->Ha, a->X1 + a->E, a->ld1, a->X2, a->ld2, nullptr, 0,
+                                a->B, a->Ha, s));
+        GT_TRY(rec_rows(a->X2, a->ld2, a->Wqp, a->part, a->Bp, a->Apad, a->Ha, a->Sq, s));
+        GT_TRY(gt_attn_energies_fwd(d, slabs(a->part, a->Sq, (int64_t)a->Bp * a->Apad, a->Apad),
+                                    a->w_hist + (int64_t)t * BT, a->cum_hist + (int64_t)t * BT, a->pm, a->Wc, a->Wd, a->v,
+                                    a->lengths, a->q_hist + (int64_t)t * a->B * a->A, a->energies, s));
+        GT_TRY(gt_attn_context_fwd(d, a->energies, a->memory, a->ldE, a->lengths, a->w_hist + (int64_t)(t + 1) * BT,
+                                   a->cum_hist + (int64_t)t * BT, a->cum_hist + (int64_t)(t + 1) * BT, a->X1, a->ld1,
+                                   a->X2 + a->Ha, a->ld2, hc_t + a->Hd, hc_ld, s));
+        GT_TRY(rec_rows(a->X2, a->ld2, a->W2p, a->part, a->Bp, N2, K2, a->S2, s));
+        GT_TRY(gt_lstm_cell_fwd(slabs(a->part, a->S2, (int64_t)a->Bp * N2, N2), a->bias2, 0,
+                                a->c2 + (int64_t)t * a->Bp * a->Hd, nullptr, 0, nullptr, 0.f, nullptr,
+                                a->gates2 + (int64_t)t * a->Bp * N2, a->c2 + (int64_t)(t + 1) * a->Bp * a->Hd, nullptr,
+                                a->X2 + a->Ha + a->E, a->ld2, hc_t, hc_ld, nullptr, 0, a->B, a->Hd, s));
+        // [mel | gate] of this step = next step's input frame, and the stop test
+        GT_TRY(small_linear(hc_t, hc_ld, q->Wpg, hc_ld, q->bpg, out_t, nout, a->Bp, nout, (int)hc_ld, stream));
+        hipLaunchKernelGGL(gate_stop_kernel, dim3((a->B + 63) / 64), dim3(64), 0, s, out_t + q->n_mel, (int64_t)nout, a->B,
+                           q->gate_threshold, t, q->stop_step);
+        GT_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 int gt_decoder_bwd(const GtDecoderBwd* a, void* stream) {
     GT_REQUIRE(a != nullptr, GT_E_ARG, "gt_decoder_bwd: NULL");
     GT_REQUIRE(rows_ok(a->B, a->Bp), GT_E_LIMIT, "gt_decoder_bwd: batch padding");

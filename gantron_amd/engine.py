@@ -20,7 +20,7 @@ import torch
 
 from . import ops
 from .ops import (ACT_NONE, ACT_RELU, ACT_TANH, IM2COL_K, IM2COL_R, KC, RC, Operand, call, ptr, roundup, sgemm)
-from ._lib import GtBiLstm, GtDecoderBwd, GtDecoderFwd, check, lib
+from ._lib import GtBiLstm, GtDecoderBwd, GtDecoderFwd, GtDecoderInfer, check, lib
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 import os as _os
@@ -216,20 +216,15 @@ class GeneratorEngine:
             active[:L, b] = 1
         return fwd.reshape(-1), rev.reshape(-1), ifwd.reshape(-1), irev.reshape(-1), active
 
-    # ------------------------------------------------------------------------------ forward
-    def forward(self, P, text, in_lens, mels, out_lens, rng, speaker_ids=None, emotions=None, training=True,
-                mask_padding=True):
-        """text (B,Ti) int64 cuda; in_lens/out_lens python lists; mels (B,n_mel,To) cuda.
-        Returns (mel (B,n_mel,To), mel_post, gate (B,To), align (B,To,Ti)), saved."""
+    def _encode(self, P, text, in_lens, rng, speaker_ids, emotions, training, sv):
+        """Embedding, encoder convolutions, packed BiLSTM and the decoder memory
+        [encoder outputs | speaker | labels | style noise] with its attention projection
+        (model.py:648-663, 193-212, 273-279, 440).  rng['noise'] is (B, noise) or, for inference with a
+        caller-supplied style, (B, Ti, noise)."""
         hp, dev = self.hp, text.device
         B, Ti = text.shape
-        To = mels.shape[2]
-        Bp = roundup(B, 16) if B <= 64 else roundup(B, 64)      # rows per decoder step (pad rows stay zero)
-        n_mel, H, E, A = self.n_mel, self.H, self.E, self.A
-        sv = dict(B=B, Bp=Bp, Ti=Ti, To=To, in_lens=list(in_lens), out_lens=list(out_lens), training=training,
-                  text=text)
-
-        PHASES.mark(None)
+        Bp = sv['Bp']
+        H, E, A = self.H, self.E, self.A
         # ---- embedding + encoder convolutions (channels-last rows = (b, t))
         x = _f32(B * Ti, hp.symbols_embedding_dim, device=dev, zero=False)
         call('gt_embedding_fwd', text, P['embedding.weight'], B * Ti, hp.symbols_embedding_dim, x,
@@ -288,11 +283,31 @@ class GeneratorEngine:
                 col += 5
             sv['speaker_ids'] = speaker_ids
         if self.noise:
-            memory[:, :, col:col + self.noise] = rng['noise'][:, None, :]
+            noise = rng['noise']
+            memory[:, :, col:col + self.noise] = noise if noise.dim() == 3 else noise[:, None, :]
         sv['memory'] = memory
         Wmem = P['decoder.attention_layer.memory_layer.linear_layer.weight']
         pm = ops.linear(mem2, Wmem, B * Ti, E, A)
         sv['pm'] = pm
+
+        return memory, mem2, pm
+
+    # ------------------------------------------------------------------------------ forward
+    def forward(self, P, text, in_lens, mels, out_lens, rng, speaker_ids=None, emotions=None, training=True,
+                mask_padding=True):
+        """text (B,Ti) int64 cuda; in_lens/out_lens python lists; mels (B,n_mel,To) cuda.
+        Returns (mel (B,n_mel,To), mel_post, gate (B,To), align (B,To,Ti)), saved."""
+        hp, dev = self.hp, text.device
+        B, Ti = text.shape
+        To = mels.shape[2]
+        Bp = roundup(B, 16) if B <= 64 else roundup(B, 64)      # rows per decoder step (pad rows stay zero)
+        n_mel, H, E, A = self.n_mel, self.H, self.E, self.A
+        sv = dict(B=B, Bp=Bp, Ti=Ti, To=To, in_lens=list(in_lens), out_lens=list(out_lens), training=training,
+                  text=text)
+
+        PHASES.mark(None)
+        memory, mem2, pm = self._encode(P, text, in_lens, rng, speaker_ids, emotions, training, sv)
+        idx = sv['idx']
 
         # ---- prenet over all teacher-forcing frames (go frame + mel[:, :, :To-1]), step-major (To, Bp, .)
         x0 = _f32(To, Bp, n_mel, device=dev)
@@ -395,6 +410,96 @@ class GeneratorEngine:
             sv['mel_cl_masked'] = mel_cl_masked
         PHASES.mark('f.postnet')
         return (mel, mel_post, gate, align), sv
+
+    # ------------------------------------------------------------------------------ inference
+    def inference(self, P, text, style, prenet_keep, speaker_ids=None, emotions=None, gate_threshold=0.5,
+                  max_decoder_steps=500, chunk=32):
+        """Tacotron2.inference (model.py:675-723): evaluation-mode encoder (no packing: every row is Ti long),
+        free-running decoder (gt_decoder_infer) and PostNet.  style: (B, noise) or (B, Ti, noise) or None when
+        the model has no noise input; prenet_keep: two (max_decoder_steps, Bp, P) uint8 keep masks.  The host
+        reads the stop flags every `chunk` steps; the reference decides after every step (:486-491) and keeps
+        the stopping frame, so the returned tensors are cut at the first stop + 1.  For B > 1 (the reference
+        only supports B = 1 here) decoding ends when every item has crossed the threshold.
+        Returns mel (B,n_mel,T), mel_post (B,n_mel,T), gate (B,T,1), align (B,T,Ti)."""
+        hp, dev = self.hp, text.device
+        B, Ti = text.shape
+        Bp = roundup(B, 16) if B <= 64 else roundup(B, 64)
+        n_mel, E, A, Pd, Ha, Hd = self.n_mel, self.E, self.A, self.P, self.Ha, self.Hd
+        To = int(max_decoder_steps)
+        sv = dict(B=B, Bp=Bp, Ti=Ti, To=To, in_lens=[Ti] * B, training=False, text=text)
+        memory, mem2, pm = self._encode(P, text, [Ti] * B, {'noise': style}, speaker_ids, emotions, False, sv)
+
+        W1ih, W1hh = P['decoder.attention_rnn.weight_ih'], P['decoder.attention_rnn.weight_hh']
+        W2ih, W2hh = P['decoder.decoder_rnn.weight_ih'], P['decoder.decoder_rnn.weight_hh']
+        bias1 = P['decoder.attention_rnn.bias_ih'] + P['decoder.attention_rnn.bias_hh']
+        bias2 = P['decoder.decoder_rnn.bias_ih'] + P['decoder.decoder_rnn.bias_hh']
+        K1, K2 = E + Ha, Ha + E + Hd
+        W1cat = torch.cat((W1ih[:, Pd:], W1hh), dim=1).contiguous()
+        W2cat = torch.cat((W2ih, W2hh), dim=1).contiguous()
+        Apad = roundup(A, 16)
+        q = GtDecoderInfer()
+        d = q.step
+        d.B, d.Bp, d.Ti, d.To, d.E, d.ldE, d.P, d.Ha, d.Hd, d.A, d.Apad, d.F, d.Kc = \
+            B, Bp, Ti, To, E, E, Pd, Ha, Hd, A, Apad, self.F, self.Kc
+        d.S1, d.S2, d.Sq = rec_splits(4 * Ha, K1), rec_splits(4 * Hd, K2), ops.pick_splits(Ha, 16)
+        d.p_att = d.p_dec = 0.0
+        packed = dict(W1p=pack_rec(W1cat, 4 * Ha, 4 * Ha, K1), W2p=pack_rec(W2cat, 4 * Hd, 4 * Hd, K2),
+                      Wqp=pack_rec(P['decoder.attention_layer.query_layer.linear_layer.weight'], Apad, A, Ha))
+        lens32 = torch.full((B,), Ti, dtype=torch.int32, device=dev)
+        ld1, ld2 = roundup(K1, 16), roundup(K2, 16)
+        nout, hc = n_mel + 1, Hd + E
+        ws = dict(X1=_f32(Bp, ld1, device=dev), X2=_f32(Bp, ld2, device=dev),
+                  part=_f32(max(d.S1 * Bp * 4 * Ha, d.S2 * Bp * 4 * Hd, d.Sq * Bp * Apad), device=dev, zero=False),
+                  energies=_f32(B, Ti, device=dev, zero=False), pre1=_f32(Bp, 4 * Ha, device=dev),
+                  p1=_f32(Bp, Pd, device=dev), p2=_f32(Bp, Pd, device=dev),
+                  gates1=_f32(To, Bp, 4 * Ha, device=dev, zero=False), c1=_f32(To + 1, Bp, Ha, device=dev),
+                  gates2=_f32(To, Bp, 4 * Hd, device=dev, zero=False), c2=_f32(To + 1, Bp, Hd, device=dev),
+                  hatt=_f32(To, Bp, Ha, device=dev, zero=False), HC=_f32(To, Bp, hc, device=dev),
+                  w_hist=_f32(To + 1, B, Ti, device=dev), cum_hist=_f32(To + 1, B, Ti, device=dev),
+                  q_hist=_f32(To, B, A, device=dev, zero=False), frames=_f32(To + 1, Bp, nout, device=dev),
+                  stop=torch.full((B,), 2 ** 31 - 1, dtype=torch.int32, device=dev))
+        Wpg = torch.cat((P['decoder.linear_projection.linear_layer.weight'],
+                         P['decoder.gate_layer.linear_layer.weight']), dim=0).contiguous()
+        bpg = torch.cat((P['decoder.linear_projection.linear_layer.bias'], P['decoder.gate_layer.linear_layer.bias']))
+        W0 = P['decoder.prenet.layers.0.linear_layer.weight'].contiguous()
+        W1 = P['decoder.prenet.layers.1.linear_layer.weight'].contiguous()
+        k0, k1 = prenet_keep
+        assert tuple(k0.shape) == tuple(k1.shape) == (To, Bp, Pd) and k0.dtype == torch.uint8, \
+            f'prenet keep masks must be ({To},{Bp},{Pd}) uint8'
+        al = 'decoder.attention_layer.'
+        d.memory, d.pm, d.lengths, d.pre1, d.bias2 = ptr(memory), ptr(pm), ptr(lens32), ptr(ws['pre1']), ptr(bias2)
+        d.W1p, d.Wqp, d.W2p = ptr(packed['W1p']), ptr(packed['Wqp']), ptr(packed['W2p'])
+        d.Wc = ptr(P[al + 'location_layer.location_conv.conv.weight'])
+        d.Wd = ptr(P[al + 'location_layer.location_dense.linear_layer.weight'])
+        d.v = ptr(P[al + 'v.linear_layer.weight'])
+        d.att_keep = d.dec_keep = None
+        d.X1, d.ld1, d.X2, d.ld2, d.part, d.energies = ptr(ws['X1']), ld1, ptr(ws['X2']), ld2, ptr(ws['part']), ptr(ws['energies'])
+        d.part2, d.ring = None, 1
+        for k in ('gates1', 'c1', 'gates2', 'c2', 'hatt', 'HC', 'w_hist', 'cum_hist', 'q_hist'):
+            setattr(d, k, ptr(ws[k]))
+        q.W0, q.W1, q.W1x, q.ldw1x, q.bias1 = ptr(W0), ptr(W1), ptr(W1ih), W1ih.stride(0), ptr(bias1)
+        q.keep0, q.keep1, q.Wpg, q.bpg = ptr(k0), ptr(k1), ptr(Wpg), ptr(bpg)
+        q.p1, q.p2, q.frames, q.stop_step = ptr(ws['p1']), ptr(ws['p2']), ptr(ws['frames']), ptr(ws['stop'])
+        q.n_mel, q.gate_threshold = n_mel, float(gate_threshold)
+        t, T = 0, To
+        while t < To:
+            q.t_lo, q.t_hi = t, min(t + chunk, To)
+            _run('gt_decoder_infer', q)
+            t = q.t_hi
+            stop = ws['stop'].tolist()                      # device sync: once per chunk
+            if max(stop) < t:
+                T = max(stop) + 1
+                break
+        else:
+            print('Warning! Reached max decoder steps')     # reference model.py:489
+        frames = ws['frames'][1:T + 1, :B]                   # (T, B, n_mel+1)
+        mel_cl = frames[:, :, :n_mel].permute(1, 0, 2).contiguous()          # (B, T, n_mel)
+        mel = mel_cl.transpose(1, 2).contiguous()
+        gate = frames[:, :, n_mel:].permute(1, 0, 2).contiguous()            # (B, T, 1)
+        align = ws['w_hist'][1:T + 1].permute(1, 0, 2).contiguous()          # (B, T, Ti)
+        post_cl = self.post_stack.forward(P, mel_cl.view(B * T, n_mel), B, T, None, False, [])
+        mel_post = mel + post_cl.view(B, T, n_mel).transpose(1, 2)
+        return mel, mel_post, gate, align
 
     # ------------------------------------------------------------------------------ backward
     def backward(self, P, G, sv, dmel, dmel_post, dgate, dalign):

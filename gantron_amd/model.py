@@ -214,8 +214,46 @@ class Tacotron2(nn.Module):
                                   emotions.contiguous() if self.use_labels else None, *params)
         return list(outs)
 
-    def inference(self, *args, **kwargs):
-        raise NotImplementedError('autoregressive inference is a "next" row of the hot-path scope (SURVEY.md 8f-3)')
+    @torch.no_grad()
+    def inference(self, text_inputs, style=None, emotions=None, speaker=None):
+        """reference model.py:675-723: text (1,Ti) ids or a raw string; style (B,Ti,noise) / (B,1,noise) /
+        (B,noise) or None (drawn U[0,1) as :469 does); emotions (B,5); speaker LongTensor (B,).
+        Returns [mel, mel_postnet, gate (B,T,1), alignments] cut at the stop gate."""
+        hp = self.hparams
+        dev = self.embedding.weight.device
+        if isinstance(text_inputs, str):
+            import numpy as np
+            from .text import text_to_sequence
+            text_inputs = torch.from_numpy(np.array(text_to_sequence(text_inputs, ['english_cleaners']))[None, :])
+        text = text_inputs.to(dev).long().contiguous()
+        B, Ti = text.shape
+        src = self.dropout_source
+        if hp.noise_size > 0:
+            if style is None:
+                style = src.uniform((B, hp.noise_size), dev)
+            style = style.to(dev).float()
+            if style.dim() == 3 and style.size(1) == 1:
+                style = style[:, 0]
+            style = style.contiguous()
+        else:
+            style = None
+        if self.use_labels and emotions is None:
+            emotions = src.uniform((B, 5), dev)
+        if self.vesus and speaker is None:
+            raise ValueError('this model was built with vesus_path: inference needs `speaker` (model.py:698-702)')
+        Bp = ops.roundup(B, 16) if B <= 64 else ops.roundup(B, 64)
+        steps = hp.max_decoder_steps
+        if self.rng_override is not None:
+            keeps = self.rng_override['prenet_keep']
+        else:
+            keeps = [src.keep((steps, Bp, hp.prenet_dim), 0.5, dev) for _ in range(2)]
+        P = {k: v.detach() for k, v in self.named_parameters()}
+        P.update({k: v for k, v in self.named_buffers()})
+        outs = self.engine.inference(P, text, style, keeps,
+                                     speaker.to(dev).long().contiguous() if self.vesus else None,
+                                     emotions.to(dev).float().contiguous() if self.use_labels else None,
+                                     gate_threshold=hp.gate_threshold, max_decoder_steps=steps)
+        return list(outs)
 
 
 class _AdversarialFn(torch.autograd.Function):

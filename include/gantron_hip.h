@@ -248,9 +248,36 @@ typedef struct GtBiLstm {
     int32_t Hpad;
 } GtBiLstm;
 
+/* Free-running decoder of Decoder.inference (model.py:456-497): every step feeds the previous mel
+ * frame back through the Prenet (dropout always on, model.py:104), runs the decode step of
+ * gt_decoder_fwd (same kernels, no LSTM dropout, lengths = Ti: inference passes mask=None) and the
+ * mel/gate projection, and records per item the first step whose sigmoid(gate) exceeds the threshold.
+ * The host issues steps [t_lo, t_hi) per call and reads stop_step between calls (model.py:486-491
+ * tests the gate every step; frames computed past the stop are simply not returned). */
+typedef struct GtDecoderInfer {
+    GtDecoderFwd step;         /* To = capacity in frames; att_keep = dec_keep = NULL; ring = 1;
+                                  pre1 = ONE step's (Bp, 4Ha) buffer, rewritten every step */
+    const float* W0;           /* Prenet layer 0 (P, n_mel), PyTorch layout */
+    const float* W1;           /* Prenet layer 1 (P, P) */
+    const float* W1x;          /* attention_rnn.weight_ih: prenet columns [0,P) of rows of stride ldw1x */
+    int64_t ldw1x;
+    const float* bias1;        /* (4Ha) b_ih + b_hh of attention_rnn */
+    const uint8_t* keep0;      /* (To, Bp, P) Prenet dropout keep masks */
+    const uint8_t* keep1;
+    const float* Wpg;          /* (n_mel+1, Hd+E): linear_projection rows then the gate_layer row */
+    const float* bpg;          /* (n_mel+1) */
+    float* p1; float* p2;      /* (Bp, P) scratch */
+    float* frames;             /* (To+1, Bp, n_mel+1): block 0 = go frame (zeros), block t+1 = [mel | gate] of step t */
+    int32_t* stop_step;        /* (B) initialised to INT32_MAX by the caller; min over steps with sigmoid(gate) > threshold */
+    int32_t n_mel;
+    float gate_threshold;
+    int32_t t_lo, t_hi;
+} GtDecoderInfer;
+
 int gt_decoder_fwd(const GtDecoderFwd* a, void* stream);
 int gt_decoder_bwd(const GtDecoderBwd* a, void* stream);
 int gt_bilstm_run(const GtBiLstm* a, void* stream);
+int gt_decoder_infer(const GtDecoderInfer* a, void* stream);
 
 /* -------------------------------------------------------------------- elementwise / reductions */
 /* per-column sums over rows: BatchNorm1d batch statistics incl. padding (model.py:123,176) and

@@ -254,6 +254,73 @@ def generator_forward(P, text: Tensor, text_lengths: Tensor, mels: Tensor, outpu
     return mel, mel_post, gate, align
 
 
+# ----------------------------------------------------------------------------- inference
+def decoder_inference(P, memory: Tensor, style: Optional[Tensor], prenet_keep: List[Tensor],
+                      gate_threshold: float = 0.5, max_decoder_steps: int = 500):
+    """Decoder.inference, model.py:456-497: free-running decode.  The previous mel frame goes back
+    through the Prenet (dropout still on, model.py:104), no attention mask (mask=None), no LSTM dropout
+    (eval), stop as soon as sigmoid(gate) > gate_threshold (the stopping frame is kept) or after
+    max_decoder_steps frames.  memory (B,Ti,Eenc); style (B,Ti,noise) or (B,noise) or None;
+    prenet_keep [2 x (steps,B,D)].  Returns mel (B,n_mel,T), gate (B,T,1), alignments (B,T,Ti)."""
+    B, Ti, _ = memory.shape
+    if style is not None:
+        if style.dim() == 2:
+            style = style[:, None, :].expand(B, Ti, style.size(1))
+        memory = torch.cat([memory, style], dim=-1)
+    n_mel = P['decoder.linear_projection.linear_layer.weight'].size(0)
+    Ha = P['decoder.attention_rnn.weight_hh'].size(1)
+    Hd = P['decoder.decoder_rnn.weight_hh'].size(1)
+    h_a = memory.new_zeros(B, Ha); c_a = memory.new_zeros(B, Ha)
+    h_d = memory.new_zeros(B, Hd); c_d = memory.new_zeros(B, Hd)
+    w = memory.new_zeros(B, Ti); w_cum = memory.new_zeros(B, Ti)
+    ctx = memory.new_zeros(B, memory.size(2))
+    pm = memory @ P['decoder.attention_layer.memory_layer.linear_layer.weight'].t()
+    pad = torch.zeros(B, Ti, dtype=torch.bool)
+    frame = memory.new_zeros(B, n_mel)
+    mel_out, gate_out, aligns = [], [], []
+    while True:
+        t = len(mel_out)
+        x = prenet_forward(P, frame, [k[t] for k in prenet_keep])
+        h_a, c_a = lstm_cell(torch.cat((x, ctx), -1), h_a, c_a,
+                             P['decoder.attention_rnn.weight_ih'], P['decoder.attention_rnn.weight_hh'],
+                             P['decoder.attention_rnn.bias_ih'], P['decoder.attention_rnn.bias_hh'])
+        ctx, w = attention_step(P, h_a, memory, pm, w, w_cum, pad)
+        w_cum = w_cum + w
+        h_d, c_d = lstm_cell(torch.cat((h_a, ctx), -1), h_d, c_d,
+                             P['decoder.decoder_rnn.weight_ih'], P['decoder.decoder_rnn.weight_hh'],
+                             P['decoder.decoder_rnn.bias_ih'], P['decoder.decoder_rnn.bias_hh'])
+        hc = torch.cat((h_d, ctx), dim=1)
+        frame = hc @ P['decoder.linear_projection.linear_layer.weight'].t() + P['decoder.linear_projection.linear_layer.bias']
+        # (B,1) per step: unlike Decoder.forward (model.py:446), inference does not squeeze the gate, so
+        # parse_decoder_outputs returns it as (B,T,1)
+        gate = hc @ P['decoder.gate_layer.linear_layer.weight'].t() + P['decoder.gate_layer.linear_layer.bias']
+        mel_out.append(frame); gate_out.append(gate); aligns.append(w)
+        if bool((torch.sigmoid(gate) > gate_threshold).all()) or len(mel_out) == max_decoder_steps:
+            break
+    aligns = torch.stack(aligns).transpose(0, 1)
+    gate_out = torch.stack(gate_out).transpose(0, 1).contiguous()
+    mel_out = torch.stack(mel_out).transpose(0, 1).transpose(1, 2).contiguous()
+    return mel_out, gate_out, aligns
+
+
+def generator_inference(P, text: Tensor, style: Optional[Tensor], prenet_keep: List[Tensor],
+                        speaker: Optional[Tensor] = None, emotions: Optional[Tensor] = None,
+                        gate_threshold: float = 0.5, max_decoder_steps: int = 500):
+    """Tacotron2.inference, model.py:675-723 (encoder_inputs=False): eval-mode encoder without packing
+    (Encoder.inference :214-224), memory = [encoder | speaker | emotions | style], free-running decoder,
+    PostNet residual; parse_output without lengths leaves the outputs unmasked."""
+    emb = F.embedding(text, P['embedding.weight']).transpose(1, 2)
+    lengths = torch.full((text.size(0),), text.size(1), dtype=torch.long)
+    enc = encoder_forward(P, emb, lengths, None, training=False)
+    if speaker is not None and 'speaker_embedding.weight' in P:
+        enc = torch.cat((enc, F.embedding(speaker, P['speaker_embedding.weight'])[:, None].repeat(1, enc.size(1), 1)), dim=2)
+    if emotions is not None:
+        enc = torch.cat((enc, emotions[:, None].repeat(1, enc.size(1), 1)), dim=2)
+    mel, gate, align = decoder_inference(P, enc, style, prenet_keep, gate_threshold, max_decoder_steps)
+    mel_post = mel + postnet_forward(P, mel, None, training=False)
+    return mel, mel_post, gate, align
+
+
 # ----------------------------------------------------------------------------- discriminator
 def disc_window_input(x: Tensor, window: int) -> Tensor:
     """Discriminator.forward input shaping, model.py:523-526.  x: (B, T, n_mel).

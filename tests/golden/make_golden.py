@@ -272,8 +272,61 @@ def allreduce_fixture():
     print('wrote allreduce.npz')
 
 
+def inference_case():
+    """Tacotron2.inference (model.py:675-723) on the tiny configuration, B=1: eval mode, explicit style
+    vector, Prenet dropout masks recorded in call order.  The gate bias is shifted so that the stop
+    condition fires inside the loop (random weights alone never cross the threshold)."""
+    hp_string = common.TINY_HPARAMS + ',max_decoder_steps=40,gate_threshold=0.5'
+    hp, G, D = build(hp_string)
+    G.eval()
+    g = torch.Generator().manual_seed(77)
+    for k, v in G.state_dict().items():                 # non-trivial running statistics
+        if k.endswith('running_mean'):
+            v.copy_(torch.randn(v.shape, generator=g) * 0.1)
+        if k.endswith('running_var'):
+            v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+    text = torch.randint(1, hp.n_symbols, (1, 9), generator=g)
+    style = torch.rand(1, 1, hp.noise_size, generator=g).repeat_interleave(9, dim=1)
+    blob = dict(hparams=np.array(hp_string), text=text.numpy(), style=style.numpy())
+    for tag in ('max', 'stop'):
+        if tag == 'max':
+            G.decoder.gate_layer.linear_layer.weight.data.mul_(40.0)      # a livelier gate trajectory
+            G.decoder.gate_layer.linear_layer.bias.data.fill_(-50.0)
+        else:
+            # the gate does not feed back, so the trajectory of the 'max' run tells where a shifted bias
+            # crosses the threshold: stop at the first running maximum after frame 8
+            raw = out[2].flatten() + 50.0
+            best = None                     # (margin, sign, cut): first crossing in frames 3..34 with the widest margin
+            for sign in (1.0, -1.0):
+                r = sign * raw
+                vals = torch.sort(r).values
+                for cut in ((vals[1:] + vals[:-1]) / 2).tolist():
+                    first = int(torch.nonzero(r > cut)[0])
+                    margin = float((r[:first + 1] - cut).abs().min())
+                    if 3 <= first < 35 and (best is None or margin > best[0]):
+                        best = (margin, sign, cut)
+            margin, sign, cut = best
+            print(f'stop placement: margin {margin:.4f}')
+            G.decoder.gate_layer.linear_layer.weight.data.mul_(sign)
+            G.decoder.gate_layer.linear_layer.bias.data.fill_(-cut)
+        inj = Injector(common.MaskStream(303))
+        with torch.no_grad(), inj:
+            out = G.inference(text, style=style)
+        n = out[0].shape[2]
+        print(f'inference[{tag}]: {n} frames, last gate {out[2].flatten()[-1].item():.4f}')
+        blob.update(common.pack_dict(f'{tag}/state', {k: v.clone() for k, v in G.state_dict().items()}))
+        blob.update(common.pack_dict(f'{tag}/out', dict(mel=out[0], mel_post=out[1], gate=out[2], align=out[3])))
+        blob[f'{tag}/keep0'] = torch.stack(inj.drops[0::2]).numpy()
+        blob[f'{tag}/keep1'] = torch.stack(inj.drops[1::2]).numpy()
+    path = os.path.join(HERE, 'tiny_inference.npz')
+    np.savez_compressed(path, **blob)
+    print('wrote', path, os.path.getsize(path) // 1024, 'KiB')
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['tiny', 'ops', 'full', 'vesus', 'allreduce']
+    which = sys.argv[1:] or ['tiny', 'ops', 'full', 'vesus', 'allreduce', 'inference']
+    if 'inference' in which:
+        inference_case()
     if 'tiny' in which:
         tiny_case()
     if 'ops' in which:

@@ -130,3 +130,20 @@ def test_hparams_mirror():
     ns = argparse.Namespace(hparams='batch_size=8', batch_size=16, wavs_path=None, n_gpus=2)
     hp.add_params(ns)
     assert hp.batch_size == 8 and hp.n_gpus == 2
+
+
+@pytest.mark.parametrize('tag,frames', [('stop', 5), ('max', 40)])
+def test_inference_matches_reference(golden_dir, tag, frames):
+    """Tacotron2.inference (model.py:675-723) of the reference, B=1: the stop-gate run ends on the same
+    frame, the max_decoder_steps run is cut at 40; outputs of every frame agree."""
+    z = _load(golden_dir, 'tiny_inference.npz')
+    hp = HParams(str(z['hparams']))
+    P = {k: v for k, v in common.unpack_dict(z, f'{tag}/state').items() if not k.endswith('num_batches_tracked')}
+    keeps = [torch.from_numpy(z[f'{tag}/keep0']), torch.from_numpy(z[f'{tag}/keep1'])]
+    out = R.generator_inference(P, torch.from_numpy(z['text']), torch.from_numpy(z['style']), keeps,
+                                gate_threshold=hp.gate_threshold, max_decoder_steps=hp.max_decoder_steps)
+    ref = common.unpack_dict(z, f'{tag}/out')
+    assert out[0].shape[2] == frames == ref['mel'].shape[2]
+    for name, t in zip(('mel', 'mel_post', 'gate', 'align'), out):
+        assert tuple(t.shape) == tuple(ref[name].shape), name       # gate is (B,T,1) on this path
+        _close(t, ref[name], rtol=2e-4, atol=1e-5, what=f'{tag}.{name}')

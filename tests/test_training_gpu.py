@@ -172,3 +172,54 @@ def test_train_loop_end_to_end(dev, tmp_path):
     out2 = tmp_path / 'out2'
     T.train(str(out2), str(out / ckpts[-1]), False, 1, 0, 'g', hp2, str(wavs) + '/')
     assert os.listdir(out2)
+
+
+def _pad_keeps(keeps, steps, Bp, dev):
+    out = []
+    for k in keeps:                                   # (n, B, P) bool -> (steps, Bp, P) uint8
+        t = torch.zeros(steps, Bp, k.shape[2], dtype=torch.uint8)
+        t[:k.shape[0], :k.shape[1]] = torch.as_tensor(k).to(torch.uint8)
+        out.append(t.to(dev))
+    return out
+
+
+@pytest.mark.parametrize('tag,frames', [('stop', 5), ('max', 40)])
+def test_inference_matches_reference_golden(dev, golden_dir, tag, frames):
+    """Tacotron2.inference against the reference's own run (tests/golden/tiny_inference.npz): the stop gate
+    fires on the same frame / the loop is cut at max_decoder_steps (crossing a host-check chunk boundary)."""
+    from gantron_amd.hparams import HParams
+    from gantron_amd.model import Tacotron2
+    z = np.load(os.path.join(golden_dir, 'tiny_inference.npz'))
+    hp = HParams(str(z['hparams']))
+    G = Tacotron2(hp).to(dev).eval()
+    G.load_state_dict(common.unpack_dict(z, f'{tag}/state'))
+    G.rng_override = dict(prenet_keep=_pad_keeps([z[f'{tag}/keep0'], z[f'{tag}/keep1']], hp.max_decoder_steps, 16, dev))
+    out = G.inference(torch.from_numpy(z['text']), style=torch.from_numpy(z['style']))
+    ref = common.unpack_dict(z, f'{tag}/out')
+    assert out[0].shape[2] == frames
+    for name, t in zip(('mel', 'mel_post', 'gate', 'align'), out):
+        close(t, ref[name], rtol=1e-3, atol=1e-5, what=f'inference[{tag}].{name}')
+
+
+def test_inference_batch_against_oracle(dev):
+    """Free-running decode at a mid-size configuration, B=3 rows (padded to 16), 37 steps: every frame of
+    every item against the oracle fed the same Prenet masks and style."""
+    from gantron_amd.hparams import HParams
+    from gantron_amd.model import Tacotron2
+    from oracle import gantron_ref as R
+    hp = HParams(MID + ',max_decoder_steps=37')
+    Gp, _ = R.init_params(hp, seed=6)
+    Gp['decoder.gate_layer.linear_layer.bias'] = torch.full((1,), -30.0)      # never stop: compare all 37 frames
+    g = torch.Generator().manual_seed(5)
+    B, Ti = 3, 19
+    text = torch.randint(1, hp.n_symbols, (B, Ti), generator=g)
+    style = torch.rand(B, hp.noise_size, generator=g)
+    keeps = [torch.rand(37, B, hp.prenet_dim, generator=g) >= 0.5 for _ in range(2)]
+    G = Tacotron2(hp).to(dev).eval()
+    G.load_state_dict(_with_counters(Gp))
+    G.rng_override = dict(prenet_keep=_pad_keeps(keeps, 37, 16, dev))
+    got = G.inference(text, style=style)
+    want = R.generator_inference(Gp, text, style, keeps, max_decoder_steps=37)
+    assert got[0].shape[2] == 37
+    for name, a, b in zip(('mel', 'mel_post', 'gate', 'align'), got, want):
+        close(a, b, rtol=1e-3, atol=1e-5, what=f'inference {name}')
