@@ -325,6 +325,42 @@ __global__ __launch_bounds__(256) void reflect_pad_kernel(const float* audio, in
     }
 }
 
+// Ragged batch: row b holds len[b] samples (ld apart); every row is reflect-padded around ITS OWN ends
+// (so each item sees exactly what a single-item call would) and zero beyond len[b] + 2*pad.
+__global__ __launch_bounds__(256) void reflect_pad_ragged_kernel(const float* audio, int B, long ld, const long* len,
+                                                                 int pad, float* out) {
+    const long np = ld + 2L * pad;
+    const long total = (long)B * np;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long b = idx / np;
+        const long n = len[b];
+        const long j = idx - b * np;
+        float v = 0.f;
+        if (j < n + 2L * pad) {
+            long i = j - pad;
+            if (i < 0) i = -i;
+            if (i >= n) i = 2 * (n - 1) - i;
+            v = audio[b * ld + i];
+        }
+        out[idx] = v;
+    }
+}
+
+// log-mel rows (B*F, n_mel) -> mel_padded (B, n_mel, F) zero beyond frames[b], gate_padded (B, F) = 1 from
+// frame frames[b]-1 on (TextMelCollate, data_utils.py:117-128)
+__global__ __launch_bounds__(256) void collate_mel_kernel(const float* rows, const long* frames, int B, int n_mel, int F,
+                                                          float* mel, float* gate) {
+    const long total = (long)B * n_mel * F;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int f = (int)(idx % F);
+        const int c = (int)((idx / F) % n_mel);
+        const int b = (int)(idx / ((long)F * n_mel));
+        const long nf = frames[b];
+        mel[idx] = f < nf ? rows[((long)b * F + f) * n_mel + c] : 0.f;
+        if (c == 0) gate[(long)b * F + f] = f >= nf - 1 ? 1.f : 0.f;
+    }
+}
+
 __global__ __launch_bounds__(256) void stft_mag_kernel(const float* ft, long rows, int cutoff, float* mag) {
     const long total = rows * cutoff;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -531,6 +567,24 @@ extern "C" int gt_adv_mean_bwd(const float* dloss, const int64_t* lengths, int32
 extern "C" int gt_reflect_pad(const float* audio, int32_t B, int64_t n, int32_t pad, float* out, void* stream) {
     GT_REQUIRE(audio && out && B > 0 && n > pad && pad >= 0, GT_E_ARG, "gt_reflect_pad: need n > pad");
     hipLaunchKernelGGL(reflect_pad_kernel, dim3(flat_blocks((long)B * (n + 2L * pad))), dim3(256), 0, ST, audio, B, (long)n, pad, out);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gt_reflect_pad_ragged(const float* audio, int32_t B, int64_t ld, const int64_t* lengths, int32_t pad,
+                                     float* out, void* stream) {
+    GT_REQUIRE(audio && out && lengths && B > 0 && ld > pad && pad >= 0, GT_E_ARG, "gt_reflect_pad_ragged: bad argument");
+    hipLaunchKernelGGL(reflect_pad_ragged_kernel, dim3(flat_blocks((long)B * (ld + 2L * pad))), dim3(256), 0, ST, audio, B,
+                       (long)ld, (const long*)lengths, pad, out);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gt_collate_mel(const float* rows, const int64_t* frames, int32_t B, int32_t n_mel, int32_t F, float* mel,
+                              float* gate, void* stream) {
+    GT_REQUIRE(rows && frames && mel && gate && B > 0 && n_mel > 0 && F > 0, GT_E_ARG, "gt_collate_mel: bad argument");
+    hipLaunchKernelGGL(collate_mel_kernel, dim3(flat_blocks((long)B * n_mel * F)), dim3(256), 0, ST, rows, (const long*)frames, B,
+                       n_mel, F, mel, gate);
     GT_LAUNCH_CHECK();
     return 0;
 }

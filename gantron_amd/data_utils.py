@@ -1,9 +1,11 @@
 """`TextMelLoader` / `TextMelCollate` with the reference's behaviour (reference data_utils.py:13-131).
 
 Differences that come with the MI355X design:
-* the mel spectrogram is computed by the HIP STFT (stft.TacotronSTFT) in the MAIN process -- a forked
-  DataLoader worker cannot touch the GPU -- so use `num_workers=0`, or precompute mels
-  (`load_mel_from_disk=True`) when workers are wanted;
+* the training path is `TextAudioLoader` (workers decode wav + text on the CPU only) -> `TextAudioCollate`
+  (raw audio padded into pinned host buffers) -> `DeviceBatches` (main process: asynchronous H2D on a
+  copy stream, ONE batched STFT-mel per batch on the GPU, double-buffered so batch i+1 is staged while
+  batch i trains).  `TextMelLoader` keeps the reference's per-item behaviour (mel per item through the
+  HIP STFT in the main process, or `load_mel_from_disk=True`) and is what validation uses;
 * wav files are decoded with scipy (16-bit PCM or float); files whose rate differs from
   `hparams.sampling_rate` are rejected instead of resampled (librosa/resampy are not in the image).
 """
@@ -150,3 +152,90 @@ class TextMelCollate:
             gate_padded[i, mel.size(1) - 1:] = 1
             output_lengths[i] = mel.size(1)
         return text_padded, input_lengths, mel_padded, gate_padded, speaker_ids, emotions, output_lengths
+
+
+class TextAudioLoader(TextMelLoader):
+    """Items are (text ids, raw audio[, speaker, emotions]): nothing here touches the GPU, so DataLoader
+    workers are allowed; the mel is computed per batch on the device (DeviceBatches)."""
+
+    def __getitem__(self, index):
+        i = self.idx[index]
+        path, text = self.audiopaths_and_text[i][0], self.audiopaths_and_text[i][1]
+        audio = load_wav_to_torch(path, self.sampling_rate)
+        assert float(audio.min()) >= -1 and float(audio.max()) <= 1        # layers.py:107-108
+        item = (self.get_text(text), audio)
+        if self.vesus:
+            item += (self.speakers[i], self.emotions[i])
+        return item
+
+
+class TextAudioCollate:
+    """TextMelCollate's ordering and padding (data_utils.py:88-131) applied to raw audio: sort by text
+    length (descending), zero-pad text and audio.  Returns
+    (text_padded, input_lengths, audio_padded, audio_lengths, speaker_ids, emotions)."""
+
+    def __call__(self, batch):
+        lengths = torch.LongTensor([len(x[0]) for x in batch])
+        input_lengths, order = torch.sort(lengths, dim=0, descending=True)
+        B = len(batch)
+        text_padded = torch.zeros(B, int(input_lengths[0]), dtype=torch.long)
+        audio_lengths = torch.zeros(B, dtype=torch.long)
+        audio_padded = torch.zeros(B, max(x[1].numel() for x in batch))
+        speaker_ids = torch.zeros(B)
+        emotions = torch.zeros(B, 5)
+        for i, src in enumerate(order.tolist()):
+            item = batch[src]
+            text, audio = item[0], item[1]
+            text_padded[i, :text.size(0)] = text
+            audio_padded[i, :audio.numel()] = audio
+            audio_lengths[i] = audio.numel()
+            if len(item) == 4:
+                speaker_ids[i] = item[2]
+                emotions[i] = item[3]
+        return text_padded, input_lengths, audio_padded, audio_lengths, speaker_ids, emotions
+
+
+class DeviceBatches:
+    """Wraps a DataLoader of TextAudioCollate batches and yields the 7-tuple `Tacotron2.parse_batch`
+    expects, with text / mel / gate already on the device and both length vectors on the host (so the
+    step never synchronises on them).  Batch i+1 is copied (pinned, non_blocking) and its mel computed
+    on a side stream while batch i trains."""
+
+    def __init__(self, loader, stft, device=None):
+        self.loader, self.stft = loader, stft
+        self.device = device or torch.device('cuda', torch.cuda.current_device())
+        self.stream = torch.cuda.Stream(device=self.device)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _stage(self, host_batch):
+        text, in_len, audio, audio_len, speakers, emotions = host_batch
+        hop = self.stft.hop_length
+        assert int(audio_len.min()) > self.stft.filter_length // 2, 'clip shorter than the STFT reflect padding'
+        pin = lambda t: t if t.is_pinned() else t.pin_memory()
+        with torch.cuda.stream(self.stream):
+            dev = lambda t: pin(t).to(self.device, non_blocking=True)
+            text_d, audio_d, len_d = dev(text), dev(audio), dev(audio_len)
+            spk_d, emo_d = dev(speakers), dev(emotions)
+            mel, gate, _ = self.stft.mel_spectrogram_batch(audio_d, len_d)
+        out_len = audio_len // hop + 1
+        return (text_d, in_len, mel, gate, spk_d, emo_d, out_len)
+
+    def __iter__(self):
+        staged = None
+        for host_batch in self.loader:
+            nxt = self._stage(host_batch)
+            if staged is not None:
+                yield self._release(staged)
+            staged = nxt
+        if staged is not None:
+            yield self._release(staged)
+
+    def _release(self, batch):
+        main = torch.cuda.current_stream(self.device)
+        main.wait_stream(self.stream)
+        for t in batch:
+            if t.is_cuda:
+                t.record_stream(main)
+        return batch

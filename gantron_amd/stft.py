@@ -101,3 +101,27 @@ class TacotronSTFT(nn.Module):
         out = torch.empty(B, nm, frames, device=y.device, dtype=torch.float32)
         ops.call('gt_permute3', mel, frames * nm, 1, nm, B, nm, frames, out, 0, 0, 0, 1.0)
         return out
+
+    def mel_spectrogram_batch(self, audio, lengths):
+        """One collated batch of raw audio -> (mel_padded (B, n_mel, F), gate_padded (B, F), frames (B,) int64).
+        audio (B, Nmax) cuda, zero beyond lengths (B,) int64 cuda.  Item b's frames [0, lengths[b]//hop + 1) equal
+        `mel_spectrogram(audio[b:b+1, :lengths[b]])`: every row is reflect-padded around its own ends; later
+        frames are zero and the gate target is 1 from the last valid frame on (data_utils.py:117-128)."""
+        assert audio.is_cuda and audio.dim() == 2 and lengths.dtype == torch.int64 and lengths.is_cuda
+        B, n = audio.shape
+        N, hop, cut, nm = self.filter_length, self.hop_length, self.cutoff, self.n_mel_channels
+        F = n // hop + 1
+        padded = torch.empty(B, n + N, device=audio.device, dtype=torch.float32)
+        ops.call('gt_reflect_pad_ragged', audio.contiguous().float(), B, n, lengths, N // 2, padded)
+        ft = torch.empty(B * F, 2 * cut, device=audio.device, dtype=torch.float32)
+        ops.sgemm(ops.Operand(padded, ops.KC, ld=hop, batch_stride=n + N),
+                  ops.Operand(self.forward_basis, ops.KC, ld=N), ft, F, 2 * cut, N, batch=B, c_batch_stride=F * 2 * cut)
+        mag = torch.empty(B * F, cut, device=audio.device, dtype=torch.float32)
+        ops.call('gt_stft_magnitude', ft, B * F, cut, mag)
+        mel = ops.linear(mag, self.mel_basis, B * F, cut, nm)
+        ops.call('gt_log_clamp', mel, mel.numel(), 1e-5, mel)
+        frames = lengths // hop + 1
+        mel_padded = torch.empty(B, nm, F, device=audio.device, dtype=torch.float32)
+        gate_padded = torch.empty(B, F, device=audio.device, dtype=torch.float32)
+        ops.call('gt_collate_mel', mel, frames, B, nm, F, mel_padded, gate_padded)
+        return mel_padded, gate_padded, frames

@@ -20,7 +20,7 @@ from torch.utils.data import DataLoader
 from torch.utils.data.distributed import DistributedSampler
 
 from . import logger
-from .data_utils import TextMelCollate, TextMelLoader
+from .data_utils import DeviceBatches, TextAudioCollate, TextAudioLoader, TextMelCollate, TextMelLoader
 from .distributed import apply_gradient_allreduce, init_distributed, reduce_tensor
 from .hparams import HParams
 from .loss_function import Tacotron2Loss
@@ -30,13 +30,21 @@ from .train_steps import discriminator_step, generator_step
 
 
 def prepare_dataloaders(hparams, wavs_path):
-    trainset = TextMelLoader(hparams.training_files, hparams, wavs_path)
+    """reference train.py:94-111.  Raw-audio training batches go through the device pipeline
+    (data_utils.DeviceBatches: workers decode on the CPU, one batched STFT-mel per batch on the GPU,
+    double-buffered); precomputed mels (`load_mel_from_disk`) keep the reference's loader."""
     valset = TextMelLoader(hparams.validation_files, hparams, wavs_path)
     collate_fn = TextMelCollate(hparams.n_frames_per_step)
+    if hparams.load_mel_from_disk:
+        trainset, train_collate = TextMelLoader(hparams.training_files, hparams, wavs_path), collate_fn
+    else:
+        trainset, train_collate = TextAudioLoader(hparams.training_files, hparams, wavs_path), TextAudioCollate()
     sampler = DistributedSampler(trainset) if hparams.distributed_run else None
-    workers = 1 if hparams.load_mel_from_disk else 0      # GPU STFT runs in the main process
-    train_loader = DataLoader(trainset, num_workers=workers, shuffle=sampler is None, sampler=sampler,
-                              batch_size=hparams.batch_size, pin_memory=True, drop_last=True, collate_fn=collate_fn)
+    train_loader = DataLoader(trainset, num_workers=1, shuffle=sampler is None, sampler=sampler,
+                              batch_size=hparams.batch_size, pin_memory=True, drop_last=True, collate_fn=train_collate)
+    if not hparams.load_mel_from_disk:
+        from .stft import TacotronSTFT
+        train_loader = DeviceBatches(train_loader, TacotronSTFT(*trainset._stft_args).cuda())
     return train_loader, valset, collate_fn
 
 

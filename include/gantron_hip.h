@@ -369,6 +369,14 @@ int gt_adam_step(float* param, const float* grad, float* m, float* v, int64_t n,
 /* -------------------------------------------------------------------------------------- STFT
  * TacotronSTFT.mel_spectrogram (layers.py:97-114, stft.py:77-105, audio_processing.py:78-84) */
 int gt_reflect_pad(const float* audio, int32_t B, int64_t n, int32_t pad, float* out, void* stream);
+/* ragged batch (one collated batch of raw audio, data_utils.py:51-64 + 88-131 done on the device): row b holds
+ * lengths[b] samples, rows ld apart, each reflect-padded around its own ends into rows of ld + 2*pad */
+int gt_reflect_pad_ragged(const float* audio, int32_t B, int64_t ld, const int64_t* lengths, int32_t pad,
+                          float* out, void* stream);
+/* log-mel rows (B*F, n_mel) -> mel_padded (B, n_mel, F), zero beyond frames[b]; gate_padded (B, F) = 1 from
+ * frame frames[b]-1 on */
+int gt_collate_mel(const float* rows, const int64_t* frames, int32_t B, int32_t n_mel, int32_t F, float* mel,
+                   float* gate, void* stream);
 int gt_stft_magnitude(const float* ft /* rows x 2*cutoff */, int64_t rows, int32_t cutoff,
                       float* mag, void* stream);
 int gt_log_clamp(const float* x, int64_t n, float clip, float* out, void* stream);

@@ -223,3 +223,62 @@ def test_inference_batch_against_oracle(dev):
     assert got[0].shape[2] == 37
     for name, a, b in zip(('mel', 'mel_post', 'gate', 'align'), got, want):
         close(a, b, rtol=1e-3, atol=1e-5, what=f'inference {name}')
+
+
+def _write_wavs(root, n, rs, sr=22050):
+    from scipy.io import wavfile
+    lines = []
+    for i in range(n):
+        m = int(rs.integers(3000, 9000))
+        audio = np.clip(rs.normal(0, 0.25, m), -1, 1)
+        wavfile.write(root / f'w{i}.wav', sr, (audio * 32767).astype(np.int16))
+        words = ' '.join(rs.choice(['alpha', 'beta', 'gamma', 'delta', 'tau'], size=int(rs.integers(2, 6))))
+        lines.append(f'w{i}.wav|{words}.')
+    return lines
+
+
+def test_device_batches_match_per_item_loader(dev, tmp_path):
+    """SURVEY 8f-1 data path: raw audio collated on the host, ONE batched STFT-mel per batch on the device
+    (ragged reflect padding) == the reference-style per-item loader + TextMelCollate on the same items."""
+    from torch.utils.data import DataLoader
+    from gantron_amd.data_utils import (DeviceBatches, TextAudioCollate, TextAudioLoader, TextMelCollate, TextMelLoader)
+    from gantron_amd.hparams import HParams
+    from gantron_amd.stft import TacotronSTFT
+    rs = np.random.default_rng(4)
+    wavs = tmp_path / 'wavs'
+    wavs.mkdir()
+    flist = tmp_path / 'list.txt'
+    flist.write_text('\n'.join(_write_wavs(wavs, 10, rs)) + '\n')
+    hp = HParams('batch_size=5')
+    files = [str(flist), str(flist)]
+    per_item = DataLoader(TextMelLoader(files, hp, str(wavs) + '/'), batch_size=5, shuffle=False,
+                          collate_fn=TextMelCollate(1))
+    raw = TextAudioLoader(files, hp, str(wavs) + '/')
+    batched = DeviceBatches(DataLoader(raw, batch_size=5, shuffle=False, num_workers=1, pin_memory=True,
+                                       collate_fn=TextAudioCollate()), TacotronSTFT(*raw._stft_args).to(dev))
+    n = 0
+    for want, got in zip(per_item, batched):
+        n += 1
+        text, il, mel, gate, spk, emo, ol = want
+        assert got[1].device.type == 'cpu' and got[6].device.type == 'cpu'       # lengths stay on the host
+        assert torch.equal(got[0].cpu(), text) and torch.equal(got[1], il) and torch.equal(got[6], ol)
+        close(got[2], mel, rtol=0, atol=2e-4, what='mel_padded')
+        assert torch.equal(got[3].cpu(), gate)
+    assert n == 2
+
+
+def test_train_loop_on_raw_audio(dev, tmp_path):
+    """train() on wav files: DataLoader worker decodes, DeviceBatches computes the mels, the schedule runs."""
+    from gantron_amd import train as T
+    from gantron_amd.hparams import HParams
+    rs = np.random.default_rng(1)
+    wavs = tmp_path / 'wavs'
+    wavs.mkdir()
+    flist = tmp_path / 'train.txt'
+    flist.write_text('\n'.join(_write_wavs(wavs, 8, rs)) + '\n')
+    hp = HParams(MID + ',batch_size=4,iters_per_checkpoint=100,disc_warmp_up=7,attn_steps=4,epochs=100')
+    hp.training_files = hp.validation_files = [str(flist), str(flist)]
+    hp.iterations = 9
+    out = tmp_path / 'out'
+    T.train(str(out), None, False, 1, 0, 'g', hp, str(wavs) + '/')
+    assert os.path.isdir(out)
