@@ -221,7 +221,7 @@ def main():
         pair(args.warmup + i)
     sync()
     elapsed = time.perf_counter() - t0
-    prof_out = (ctypes.c_double * 32)()
+    prof_out = (ctypes.c_double * 40)()
     _lib.check(lib.gt_prof_end(prof_out), 'gt_prof_end')
     log(f'timed region: {elapsed:.3f} s for {args.steps} pairs')
     if world > 1:
@@ -233,6 +233,26 @@ def main():
     else:
         total_frames = float(frames)
 
+    # ---- SURVEY 8(d) side figures (outside the timed region): G step and D step alone, for the
+    # schedule-faithful mix of g_freq=2 generator steps per d_freq=1 discriminator step (hparams.py:95-96)
+    def alone(fn, n=2):
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t1) / n
+    gen_holder = {}
+
+    def g_only():
+        gen_holder['fake'] = generator_step(G, D, g_opt, crit, batch, hp, iteration=args.warmup + args.steps)[1]
+    g_s = alone(g_only)
+    d_s = alone(lambda: discriminator_step(G, D, d_opt, batch, gen_holder['fake'], hp))
+    if world > 1:
+        t = torch.tensor([g_s, d_s], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        g_s, d_s = float(t[0]), float(t[1])
+
     # ---- roofline of the dominant kernel family from the sampled brackets of the timed region
     roof = None
     cpu = None
@@ -242,8 +262,10 @@ def main():
         # every bracket = kernel execution + the launch latency an empty kernel also shows: subtract it
         fam = [dict(name=FAMILIES[f], launches=int(out[4 * f]),
                     ms=max(out[4 * f + 1] - null_ms * out[4 * f], 1e-9) if out[4 * f] else 0.0, flops=out[4 * f + 2],
-                    bytes=out[4 * f + 3]) for f in range(8)]
-        dom = max(fam, key=lambda r: r['ms'])
+                    bytes=out[4 * f + 3], seen=int(out[32 + f])) for f in range(8)]
+        for r in fam:                            # estimated time of ALL launches of the family in the timed region
+            r['est_total_ms'] = r['ms'] / r['launches'] * r['seen'] if r['launches'] else 0.0
+        dom = max(fam, key=lambda r: r['est_total_ms'])
         avg_ms = dom['ms'] / max(dom['launches'], 1)
         if dom['name'] in MFMA_BOUND:
             ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12 if dom['ms'] > 0 else 0.0
@@ -265,7 +287,8 @@ def main():
         roof.update(kernel=KERNEL_OF[dom['name']], sampled_launches=dom['launches'], sample_stride=PROF_STRIDE,
                     avg_launch_us=avg_ms * 1e3,
                     event_bracket_null_us=null_us.value,
-                    families={r['name']: dict(launches=r['launches'], ms=round(r['ms'], 3),
+                    families={r['name']: dict(launches=r['launches'], ms=round(r['ms'], 3), all_launches=r['seen'],
+                                              est_ms_per_pair=round(r['est_total_ms'] / args.steps, 2),
                                               tflops=round(r['flops'] / max(r['ms'], 1e-9) / 1e9, 2),
                                               gbs=round(r['bytes'] / max(r['ms'], 1e-9) / 1e6, 1)) for r in fam})
         if world == 1 and not args.no_cpu_baseline:
@@ -285,6 +308,9 @@ def main():
                                 per_gpu_batch=args.batch, global_batch=args.batch * world, Ti_max=Ti, To_max=To,
                                 valid_frames_per_rank=frames, padded_frames_per_rank=args.batch * To,
                                 parallelism='dp%d' % world, pair_tflop=fl / 1e12,
+                                padded_frames_per_s=args.batch * To * world * args.steps / elapsed,
+                                g_step_ms=g_s * 1e3, d_step_ms=d_s * 1e3,
+                                schedule_2g1d_frames_per_s=2 * total_frames / (2 * g_s + d_s),
                                 pair_mfma_frac=fl / (elapsed / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS),
                     roofline=roof, cpu_baseline=cpu)
         print(json.dumps(line))

@@ -62,7 +62,10 @@ void gt_prof_mark(int family, double flops, double bytes, hipStream_t st, bool b
 static int g_prof_stride = 1;
 static long g_prof_count[GT_FAM_COUNT];
 
-bool gt_prof_sample(int family) { return (g_prof_count[family]++ % g_prof_stride) == 0; }
+bool gt_prof_sample(int family) {
+    const int stride = family == GT_FAM_SGEMM ? (g_prof_stride >= 16 ? g_prof_stride / 16 : 1) : g_prof_stride;
+    return (g_prof_count[family]++ % stride) == 0;
+}
 
 extern "C" int gt_prof_begin(void) { return gt_prof_begin_sampled(1); }
 
@@ -77,11 +80,13 @@ extern "C" int gt_prof_begin_sampled(int32_t stride) {
 }
 
 // Stops recording, waits for the recorded events and fills per-family totals:
-// out[f*4+0] = launches, +1 = total ms, +2 = total flops, +3 = total bytes  (f < GT_FAM_COUNT)
+// out[f*4+0] = bracketed launches, +1 = total ms, +2 = total flops, +3 = total bytes  (f < GT_FAM_COUNT);
+// out[32+f] = all launches of the family seen while profiling
 extern "C" int gt_prof_end(double* out) {
     g_gt_prof_on = false;
     GT_REQUIRE(out != nullptr, GT_E_ARG, "gt_prof_end: NULL");
     for (int i = 0; i < GT_FAM_COUNT * 4; ++i) out[i] = 0.0;
+    for (int i = 0; i < GT_FAM_COUNT; ++i) out[GT_FAM_COUNT * 4 + i] = (double)g_prof_count[i];
     for (auto& r : g_recs) {
         hipError_t e = hipEventSynchronize(r.e1);
         GT_REQUIRE(e == hipSuccess, (int)e, "gt_prof_end: event sync failed");

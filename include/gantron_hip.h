@@ -41,10 +41,13 @@ int64_t gt_abi_sizeof(int32_t which);
  * leg).  Between gt_prof_begin() and gt_prof_end() every launch of a profiled kernel family is
  * bracketed by two events; gt_prof_end waits for them and fills, per family f (0 rec_gemm,
  * 1 sgemm, 2 attn_energies_fwd, 3 attn_context_fwd, 4 attn_context_bwd, 5 attn_energies_bwd,
- * 6 lstm_cell_fwd, 7 lstm_cell_bwd): out[4f] launches, out[4f+1] total ms, out[4f+2] algorithmic
- * flops, out[4f+3] algorithmic bytes.  `out` is a HOST array of 32 doubles.  Not thread-safe. */
+ * 6 lstm_cell_fwd, 7 lstm_cell_bwd): out[4f] bracketed launches, out[4f+1] their total ms, out[4f+2]
+ * their algorithmic flops, out[4f+3] their algorithmic bytes, and out[32+f] ALL launches of the family
+ * issued while profiling (bracketed or not).  `out` is a HOST array of 40 doubles.  Not thread-safe. */
 int gt_prof_begin(void);
-int gt_prof_begin_sampled(int32_t stride);   /* bracket only every stride-th launch of each family */
+/* bracket only every stride-th launch of each family (the millisecond-scale sgemm family every
+ * max(1, stride/16)-th: its few, very unequal launches need a denser sample and do not feel the bracket) */
+int gt_prof_begin_sampled(int32_t stride);
 int gt_prof_end(double* out);
 /* average event-bracket time (us) of an EMPTY kernel on `stream`: the launch latency every bracket
  * includes on top of the kernel's execution time (HOST pointer out_us) */
