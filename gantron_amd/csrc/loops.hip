@@ -8,6 +8,7 @@
 // mel/gate projection of all steps (reads HC), every weight gradient (dW = dGates^T . inputs with
 // K = To*B) and d(memory) (batched W^T . dctx).  Inside the loop only the recurrent products
 // ([ctx|h] . W) remain, as weight-streaming small-M MFMA kernels (recurrent.hip).
+#include <stdlib.h>
 #include <vector>
 #include "common.h"
 
@@ -85,6 +86,11 @@ int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
     const int64_t BT = (int64_t)a->B * a->Ti;
     const int R = a->ring;
     const bool two = R > 1;
+    // fused LSTM steps write h into the operand buffer of the NEXT step while other workgroups may still read the
+    // current one: X1 ping-pongs between two slots and X2 needs the ring (ring == 1 keeps the two-launch path)
+    const bool fused = two && a->W1g != nullptr && a->W2g != nullptr && a->Ha % 4 == 0 && a->Hd % 4 == 0;
+    const int64_t x1_slot = fused ? (int64_t)a->Bp * a->ld1 : 0;
+    const bool fused1 = fused, fused2 = fused;
     hipStream_t sA = (hipStream_t)stream, sB = sA;
     float* partB = two ? a->part2 : a->part;
     hipEvent_t ev;
@@ -103,23 +109,31 @@ int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
         float* hc_t = a->HC + (int64_t)t * a->Bp * hc_ld;
         float* X2t = a->X2 + (int64_t)(t % R) * a->Bp * a->ld2;
         float* X2n = a->X2 + (int64_t)((t + 1) % R) * a->Bp * a->ld2;
+        float* X1c = a->X1 + (t & 1) * x1_slot;            // [ctx_{t-1} | h_att_{t-1}]
+        float* X1n = a->X1 + ((t + 1) & 1) * x1_slot;      // receives h_att_t (cell) and ctx_t (context kernel)
         // ---- attention chain (stream A)
-        GT_TRY(rec_rows(a->X1, a->ld1, a->W1p, a->part, a->Bp, N1, K1, a->S1, sA));
+        if (!fused1) GT_TRY(rec_rows(X1c, a->ld1, a->W1p, a->part, a->Bp, N1, K1, a->S1, sA));
         if (two && t >= R) {     // X2 ring slot t%R was last read by the decoder chain of step t-R
             GT_TRY(evB(t - R, &ev));
             GT_HIP(hipStreamWaitEvent(sA, ev, 0));
         }
+        if (fused1)
+            GT_TRY(gt_lstm_step_fused(X1c, a->ld1, a->W1g, K1, a->pre1 + (int64_t)t * a->Bp * N1, N1,
+                                      a->c1 + (int64_t)t * a->Bp * a->Ha, k1, a->p_att, a->gates1 + (int64_t)t * a->Bp * N1,
+                                      a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha, a->hatt + (int64_t)t * a->Bp * a->Ha,
+                                      X1n + a->E, a->ld1, X2t, a->ld2, nullptr, 0, a->B, a->Bp, a->Ha, sA));
+        else
         GT_TRY(gt_lstm_cell_fwd(slabs(a->part, a->S1, (int64_t)a->Bp * N1, N1), a->pre1 + (int64_t)t * a->Bp * N1, N1,
                                 a->c1 + (int64_t)t * a->Bp * a->Ha, nullptr, 0, k1, a->p_att, nullptr,
                                 a->gates1 + (int64_t)t * a->Bp * N1, a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha,
-                                a->hatt + (int64_t)t * a->Bp * a->Ha, a->X1 + a->E, a->ld1, X2t, a->ld2, nullptr, 0,
+                                a->hatt + (int64_t)t * a->Bp * a->Ha, X1n + a->E, a->ld1, X2t, a->ld2, nullptr, 0,
                                 a->B, a->Ha, sA));
         GT_TRY(rec_rows(X2t, a->ld2, a->Wqp, a->part, a->Bp, a->Apad, a->Ha, a->Sq, sA));
         GT_TRY(gt_attn_energies_fwd(d, slabs(a->part, a->Sq, (int64_t)a->Bp * a->Apad, a->Apad),
                                     a->w_hist + (int64_t)t * BT, a->cum_hist + (int64_t)t * BT, a->pm, a->Wc, a->Wd, a->v,
                                     a->lengths, a->q_hist + (int64_t)t * a->B * a->A, a->energies, sA));
         GT_TRY(gt_attn_context_fwd(d, a->energies, a->memory, a->ldE, a->lengths, a->w_hist + (int64_t)(t + 1) * BT,
-                                   a->cum_hist + (int64_t)t * BT, a->cum_hist + (int64_t)(t + 1) * BT, a->X1, a->ld1,
+                                   a->cum_hist + (int64_t)t * BT, a->cum_hist + (int64_t)(t + 1) * BT, X1n, a->ld1,
                                    X2t + a->Ha, a->ld2, hc_t + a->Hd, hc_ld, sA));
         if (two) {
             GT_TRY(evA(t, &ev));
@@ -127,11 +141,17 @@ int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
             GT_HIP(hipStreamWaitEvent(sB, ev, 0));
         }
         // ---- decoder LSTM chain (stream B): [h_att_t | ctx_t | h_dec_{t-1}] . W2 + bias
-        GT_TRY(rec_rows(X2t, a->ld2, a->W2p, partB, a->Bp, N2, K2, a->S2, sB));
-        GT_TRY(gt_lstm_cell_fwd(slabs(partB, a->S2, (int64_t)a->Bp * N2, N2), a->bias2, 0,
-                                a->c2 + (int64_t)t * a->Bp * a->Hd, nullptr, 0, k2, a->p_dec, nullptr,
-                                a->gates2 + (int64_t)t * a->Bp * N2, a->c2 + (int64_t)(t + 1) * a->Bp * a->Hd, nullptr,
-                                X2n + a->Ha + a->E, a->ld2, hc_t, hc_ld, nullptr, 0, a->B, a->Hd, sB));
+        if (fused2) {
+            GT_TRY(gt_lstm_step_fused(X2t, a->ld2, a->W2g, K2, a->bias2, 0, a->c2 + (int64_t)t * a->Bp * a->Hd, k2, a->p_dec,
+                                      a->gates2 + (int64_t)t * a->Bp * N2, a->c2 + (int64_t)(t + 1) * a->Bp * a->Hd, nullptr,
+                                      X2n + a->Ha + a->E, a->ld2, hc_t, hc_ld, nullptr, 0, a->B, a->Bp, a->Hd, sB));
+        } else {
+            GT_TRY(rec_rows(X2t, a->ld2, a->W2p, partB, a->Bp, N2, K2, a->S2, sB));
+            GT_TRY(gt_lstm_cell_fwd(slabs(partB, a->S2, (int64_t)a->Bp * N2, N2), a->bias2, 0,
+                                    a->c2 + (int64_t)t * a->Bp * a->Hd, nullptr, 0, k2, a->p_dec, nullptr,
+                                    a->gates2 + (int64_t)t * a->Bp * N2, a->c2 + (int64_t)(t + 1) * a->Bp * a->Hd, nullptr,
+                                    X2n + a->Ha + a->E, a->ld2, hc_t, hc_ld, nullptr, 0, a->B, a->Hd, sB));
+        }
         if (two) {
             GT_TRY(evB(t, &ev));
             GT_HIP(hipEventRecord(ev, sB));

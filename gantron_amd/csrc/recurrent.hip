@@ -13,7 +13,9 @@
 
 namespace {
 
-// W (N x K, row stride ldw; or K x N when transposed) -> Wp[N/16][KB][64][4], zero padded.
+// W (N x K, row stride ldw; or K x N when transposed == 1) -> Wp[N/16][KB][64][4], zero padded.
+// transposed == 2: gate-interleaved rows for the fused step kernel (recurrent_fused.hip): packed row
+// n = 4*unit + gate reads source row gate*(N/4) + unit of an (N x K) LSTM weight.
 __global__ __launch_bounds__(256) void pack_rec_weight_kernel(const float* W, long ldw, int transposed,
                                                               int N, int n_valid, int K, int KB, float* Wp) {
     const long total = (long)(N / 16) * KB * 64;
@@ -23,14 +25,15 @@ __global__ __launch_bounds__(256) void pack_rec_weight_kernel(const float* W, lo
         const long blk = idx >> 6;
         const int kb = (int)(blk % KB);
         const int nb = (int)(blk / KB);
-        const int n = nb * 16 + (lane & 15);
+        int n = nb * 16 + (lane & 15);
+        if (transposed == 2) n = (n & 3) * (N / 4) + (n >> 2);
         const int k = kb * 16 + 4 * (lane >> 4);
         float4 v;
         float* vv = reinterpret_cast<float*>(&v);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int kk = k + j;
-            vv[j] = (kk < K && n < n_valid) ? (transposed ? W[(long)kk * ldw + n] : W[(long)n * ldw + kk]) : 0.f;
+            vv[j] = (kk < K && n < n_valid) ? (transposed == 1 ? W[(long)kk * ldw + n] : W[(long)n * ldw + kk]) : 0.f;
         }
         reinterpret_cast<float4*>(Wp)[idx] = v;
     }
@@ -412,6 +415,19 @@ extern "C" int gt_pack_rec_weight(const float* W, int64_t ldw, int32_t transpose
     const int blocks = (int)std::min<long>(cdiv64(total, 256), 4096);
     hipLaunchKernelGGL(pack_rec_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, W, (long)ldw,
                        transposed, N, n_valid, K, KB, Wp);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+// gate-interleaved packing for gt_lstm_step_fused: KB covers gt_fused_k_padded(K) columns (zeros beyond K)
+extern "C" int gt_pack_gates(const float* W, int64_t ldw, int32_t H, int32_t K, float* Wg, void* stream) {
+    GT_REQUIRE(W && Wg && H > 0 && H % 4 == 0 && K > 0, GT_E_ARG, "gt_pack_gates: H=%d must be a multiple of 4", H);
+    GT_REQUIRE(aligned16(Wg), GT_E_ALIGN, "gt_pack_gates: Wg must be 16-byte aligned");
+    const int N = 4 * H;
+    const int KB = (int)(gt_fused_k_padded(K) / 16);
+    const long total = (long)(N / 16) * KB * 64;
+    const int blocks = (int)std::min<long>(cdiv64(total, 256), 4096);
+    hipLaunchKernelGGL(pack_rec_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, W, (long)ldw, 2, N, N, K, KB, Wg);
     GT_LAUNCH_CHECK();
     return 0;
 }

@@ -25,6 +25,10 @@ from ._lib import GtBiLstm, GtDecoderBwd, GtDecoderFwd, GtDecoderInfer, check, l
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 import os as _os
 REC_SPLITS = int(_os.environ.get("GANTRON_REC_SPLITS", "4"))
+# forward LSTM steps as ONE fused launch (gt_lstm_step_fused).  Stand-alone it beats product + cell (20.4 vs 23.2 us,
+# 25.5 vs 28.1 us) but every workgroup stages the whole activation matrix (4x the L2->LDS traffic), which slows the
+# kernels of the other chain in the two-stream loop: 69 ms per forward loop instead of 62.  Off by default.
+FUSED_CELL = _os.environ.get('GANTRON_FUSED_CELL', '0') != '0'
 HIGH_PRIORITY_BACKWARD = _os.environ.get('GANTRON_HIGH_PRIO', '0') != '0'   # measured: no gain on MI355X
 _HIGH_STREAM = None
 BWD_CHUNKS = int(_os.environ.get("GANTRON_BWD_CHUNKS", "6"))
@@ -117,6 +121,13 @@ def pack_rec(W2d, N, n_valid, K, transposed=False):
     """Pack a (n_valid x K) [or (K x n_valid) when transposed] matrix for gt_rec_gemm."""
     out = torch.empty(int(lib().gt_rec_weight_elems(N, K)), device=W2d.device, dtype=torch.float32)
     call('gt_pack_rec_weight', W2d, W2d.stride(0), int(transposed), N, n_valid, K, out)
+    return out
+
+
+def pack_gates(W2d, H, K):
+    """Pack a (4H x K) LSTM weight gate-interleaved (row 4*unit + gate) for gt_lstm_step_fused."""
+    out = torch.empty(4 * H * int(lib().gt_fused_k_padded(K)), device=W2d.device, dtype=torch.float32)
+    call('gt_pack_gates', W2d, W2d.stride(0), H, K, out)
     return out
 
 
@@ -343,11 +354,16 @@ class GeneratorEngine:
         d.S1, d.S2, d.Sq = rec_splits(4 * Ha, K1), rec_splits(4 * Hd, K2), ops.pick_splits(Ha, 16)
         d.p_att = hp.p_attention_dropout if training else 0.0
         d.p_dec = hp.p_decoder_dropout if training else 0.0
-        keep_t = dict(W1p=pack_rec(W1cat, 4 * Ha, 4 * Ha, K1), W2p=pack_rec(W2cat, 4 * Hd, 4 * Hd, K2),
-                      Wqp=pack_rec(P['decoder.attention_layer.query_layer.linear_layer.weight'], Apad, A, Ha))
+        fused = FUSED_CELL and Ha % 4 == 0 and Hd % 4 == 0
+        keep_t = dict(Wqp=pack_rec(P['decoder.attention_layer.query_layer.linear_layer.weight'], Apad, A, Ha))
+        if fused:
+            keep_t.update(W1g=pack_gates(W1cat, Ha, K1), W2g=pack_gates(W2cat, Hd, K2))
+        else:
+            keep_t.update(W1p=pack_rec(W1cat, 4 * Ha, 4 * Ha, K1), W2p=pack_rec(W2cat, 4 * Hd, 4 * Hd, K2))
         lens32 = torch.tensor(in_lens, dtype=torch.int32, device=dev)
-        ld1, ld2 = roundup(K1, 16), roundup(K2, 16)
-        ws = dict(X1=_f32(Bp, ld1, device=dev), X2=_f32(DEC_RING, Bp, ld2, device=dev),
+        ld1, ld2 = (int(lib().gt_fused_k_padded(K1)), int(lib().gt_fused_k_padded(K2))) if fused else \
+            (roundup(K1, 16), roundup(K2, 16))
+        ws = dict(X1=_f32(2, Bp, ld1, device=dev), X2=_f32(DEC_RING, Bp, ld2, device=dev),
                   part=_f32(max(d.S1 * Bp * 4 * Ha, d.S2 * Bp * 4 * Hd, d.Sq * Bp * Apad), device=dev, zero=False),
                   part2=_f32(d.S2 * Bp * 4 * Hd, device=dev, zero=False),
                   energies=_f32(B, Ti, device=dev, zero=False))
@@ -358,7 +374,8 @@ class GeneratorEngine:
                     q_hist=_f32(To, B, A, device=dev, zero=False))
         al = 'decoder.attention_layer.'
         d.memory, d.pm, d.lengths, d.pre1, d.bias2 = ptr(memory), ptr(pm), ptr(lens32), ptr(pre1), ptr(bias2)
-        d.W1p, d.Wqp, d.W2p = ptr(keep_t['W1p']), ptr(keep_t['Wqp']), ptr(keep_t['W2p'])
+        d.W1p, d.Wqp, d.W2p = ptr(keep_t.get('W1p')), ptr(keep_t['Wqp']), ptr(keep_t.get('W2p'))
+        d.W1g, d.W2g = ptr(keep_t.get('W1g')), ptr(keep_t.get('W2g'))
         d.Wc = ptr(P[al + 'location_layer.location_conv.conv.weight'])
         d.Wd = ptr(P[al + 'location_layer.location_dense.linear_layer.weight'])
         d.v = ptr(P[al + 'v.linear_layer.weight'])

@@ -97,11 +97,26 @@ int gt_sgemm(const GtGemm* g, void* stream);
  * consumer (cell kernels) sums them.  nz > 1 runs independent problems (BiLSTM directions).
  */
 int gt_pack_rec_weight(const float* W, int64_t ldw, int32_t transposed, int32_t N, int32_t n_valid,
-                       int32_t K, float* Wp, void* stream);   /* rows n >= n_valid are zero */
+                       int32_t K, float* Wp, void* stream);   /* rows n >= n_valid are zero; transposed: 0 W is (N,K),
+                       1 W is (K,N) */
 int64_t gt_rec_weight_elems(int32_t N, int32_t K);
 int gt_rec_gemm(const float* X, int64_t ldx, const float* Wp, float* part, int32_t mtiles,
                 int32_t N, int32_t K, int32_t splits, int64_t part_sstride, int32_t nz,
                 int64_t x_zstride, int64_t w_zstride, int64_t part_zstride, void* stream);
+
+/* One whole LSTMCell step forward in a single launch: gates = X.W^T + pre, pointwise cell, dropout, h
+ * written to up to three operand buffers (model.py:391-394, 406-409).  Wg is the gate-interleaved packing
+ * (gt_pack_rec_weight mode 2) of the (4H, K) weight matching X's column order; pre (row stride ld_pre, 0 = one
+ * bias row) is added to the pre-activations; gates (Bp,4H), c_out, h_raw in the layouts of gt_lstm_cell_fwd.
+ * One workgroup per 4 hidden units sees all of K: no K-split slabs, no second launch.
+ * The loop is branch-free: Wg is packed by gt_pack_gates for Kp = gt_fused_k_padded(K) columns (K rounded up
+ * to a multiple of 512, zeros beyond K) and X needs ldx >= Kp zero-padded columns. */
+int64_t gt_fused_k_padded(int32_t K);
+int gt_pack_gates(const float* W, int64_t ldw, int32_t H, int32_t K, float* Wg, void* stream);   /* Wg: 4H*Kp floats */
+int gt_lstm_step_fused(const float* X, int64_t ldx, const float* Wg, int32_t K, const float* pre,
+                       int64_t ld_pre, const float* c_prev, const uint8_t* keep, float p_drop, float* gates,
+                       float* c_out, float* h_raw, float* h0, int64_t ld0, float* h1, int64_t ld1, float* h2,
+                       int64_t ld2, int32_t B, int32_t Bp, int32_t H, void* stream);
 
 /* ------------------------------------------------------------------------------------ LSTM cell
  * nn.LSTMCell pointwise part + dropout (model.py:391-394,406-409); gate order i,f,g,o.
@@ -184,10 +199,12 @@ typedef struct GtDecoderFwd {
     const float* W1p;          /* packed [4Ha] x [ctx(E) | h_att(Ha)] */
     const float* Wqp;          /* packed [Apad] x [Ha] */
     const float* W2p;          /* packed [4Hd] x [h_att(Ha) | ctx(E) | h_dec(Hd)] */
+    const float* W1g;          /* the same two weights packed gate-interleaved: when both are non-NULL the LSTM */
+    const float* W2g;          /*   steps run as gt_lstm_step_fused (W1p / W2p, part / part2 are then unused)   */
     const float* Wc; const float* Wd; const float* v;
     const uint8_t* att_keep;   /* (To, Bp, Ha) or NULL */
     const uint8_t* dec_keep;   /* (To, Bp, Hd) or NULL */
-    float* X1; int64_t ld1;    /* (Bp, ld1) zero-initialised */
+    float* X1; int64_t ld1;    /* (2, Bp, ld1) zero-initialised (the fused steps ping-pong between the two slots) */
     float* X2; int64_t ld2;    /* (ring, Bp, ld2) zero-initialised */
     float* part;               /* slab scratch of the attention chain */
     float* part2;              /* slab scratch of the decoder-LSTM chain (ring > 1) */

@@ -116,6 +116,39 @@ def test_rec_gemm(dev, Bsz, N, K, S):
     close(part2.sum(0)[:Bsz, :K], X2[:Bsz].double() @ W.double(), rtol=1e-5, atol=1e-4, what='rec_gemm transposed')
 
 
+@pytest.mark.parametrize('Bsz,H,K,bias_row', [(64, 1024, 2048, False), (5, 32, 100, True), (33, 64, 333, False), (70, 16, 48, True)])
+def test_lstm_step_fused(dev, Bsz, H, K, bias_row):
+    """gt_lstm_step_fused (product + cell + dropout in one launch, gate-interleaved packing) against fp64."""
+    from gantron_amd import ops
+    from gantron_amd._lib import lib
+    from gantron_amd.engine import pack_gates
+    p = 0.1
+    Bp = ops.roundup(Bsz, 16) if Bsz <= 64 else ops.roundup(Bsz, 64)
+    ld = int(lib().gt_fused_k_padded(K))
+    W = g(4 * H, K, scale=1.0 / math.sqrt(K))
+    X = torch.zeros(Bp, ld)
+    X[:Bsz, :K] = g(Bsz, K, seed=1)
+    pre = g(1, 4 * H, seed=6, scale=0.5) if bias_row else g(Bp, 4 * H, seed=6, scale=0.5)
+    c_prev = g(Bp, H, seed=2)
+    keep = (torch.rand(Bp, H, generator=torch.Generator().manual_seed(3)) >= p)
+    gates_in = X[:Bsz, :K].double() @ W.double().t() + pre.double()[:Bsz if not bias_row else 1]
+    i, f, gg, o = gates_in.chunk(4, dim=1)
+    c = torch.sigmoid(f) * c_prev[:Bsz].double() + torch.sigmoid(i) * torch.tanh(gg)
+    h = torch.sigmoid(o) * torch.tanh(c) * keep[:Bsz].double() / (1 - p)
+    Wg = pack_gates(W.to(dev), H, K)
+    gates = torch.zeros(Bp, 4 * H, device=dev); c_out = torch.zeros(Bp, H, device=dev)
+    h_raw = torch.zeros(Bp, H, device=dev); h0 = torch.zeros(Bp, H + 8, device=dev); h1 = torch.zeros(Bp, H, device=dev)
+    ops.call('gt_lstm_step_fused', X.to(dev), ld, Wg, K, pre.to(dev), 0 if bias_row else 4 * H, c_prev.to(dev),
+             keep.to(torch.uint8).to(dev), p, gates, c_out, h_raw, ops.ptr(h0, 4), H + 8, h1, H, None, 0, Bsz, Bp, H)
+    close(gates[:Bsz], torch.cat((torch.sigmoid(i), torch.sigmoid(f), torch.tanh(gg), torch.sigmoid(o)), 1), rtol=1e-5,
+          atol=1e-5, what='fused gates')
+    close(c_out[:Bsz], c, rtol=1e-5, atol=1e-5, what='fused c')
+    close(h_raw[:Bsz], h, rtol=1e-5, atol=1e-5, what='fused h')
+    close(h0[:Bsz, 4:4 + H], h, rtol=1e-5, atol=1e-5, what='fused h strided')
+    close(h1[:Bsz], h, rtol=1e-5, atol=1e-5, what='fused h second destination')
+    assert float(c_out[Bsz:].abs().max()) == 0.0 if Bsz < Bp else True        # pad rows are never written
+
+
 def test_lstm_cell_fwd_bwd(dev):
     from gantron_amd import ops
     B, H, S, p = 5, 48, 3, 0.1

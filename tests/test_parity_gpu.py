@@ -98,6 +98,14 @@ def test_tiny_pair_matches_reference_golden(dev, golden_dir):
     assert not bad, '\n'.join(bad)
 
 
+def test_tiny_pair_with_fused_lstm_steps(dev, golden_dir, monkeypatch):
+    """The opt-in fused product+cell forward path (GANTRON_FUSED_CELL=1, gt_lstm_step_fused with ping-pong operand
+    buffers) must reproduce the same golden outputs and gradients."""
+    from gantron_amd import engine
+    monkeypatch.setattr(engine, 'FUSED_CELL', True)
+    test_tiny_pair_matches_reference_golden(dev, golden_dir)
+
+
 @pytest.mark.parametrize('name', ['full_pair_summary.npz', 'vesus_pair_summary.npz'])
 def test_full_size_matches_reference_summaries(dev, golden_dir, name):
     """Full hparams (E=1024 vanilla / E=1093 VESUS labels+noise), B=2: closed-form weights; the
