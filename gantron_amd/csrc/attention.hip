@@ -203,7 +203,7 @@ __device__ __forceinline__ void softmax_row(const GtAttnDims& d, const float* en
 }
 
 // grid (256-column chunks of E, B).  VEC: E, ld_mem multiples of 4 and 16-byte aligned memory: every
-// wave streams float4 columns of a quarter of the rows (4 rows in flight), partial sums fold through LDS.
+// wave streams float4 columns of a quarter of the rows (8-16 rows in flight), partial sums fold through LDS.
 template <bool VEC>
 __global__ __launch_bounds__(256) void attn_context_fwd_kernel(GtAttnDims d, const float* energies, const float* memory,
                                                                long ld_mem, const int* lengths, float* w_out,
@@ -213,6 +213,20 @@ __global__ __launch_bounds__(256) void attn_context_fwd_kernel(GtAttnDims d, con
     __shared__ float red[16];
     __shared__ __attribute__((aligned(16))) float psum[4][256];
     const int b = blockIdx.y;
+    // rows beyond the memory length have weight exactly 0 (energy -inf): never read them
+    const int Tv = lengths != nullptr ? min(lengths[b], d.Ti) : d.Ti;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col4 = min(blockIdx.x * 256 + 4 * lane, (d.E - 4) & ~3);        // clamped: loads stay unconditional
+    // VEC: the first 8 memory rows of every wave are requested BEFORE the softmax (they do not depend on it);
+    // afterwards 8 rows are in flight per wave while the previous 8 are consumed.  Row indices are clamped and
+    // invalid rows get weight 0, so no load is predicated (predicated loads make the compiler wait with vmcnt(0)).
+    const float* mrow = memory + (long)b * d.Ti * ld_mem + col4;
+    float4 ra[8], rb[8];
+    if (VEC) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            ra[j] = *reinterpret_cast<const float4*>(mrow + (long)min(wave + 4 * j, Tv - 1) * ld_mem);
+    }
     softmax_row(d, energies, b, w, red);
     if (blockIdx.x == 0) {
         for (int t = threadIdx.x; t < d.Ti; t += blockDim.x) {
@@ -222,31 +236,27 @@ __global__ __launch_bounds__(256) void attn_context_fwd_kernel(GtAttnDims d, con
     }
     float c = 0.f;
     const int col = blockIdx.x * 256 + threadIdx.x;
-    // rows beyond the memory length have weight exactly 0 (energy -inf): never read them
-    const int Tv = lengths != nullptr ? min(lengths[b], d.Ti) : d.Ti;
     if (VEC) {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int col4 = blockIdx.x * 256 + 4 * lane;
         float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-        if (col4 < d.E) {
-            const float* m = memory + (long)b * d.Ti * ld_mem + col4;
-            int t = wave;
-            for (; t + 12 < Tv; t += 16) {
-                const float4 m0 = *reinterpret_cast<const float4*>(m + (long)t * ld_mem);
-                const float4 m1 = *reinterpret_cast<const float4*>(m + (long)(t + 4) * ld_mem);
-                const float4 m2 = *reinterpret_cast<const float4*>(m + (long)(t + 8) * ld_mem);
-                const float4 m3 = *reinterpret_cast<const float4*>(m + (long)(t + 12) * ld_mem);
-                const float w0 = w[t], w1 = w[t + 4], w2 = w[t + 8], w3 = w[t + 12];
-                a0.x += w0 * m0.x; a0.y += w0 * m0.y; a0.z += w0 * m0.z; a0.w += w0 * m0.w;
-                a1.x += w1 * m1.x; a1.y += w1 * m1.y; a1.z += w1 * m1.z; a1.w += w1 * m1.w;
-                a0.x += w2 * m2.x; a0.y += w2 * m2.y; a0.z += w2 * m2.z; a0.w += w2 * m2.w;
-                a1.x += w3 * m3.x; a1.y += w3 * m3.y; a1.z += w3 * m3.z; a1.w += w3 * m3.w;
+        auto fetch = [&](float4 (&r)[8], int base) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                r[j] = *reinterpret_cast<const float4*>(mrow + (long)min(base + wave + 4 * j, Tv - 1) * ld_mem);
+        };
+        auto consume = [&](const float4 (&r)[8], int base) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const int t0 = base + wave + 4 * j, t1 = t0 + 4;
+                const float w0 = t0 < Tv ? w[t0] : 0.f, w1 = t1 < Tv ? w[t1] : 0.f;
+                a0.x += w0 * r[j].x; a0.y += w0 * r[j].y; a0.z += w0 * r[j].z; a0.w += w0 * r[j].w;
+                a1.x += w1 * r[j + 1].x; a1.y += w1 * r[j + 1].y; a1.z += w1 * r[j + 1].z; a1.w += w1 * r[j + 1].w;
             }
-            for (; t < Tv; t += 4) {
-                const float4 m0 = *reinterpret_cast<const float4*>(m + (long)t * ld_mem);
-                const float w0 = w[t];
-                a0.x += w0 * m0.x; a0.y += w0 * m0.y; a0.z += w0 * m0.z; a0.w += w0 * m0.w;
-            }
+        };
+        for (int base = 0; base < Tv; base += 64) {       // two batches of 32 rows (8 per wave) per trip
+            fetch(rb, base + 32);
+            consume(ra, base);
+            fetch(ra, base + 64);
+            consume(rb, base + 32);
         }
         *reinterpret_cast<float4*>(&psum[wave][4 * lane]) = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
         __syncthreads();
@@ -272,7 +282,10 @@ __global__ __launch_bounds__(256) void attn_context_fwd_kernel(GtAttnDims d, con
 }
 
 // grid (chunks of CT positions, B).  dw[t'] = memory[b][t'] . dctx + carried alignment gradients.
-template <bool VEC>
+// NE4 > 0 (E == 256 * NE4, VEC): the workgroup's 32 memory rows and the carried per-position values are requested
+// at the very top and arrive while the upstream context gradient is being summed from its K-split slabs, so the
+// kernel is two memory round trips deep instead of five.
+template <bool VEC, int NE4 = 0>
 __global__ __launch_bounds__(256) void attn_context_bwd_kernel(GtAttnDims d, GtSlabs da, GtSlabs db,
                                                                const float* dctx_direct, long ld_direct,
                                                                const float* memory, long ld_mem, const int* lengths,
@@ -293,6 +306,48 @@ __global__ __launch_bounds__(256) void attn_context_bwd_kernel(GtAttnDims d, GtS
         }
         return;
     }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* mb = memory + (long)b * d.Ti * ld_mem;
+    constexpr int NR = NE4 > 0 ? NE4 : 1;
+    float4 mr[8][NR];
+    float pf_cum = 0.f, pf_w0 = 0.f, pf_w1 = 0.f, pf_ext = 0.f;
+    const long pi = (long)b * d.Ti + min(t0 + (int)threadIdx.x, d.Ti - 1);
+    const long plane = (long)d.B * d.Ti;
+    if (NE4 > 0) {
+        // wave w owns rows t0 + w + 4*r (r < 8); row indices are clamped so that no load is predicated
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float* row = mb + (long)min(t0 + wave + 4 * r, Tv - 1) * ld_mem + 4 * lane;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) mr[r][i] = *reinterpret_cast<const float4*>(row + 256 * i);
+        }
+        if (threadIdx.x < CT) {
+            if (dwcat_in != nullptr) { pf_cum = dcum_acc[pi]; pf_w0 = dwcat_in[pi]; pf_w1 = dwcat_in[plane + pi]; }
+            if (dw_extern != nullptr) pf_ext = dw_extern[pi];
+        }
+    }
+    if (NE4 == 1 * 4 && blockDim.x == 256) {
+        // E == 1024: one float4 of the context gradient per thread, all slab loads of a thread issued together
+        const int e = 4 * threadIdx.x;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto add_slabs = [&](const GtSlabs& sl) __attribute__((always_inline)) {
+            if (sl.p == nullptr) return;
+            const float* p = sl.p + (long)b * sl.ld + e;
+#pragma unroll 4
+            for (int s2 = 0; s2 < sl.n; ++s2) {
+                const float4 t = *reinterpret_cast<const float4*>(p + (long)s2 * sl.slab_stride);
+                g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+            }
+        };
+        add_slabs(da);
+        add_slabs(db);
+        if (dctx_direct != nullptr) {
+            const float4 t = *reinterpret_cast<const float4*>(dctx_direct + (long)b * ld_direct + e);
+            g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+        }
+        *reinterpret_cast<float4*>(&dctx[e]) = g;
+        if (blockIdx.x == 0 && dctx_out != nullptr) *reinterpret_cast<float4*>(dctx_out + (long)b * ld_dctx_out + e) = g;
+    } else
     for (int e = threadIdx.x; e < d.E; e += blockDim.x) {
         float g = 0.f;
         if (da.p != nullptr) g += slab_sum(da.p, da.n, da.slab_stride, (long)b * da.ld + e);
@@ -304,9 +359,22 @@ __global__ __launch_bounds__(256) void attn_context_bwd_kernel(GtAttnDims d, GtS
     if (blockIdx.x == 0 && dq_zero != nullptr)
         for (int i = threadIdx.x; i < d.A; i += blockDim.x) dq_zero[(long)b * ld_dq + i] = 0.f;
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* mb = memory + (long)b * d.Ti * ld_mem;
-    if (VEC) {
+    if (NE4 > 0) {
+        const float4* dc4 = reinterpret_cast<const float4*>(dctx);
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const float4 dc = dc4[lane + 64 * i];
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                acc[r] += mr[r][i].x * dc.x + mr[r][i].y * dc.y + mr[r][i].z * dc.z + mr[r][i].w * dc.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float v = wave_sum(acc[r]);
+            if (lane == 0) dots[wave + 4 * r] = v;
+        }
+    } else if (VEC) {
         // wave w owns rows t0 + w + 4*i (i < 8); 4 rows in flight per pass
         const int e4n = d.E / 4;
         const float4* dc4 = reinterpret_cast<const float4*>(dctx);
@@ -342,16 +410,15 @@ __global__ __launch_bounds__(256) void attn_context_bwd_kernel(GtAttnDims d, GtS
     __syncthreads();
     if (threadIdx.x < CT && t0 + threadIdx.x < d.Ti) {
         const long i = (long)b * d.Ti + t0 + threadIdx.x;
-        const long plane = (long)d.B * d.Ti;
         float carried = 0.f;
         if (dwcat_in != nullptr) {
-            const float cum = dcum_acc[i] + dwcat_in[plane + i];
+            const float cum = (NE4 > 0 ? pf_cum + pf_w1 : dcum_acc[i] + dwcat_in[plane + i]);
             dcum_acc[i] = cum;
-            carried = dwcat_in[i] + cum;
+            carried = (NE4 > 0 ? pf_w0 : dwcat_in[i]) + cum;
             dwcat_in[i] = 0.f;
             dwcat_in[plane + i] = 0.f;
         }
-        if (dw_extern != nullptr) carried += dw_extern[i];
+        if (dw_extern != nullptr) carried += (NE4 > 0 ? pf_ext : dw_extern[i]);
         dw_out[i] = (t0 + (int)threadIdx.x < Tv) ? dots[threadIdx.x] + carried : 0.f;
     }
 }
@@ -630,7 +697,14 @@ extern "C" int gt_attn_context_bwd(GtAttnDims d, GtSlabs dctx_a, GtSlabs dctx_b,
     GtProfScope prof(GT_FAM_ATTN_C_BWD, 2.0 * d.B * d.Ti * (double)d.E, 4.0 * d.B * ((double)d.Ti * d.E + 4.0 * d.E + 6.0 * d.Ti),
                      (hipStream_t)stream);
     const bool vec = (d.E % 4 == 0) && (ld_mem % 4 == 0) && aligned16(memory);
-    if (vec)
+    auto sl4 = [](const GtSlabs& sl) { return sl.p == nullptr || (aligned16(sl.p) && sl.ld % 4 == 0 && sl.slab_stride % 4 == 0); };
+    const bool vec_slabs = sl4(dctx_a) && sl4(dctx_b) && (dctx_direct == nullptr || (aligned16(dctx_direct) && ld_direct % 4 == 0)) &&
+                           (dctx_out == nullptr || (aligned16(dctx_out) && ld_dctx_out % 4 == 0));
+    if (vec && d.E == 1024 && vec_slabs)
+        hipLaunchKernelGGL((attn_context_bwd_kernel<true, 4>), grid, dim3(256), (size_t)d.E * 4, (hipStream_t)stream, d,
+                           dctx_a, dctx_b, dctx_direct, (long)ld_direct, memory, (long)ld_mem, lengths, dwcat_in, dcum_acc,
+                           dw_extern, dctx_out, (long)ld_dctx_out, dq_zero, (long)ld_dq, dw_out);
+    else if (vec)
         hipLaunchKernelGGL((attn_context_bwd_kernel<true>), grid, dim3(256), (size_t)d.E * 4, (hipStream_t)stream, d,
                            dctx_a, dctx_b, dctx_direct, (long)ld_direct, memory, (long)ld_mem, lengths, dwcat_in, dcum_acc,
                            dw_extern, dctx_out, (long)ld_dctx_out, dq_zero, (long)ld_dq, dw_out);

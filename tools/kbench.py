@@ -44,6 +44,11 @@ def rec(name, N, K, S):
 
 
 splits = [int(x) for x in os.environ.get('SPLITS', '4').split(',')]
+if os.environ.get('ONLY'):          # e.g. ONLY=G2 under rocprofv3: one shape, so that the stats file is per shape
+    shapes = {'G1': (4096, 2048), 'G2': (4096, 3072), 'G2T': (3072, 4096), 'G1T': (2048, 4096)}
+    for S in splits:
+        rec(os.environ['ONLY'], *shapes[os.environ['ONLY']], S)
+    sys.exit(0)
 for S in splits:
     rec('G1 ', 4096, 2048, S)
     rec('G2 ', 4096, 3072, S)
