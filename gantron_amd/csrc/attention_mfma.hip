@@ -58,7 +58,8 @@ __device__ __forceinline__ void stage_common(SharedM& S, const GtAttnDims& d, co
                                              const float* v, const float* w_prev, const float* w_cum, int b, int t0) {
     for (int i = threadIdx.x; i < F * LDC; i += 256) {
         const int f = i / LDC, kk = i - f * LDC;
-        S.wc[i] = kk < KK ? Wc[f * KK + kk] : 0.f;
+        const float wv = Wc[f * KK + min(kk, KK - 1)];        // unconditional load, selected below: predicated
+        S.wc[i] = kk < KK ? wv : 0.f;                         // loads would force s_waitcnt vmcnt(0) everywhere
     }
     for (int i = threadIdx.x; i < A * F; i += 256) S.wd[(i >> 5) * LDD + (i & 31)] = Wd[i];
     if (threadIdx.x < A) S.v[threadIdx.x] = v[threadIdx.x];
@@ -66,7 +67,8 @@ __device__ __forceinline__ void stage_common(SharedM& S, const GtAttnDims& d, co
         const int c = threadIdx.x / WL, p = threadIdx.x - c * WL;
         const int t = t0 + p - (KC - 1) / 2;
         const float* src = c == 0 ? w_prev : w_cum;
-        S.win[c][p] = (p < CT + KC - 1 && t >= 0 && t < d.Ti) ? src[(long)b * d.Ti + t] : 0.f;
+        const float wv = src[(long)b * d.Ti + min(max(t, 0), d.Ti - 1)];
+        S.win[c][p] = (p < CT + KC - 1 && t >= 0 && t < d.Ti) ? wv : 0.f;
     }
 }
 
@@ -136,12 +138,17 @@ __global__ __launch_bounds__(256) void attn_energies_fwd_mfma(GtAttnDims d, GtSl
         for (int nl = 0; nl < 2; ++nl)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int t = t0 + 16 * mt + 4 * kq + e;
-                pmv[mt][nl][e] = t < d.Ti ? pm[((long)b * d.Ti + t) * A + 32 * wave + 16 * nl + r] : 0.f;
+                const int t = min(t0 + 16 * mt + 4 * kq + e, d.Ti - 1);     // rows beyond Ti are never stored
+                pmv[mt][nl][e] = pm[((long)b * d.Ti + t) * A + 32 * wave + 16 * nl + r];
             }
+    float qv = 0.f;
+    {   // query = sum of the K-split slabs of the query product (all loads in flight together)
+        const float* qp = qpart.p + (long)b * qpart.ld + (threadIdx.x & (A - 1));
+#pragma unroll 8
+        for (int s2 = 0; s2 < qpart.n; ++s2) qv += qp[(long)s2 * qpart.slab_stride];
+    }
     stage_common(S, d, Wc, Wd, v, w_prev, w_cum, b, t0);
     if (threadIdx.x < A) {
-        const float qv = slab_sum(qpart.p, qpart.n, qpart.slab_stride, (long)b * qpart.ld + threadIdx.x);
         S.q[threadIdx.x] = qv;
         if (blockIdx.x == 0 && q_out != nullptr) q_out[(long)b * A + threadIdx.x] = qv;
     }
@@ -197,7 +204,9 @@ __global__ __launch_bounds__(256) void attn_energies_bwd_mfma(GtAttnDims d, cons
     const int r = lane & 15, kq = lane >> 4;
     constexpr int PER = A + A * F + F * KK;
     float* acc_wg = acc_slabs + ((long)b * gridDim.x + blockIdx.x) * PER;
-    // long-latency global loads first: pm and the dpm accumulator in accumulator layout
+    // every global input is requested here, unconditionally (clamped indices): pm and the dpm accumulator in
+    // accumulator layout, this workgroup's dv / dWd / dWc accumulator slab, and the softmax row.  The kernel is
+    // then one memory round trip deep instead of five.
     float pmv[2][2][4], dpmv[2][2][4];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -205,20 +214,41 @@ __global__ __launch_bounds__(256) void attn_energies_bwd_mfma(GtAttnDims d, cons
         for (int nl = 0; nl < 2; ++nl)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int t = t0 + 16 * mt + 4 * kq + e;
+                const int t = min(t0 + 16 * mt + 4 * kq + e, d.Ti - 1);
                 const long pi = ((long)b * d.Ti + t) * A + 32 * wave + 16 * nl + r;
-                pmv[mt][nl][e] = t < d.Ti ? pm[pi] : 0.f;
-                dpmv[mt][nl][e] = t < d.Ti ? dpm[pi] : 0.f;
+                pmv[mt][nl][e] = pm[pi];
+                dpmv[mt][nl][e] = dpm[pi];
             }
+    float old_dv[2], old_wd[2][2][4], old_wc[2][4];
+#pragma unroll
+    for (int nl = 0; nl < 2; ++nl) old_dv[nl] = acc_wg[32 * wave + 16 * nl + r];
+#pragma unroll
+    for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                old_wd[ml][nt][e] = acc_wg[A + (32 * wave + 16 * ml + 4 * kq + e) * F + 16 * nt + r];
+#pragma unroll
+    for (int nl = 0; nl < 2; ++nl) {
+        const int kk = min(16 * (2 * (wave & 1) + nl) + r, KK - 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) old_wc[nl][e] = acc_wg[A + A * F + (16 * (wave >> 1) + 4 * kq + e) * KK + kk];
+    }
+    // softmax backward: de = w * (dw - sum_t w*dw); Ti <= 256 on this path, so one element per thread
+    const long ti = (long)b * d.Ti + min((int)threadIdx.x, d.Ti - 1);
+    const float w_t = w[ti], dw_t = dw[ti];
+    const long tci = (long)b * d.Ti + min(t0 + (int)(threadIdx.x & (CT - 1)), d.Ti - 1);
+    const float w_c = w[tci], dw_c = dw[tci];
+    const float q_t = q[(long)b * A + (threadIdx.x & (A - 1))];
     stage_common(S, d, Wc, Wd, v, w_prev, w_cum, b, t0);
-    if (threadIdx.x < A) S.q[threadIdx.x] = q[(long)b * A + threadIdx.x];
-    // softmax backward: de = w * (dw - sum_t w*dw)
-    float part = 0.f;
-    for (int t = threadIdx.x; t < d.Ti; t += 256) part += w[(long)b * d.Ti + t] * dw[(long)b * d.Ti + t];
+    if (threadIdx.x < A) S.q[threadIdx.x] = q_t;
+    float part = (int)threadIdx.x < d.Ti ? w_t * dw_t : 0.f;
+    for (int t = threadIdx.x + 256; t < d.Ti; t += 256) part += w[(long)b * d.Ti + t] * dw[(long)b * d.Ti + t];
     const float dot = block_sum(part, S.red);
     if (threadIdx.x < CT) {
         const int t = t0 + threadIdx.x;
-        S.de[threadIdx.x] = (t < d.Ti) ? w[(long)b * d.Ti + t] * (dw[(long)b * d.Ti + t] - dot) : 0.f;
+        S.de[threadIdx.x] = (t < d.Ti) ? w_c * (dw_c - dot) : 0.f;
     }
     __syncthreads();
     conv_tile(S, wave, lane);
@@ -257,7 +287,7 @@ __global__ __launch_bounds__(256) void attn_energies_bwd_mfma(GtAttnDims d, cons
         if (kq == 0) {
             const int dd = 32 * wave + 16 * nl + r;
             atomicAdd(&dq[(long)b * ld_dq + dd], dqs[nl]);
-            acc_wg[dd] += dvs[nl];
+            acc_wg[dd] = old_dv[nl] + dvs[nl];
         }
     }
     __syncthreads();                                   // ds complete
@@ -280,16 +310,10 @@ __global__ __launch_bounds__(256) void attn_energies_bwd_mfma(GtAttnDims d, cons
     {
         float* acc_wd = acc_wg + A;
         f32x4 c4[2][2];
-        float old[2][2][4];
 #pragma unroll
         for (int ml = 0; ml < 2; ++ml)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                c4[ml][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    old[ml][nt][e] = acc_wd[(32 * wave + 16 * ml + 4 * kq + e) * F + 16 * nt + r];
-            }
+            for (int nt = 0; nt < 2; ++nt) c4[ml][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s4 = 0; s4 < 2; ++s4) {
             const int k0 = 16 * s4 + 4 * kq;     // tl
@@ -309,7 +333,7 @@ __global__ __launch_bounds__(256) void attn_energies_bwd_mfma(GtAttnDims d, cons
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    acc_wd[(32 * wave + 16 * ml + 4 * kq + e) * F + 16 * nt + r] = old[ml][nt][e] + c4[ml][nt][e];
+                    acc_wd[(32 * wave + 16 * ml + 4 * kq + e) * F + 16 * nt + r] = old_wd[ml][nt][e] + c4[ml][nt][e];
     }
     __syncthreads();                                   // dlocf complete
     // G5: dWc[f][kk] += dlocf^T . im2col ; wave w: filter tile mt = w>>1, kk tiles nt in {2*(w&1), 2*(w&1)+1}
@@ -318,14 +342,10 @@ __global__ __launch_bounds__(256) void attn_energies_bwd_mfma(GtAttnDims d, cons
         float* acc_wc = acc_wg + A + A * F;
         const int mt = wave >> 1;
         f32x4 c5[2], c6[2];
-        float old[2][4];
 #pragma unroll
         for (int nl = 0; nl < 2; ++nl) {
             c5[nl] = (f32x4){0.f, 0.f, 0.f, 0.f};
             c6[nl] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int kk = 16 * (2 * (wave & 1) + nl) + r;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) old[nl][e] = kk < KK ? acc_wc[(16 * mt + 4 * kq + e) * KK + kk] : 0.f;
         }
 #pragma unroll
         for (int s4 = 0; s4 < 2; ++s4) {
@@ -347,7 +367,7 @@ __global__ __launch_bounds__(256) void attn_energies_bwd_mfma(GtAttnDims d, cons
             const int kk = 16 * (2 * (wave & 1) + nl) + r;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (kk < KK) acc_wc[(16 * mt + 4 * kq + e) * KK + kk] = old[nl][e] + c5[nl][e];
+                if (kk < KK) acc_wc[(16 * mt + 4 * kq + e) * KK + kk] = old_wc[nl][e] + c5[nl][e];
                 S.g[(16 * mt + 4 * kq + e) * LDG + kk] = c6[nl][e];
             }
         }
