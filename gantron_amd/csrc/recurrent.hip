@@ -92,6 +92,7 @@ __global__ __launch_bounds__(REC_THREADS) void rec_gemm_kernel(const float* __re
                                                                long xz, long wz, long pz, long ps) {
     static_assert(MT == 4 || MT == 2 || MT == 1 || MT == 3, "row tiles");
     __shared__ __attribute__((aligned(16))) float Xs[MT * 16 * REC_LD];
+    if (DBG & 8) return;                  // diagnostics: pure launch + wave start-up cost
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = wave >> 2;
     const int s = blockIdx.y, z = blockIdx.z;
@@ -168,23 +169,36 @@ __global__ __launch_bounds__(REC_THREADS) void rec_gemm_kernel(const float* __re
         chunk(wa, wb, kb);
         if (kb + REC_CK < kb1) chunk(wb, wa, kb + REC_CK);
     }
-    // fold the two K-halves through LDS (Xs is free after the last barrier): [wave&3][mt][reg][lane]
+    // Epilogue through LDS (Xs is free after the last barrier): the two K-halves are folded into a row-major
+    // [row][64 columns] tile so that the slab is written with full-line float4 stores by all 8 waves (the MFMA
+    // C layout would give 16 scalar stores of 64-byte pieces per lane, by half of the waves only).
+    constexpr int EP_LD = 68;             // 4 rows apart = 16 banks apart: the scalar tile writes are conflict free
+    static_assert(MT * 16 * EP_LD <= MT * 16 * REC_LD, "epilogue tile fits the staging buffer");
     float* red = Xs;
+    const int ecol = (wave & 3) * 16 + (lane & 15), erow = 4 * (lane >> 4);
     if (half == 1) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[(((wave & 3) * MT + mt) * 4 + r) * 64 + lane] = acc[mt][r];
+            for (int r = 0; r < 4; ++r) red[(mt * 16 + erow + r) * EP_LD + ecol] = acc[mt][r];
     }
     __syncthreads();
-    if (half == 1 || !active) return;
-    // C/D map of the 16x16 MFMA: n = lane&15, m = 4*(lane>>4) + reg
-    float* out = part + (long)z * pz + (long)s * ps + nb * 16 + (lane & 15);
+    if (half == 0) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            out[(long)(mt * 16 + 4 * (lane >> 4) + r) * N] = acc[mt][r] + red[(((wave & 3) * MT + mt) * 4 + r) * 64 + lane];
+            for (int r = 0; r < 4; ++r) red[(mt * 16 + erow + r) * EP_LD + ecol] += acc[mt][r];
+    }
+    __syncthreads();
+    float* out = part + (long)z * pz + (long)s * ps + (long)blockIdx.x * 64;
+    const int ncols = min(64, N - (int)blockIdx.x * 64);      // N % 16 == 0: whole float4s
+#pragma unroll
+    for (int i = 0; i < (MT * 16 * 16 + REC_THREADS - 1) / REC_THREADS; ++i) {
+        const int f = tid + REC_THREADS * i;
+        const int row = f >> 4, c4 = f & 15;
+        if (row < MT * 16 && 4 * c4 < ncols)
+            *reinterpret_cast<float4*>(out + (long)row * N + 4 * c4) = *reinterpret_cast<const float4*>(&red[row * EP_LD + 4 * c4]);
+    }
 }
 
 struct CellFwd {
@@ -443,6 +457,8 @@ extern "C" int gt_rec_gemm(const float* X, int64_t ldx, const float* Wp, float* 
                    w_zstride % 4 == 0,
                GT_E_ALIGN, "gt_rec_gemm: X needs ldx >= 16*ceil(K/16) (=%d), ldx%%4==0 and 16-byte alignment", KB * 16);
     GT_REQUIRE(part_sstride >= (int64_t)mtiles * 16 * N, GT_E_ARG, "gt_rec_gemm: part_sstride too small");
+    GT_REQUIRE(aligned16(part) && part_sstride % 4 == 0 && part_zstride % 4 == 0, GT_E_ALIGN,
+               "gt_rec_gemm: part must be 16-byte aligned with slab strides that are multiples of 4");
     const int KBS = cdiv(KB, splits);
     const int ns = cdiv(KB, KBS);
     GT_REQUIRE(ns == splits, GT_E_ARG, "gt_rec_gemm: splits=%d leaves empty slabs for K=%d (use <= %d)", splits, K, ns);
@@ -468,6 +484,7 @@ extern "C" int gt_rec_gemm(const float* X, int64_t ldx, const float* Wp, float* 
             case 4: GT_RECD(4); break;
             case 5: GT_RECD(5); break;
             case 6: GT_RECD(6); break;
+            case 8: GT_RECD(8); break;
             default: GT_RECD(7); break;
         }
 #undef GT_RECD
