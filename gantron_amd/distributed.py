@@ -15,11 +15,22 @@ that is below 1 % of a generator step, so the collective is issued once per back
 reference, without bucketing.  The backend string comes from hparams.dist_backend ("nccl" is RCCL
 on ROCm; "gloo" is used by the CPU tests of the wiring).
 """
+import os
+
 import torch
 import torch.distributed as dist
 from torch.autograd import Variable
 
 from .optim import flatten_module
+
+
+def _tick(on):
+    if not on:
+        return 0.0
+    import time
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    return time.perf_counter()
 
 
 def _average_flat(module):
@@ -39,17 +50,27 @@ def apply_gradient_allreduce(module):
     for buf in module.buffers():
         dist.broadcast(buf, 0)
 
+    timing = os.environ.get('GANTRON_DIST_TIMING') == '1'      # diagnostics: synchronising per-phase timer
+
     def allreduce_params():
         if not getattr(module, 'needs_reduction', False):
             return
         module.needs_reduction = False
         views = module._grad_views
-        module._flat_grad.zero_()
+        t0 = _tick(timing)
         for name, p in module.named_parameters():
-            if p.requires_grad and p.grad is not None:
+            if p.grad is None:
+                views[name].zero_()
+            elif p.grad.data_ptr() != views[name].data_ptr():     # autograd handed back its own tensor
                 views[name].copy_(p.grad)
                 p.grad = views[name]
+            # else: the gradient was accumulated in place in the flat buffer already
+        t1 = _tick(timing)
         _average_flat(module)
+        t2 = _tick(timing)
+        if timing:
+            print(f'[dist] gather {1e3 * (t1 - t0):.2f} ms  all-reduce + scale {1e3 * (t2 - t1):.2f} ms '
+                  f'({module._flat_grad.numel() * 4 / 1e6:.1f} MB)', flush=True)
 
     def allreduce_hook(*unused):
         Variable._execution_engine.queue_callback(allreduce_params)
