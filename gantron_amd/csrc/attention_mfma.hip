@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void attn_energies_bwd_mfma(GtAttnDims d, cons
 #pragma unroll
         for (int e = 0; e < 4; ++e) old_wc[nl][e] = acc_wg[A + A * F + (16 * (wave >> 1) + 4 * kq + e) * KK + kk];
     }
-    // softmax backward: de = w * (dw - sum_t w*dw); Ti <= 256 on this path, so one element per thread
+    // softmax backward: de = w * (dw - sum_t w*dw); the first 256 positions are prefetched, one per thread
     const long ti = (long)b * d.Ti + min((int)threadIdx.x, d.Ti - 1);
     const float w_t = w[ti], dw_t = dw[ti];
     const long tci = (long)b * d.Ti + min(t0 + (int)(threadIdx.x & (CT - 1)), d.Ti - 1);

@@ -180,7 +180,8 @@ def test_lstm_cell_fwd_bwd(dev):
 
 
 # ------------------------------------------------------------------------------------ attention
-@pytest.mark.parametrize('B,Ti,E,A,Fn,Kc', [(3, 45, 40, 8, 4, 5), (2, 70, 96, 128, 32, 31)])
+@pytest.mark.parametrize('B,Ti,E,A,Fn,Kc', [(3, 45, 40, 8, 4, 5), (2, 70, 96, 128, 32, 31), (2, 300, 64, 128, 32, 31),
+                                            (3, 45, 1024, 128, 32, 31)])
 def test_attention_step_fwd_bwd(dev, B, Ti, E, A, Fn, Kc):
     from gantron_amd import ops
     from gantron_amd._lib import lib
