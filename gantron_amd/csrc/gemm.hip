@@ -36,15 +36,13 @@ constexpr int BK = 16;
 // float4 along k for row r (modes KC / IM2COL_K).  (b,t) = position of row r (im2col only).
 template <int MODE>
 __device__ __forceinline__ float4 load_kvec(const OpDev& o, const float* base, int r, int R, int k,
-                                            int K, int b, int t) {
+                                            int K, int b, int t, int tap, int c) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r >= R || k >= K) return v;
     const float* p;
     if (MODE == GT_OP_KC) {
         p = base + (long)r * o.ld + k;
     } else {
-        const int tap = k / o.C;
-        const int c = k - tap * o.C;
         const int tt = t + tap * o.dil - o.pad;
         if (tt < 0 || tt >= o.T) return v;
         p = base + ((long)b * o.T + tt) * o.C + c;
@@ -63,15 +61,13 @@ __device__ __forceinline__ float4 load_kvec(const OpDev& o, const float* base, i
 // float4 along r at reduction index k (modes RC / IM2COL_R).  (tap,c) = decomposition of row r.
 template <int MODE>
 __device__ __forceinline__ float4 load_rvec(const OpDev& o, const float* base, int r, int R, int k,
-                                            int K, int tap, int c) {
+                                            int K, int tap, int c, int b, int t) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r >= R || k >= K) return v;
     const float* p;
     if (MODE == GT_OP_RC) {
         p = base + (long)k * o.ld + r;
     } else {
-        const int b = k / o.T;
-        const int t = k - b * o.T;
         const int tt = t + tap * o.dil - o.pad;
         if (tt < 0 || tt >= o.T) return v;
         p = base + ((long)b * o.T + tt) * o.C + c;
@@ -95,13 +91,22 @@ template <int MODE, int BR>
 struct TileLoader {
     static constexpr int NIT = BR / 64;
     static constexpr int LD = BR + 4;
-    int p0[NIT], p1[NIT];   // (b,t) for IM2COL_K, (tap,c) for IM2COL_R
+    int p0[NIT], p1[NIT];   // (b,t) for IM2COL_K, (tap,c) for IM2COL_R: decomposition of the ROW index (fixed)
+    int q0[NIT], q1[NIT];   // decomposition of the running REDUCTION index k of the next load: (tap,c) for
+                            // IM2COL_K, (b,t) for IM2COL_R; advanced by BK per load instead of dividing every time
     float4 reg[NIT];
 
-    __device__ __forceinline__ void init(const OpDev& o, int r0, int tid) {
+    __device__ __forceinline__ void init(const OpDev& o, int r0, int kbeg, int tid) {
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            p0[i] = 0; p1[i] = 0;
+            p0[i] = 0; p1[i] = 0; q0[i] = 0; q1[i] = 0;
+            if (MODE == GT_OP_IM2COL_K) {
+                const int k = kbeg + 4 * (tid >> 6);
+                q0[i] = k / o.C; q1[i] = k - q0[i] * o.C;
+            } else if (MODE == GT_OP_IM2COL_R) {
+                const int k = kbeg + (tid + 256 * i) / (BR / 4);
+                q0[i] = k / o.T; q1[i] = k - q0[i] * o.T;
+            }
             if (MODE == GT_OP_IM2COL_K) {
                 const int r = r0 + (tid & 63) + 64 * i;
                 p0[i] = r / o.T; p1[i] = r - p0[i] * o.T;
@@ -119,12 +124,20 @@ struct TileLoader {
             if (is_ktype<MODE>()) {
                 const int r = r0 + (tid & 63) + 64 * i;
                 const int k = k0 + 4 * (tid >> 6);
-                reg[i] = load_kvec<MODE>(o, base, r, R, k, K, p0[i], p1[i]);
+                reg[i] = load_kvec<MODE>(o, base, r, R, k, K, p0[i], p1[i], q0[i], q1[i]);
+                if (MODE == GT_OP_IM2COL_K) {
+                    q1[i] += BK;
+                    while (q1[i] >= o.C) { q1[i] -= o.C; ++q0[i]; }
+                }
             } else {
                 const int f = tid + 256 * i;
                 const int r = r0 + 4 * (f % (BR / 4));
                 const int k = k0 + f / (BR / 4);
-                reg[i] = load_rvec<MODE>(o, base, r, R, k, K, p0[i], p1[i]);
+                reg[i] = load_rvec<MODE>(o, base, r, R, k, K, p0[i], p1[i], q0[i], q1[i]);
+                if (MODE == GT_OP_IM2COL_R) {
+                    q1[i] += BK;
+                    while (q1[i] >= o.T) { q1[i] -= o.T; ++q0[i]; }
+                }
             }
         }
     }
@@ -166,8 +179,8 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmDev g) {
 
     TileLoader<AMODE, BM> la;
     TileLoader<BMODE, BN> lb;
-    la.init(g.A, m0, tid);
-    lb.init(g.B, n0, tid);
+    la.init(g.A, m0, kbeg, tid);
+    lb.init(g.B, n0, kbeg, tid);
 
     f32x16 acc[TM][TN];
 #pragma unroll

@@ -544,6 +544,9 @@ class GeneratorEngine:
         hc, nout = Hd + E, n_mel + 1
 
         PHASES.mark(None)
+        # weight-gradient GEMMs issued from here to the end of the decoder loop run UNDER that loop (leaf stream)
+        gentle = ops.splitk_target(ops.SPLITK_OVERLAPPED)
+        gentle.__enter__()
         # ---- PostNet backward (channels-last)
         dmel_cl = _f32(B * To, n_mel, device=dev)
         if dmel is not None:
@@ -659,6 +662,7 @@ class GeneratorEngine:
                               G[al + 'location_layer.location_dense.linear_layer.weight'],
                               G[al + 'location_layer.location_conv.conv.weight']), buf['acc'])
         rows = To * Bp
+        gentle.__exit__()
         PHASES.mark('b.dec_loop+dW')
 
         # ---- prenet backward

@@ -12,7 +12,31 @@ import torch
 from . import _lib
 from ._lib import GtAttnDims, GtGemm, GtOperand, GtSlabs, check, lib
 
+import os as _os
+
 KC, RC, IM2COL_K, IM2COL_R = 0, 1, 2, 3
+# Workgroups a weight-gradient GEMM should reach (default_split_k).  Two regimes, both measured on the benchmark
+# batch: a GEMM nothing else overlaps wants ~1024 workgroups of 128x128 tiles (postnet conv dW 41 -> 103 TFLOP/s);
+# the same setting for the GEMMs that run on the leaf stream UNDER the decoder backward loop makes the pair 2 ms
+# slower (they crowd out the latency-bound loop kernels), so the engine lowers the target there.
+SPLITK_EXPOSED = int(_os.environ.get('GANTRON_SPLITK_TARGET', '1024'))
+SPLITK_OVERLAPPED = int(_os.environ.get('GANTRON_SPLITK_OVERLAPPED', '128'))
+SPLITK_TARGET = SPLITK_EXPOSED
+
+
+class splitk_target:
+    """with ops.splitk_target(n): ... -- temporary target for default_split_k."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __enter__(self):
+        global SPLITK_TARGET
+        self.old, SPLITK_TARGET = SPLITK_TARGET, self.n
+
+    def __exit__(self, *exc):
+        global SPLITK_TARGET
+        SPLITK_TARGET = self.old
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 
 
@@ -53,11 +77,16 @@ class Operand:
 
 
 def default_split_k(M, N, K, batch=1):
-    """Split the reduction when the output grid alone cannot fill 256 CUs."""
-    tiles = -(-M // 64) * -(-N // 64) * batch
-    if tiles >= 256 or K < 1024:
+    """Split the reduction of a weight-gradient GEMM until about 1024 workgroups of the tile size gt_sgemm will pick
+    exist (two co-resident workgroups per CU, two rounds for the tail).  Measured on the postnet conv dW
+    (M=512, N=2560, K=55680): 41 TFLOP/s unsplit on 64x64 tiles, 103 TFLOP/s with 16 splits of 128x128 tiles."""
+    if M > 64 and N > 64:
+        tiles = -(-M // 128) * -(-N // 128) * batch
+    else:
+        tiles = -(-M // 64) * -(-N // 64) * batch
+    if tiles >= SPLITK_TARGET or K < 1024:
         return 1
-    return max(1, min(-(-512 // tiles), K // 256, 64))
+    return max(1, min(-(-SPLITK_TARGET // tiles), K // 512, 64))
 
 
 def sgemm(A, B, C, M, N, K, ldc=None, bias=None, accumulate=False, split_k=1, batch=1,
