@@ -91,6 +91,9 @@ int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
     const bool fused = two && a->W1g != nullptr && a->W2g != nullptr && a->Ha % 4 == 0 && a->Hd % 4 == 0;
     const int64_t x1_slot = fused ? (int64_t)a->Bp * a->ld1 : 0;
     const bool fused1 = fused, fused2 = fused;
+    // attention cell + query product as one launch (needs float4-friendly sizes; the fused step supersedes it)
+    const bool cq = !fused1 && a->Wq != nullptr && a->partq != nullptr && a->Ha % 32 == 0 && a->ld1 % 4 == 0 && a->ld2 % 4 == 0 &&
+                    a->E % 4 == 0;
     hipStream_t sA = (hipStream_t)stream, sB = sA;
     float* partB = two ? a->part2 : a->part;
     hipEvent_t ev;
@@ -122,14 +125,21 @@ int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
                                       a->c1 + (int64_t)t * a->Bp * a->Ha, k1, a->p_att, a->gates1 + (int64_t)t * a->Bp * N1,
                                       a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha, a->hatt + (int64_t)t * a->Bp * a->Ha,
                                       X1n + a->E, a->ld1, X2t, a->ld2, nullptr, 0, a->B, a->Bp, a->Ha, sA));
+        else if (cq)      // cell + query projection in one launch
+            GT_TRY(gt_cell_query_fwd(slabs(a->part, a->S1, (int64_t)a->Bp * N1, N1), a->pre1 + (int64_t)t * a->Bp * N1, N1,
+                                     a->c1 + (int64_t)t * a->Bp * a->Ha, k1, a->p_att, a->gates1 + (int64_t)t * a->Bp * N1,
+                                     a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha, a->hatt + (int64_t)t * a->Bp * a->Ha,
+                                     X1n + a->E, a->ld1, X2t, a->ld2, a->Wq, a->Ha, a->partq, (int64_t)a->Bp * a->Apad, a->B,
+                                     a->Bp, a->Ha, a->A, a->Apad, sA));
         else
         GT_TRY(gt_lstm_cell_fwd(slabs(a->part, a->S1, (int64_t)a->Bp * N1, N1), a->pre1 + (int64_t)t * a->Bp * N1, N1,
                                 a->c1 + (int64_t)t * a->Bp * a->Ha, nullptr, 0, k1, a->p_att, nullptr,
                                 a->gates1 + (int64_t)t * a->Bp * N1, a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha,
                                 a->hatt + (int64_t)t * a->Bp * a->Ha, X1n + a->E, a->ld1, X2t, a->ld2, nullptr, 0,
                                 a->B, a->Ha, sA));
-        GT_TRY(rec_rows(X2t, a->ld2, a->Wqp, a->part, a->Bp, a->Apad, a->Ha, a->Sq, sA));
-        GT_TRY(gt_attn_energies_fwd(d, slabs(a->part, a->Sq, (int64_t)a->Bp * a->Apad, a->Apad),
+        if (!cq) GT_TRY(rec_rows(X2t, a->ld2, a->Wqp, a->part, a->Bp, a->Apad, a->Ha, a->Sq, sA));
+        GT_TRY(gt_attn_energies_fwd(d, cq ? slabs(a->partq, a->Ha / 32, (int64_t)a->Bp * a->Apad, a->Apad)
+                                          : slabs(a->part, a->Sq, (int64_t)a->Bp * a->Apad, a->Apad),
                                     a->w_hist + (int64_t)t * BT, a->cum_hist + (int64_t)t * BT, a->pm, a->Wc, a->Wd, a->v,
                                     a->lengths, a->q_hist + (int64_t)t * a->B * a->A, a->energies, sA));
         GT_TRY(gt_attn_context_fwd(d, a->energies, a->memory, a->ldE, a->lengths, a->w_hist + (int64_t)(t + 1) * BT,

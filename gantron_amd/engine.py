@@ -29,6 +29,7 @@ REC_SPLITS = int(_os.environ.get("GANTRON_REC_SPLITS", "4"))
 # 25.5 vs 28.1 us) but every workgroup stages the whole activation matrix (4x the L2->LDS traffic), which slows the
 # kernels of the other chain in the two-stream loop: 69 ms per forward loop instead of 62.  Off by default.
 FUSED_CELL = _os.environ.get('GANTRON_FUSED_CELL', '0') != '0'
+CELL_QUERY = _os.environ.get('GANTRON_CELL_QUERY', '1') != '0'    # attention cell + query product in one launch
 HIGH_PRIORITY_BACKWARD = _os.environ.get('GANTRON_HIGH_PRIO', '0') != '0'   # measured: no gain on MI355X
 _HIGH_STREAM = None
 BWD_CHUNKS = int(_os.environ.get("GANTRON_BWD_CHUNKS", "6"))
@@ -376,6 +377,10 @@ class GeneratorEngine:
         d.memory, d.pm, d.lengths, d.pre1, d.bias2 = ptr(memory), ptr(pm), ptr(lens32), ptr(pre1), ptr(bias2)
         d.W1p, d.Wqp, d.W2p = ptr(keep_t.get('W1p')), ptr(keep_t['Wqp']), ptr(keep_t.get('W2p'))
         d.W1g, d.W2g = ptr(keep_t.get('W1g')), ptr(keep_t.get('W2g'))
+        if CELL_QUERY and Ha % 32 == 0 and E % 4 == 0:
+            Wq = P['decoder.attention_layer.query_layer.linear_layer.weight']
+            ws['partq'] = _f32(Ha // 32, Bp, Apad, device=dev, zero=False)
+            d.Wq, d.partq = ptr(Wq), ptr(ws['partq'])
         d.Wc = ptr(P[al + 'location_layer.location_conv.conv.weight'])
         d.Wd = ptr(P[al + 'location_layer.location_dense.linear_layer.weight'])
         d.v = ptr(P[al + 'v.linear_layer.weight'])

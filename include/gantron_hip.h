@@ -132,6 +132,14 @@ int gt_lstm_cell_fwd(GtSlabs part, const float* pre, int64_t ld_pre, const float
                      float* h0, int64_t ld0, float* h1, int64_t ld1, float* h2, int64_t ld2,
                      int32_t B, int32_t H, void* stream);
 
+/* gt_lstm_cell_fwd fused with the attention query projection (model.py:56 query_layer): the cell of 32 hidden
+ * units per workgroup, then qpart[g] = h[:, 32g..32g+32) . Wq[:, 32g..]^T as H/32 slabs of (Bp, Apad) that
+ * gt_attn_energies_fwd sums.  Wq is the (A, Ha) weight in PyTorch layout.  H % 32 == 0, float4-aligned buffers. */
+int gt_cell_query_fwd(GtSlabs part, const float* pre, int64_t ld_pre, const float* c_prev, const uint8_t* keep,
+                      float p_drop, float* gates, float* c_out, float* h_raw, float* h0, int64_t ld0, float* h1,
+                      int64_t ld1, const float* Wq, int64_t ldwq, float* qpart, int64_t q_sstride, int32_t B,
+                      int32_t Bp, int32_t H, int32_t A, int32_t Apad, void* stream);
+
 /* dh = (sum of up to three slab sources + direct) ; returns pre-activation gate grads + dc_prev. */
 int gt_lstm_cell_bwd(GtSlabs dh_a, GtSlabs dh_b, GtSlabs dh_c, const float* dh_direct,
                      int64_t ld_direct, const float* dc_next, const float* gates,
@@ -199,6 +207,10 @@ typedef struct GtDecoderFwd {
     const float* W1p;          /* packed [4Ha] x [ctx(E) | h_att(Ha)] */
     const float* Wqp;          /* packed [Apad] x [Ha] */
     const float* W2p;          /* packed [4Hd] x [h_att(Ha) | ctx(E) | h_dec(Hd)] */
+    const float* Wq;           /* query_layer weight (A, Ha), PyTorch layout: when non-NULL (and Ha % 32 == 0) the
+                                  attention cell and the query product run as ONE launch (gt_cell_query_fwd)
+                                  writing Ha/32 query slabs to partq */
+    float* partq;              /* (Ha/32, Bp, Apad) */
     const float* W1g;          /* the same two weights packed gate-interleaved: when both are non-NULL the LSTM */
     const float* W2g;          /*   steps run as gt_lstm_step_fused (W1p / W2p, part / part2 are then unused)   */
     const float* Wc; const float* Wd; const float* v;

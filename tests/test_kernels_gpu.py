@@ -149,6 +149,39 @@ def test_lstm_step_fused(dev, Bsz, H, K, bias_row):
     assert float(c_out[Bsz:].abs().max()) == 0.0 if Bsz < Bp else True        # pad rows are never written
 
 
+@pytest.mark.parametrize('Bsz,H,A,S', [(64, 1024, 128, 4), (5, 32, 8, 2), (70, 64, 32, 3)])
+def test_cell_query_fused(dev, Bsz, H, A, S):
+    """gt_cell_query_fwd = gt_lstm_cell_fwd + the query projection h . Wq^T (as H/32 slabs), one launch."""
+    from gantron_amd import ops
+    p = 0.1
+    Bp = ops.roundup(Bsz, 16) if Bsz <= 64 else ops.roundup(Bsz, 64)
+    Apad = ops.roundup(A, 16)
+    part = g(S, Bp, 4 * H, scale=0.5)
+    pre = g(Bp, 4 * H, seed=1, scale=0.5)
+    c_prev = g(Bp, H, seed=2)
+    keep = (torch.rand(Bp, H, generator=torch.Generator().manual_seed(3)) >= p)
+    Wq = g(A, H, seed=4, scale=0.1)
+    gates_in = (part.sum(0) + pre).double()[:Bsz]
+    i, f, gg, o = gates_in.chunk(4, dim=1)
+    c = torch.sigmoid(f) * c_prev[:Bsz].double() + torch.sigmoid(i) * torch.tanh(gg)
+    h = torch.sigmoid(o) * torch.tanh(c) * keep[:Bsz].double() / (1 - p)
+    gates = torch.zeros(Bp, 4 * H, device=dev); c_out = torch.zeros(Bp, H, device=dev); h_raw = torch.zeros(Bp, H, device=dev)
+    h0 = torch.zeros(Bp, H + 8, device=dev); h1 = torch.zeros(Bp, H, device=dev)
+    qpart = torch.full((H // 32, Bp, Apad), float('nan'), device=dev)
+    part_d = part.to(dev)
+    ops.call('gt_cell_query_fwd', ops.slabs(part_d, S, Bp * 4 * H, 4 * H), pre.to(dev), 4 * H, c_prev.to(dev),
+             keep.to(torch.uint8).to(dev), p, gates, c_out, h_raw, ops.ptr(h0, 4), H + 8, h1, H, Wq.to(dev), H, qpart,
+             Bp * Apad, Bsz, Bp, H, A, Apad)
+    close(c_out[:Bsz], c, rtol=1e-5, atol=1e-5, what='c')
+    close(h_raw[:Bsz], h, rtol=1e-5, atol=1e-5, what='h')
+    close(h0[:Bsz, 4:4 + H], h, rtol=1e-5, atol=1e-5, what='h strided')
+    close(h1[:Bsz], h, rtol=1e-5, atol=1e-5, what='h second destination')
+    close(gates[:Bsz], torch.cat((torch.sigmoid(i), torch.sigmoid(f), torch.tanh(gg), torch.sigmoid(o)), 1), rtol=1e-5,
+          atol=1e-5, what='gates')
+    close(qpart.sum(0)[:Bsz, :A], h @ Wq.double().t(), rtol=1e-5, atol=1e-5, what='query')
+    assert torch.isfinite(qpart).all()                   # every slab element was written
+
+
 def test_lstm_cell_fwd_bwd(dev):
     from gantron_amd import ops
     B, H, S, p = 5, 48, 3, 0.1
