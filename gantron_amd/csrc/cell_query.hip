@@ -152,3 +152,139 @@ extern "C" int gt_cell_query_fwd(GtSlabs part, const float* pre, int64_t ld_pre,
     GT_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Backward counterpart: the attention-LSTM cell backward with the query-projection input gradient
+// dh_q = dq . Wq computed inside (K = attention_dim), instead of gt_rec_gemm (slabs) + gt_lstm_cell_bwd.
+// Workgroup g owns hidden units [16g, 16g+16) of all (<= 64) rows of its row block: 4 waves, wave w computes
+// the 16 x 16 tile (rows 16w.., units 16g..) of dq . Wq on the matrix cores and parks it in LDS; then 256
+// threads (row, float4 of units) add it to the slab sources and run the cell backward.
+namespace {
+
+constexpr int CB_U = 16;
+constexpr int CB_LD = CB_U + 4;
+
+struct CellBwdQuery {
+    GtSlabs da, dc;                   // d h_att from the decoder-LSTM product and from the next step's product
+    const float* dq; long ld_dq;      // (Bp, ld_dq) gradient of the query, columns [0, A)
+    const float* Wq; long ldwq;       // (A, Ha)
+    const float* dc_next;
+    const float* gates; const float* c_new; const float* c_prev;
+    const uint8_t* keep; float scale;
+    float* dgates; float* dc_prev;
+    int B, H, A, mtiles;
+};
+
+__global__ __launch_bounds__(256) void cell_bwd_query_kernel(CellBwdQuery a) {
+    __shared__ __attribute__((aligned(16))) float T[64 * CB_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x, row0 = blockIdx.y * 64;
+    const int H = a.H;
+    const int u0 = g * CB_U;
+    // ---- dh_q tile of this wave: C[m][n] = sum_a dq[m][a] * Wq[a][u0 + n]
+    if (wave < a.mtiles) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* xq = a.dq + (long)(row0 + wave * 16 + (lane & 15)) * a.ld_dq + 4 * (lane >> 4);
+        const int nkb = (a.A + 15) / 16;
+        for (int kb = 0; kb < nkb; ++kb) {
+            // A operand: dq[m = lane & 15][k = 16 kb + 4 (lane >> 4) + j]; columns >= A of dq are zero (padded buffer)
+            const float4 x = *reinterpret_cast<const float4*>(xq + 16 * kb);
+            const int k0 = 16 * kb + 4 * (lane >> 4);
+            // B operand: Wq[k][n = lane & 15], rows clamped (the matching dq columns are zero)
+            const float* wc = a.Wq + u0 + (lane & 15);
+            const float b0 = wc[(long)min(k0 + 0, a.A - 1) * a.ldwq];
+            const float b1 = wc[(long)min(k0 + 1, a.A - 1) * a.ldwq];
+            const float b2 = wc[(long)min(k0 + 2, a.A - 1) * a.ldwq];
+            const float b3 = wc[(long)min(k0 + 3, a.A - 1) * a.ldwq];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, b1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, b2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, b3, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[(wave * 16 + 4 * (lane >> 4) + r) * CB_LD + (lane & 15)] = acc[r];
+    }
+    // ---- cell backward inputs of this thread (requested before the barrier)
+    const int rl = tid >> 2, ug = tid & 3;
+    const int m = row0 + rl;
+    const int u = u0 + 4 * ug;
+    const bool live = rl < a.mtiles * 16 && m < a.B;
+    const long idx = (long)m * H + u;
+    float4 dh = make_float4(0.f, 0.f, 0.f, 0.f), dcn = dh, gi = dh, gf = dh, gg = dh, go = dh, cn = dh, cp = dh;
+    uchar4 kp = make_uchar4(1, 1, 1, 1);
+    if (live) {
+        auto add_slabs = [&](const GtSlabs& sl) __attribute__((always_inline)) {
+            if (sl.p == nullptr) return;
+            const float* p = sl.p + (long)m * sl.ld + u;
+#pragma unroll 4
+            for (int s = 0; s < sl.n; ++s) {
+                const float4 t = *reinterpret_cast<const float4*>(p + (long)s * sl.slab_stride);
+                dh.x += t.x; dh.y += t.y; dh.z += t.z; dh.w += t.w;
+            }
+        };
+        add_slabs(a.da);
+        add_slabs(a.dc);
+        if (a.dc_next != nullptr) dcn = *reinterpret_cast<const float4*>(a.dc_next + idx);
+        const float* gt = a.gates + (long)m * 4 * H + u;
+        gi = *reinterpret_cast<const float4*>(gt); gf = *reinterpret_cast<const float4*>(gt + H);
+        gg = *reinterpret_cast<const float4*>(gt + 2 * H); go = *reinterpret_cast<const float4*>(gt + 3 * H);
+        cn = *reinterpret_cast<const float4*>(a.c_new + idx);
+        cp = *reinterpret_cast<const float4*>(a.c_prev + idx);
+        if (a.keep != nullptr) kp = *reinterpret_cast<const uchar4*>(a.keep + idx);
+    }
+    __syncthreads();
+    if (!live) return;
+    const float4 dhq = *reinterpret_cast<const float4*>(&T[rl * CB_LD + 4 * ug]);
+    const float dhv[4] = {dh.x + dhq.x, dh.y + dhq.y, dh.z + dhq.z, dh.w + dhq.w};
+    const float dcv[4] = {dcn.x, dcn.y, dcn.z, dcn.w};
+    const float giv[4] = {gi.x, gi.y, gi.z, gi.w}, gfv[4] = {gf.x, gf.y, gf.z, gf.w};
+    const float ggv[4] = {gg.x, gg.y, gg.z, gg.w}, gov[4] = {go.x, go.y, go.z, go.w};
+    const float cnv[4] = {cn.x, cn.y, cn.z, cn.w}, cpv[4] = {cp.x, cp.y, cp.z, cp.w};
+    const unsigned char kpv[4] = {kp.x, kp.y, kp.z, kp.w};
+    float dgi[4], dgf[4], dgg[4], dgo[4], dcp[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float d = dhv[e];
+        if (a.keep != nullptr) d *= (kpv[e] ? a.scale : 0.f);
+        const float tc = tanhf(cnv[e]);
+        const float dcell = dcv[e] + d * gov[e] * (1.f - tc * tc);
+        dgi[e] = dcell * ggv[e] * giv[e] * (1.f - giv[e]);
+        dgf[e] = dcell * cpv[e] * gfv[e] * (1.f - gfv[e]);
+        dgg[e] = dcell * giv[e] * (1.f - ggv[e] * ggv[e]);
+        dgo[e] = d * tc * gov[e] * (1.f - gov[e]);
+        dcp[e] = dcell * gfv[e];
+    }
+    float* dg = a.dgates + (long)m * 4 * H + u;
+    *reinterpret_cast<float4*>(dg) = make_float4(dgi[0], dgi[1], dgi[2], dgi[3]);
+    *reinterpret_cast<float4*>(dg + H) = make_float4(dgf[0], dgf[1], dgf[2], dgf[3]);
+    *reinterpret_cast<float4*>(dg + 2 * H) = make_float4(dgg[0], dgg[1], dgg[2], dgg[3]);
+    *reinterpret_cast<float4*>(dg + 3 * H) = make_float4(dgo[0], dgo[1], dgo[2], dgo[3]);
+    *reinterpret_cast<float4*>(a.dc_prev + idx) = make_float4(dcp[0], dcp[1], dcp[2], dcp[3]);
+}
+
+}  // namespace
+
+extern "C" int gt_cell_bwd_query(GtSlabs dh_a, GtSlabs dh_c, const float* dq, int64_t ld_dq, const float* Wq, int64_t ldwq,
+                                 const float* dc_next, const float* gates, const float* c_new, const float* c_prev,
+                                 const uint8_t* keep, float p_drop, float* dgates, float* dc_prev, int32_t B, int32_t Bp,
+                                 int32_t H, int32_t A, void* stream) {
+    GT_REQUIRE(dq && Wq && gates && c_new && c_prev && dgates && dc_prev, GT_E_ARG, "gt_cell_bwd_query: NULL pointer");
+    GT_REQUIRE(B > 0 && Bp >= B && ((Bp <= 64 && Bp % 16 == 0) || Bp % 64 == 0) && H > 0 && H % CB_U == 0 && A > 0, GT_E_ARG,
+               "gt_cell_bwd_query: bad sizes B=%d Bp=%d H=%d A=%d (H must be a multiple of %d)", B, Bp, H, A, CB_U);
+    GT_REQUIRE(ld_dq >= (int64_t)((A + 15) / 16) * 16, GT_E_ARG, "gt_cell_bwd_query: dq needs ld >= A rounded up to 16 (zero padded)");
+    auto sl4 = [](const GtSlabs& sl) { return sl.p == nullptr || (aligned16(sl.p) && sl.ld % 4 == 0 && sl.slab_stride % 4 == 0); };
+    GT_REQUIRE(sl4(dh_a) && sl4(dh_c) && aligned16(dq) && ld_dq % 4 == 0 && (dc_next == nullptr || aligned16(dc_next)) &&
+                   aligned16(gates) && aligned16(c_new) && aligned16(c_prev) && (keep == nullptr || (((uintptr_t)keep) & 3) == 0) &&
+                   aligned16(dgates) && aligned16(dc_prev) && H % 4 == 0,
+               GT_E_ALIGN, "gt_cell_bwd_query: every pointer must be 16-byte aligned with leading dimensions %% 4 == 0");
+    CellBwdQuery a;
+    a.da = dh_a; a.dc = dh_c; a.dq = dq; a.ld_dq = ld_dq; a.Wq = Wq; a.ldwq = ldwq; a.dc_next = dc_next; a.gates = gates;
+    a.c_new = c_new; a.c_prev = c_prev; a.keep = keep; a.scale = 1.0f / (1.0f - p_drop); a.dgates = dgates; a.dc_prev = dc_prev;
+    a.B = B; a.H = H; a.A = A; a.mtiles = Bp <= 64 ? Bp / 16 : 4;
+    dim3 grid(H / CB_U, Bp <= 64 ? 1 : Bp / 64);
+    const long n = (long)B * H;
+    GtProfScope prof(GT_FAM_CELL_BWD, 2.0 * Bp * (double)H * A, 4.0 * n * (dh_a.n + dh_c.n + 1 + 4 + 2 + 4 + 1), (hipStream_t)stream);
+    hipLaunchKernelGGL(cell_bwd_query_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    GT_LAUNCH_CHECK();
+    return 0;
+}

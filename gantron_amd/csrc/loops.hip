@@ -271,6 +271,7 @@ int gt_decoder_bwd(const GtDecoderBwd* a, void* stream) {
     auto evA = [&](int t, hipEvent_t* e) { return loop_event(1 + (size_t)(t % (R + 1)), e); };
     auto evB = [&](int t, hipEvent_t* e) { return loop_event(2 + R + (size_t)(t % (R + 1)), e); };
     auto ringX2 = [&](int t) { return a->partX2 + (int64_t)(t % R) * a->S2 * sX2; };
+    const bool bq = a->Wq != nullptr && a->Ha % 16 == 0 && a->E % 4 == 0 && a->N1pad % 4 == 0 && a->N2pad % 4 == 0;
     const int t_hi = (a->t_hi >= a->t_lo && a->t_hi < a->To) ? a->t_hi : a->To - 1;
     const int t_lo = (a->t_hi >= a->t_lo && a->t_lo >= 0 && a->t_hi < a->To) ? a->t_lo : 0;
     for (int t = t_hi; t >= t_lo; --t) {
@@ -309,13 +310,22 @@ int gt_decoder_bwd(const GtDecoderBwd* a, void* stream) {
         GT_TRY(gt_attn_energies_bwd(d, a->dw, a->w_hist + (int64_t)(t + 1) * BT, a->q_hist + (int64_t)t * a->B * a->A,
                                     a->w_hist + (int64_t)t * BT, a->cum_hist + (int64_t)t * BT, a->pm, a->Wc, a->Wd, a->v,
                                     a->lengths, dq_t, a->Apad, a->dpm, dwcat_out, a->acc, sA));
+        if (bq) {
+            // attention LSTM cell backward with dq . Wq computed inside: one dependent launch less per step
+            GT_TRY(gt_cell_bwd_query(slabs(pX2, a->S2, sX2, a->N2pad),
+                                     last ? kNoSlabs : slabs(a->partX1 + a->E, a->S1, sX1, a->N1pad), dq_t, a->Apad, a->Wq,
+                                     a->Ha, a->dc1, a->gates1 + (int64_t)t * a->Bp * N1, a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha,
+                                     a->c1 + (int64_t)t * a->Bp * a->Ha, k1, a->p_att, dG1_t, a->dc1, a->B, a->Bp, a->Ha, a->A,
+                                     sA));
+        } else {
         GT_TRY(rec_rows(dq_t, a->Apad, a->WqTp, a->partQ, a->Bp, a->Ha, a->A, a->Sq, sA));
-        // attention LSTM cell: dh = d(h_att as decoder-LSTM input) + d(query) + recurrent grad from t+1
-        GT_TRY(gt_lstm_cell_bwd(slabs(pX2, a->S2, sX2, a->N2pad), slabs(a->partQ, a->Sq, sQ, a->Ha),
-                                last ? kNoSlabs : slabs(a->partX1 + a->E, a->S1, sX1, a->N1pad), nullptr, 0, a->dc1,
-                                a->gates1 + (int64_t)t * a->Bp * N1, a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha,
-                                a->c1 + (int64_t)t * a->Bp * a->Ha, k1, a->p_att, nullptr, dG1_t, a->dc1, nullptr, a->B,
-                                a->Ha, sA));
+            // attention LSTM cell: dh = d(h_att as decoder-LSTM input) + d(query) + recurrent grad from t+1
+            GT_TRY(gt_lstm_cell_bwd(slabs(pX2, a->S2, sX2, a->N2pad), slabs(a->partQ, a->Sq, sQ, a->Ha),
+                                    last ? kNoSlabs : slabs(a->partX1 + a->E, a->S1, sX1, a->N1pad), nullptr, 0, a->dc1,
+                                    a->gates1 + (int64_t)t * a->Bp * N1, a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha,
+                                    a->c1 + (int64_t)t * a->Bp * a->Ha, k1, a->p_att, nullptr, dG1_t, a->dc1, nullptr, a->B,
+                                    a->Ha, sA));
+        }
         if (two) {
             GT_TRY(evA(t, &ev));
             GT_HIP(hipEventRecord(ev, sA));

@@ -602,6 +602,8 @@ class GeneratorEngine:
             B, Bp, Ti, To, E, E, Pd, Ha, Hd, A, Apad, self.F, self.Kc
         b.S1, b.S2, b.Sq = rec_splits(N1pad, 4 * Ha), rec_splits(N2pad, 4 * Hd), ops.pick_splits(A, 2)
         b.N1pad, b.N2pad = N1pad, N2pad
+        if CELL_QUERY and Ha % 16 == 0 and E % 4 == 0:
+            b.Wq = ptr(P['decoder.attention_layer.query_layer.linear_layer.weight'])
         training = sv['training']
         b.p_att = hp.p_attention_dropout if training else 0.0
         b.p_dec = hp.p_decoder_dropout if training else 0.0

@@ -140,6 +140,14 @@ int gt_cell_query_fwd(GtSlabs part, const float* pre, int64_t ld_pre, const floa
                       int64_t ld1, const float* Wq, int64_t ldwq, float* qpart, int64_t q_sstride, int32_t B,
                       int32_t Bp, int32_t H, int32_t A, int32_t Apad, void* stream);
 
+/* backward counterpart: gt_lstm_cell_bwd of the attention LSTM with the query-projection input gradient
+ * dh += dq . Wq computed inside (dq (Bp, ld_dq) zero padded to a multiple of 16 columns), instead of a
+ * gt_rec_gemm for dq . Wq whose slabs the cell kernel would sum.  H % 16 == 0, float4-aligned buffers. */
+int gt_cell_bwd_query(GtSlabs dh_a, GtSlabs dh_c, const float* dq, int64_t ld_dq, const float* Wq, int64_t ldwq,
+                      const float* dc_next, const float* gates, const float* c_new, const float* c_prev,
+                      const uint8_t* keep, float p_drop, float* dgates, float* dc_prev, int32_t B, int32_t Bp,
+                      int32_t H, int32_t A, void* stream);
+
 /* dh = (sum of up to three slab sources + direct) ; returns pre-activation gate grads + dc_prev. */
 int gt_lstm_cell_bwd(GtSlabs dh_a, GtSlabs dh_b, GtSlabs dh_c, const float* dh_direct,
                      int64_t ld_direct, const float* dc_next, const float* gates,
@@ -245,6 +253,9 @@ typedef struct GtDecoderBwd {
     const float* W1Tp;         /* packed [N1pad] x [4Ha]  (transpose of the forward operand) */
     const float* W2Tp;         /* packed [N2pad] x [4Hd] */
     const float* WqTp;         /* packed [Ha] x [Apad] */
+    const float* Wq;           /* query_layer weight (A, Ha), PyTorch layout: when non-NULL (and Ha % 16 == 0) the query
+                                  input gradient dq . Wq is computed inside the attention cell backward
+                                  (gt_cell_bwd_query) instead of a gt_rec_gemm into partQ */
     const float* dHC;          /* (To, Bp, Hd+E) gradient of the projection input */
     const float* dalign;       /* (To, B, Ti) gradient of the returned alignments, or NULL */
     float* dG1; float* dG2;    /* (To, Bp, 4Ha), (To, Bp, 4Hd) pre-activation gate gradients */

@@ -182,6 +182,35 @@ def test_cell_query_fused(dev, Bsz, H, A, S):
     assert torch.isfinite(qpart).all()                   # every slab element was written
 
 
+@pytest.mark.parametrize('Bsz,H,A,S', [(64, 1024, 128, 6), (5, 32, 8, 2), (70, 64, 40, 3)])
+def test_cell_bwd_query_fused(dev, Bsz, H, A, S):
+    """gt_cell_bwd_query = gt_lstm_cell_bwd whose dh also receives dq . Wq computed inside the kernel."""
+    from gantron_amd import ops
+    p = 0.1
+    Bp = ops.roundup(Bsz, 16) if Bsz <= 64 else ops.roundup(Bsz, 64)
+    Apad = ops.roundup(A, 16)
+    gates = torch.sigmoid(g(Bp, 4 * H, seed=1)); c_new = g(Bp, H, seed=2); c_prev = g(Bp, H, seed=3)
+    keep = (torch.rand(Bp, H, generator=torch.Generator().manual_seed(4)) >= p)
+    da = g(S, Bp, H + 16, seed=5, scale=0.3); dcs = g(2, Bp, H, seed=6, scale=0.3)
+    dq = torch.zeros(Bp, Apad); dq[:Bsz, :A] = g(Bsz, A, seed=7)
+    Wq = g(A, H, seed=8, scale=0.1)
+    dc_next = g(Bp, H, seed=9, scale=0.3)
+    dh = (da[:, :, 8:8 + H].sum(0) + dcs.sum(0) + dq[:, :A] @ Wq).double()
+    gi, gf, gg, go = gates.double().chunk(4, dim=1)
+    dhd = dh * keep.double() / (1 - p)
+    tc = torch.tanh(c_new.double())
+    dcell = dc_next.double() + dhd * go * (1 - tc * tc)
+    want = torch.cat((dcell * gg * gi * (1 - gi), dcell * c_prev.double() * gf * (1 - gf), dcell * gi * (1 - gg * gg),
+                      dhd * tc * go * (1 - go)), 1)
+    dgates = torch.zeros(Bp, 4 * H, device=dev); dcp = dc_next.clone().to(dev)
+    da_d, dcs_d = da.to(dev), dcs.to(dev)
+    ops.call('gt_cell_bwd_query', ops.slabs(da_d, S, Bp * (H + 16), H + 16, offset=8), ops.slabs(dcs_d, 2, Bp * H, H),
+             dq.to(dev), Apad, Wq.to(dev), H, dcp, gates.to(dev), c_new.to(dev), c_prev.to(dev),
+             keep.to(torch.uint8).to(dev), p, dgates, dcp, Bsz, Bp, H, A)
+    close(dgates[:Bsz], want[:Bsz], rtol=1e-5, atol=1e-5, what='dgates')
+    close(dcp[:Bsz], (dcell * gf)[:Bsz], rtol=1e-5, atol=1e-5, what='dc_prev')
+
+
 def test_lstm_cell_fwd_bwd(dev):
     from gantron_amd import ops
     B, H, S, p = 5, 48, 3, 0.1
