@@ -24,7 +24,7 @@ from ._lib import GtBiLstm, GtDecoderBwd, GtDecoderFwd, GtDecoderInfer, check, l
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 import os as _os
-REC_SPLITS = int(_os.environ.get("GANTRON_REC_SPLITS", "4"))
+REC_SPLITS_OVERRIDE = int(_os.environ.get("GANTRON_REC_SPLITS", "0"))     # diagnostics: force the K-split count
 # forward LSTM steps as ONE fused launch (gt_lstm_step_fused).  Stand-alone it beats product + cell (20.4 vs 23.2 us,
 # 25.5 vs 28.1 us) but every workgroup stages the whole activation matrix (4x the L2->LDS traffic), which slows the
 # kernels of the other chain in the two-stream loop: 69 ms per forward loop instead of 62.  Off by default.
@@ -110,12 +110,26 @@ def acc_add(dst, src):
     call('gt_axpby', dst, 1.0, src, 1.0, dst, dst.numel())
 
 
-def rec_splits(N, K):
-    """K-splits of a per-step recurrent GEMM: enough that (N/64) x splits covers the 256 CUs, not more
-    (every extra slab is 4*Bp*N bytes the cell kernel has to read back)."""
-    want = max(REC_SPLITS, -(-256 // max(N // 64, 1)))
-    want = min(want, 16, max(1, -(-K // 16) // 8))      # at least one 8-block LDS chunk of K per workgroup
-    return ops.pick_splits(K, want)
+def rec_splits(N, K, nz=1):
+    """K-splits of a per-step recurrent GEMM, from a cost model of the weight-streaming kernel fitted to
+    rocprofv3 timings on MI355X: a workgroup (64 columns x one K-slice) costs ~4 us of fixed latency plus ~1.7 us
+    per 8-block LDS chunk of its slice, workgroups beyond the 256 CUs run as further rounds, and every extra slab
+    costs the consuming cell kernel a little.  (N=3072, K=4096 is the case a plain 'fill the CUs' rule got wrong:
+    6 splits = 288 workgroups = two rounds, 33 us; 5 splits = 240 workgroups in one round.)"""
+    kb = -(-K // 16)
+    groups = -(-N // 64) * nz
+    best, best_cost = 1, None
+    for s in range(1, min(16, kb) + 1):
+        kbs = -(-kb // s)
+        if -(-kb // kbs) != s:                 # would leave an empty slab (gt_rec_gemm rejects it)
+            continue
+        rounds = -(-groups * s // 256)
+        cost = rounds * (-(-kbs // 8) * 1.7 + 4.0) + 0.15 * s
+        if best_cost is None or cost < best_cost - 1e-9:
+            best, best_cost = s, cost
+    if REC_SPLITS_OVERRIDE:
+        return ops.pick_splits(K, REC_SPLITS_OVERRIDE)
+    return best
 
 
 def pack_rec(W2d, N, n_valid, K, transposed=False):
@@ -263,7 +277,7 @@ class GeneratorEngine:
             Whp.append(pack_rec(P['encoder.lstm.weight_hh_l0' + sfx], 4 * H, 4 * H, H))
         Whp = torch.stack(Whp)
         ldx = roundup(H, 16)
-        S = rec_splits(4 * H, H)
+        S = rec_splits(4 * H, H, nz=2)
         a = GtBiLstm()
         a.B, a.Bp, a.T, a.H, a.S, a.backward = B, Bp, Ti, H, S, 0
         gates = _f32(2, Ti, Bp, 4 * H, device=dev, zero=False)
@@ -711,7 +725,7 @@ class GeneratorEngine:
         Hpad = roundup(H, 16)
         WhT = torch.stack([pack_rec(P['encoder.lstm.weight_hh_l0' + sfx], Hpad, H, 4 * H, transposed=True)
                            for sfx in ('', '_reverse')])
-        S = rec_splits(Hpad, 4 * H)
+        S = rec_splits(Hpad, 4 * H, nz=2)
         a = GtBiLstm()
         a.B, a.Bp, a.T, a.H, a.S, a.backward, a.Hpad = B, Bp, Ti, H, S, 1, Hpad
         dG = _f32(2, Ti * Bp, 4 * H, device=dev)
