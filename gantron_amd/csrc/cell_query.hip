@@ -2,10 +2,11 @@
 //   h_att = LSTMCell pointwise(sum of K-split slabs of the gate product + pre) with dropout  (model.py:391-394)
 //   q partial = h_att[:, 32 units of this workgroup] . Wq[:, those units]^T                 (model.py:56, query_layer)
 // One launch instead of gt_lstm_cell_fwd + gt_rec_gemm for the query: a dependent kernel less per decoder step.
-// Workgroup g owns hidden units [32g, 32g+32) of all (<= 64) batch rows of its row block: 512 threads each take
-// one float4 of units of one row (all slab loads in flight together), write h to global and to an LDS tile, then
-// the 8 waves multiply that [64 x 32] tile with the matching 32 columns of Wq (wave w: attention channels
-// [16w, 16w+16), fragments read straight from global, requested at kernel start) and store query slab g.
+// Workgroup (g, r) owns hidden units [32g, 32g+32) of batch rows [16r, 16r+16): 128 threads each take one float4
+// of units of one row (all slab loads in flight together), write h to global and to an LDS tile, then the 2 waves
+// multiply that [16 x 32] tile with the matching 32 columns of Wq (wave w: column blocks w, w+2, ...; fragments read
+// straight from global, requested at kernel start) and store their part of query slab g.  Many small workgroups
+// (128 for B=64) rather than few large ones: the kernel is latency bound and shares the CUs with the other chain.
 // The energies kernel sums the Ha/32 slabs.
 #include "common.h"
 
@@ -13,6 +14,7 @@ namespace {
 
 constexpr int CQ_U = 32;            // hidden units per workgroup
 constexpr int CQ_LD = CQ_U + 4;     // LDS row stride: conflict-free b128 fragment reads
+constexpr int CQ_MAXCB = 16;        // attention_dim <= 256: 16 column blocks of 16, 8 per wave
 
 struct CellQuery {
     GtSlabs part;
@@ -26,18 +28,18 @@ struct CellQuery {
     int B, H, A, Apad, mtiles;
 };
 
-__global__ __launch_bounds__(512) void cell_query_kernel(CellQuery a) {
-    __shared__ __attribute__((aligned(16))) float Xh[64 * CQ_LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = blockIdx.x, row0 = blockIdx.y * 64;
+__global__ __launch_bounds__(128) void cell_query_kernel(CellQuery a) {
+    __shared__ __attribute__((aligned(16))) float Xh[16 * CQ_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;          // 2 waves
+    const int g = blockIdx.x, row0 = blockIdx.y * 16;
     const int H = a.H;
-    // ---- query weight fragments of this wave's column blocks, requested first (they only depend on g)
+    // ---- query weight fragments of this wave's column blocks (cb = wave, wave + 2, ...), requested first.
     // B operand of the 16x16x4 MFMA: lane supplies W[n = lane & 15][k = 4 * (lane >> 4) + j]
     const int ncb = a.Apad / 16;
-    float4 wq[2][2];                 // [column block slot][k-block]
+    float4 wq[CQ_MAXCB / 2][2];      // [column block slot][k-block]
 #pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
-        const int cb = wave + 8 * sl;
+    for (int sl = 0; sl < CQ_MAXCB / 2; ++sl) {
+        const int cb = wave + 2 * sl;
         const int ch = min(cb * 16 + (lane & 15), a.A - 1);           // clamped: rows >= A are masked below
         const float* wp = a.Wq + (long)ch * a.ldwq + g * CQ_U + 4 * (lane >> 4);
 #pragma unroll
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(512) void cell_query_kernel(CellQuery a) {
     const int m = row0 + rl;
     const int u = g * CQ_U + 4 * ug;
     float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (rl < a.mtiles * 16 && m < a.B) {
+    if (m < a.B) {
         float4 gi[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -98,28 +100,28 @@ __global__ __launch_bounds__(512) void cell_query_kernel(CellQuery a) {
     }
     *reinterpret_cast<float4*>(&Xh[rl * CQ_LD + 4 * ug]) = hv;         // rows beyond the batch contribute zeros
     __syncthreads();
-    // ---- query partial: [16*mtiles x 32] . [32 x Apad]
+    // ---- query partial: [16 x 32] . [32 x Apad]
     float* out = a.qpart + (long)g * a.q_sstride;
+    float4 x[2];
 #pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
-        const int cb = wave + 8 * sl;
+    for (int kb = 0; kb < 2; ++kb) x[kb] = *reinterpret_cast<const float4*>(&Xh[(lane & 15) * CQ_LD + 16 * kb + 4 * (lane >> 4)]);
+#pragma unroll
+    for (int sl = 0; sl < CQ_MAXCB / 2; ++sl) {
+        const int cb = wave + 2 * sl;
         if (cb >= ncb) break;
-        for (int mt = 0; mt < a.mtiles; ++mt) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                const float4 x = *reinterpret_cast<const float4*>(&Xh[(mt * 16 + (lane & 15)) * CQ_LD + 16 * kb + 4 * (lane >> 4)]);
-                const float4 b = wq[sl][kb];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, b.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, b.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, b.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, b.w, acc, 0, 0, 0);
-            }
-            // C layout: column n = lane & 15, rows 4*(lane>>4) + r
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                out[(long)(row0 + mt * 16 + 4 * (lane >> 4) + r) * a.Apad + cb * 16 + (lane & 15)] = acc[r];
+        for (int kb = 0; kb < 2; ++kb) {
+            const float4 b = wq[sl][kb];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[kb].x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[kb].y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[kb].z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[kb].w, b.w, acc, 0, 0, 0);
         }
+        // C layout: column n = lane & 15, rows 4*(lane>>4) + r
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            out[(long)(row0 + 4 * (lane >> 4) + r) * a.Apad + cb * 16 + (lane & 15)] = acc[r];
     }
 }
 
@@ -144,11 +146,11 @@ extern "C" int gt_cell_query_fwd(GtSlabs part, const float* pre, int64_t ld_pre,
     a.part = part; a.pre = pre; a.ld_pre = ld_pre; a.c_prev = c_prev; a.keep = keep; a.scale = 1.0f / (1.0f - p_drop);
     a.gates = gates; a.c_out = c_out; a.h_raw = h_raw; a.h0 = h0; a.ld0 = ld0; a.h1 = h1; a.ld1 = ld1;
     a.Wq = Wq; a.ldwq = ldwq; a.qpart = qpart; a.q_sstride = q_sstride; a.B = B; a.H = H; a.A = A; a.Apad = Apad;
-    a.mtiles = Bp <= 64 ? Bp / 16 : 4;
-    dim3 grid(H / CQ_U, Bp <= 64 ? 1 : Bp / 64);
+    a.mtiles = 1;
+    dim3 grid(H / CQ_U, Bp / 16);
     const long n = (long)B * H;
     GtProfScope prof(GT_FAM_CELL_FWD, 2.0 * Bp * (double)H * A, 4.0 * n * (4.0 * part.n + 4 + 1 + 4 + 1 + 3), (hipStream_t)stream);
-    hipLaunchKernelGGL(cell_query_kernel, grid, dim3(512), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(cell_query_kernel, grid, dim3(128), 0, (hipStream_t)stream, a);
     GT_LAUNCH_CHECK();
     return 0;
 }
@@ -156,9 +158,9 @@ extern "C" int gt_cell_query_fwd(GtSlabs part, const float* pre, int64_t ld_pre,
 // ---------------------------------------------------------------------------------------------------
 // Backward counterpart: the attention-LSTM cell backward with the query-projection input gradient
 // dh_q = dq . Wq computed inside (K = attention_dim), instead of gt_rec_gemm (slabs) + gt_lstm_cell_bwd.
-// Workgroup g owns hidden units [16g, 16g+16) of all (<= 64) rows of its row block: 4 waves, wave w computes
-// the 16 x 16 tile (rows 16w.., units 16g..) of dq . Wq on the matrix cores and parks it in LDS; then 256
-// threads (row, float4 of units) add it to the slab sources and run the cell backward.
+// Workgroup (g, r) = one wave owns hidden units [16g, 16g+16) of rows [16r, 16r+16): it computes that 16 x 16 tile
+// of dq . Wq on the matrix cores, parks it in LDS, then its 64 threads (row, float4 of units) add it to the slab
+// sources and run the cell backward (256 one-wave workgroups for B=64, H=1024, like gt_lstm_cell_bwd).
 namespace {
 
 constexpr int CB_U = 16;
@@ -175,23 +177,24 @@ struct CellBwdQuery {
     int B, H, A, mtiles;
 };
 
-__global__ __launch_bounds__(256) void cell_bwd_query_kernel(CellBwdQuery a) {
-    __shared__ __attribute__((aligned(16))) float T[64 * CB_LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = blockIdx.x, row0 = blockIdx.y * 64;
+__global__ __launch_bounds__(64) void cell_bwd_query_kernel(CellBwdQuery a) {
+    __shared__ __attribute__((aligned(16))) float T[16 * CB_LD];
+    const int tid = threadIdx.x, lane = tid;
+    const int g = blockIdx.x, row0 = blockIdx.y * 16;
     const int H = a.H;
     const int u0 = g * CB_U;
-    // ---- dh_q tile of this wave: C[m][n] = sum_a dq[m][a] * Wq[a][u0 + n]
-    if (wave < a.mtiles) {
+    // ---- dh_q tile: C[m][n] = sum_a dq[m][a] * Wq[a][u0 + n]
+    {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const float* xq = a.dq + (long)(row0 + wave * 16 + (lane & 15)) * a.ld_dq + 4 * (lane >> 4);
+        const float* xq = a.dq + (long)(row0 + (lane & 15)) * a.ld_dq + 4 * (lane >> 4);
+        const float* wc = a.Wq + u0 + (lane & 15);
         const int nkb = (a.A + 15) / 16;
+#pragma unroll 4
         for (int kb = 0; kb < nkb; ++kb) {
             // A operand: dq[m = lane & 15][k = 16 kb + 4 (lane >> 4) + j]; columns >= A of dq are zero (padded buffer)
             const float4 x = *reinterpret_cast<const float4*>(xq + 16 * kb);
             const int k0 = 16 * kb + 4 * (lane >> 4);
             // B operand: Wq[k][n = lane & 15], rows clamped (the matching dq columns are zero)
-            const float* wc = a.Wq + u0 + (lane & 15);
             const float b0 = wc[(long)min(k0 + 0, a.A - 1) * a.ldwq];
             const float b1 = wc[(long)min(k0 + 1, a.A - 1) * a.ldwq];
             const float b2 = wc[(long)min(k0 + 2, a.A - 1) * a.ldwq];
@@ -202,13 +205,13 @@ __global__ __launch_bounds__(256) void cell_bwd_query_kernel(CellBwdQuery a) {
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, b3, acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) T[(wave * 16 + 4 * (lane >> 4) + r) * CB_LD + (lane & 15)] = acc[r];
+        for (int r = 0; r < 4; ++r) T[(4 * (lane >> 4) + r) * CB_LD + (lane & 15)] = acc[r];
     }
     // ---- cell backward inputs of this thread (requested before the barrier)
     const int rl = tid >> 2, ug = tid & 3;
     const int m = row0 + rl;
     const int u = u0 + 4 * ug;
-    const bool live = rl < a.mtiles * 16 && m < a.B;
+    const bool live = m < a.B;
     const long idx = (long)m * H + u;
     float4 dh = make_float4(0.f, 0.f, 0.f, 0.f), dcn = dh, gi = dh, gf = dh, gg = dh, go = dh, cn = dh, cp = dh;
     uchar4 kp = make_uchar4(1, 1, 1, 1);
@@ -280,11 +283,11 @@ extern "C" int gt_cell_bwd_query(GtSlabs dh_a, GtSlabs dh_c, const float* dq, in
     CellBwdQuery a;
     a.da = dh_a; a.dc = dh_c; a.dq = dq; a.ld_dq = ld_dq; a.Wq = Wq; a.ldwq = ldwq; a.dc_next = dc_next; a.gates = gates;
     a.c_new = c_new; a.c_prev = c_prev; a.keep = keep; a.scale = 1.0f / (1.0f - p_drop); a.dgates = dgates; a.dc_prev = dc_prev;
-    a.B = B; a.H = H; a.A = A; a.mtiles = Bp <= 64 ? Bp / 16 : 4;
-    dim3 grid(H / CB_U, Bp <= 64 ? 1 : Bp / 64);
+    a.B = B; a.H = H; a.A = A; a.mtiles = 1;
+    dim3 grid(H / CB_U, Bp / 16);
     const long n = (long)B * H;
     GtProfScope prof(GT_FAM_CELL_BWD, 2.0 * Bp * (double)H * A, 4.0 * n * (dh_a.n + dh_c.n + 1 + 4 + 2 + 4 + 1), (hipStream_t)stream);
-    hipLaunchKernelGGL(cell_bwd_query_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(cell_bwd_query_kernel, grid, dim3(64), 0, (hipStream_t)stream, a);
     GT_LAUNCH_CHECK();
     return 0;
 }
