@@ -13,11 +13,13 @@
 // matrix-core versions for the reference's default dimensions (attention_mfma.hip)
 void gt_launch_attn_energies_fwd_mfma(GtAttnDims d, GtSlabs qpart, const float* w_prev, const float* w_cum,
                                       const float* pm, const float* Wc, const float* Wd, const float* v,
-                                      const int* lengths, float* q_out, float* energies, hipStream_t st);
+                                      const int* lengths, float* q_out, float* energies, const float* wpack, hipStream_t st);
 void gt_launch_attn_energies_bwd_mfma(GtAttnDims d, const float* dw, const float* w, const float* q,
                                       const float* w_prev, const float* w_cum, const float* pm, const float* Wc,
                                       const float* Wd, const float* v, const int* lengths, float* dq, long ld_dq,
-                                      float* dpm, float* dwcat_out, float* acc, hipStream_t st);
+                                      float* dpm, float* dwcat_out, float* acc, const float* wpack, hipStream_t st);
+int gt_attn_wpack_elems_mfma();
+void gt_launch_attn_pack_weights(const float* Wc, const float* Wd, float* out, hipStream_t st);
 
 namespace {
 
@@ -633,9 +635,28 @@ extern "C" int64_t gt_attn_acc_elems(GtAttnDims d) {
     return (int64_t)d.B * cdiv(d.Ti, CT) * (d.A + d.A * d.F + d.F * 2 * d.Kc);
 }
 
+extern "C" int64_t gt_attn_wpack_elems(GtAttnDims d) {
+    return (d.A == 128 && d.F == 32 && d.Kc == 31) ? gt_attn_wpack_elems_mfma() : 0;
+}
+
+extern "C" int gt_attn_pack_weights(GtAttnDims d, const float* Wc, const float* Wd, float* wpack, void* stream) {
+    GT_REQUIRE(Wc && Wd && wpack && aligned16(wpack), GT_E_ARG, "gt_attn_pack_weights: bad argument");
+    GT_REQUIRE(gt_attn_wpack_elems(d) > 0, GT_E_ARG, "gt_attn_pack_weights: only the (128, 32, 31) matrix-core path stages packed weights");
+    gt_launch_attn_pack_weights(Wc, Wd, wpack, (hipStream_t)stream);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int gt_attn_energies_fwd(GtAttnDims d, GtSlabs qpart, const float* w_prev, const float* w_cum,
                                     const float* pm, const float* Wc, const float* Wd, const float* v,
                                     const int32_t* lengths, float* q_out, float* energies, void* stream) {
+    return gt_attn_energies_fwd_w(d, qpart, w_prev, w_cum, pm, Wc, Wd, v, lengths, q_out, energies, nullptr, stream);
+}
+
+extern "C" int gt_attn_energies_fwd_w(GtAttnDims d, GtSlabs qpart, const float* w_prev, const float* w_cum,
+                                      const float* pm, const float* Wc, const float* Wd, const float* v,
+                                      const int32_t* lengths, float* q_out, float* energies, const float* wpack,
+                                      void* stream) {
     int rc = check_dims(d, "gt_attn_energies_fwd");
     if (rc) return rc;
     GT_REQUIRE(qpart.p && w_prev && w_cum && pm && Wc && Wd && v && energies, GT_E_ARG, "gt_attn_energies_fwd: NULL pointer");
@@ -646,7 +667,7 @@ extern "C" int gt_attn_energies_fwd(GtAttnDims d, GtSlabs qpart, const float* w_
     hipLaunchKernelGGL((attn_energies_fwd_kernel<NIT, CA, CF, CK>), grid, dim3(256), 0, (hipStream_t)stream, d,  \
                        qpart, w_prev, w_cum, pm, Wc, Wd, v, lengths, q_out, energies)
     if (d.A == 128 && d.F == 32 && d.Kc == 31 && !getenv("GANTRON_ATTN_VALU")) {
-        gt_launch_attn_energies_fwd_mfma(d, qpart, w_prev, w_cum, pm, Wc, Wd, v, lengths, q_out, energies,
+        gt_launch_attn_energies_fwd_mfma(d, qpart, w_prev, w_cum, pm, Wc, Wd, v, lengths, q_out, energies, wpack,
                                          (hipStream_t)stream);      // the reference's default hparams
     } else if (d.A == 128 && d.F == 32 && d.Kc == 31) {
         GT_EF(16, 128, 32, 31);
@@ -720,6 +741,13 @@ extern "C" int gt_attn_energies_bwd(GtAttnDims d, const float* dw, const float* 
                                       const float* w_prev, const float* w_cum, const float* pm, const float* Wc,
                                       const float* Wd, const float* v, const int32_t* lengths, float* dq, int64_t ld_dq,
                                       float* dpm, float* dwcat_out, float* acc, void* stream) {
+    return gt_attn_energies_bwd_w(d, dw, w, q, w_prev, w_cum, pm, Wc, Wd, v, lengths, dq, ld_dq, dpm, dwcat_out, acc, nullptr, stream);
+}
+
+extern "C" int gt_attn_energies_bwd_w(GtAttnDims d, const float* dw, const float* w, const float* q,
+                                      const float* w_prev, const float* w_cum, const float* pm, const float* Wc,
+                                      const float* Wd, const float* v, const int32_t* lengths, float* dq, int64_t ld_dq,
+                                      float* dpm, float* dwcat_out, float* acc, const float* wpack, void* stream) {
     int rc = check_dims(d, "gt_attn_energies_bwd");
     if (rc) return rc;
     GT_REQUIRE(dw && w && q && w_prev && w_cum && pm && Wc && Wd && v && dq && dpm && dwcat_out && acc, GT_E_ARG,
@@ -732,7 +760,7 @@ extern "C" int gt_attn_energies_bwd(GtAttnDims d, const float* dw, const float* 
                        dw, w, q, w_prev, w_cum, pm, Wc, Wd, v, lengths, dq, (long)ld_dq, dpm, dwcat_out, acc)
     if (d.A == 128 && d.F == 32 && d.Kc == 31 && !getenv("GANTRON_ATTN_VALU")) {
         gt_launch_attn_energies_bwd_mfma(d, dw, w, q, w_prev, w_cum, pm, Wc, Wd, v, lengths, dq, (long)ld_dq, dpm, dwcat_out, acc,
-                                         (hipStream_t)stream);
+                                         wpack, (hipStream_t)stream);
     } else if (d.A == 128 && d.F == 32 && d.Kc == 31) {
         GT_EB(16, 128, 32, 31);
     } else {

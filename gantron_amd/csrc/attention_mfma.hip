@@ -14,6 +14,7 @@
 // MFMAs of a 16-wide k-step then take elements j=0..3, i.e. k = 16*s + 4*(lane>>4) + j for BOTH
 // operands) and as four ds_read_b32 otherwise; row strides are chosen so that every such read is
 // bank-conflict free (see the LD* constants).
+#include <stddef.h>
 #include "common.h"
 
 namespace {
@@ -54,14 +55,30 @@ __device__ __forceinline__ float4 ld4s(const float* p, int stride) {
     return make_float4(p[0], p[stride], p[2 * stride], p[3 * stride]);
 }
 
+// wpack (optional): the LDS image of [wc | wd] prepared once per loop by gt_attn_pack_weights, so that staging is
+// 7 float4 copies per thread instead of 26 scalar loads with index arithmetic
+constexpr int WPACK_F4 = (F * LDC + A * LDD) / 4;
+static_assert((F * LDC) % 4 == 0 && (A * LDD) % 4 == 0 && offsetof(SharedM, wd) == sizeof(float) * F * LDC, "[wc | wd] is one block");
+
 __device__ __forceinline__ void stage_common(SharedM& S, const GtAttnDims& d, const float* Wc, const float* Wd,
-                                             const float* v, const float* w_prev, const float* w_cum, int b, int t0) {
+                                             const float* v, const float* w_prev, const float* w_cum, int b, int t0,
+                                             const float* wpack) {
+    if (wpack != nullptr) {
+        const float4* src = reinterpret_cast<const float4*>(wpack);
+        float4* dst = reinterpret_cast<float4*>(&S.wc[0]);
+#pragma unroll
+        for (int i = 0; i < (WPACK_F4 + 255) / 256; ++i) {
+            const int j = min((int)threadIdx.x + 256 * i, WPACK_F4 - 1);      // clamped: a few threads copy the last one twice
+            dst[j] = src[j];
+        }
+    } else {
     for (int i = threadIdx.x; i < F * LDC; i += 256) {
         const int f = i / LDC, kk = i - f * LDC;
         const float wv = Wc[f * KK + min(kk, KK - 1)];        // unconditional load, selected below: predicated
         S.wc[i] = kk < KK ? wv : 0.f;                         // loads would force s_waitcnt vmcnt(0) everywhere
     }
     for (int i = threadIdx.x; i < A * F; i += 256) S.wd[(i >> 5) * LDD + (i & 31)] = Wd[i];
+    }
     if (threadIdx.x < A) S.v[threadIdx.x] = v[threadIdx.x];
     if (threadIdx.x < 2 * WL) {
         const int c = threadIdx.x / WL, p = threadIdx.x - c * WL;
@@ -69,6 +86,20 @@ __device__ __forceinline__ void stage_common(SharedM& S, const GtAttnDims& d, co
         const float* src = c == 0 ? w_prev : w_cum;
         const float wv = src[(long)b * d.Ti + min(max(t, 0), d.Ti - 1)];
         S.win[c][p] = (p < CT + KC - 1 && t >= 0 && t < d.Ti) ? wv : 0.f;
+    }
+}
+
+__global__ void attn_pack_weights_kernel(const float* Wc, const float* Wd, float* out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < F * LDC + A * LDD; i += gridDim.x * blockDim.x) {
+        float val = 0.f;
+        if (i < F * LDC) {
+            const int f = i / LDC, kk = i - f * LDC;
+            if (kk < KK) val = Wc[f * KK + kk];
+        } else {
+            const int j = i - F * LDC, dd = j / LDD, f = j - dd * LDD;
+            if (f < F) val = Wd[dd * F + f];
+        }
+        out[i] = val;
     }
 }
 
@@ -121,7 +152,7 @@ __device__ __forceinline__ void dense_tiles(const SharedM& S, int wave, int lane
 __global__ __launch_bounds__(256) void attn_energies_fwd_mfma(GtAttnDims d, GtSlabs qpart, const float* w_prev,
                                                               const float* w_cum, const float* pm, const float* Wc,
                                                               const float* Wd, const float* v, const int* lengths,
-                                                              float* q_out, float* energies) {
+                                                              float* q_out, float* energies, const float* wpack) {
     __shared__ SharedM S;
     const int b = blockIdx.y, t0 = blockIdx.x * CT;
     if (lengths != nullptr && t0 >= lengths[b]) {      // chunk entirely in the padding: energies are -inf
@@ -147,7 +178,7 @@ __global__ __launch_bounds__(256) void attn_energies_fwd_mfma(GtAttnDims d, GtSl
 #pragma unroll 8
         for (int s2 = 0; s2 < qpart.n; ++s2) qv += qp[(long)s2 * qpart.slab_stride];
     }
-    stage_common(S, d, Wc, Wd, v, w_prev, w_cum, b, t0);
+    stage_common(S, d, Wc, Wd, v, w_prev, w_cum, b, t0, wpack);
     if (threadIdx.x < A) {
         S.q[threadIdx.x] = qv;
         if (blockIdx.x == 0 && q_out != nullptr) q_out[(long)b * A + threadIdx.x] = qv;
@@ -196,7 +227,7 @@ __global__ __launch_bounds__(256) void attn_energies_bwd_mfma(GtAttnDims d, cons
                                                               const float* q, const float* w_prev, const float* w_cum,
                                                               const float* pm, const float* Wc, const float* Wd,
                                                               const float* v, const int* lengths, float* dq, long ld_dq,
-                                                              float* dpm, float* dwcat_out, float* acc_slabs) {
+                                                              float* dpm, float* dwcat_out, float* acc_slabs, const float* wpack) {
     __shared__ SharedM S;
     const int b = blockIdx.y, t0 = blockIdx.x * CT;
     if (lengths != nullptr && t0 >= lengths[b]) return;      // all-padding chunk: every gradient is zero
@@ -241,7 +272,7 @@ __global__ __launch_bounds__(256) void attn_energies_bwd_mfma(GtAttnDims d, cons
     const long tci = (long)b * d.Ti + min(t0 + (int)(threadIdx.x & (CT - 1)), d.Ti - 1);
     const float w_c = w[tci], dw_c = dw[tci];
     const float q_t = q[(long)b * A + (threadIdx.x & (A - 1))];
-    stage_common(S, d, Wc, Wd, v, w_prev, w_cum, b, t0);
+    stage_common(S, d, Wc, Wd, v, w_prev, w_cum, b, t0, wpack);
     if (threadIdx.x < A) S.q[threadIdx.x] = q_t;
     float part = (int)threadIdx.x < d.Ti ? w_t * dw_t : 0.f;
     for (int t = threadIdx.x + 256; t < d.Ti; t += 256) part += w[(long)b * d.Ti + t] * dw[(long)b * d.Ti + t];
@@ -391,17 +422,22 @@ __global__ __launch_bounds__(256) void attn_energies_bwd_mfma(GtAttnDims d, cons
 // entry points used by attention.hip when the dimensions match (128, 32, 31)
 void gt_launch_attn_energies_fwd_mfma(GtAttnDims d, GtSlabs qpart, const float* w_prev, const float* w_cum,
                                       const float* pm, const float* Wc, const float* Wd, const float* v,
-                                      const int* lengths, float* q_out, float* energies, hipStream_t st) {
+                                      const int* lengths, float* q_out, float* energies, const float* wpack, hipStream_t st) {
     dim3 grid(cdiv(d.Ti, CT), d.B);
     hipLaunchKernelGGL(attn_energies_fwd_mfma, grid, dim3(256), 0, st, d, qpart, w_prev, w_cum, pm, Wc, Wd, v, lengths,
-                       q_out, energies);
+                       q_out, energies, wpack);
 }
 
 void gt_launch_attn_energies_bwd_mfma(GtAttnDims d, const float* dw, const float* w, const float* q,
                                       const float* w_prev, const float* w_cum, const float* pm, const float* Wc,
                                       const float* Wd, const float* v, const int* lengths, float* dq, long ld_dq,
-                                      float* dpm, float* dwcat_out, float* acc, hipStream_t st) {
+                                      float* dpm, float* dwcat_out, float* acc, const float* wpack, hipStream_t st) {
     dim3 grid(cdiv(d.Ti, CT), d.B);
     hipLaunchKernelGGL(attn_energies_bwd_mfma, grid, dim3(256), 0, st, d, dw, w, q, w_prev, w_cum, pm, Wc, Wd, v, lengths,
-                       dq, ld_dq, dpm, dwcat_out, acc);
+                       dq, ld_dq, dpm, dwcat_out, acc, wpack);
+}
+
+int gt_attn_wpack_elems_mfma() { return F * LDC + A * LDD; }
+void gt_launch_attn_pack_weights(const float* Wc, const float* Wd, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(attn_pack_weights_kernel, dim3(8), dim3(256), 0, st, Wc, Wd, out);
 }

@@ -106,6 +106,11 @@ int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
     // events: [1 .. R+1] attention chain done (ring), [R+2 .. 2R+2] decoder chain done (ring)
     auto evA = [&](int t, hipEvent_t* e) { return loop_event(1 + (size_t)(t % (R + 1)), e); };
     auto evB = [&](int t, hipEvent_t* e) { return loop_event(2 + R + (size_t)(t % (R + 1)), e); };
+    const float* wpack = nullptr;
+    if (a->attn_wpack != nullptr && gt_attn_wpack_elems(d) > 0) {
+        GT_TRY(gt_attn_pack_weights(d, a->Wc, a->Wd, a->attn_wpack, sA));
+        wpack = a->attn_wpack;
+    }
     for (int t = 0; t < a->To; ++t) {
         const uint8_t* k1 = a->att_keep ? a->att_keep + (int64_t)t * a->Bp * a->Ha : nullptr;
         const uint8_t* k2 = a->dec_keep ? a->dec_keep + (int64_t)t * a->Bp * a->Hd : nullptr;
@@ -138,10 +143,10 @@ int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
                                 a->hatt + (int64_t)t * a->Bp * a->Ha, X1n + a->E, a->ld1, X2t, a->ld2, nullptr, 0,
                                 a->B, a->Ha, sA));
         if (!cq) GT_TRY(rec_rows(X2t, a->ld2, a->Wqp, a->part, a->Bp, a->Apad, a->Ha, a->Sq, sA));
-        GT_TRY(gt_attn_energies_fwd(d, cq ? slabs(a->partq, a->Ha / 32, (int64_t)a->Bp * a->Apad, a->Apad)
-                                          : slabs(a->part, a->Sq, (int64_t)a->Bp * a->Apad, a->Apad),
-                                    a->w_hist + (int64_t)t * BT, a->cum_hist + (int64_t)t * BT, a->pm, a->Wc, a->Wd, a->v,
-                                    a->lengths, a->q_hist + (int64_t)t * a->B * a->A, a->energies, sA));
+        GT_TRY(gt_attn_energies_fwd_w(d, cq ? slabs(a->partq, a->Ha / 32, (int64_t)a->Bp * a->Apad, a->Apad)
+                                            : slabs(a->part, a->Sq, (int64_t)a->Bp * a->Apad, a->Apad),
+                                      a->w_hist + (int64_t)t * BT, a->cum_hist + (int64_t)t * BT, a->pm, a->Wc, a->Wd, a->v,
+                                      a->lengths, a->q_hist + (int64_t)t * a->B * a->A, a->energies, wpack, sA));
         GT_TRY(gt_attn_context_fwd(d, a->energies, a->memory, a->ldE, a->lengths, a->w_hist + (int64_t)(t + 1) * BT,
                                    a->cum_hist + (int64_t)t * BT, a->cum_hist + (int64_t)(t + 1) * BT, X1n, a->ld1,
                                    X2t + a->Ha, a->ld2, hc_t + a->Hd, hc_ld, sA));
@@ -274,6 +279,11 @@ int gt_decoder_bwd(const GtDecoderBwd* a, void* stream) {
     const bool bq = a->Wq != nullptr && a->Ha % 16 == 0 && a->E % 4 == 0 && a->N1pad % 4 == 0 && a->N2pad % 4 == 0;
     const int t_hi = (a->t_hi >= a->t_lo && a->t_hi < a->To) ? a->t_hi : a->To - 1;
     const int t_lo = (a->t_hi >= a->t_lo && a->t_lo >= 0 && a->t_hi < a->To) ? a->t_lo : 0;
+    const float* wpack = nullptr;
+    if (a->attn_wpack != nullptr && gt_attn_wpack_elems(d) > 0) {
+        GT_TRY(gt_attn_pack_weights(d, a->Wc, a->Wd, a->attn_wpack, sA));
+        wpack = a->attn_wpack;
+    }
     for (int t = t_hi; t >= t_lo; --t) {
         const bool last = (t == a->To - 1);
         const uint8_t* k1 = a->att_keep ? a->att_keep + (int64_t)t * a->Bp * a->Ha : nullptr;
@@ -307,9 +317,9 @@ int gt_decoder_bwd(const GtDecoderBwd* a, void* stream) {
                                    a->memory, a->ldE, a->lengths, dwcat_in, a->dcum_acc,
                                    a->dalign ? a->dalign + (int64_t)t * BT : nullptr,
                                    a->dctx_hist + (int64_t)t * a->B * a->E, a->E, dq_t, a->Apad, a->dw, sA));
-        GT_TRY(gt_attn_energies_bwd(d, a->dw, a->w_hist + (int64_t)(t + 1) * BT, a->q_hist + (int64_t)t * a->B * a->A,
+        GT_TRY(gt_attn_energies_bwd_w(d, a->dw, a->w_hist + (int64_t)(t + 1) * BT, a->q_hist + (int64_t)t * a->B * a->A,
                                     a->w_hist + (int64_t)t * BT, a->cum_hist + (int64_t)t * BT, a->pm, a->Wc, a->Wd, a->v,
-                                    a->lengths, dq_t, a->Apad, a->dpm, dwcat_out, a->acc, sA));
+                                    a->lengths, dq_t, a->Apad, a->dpm, dwcat_out, a->acc, wpack, sA));
         if (bq) {
             // attention LSTM cell backward with dq . Wq computed inside: one dependent launch less per step
             GT_TRY(gt_cell_bwd_query(slabs(pX2, a->S2, sX2, a->N2pad),

@@ -391,6 +391,10 @@ class GeneratorEngine:
         d.memory, d.pm, d.lengths, d.pre1, d.bias2 = ptr(memory), ptr(pm), ptr(lens32), ptr(pre1), ptr(bias2)
         d.W1p, d.Wqp, d.W2p = ptr(keep_t.get('W1p')), ptr(keep_t['Wqp']), ptr(keep_t.get('W2p'))
         d.W1g, d.W2g = ptr(keep_t.get('W1g')), ptr(keep_t.get('W2g'))
+        n_wpack = int(lib().gt_attn_wpack_elems(ops.attn_dims(B, Ti, E, A, self.F, self.Kc)))
+        if n_wpack:
+            ws['attn_wpack'] = _f32(n_wpack, device=dev, zero=False)
+            d.attn_wpack = ptr(ws['attn_wpack'])
         if CELL_QUERY and Ha % 32 == 0 and E % 4 == 0:
             Wq = P['decoder.attention_layer.query_layer.linear_layer.weight']
             ws['partq'] = _f32(Ha // 32, Bp, Apad, device=dev, zero=False)
@@ -618,6 +622,9 @@ class GeneratorEngine:
         b.N1pad, b.N2pad = N1pad, N2pad
         if CELL_QUERY and Ha % 16 == 0 and E % 4 == 0:
             b.Wq = ptr(P['decoder.attention_layer.query_layer.linear_layer.weight'])
+        n_wpack = int(lib().gt_attn_wpack_elems(ops.attn_dims(B, Ti, E, A, self.F, self.Kc)))
+        wpack_b = _f32(n_wpack, device=dev, zero=False) if n_wpack else None
+        b.attn_wpack = ptr(wpack_b)
         training = sv['training']
         b.p_att = hp.p_attention_dropout if training else 0.0
         b.p_dec = hp.p_decoder_dropout if training else 0.0

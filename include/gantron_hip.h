@@ -169,6 +169,13 @@ typedef struct GtAttnDims { int32_t B, Ti, E, A, F, Kc; } GtAttnDims;
 int gt_attn_energies_fwd(GtAttnDims d, GtSlabs qpart, const float* w_prev, const float* w_cum,
                          const float* pm, const float* Wc, const float* Wd, const float* v,
                          const int32_t* lengths, float* q_out, float* energies, void* stream);
+/* the same with `wpack` (may be NULL): the weight image of gt_attn_pack_weights (gt_attn_wpack_elems(d) floats, 0 when
+ * the dimensions have no packed path), prepared once per decoder loop so that every launch stages it with float4 copies */
+int gt_attn_energies_fwd_w(GtAttnDims d, GtSlabs qpart, const float* w_prev, const float* w_cum,
+                         const float* pm, const float* Wc, const float* Wd, const float* v,
+                         const int32_t* lengths, float* q_out, float* energies, const float* wpack, void* stream);
+int64_t gt_attn_wpack_elems(GtAttnDims d);
+int gt_attn_pack_weights(GtAttnDims d, const float* Wc, const float* Wd, float* wpack, void* stream);
 int gt_attn_context_fwd(GtAttnDims d, const float* energies, const float* memory, int64_t ld_mem,
                         const int32_t* lengths, float* w_out, const float* cum_in, float* cum_out,
                         float* c0, int64_t ld0, float* c1, int64_t ld1, float* c2, int64_t ld2,
@@ -191,6 +198,10 @@ int gt_attn_energies_bwd(GtAttnDims d, const float* dw, const float* w, const fl
                          const float* w_prev, const float* w_cum, const float* pm, const float* Wc,
                          const float* Wd, const float* v, const int32_t* lengths, float* dq,
                          int64_t ld_dq, float* dpm, float* dwcat_out, float* acc, void* stream);
+int gt_attn_energies_bwd_w(GtAttnDims d, const float* dw, const float* w, const float* q,
+                         const float* w_prev, const float* w_cum, const float* pm, const float* Wc,
+                         const float* Wd, const float* v, const int32_t* lengths, float* dq,
+                         int64_t ld_dq, float* dpm, float* dwcat_out, float* acc, const float* wpack, void* stream);
 int64_t gt_attn_acc_elems(GtAttnDims d);     /* size of `acc` (dv | dWd | dWc per workgroup) */
 int gt_attn_acc_reduce(GtAttnDims d, const float* acc, float* dv, float* dWd, float* dWc,
                        void* stream);
@@ -222,6 +233,7 @@ typedef struct GtDecoderFwd {
     const float* W1g;          /* the same two weights packed gate-interleaved: when both are non-NULL the LSTM */
     const float* W2g;          /*   steps run as gt_lstm_step_fused (W1p / W2p, part / part2 are then unused)   */
     const float* Wc; const float* Wd; const float* v;
+    float* attn_wpack;         /* gt_attn_wpack_elems floats of scratch (or NULL): packed [Wc | Wd] image, filled by the loop */
     const uint8_t* att_keep;   /* (To, Bp, Ha) or NULL */
     const uint8_t* dec_keep;   /* (To, Bp, Hd) or NULL */
     float* X1; int64_t ld1;    /* (2, Bp, ld1) zero-initialised (the fused steps ping-pong between the two slots) */
@@ -247,6 +259,7 @@ typedef struct GtDecoderBwd {
     const float* memory; const float* pm;
     const int32_t* lengths;    /* (B) memory lengths */
     const float* Wc; const float* Wd; const float* v;
+    float* attn_wpack;         /* as in GtDecoderFwd */
     const uint8_t* att_keep; const uint8_t* dec_keep;
     const float* gates1; const float* c1; const float* gates2; const float* c2;
     const float* w_hist; const float* cum_hist; const float* q_hist;
