@@ -161,17 +161,14 @@ __global__ __launch_bounds__(256) void attn_energies_fwd_mfma(GtAttnDims d, GtSl
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, kq = lane >> 4;
-    // processed-memory values in accumulator layout, issued before anything else
-    float pmv[2][2][4];
+    // processed-memory tile [32 positions x 128 channels]: coalesced float4 loads issued before anything else,
+    // parked in LDS (S.ds is free in the forward kernel) and picked up in accumulator layout after the barrier
+    float4 pm4[4];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nl = 0; nl < 2; ++nl)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int t = min(t0 + 16 * mt + 4 * kq + e, d.Ti - 1);     // rows beyond Ti are never stored
-                pmv[mt][nl][e] = pm[((long)b * d.Ti + t) * A + 32 * wave + 16 * nl + r];
-            }
+    for (int i = 0; i < 4; ++i) {
+        const int f = threadIdx.x + 256 * i, tl = f >> 5, c4 = f & 31;
+        pm4[i] = *reinterpret_cast<const float4*>(pm + ((long)b * d.Ti + min(t0 + tl, d.Ti - 1)) * A + 4 * c4);
+    }
     float qv = 0.f;
     {   // query = sum of the K-split slabs of the query product (all loads in flight together)
         const float* qp = qpart.p + (long)b * qpart.ld + (threadIdx.x & (A - 1));
@@ -179,6 +176,11 @@ __global__ __launch_bounds__(256) void attn_energies_fwd_mfma(GtAttnDims d, GtSl
         for (int s2 = 0; s2 < qpart.n; ++s2) qv += qp[(long)s2 * qpart.slab_stride];
     }
     stage_common(S, d, Wc, Wd, v, w_prev, w_cum, b, t0, wpack);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = threadIdx.x + 256 * i, tl = f >> 5, c4 = f & 31;
+        *reinterpret_cast<float4*>(&S.ds[tl * LDS_ + 4 * c4]) = pm4[i];
+    }
     if (threadIdx.x < A) {
         S.q[threadIdx.x] = qv;
         if (blockIdx.x == 0 && q_out != nullptr) q_out[(long)b * A + threadIdx.x] = qv;
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256) void attn_energies_fwd_mfma(GtAttnDims d, GtSl
 #pragma unroll
             for (int nl = 0; nl < 2; ++nl) {
                 const int dd = 32 * wave + 16 * nl + r;
-                sum += S.v[dd] * tanhf(acc[mt][nl][e] + S.q[dd] + pmv[mt][nl][e]);
+                sum += S.v[dd] * tanhf(acc[mt][nl][e] + S.q[dd] + S.ds[(16 * mt + 4 * kq + e) * LDS_ + dd]);
             }
             sum += __shfl_xor(sum, 1, 64);
             sum += __shfl_xor(sum, 2, 64);
@@ -238,18 +240,14 @@ __global__ __launch_bounds__(256) void attn_energies_bwd_mfma(GtAttnDims d, cons
     // every global input is requested here, unconditionally (clamped indices): pm and the dpm accumulator in
     // accumulator layout, this workgroup's dv / dWd / dWc accumulator slab, and the softmax row.  The kernel is
     // then one memory round trip deep instead of five.
-    float pmv[2][2][4], dpmv[2][2][4];
+    float4 pm4[4], dpm4[4];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nl = 0; nl < 2; ++nl)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int t = min(t0 + 16 * mt + 4 * kq + e, d.Ti - 1);
-                const long pi = ((long)b * d.Ti + t) * A + 32 * wave + 16 * nl + r;
-                pmv[mt][nl][e] = pm[pi];
-                dpmv[mt][nl][e] = dpm[pi];
-            }
+    for (int i = 0; i < 4; ++i) {
+        const int f = threadIdx.x + 256 * i, tl = f >> 5, c4 = f & 31;
+        const long pi = ((long)b * d.Ti + min(t0 + tl, d.Ti - 1)) * A + 4 * c4;
+        pm4[i] = *reinterpret_cast<const float4*>(pm + pi);
+        dpm4[i] = *reinterpret_cast<const float4*>(dpm + pi);
+    }
     float old_dv[2], old_wd[2][2][4], old_wc[2][4];
 #pragma unroll
     for (int nl = 0; nl < 2; ++nl) old_dv[nl] = acc_wg[32 * wave + 16 * nl + r];
@@ -273,6 +271,11 @@ __global__ __launch_bounds__(256) void attn_energies_bwd_mfma(GtAttnDims d, cons
     const float w_c = w[tci], dw_c = dw[tci];
     const float q_t = q[(long)b * A + (threadIdx.x & (A - 1))];
     stage_common(S, d, Wc, Wd, v, w_prev, w_cum, b, t0, wpack);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {       // pm tile parked in S.ds; every thread later overwrites exactly the elements it read
+        const int f = threadIdx.x + 256 * i, tl = f >> 5, c4 = f & 31;
+        *reinterpret_cast<float4*>(&S.ds[tl * LDS_ + 4 * c4]) = pm4[i];
+    }
     if (threadIdx.x < A) S.q[threadIdx.x] = q_t;
     float part = (int)threadIdx.x < d.Ti ? w_t * dw_t : 0.f;
     for (int t = threadIdx.x + 256; t < d.Ti; t += 256) part += w[(long)b * d.Ti + t] * dw[(long)b * d.Ti + t];
@@ -299,12 +302,11 @@ __global__ __launch_bounds__(256) void attn_energies_bwd_mfma(GtAttnDims d, cons
                 const int tl = 16 * mt + 4 * kq + e;
                 float dsv = 0.f;
                 if (t0 + tl < d.Ti) {
-                    const float u = tanhf(acc[mt][nl][e] + qd + pmv[mt][nl][e]);
+                    const float u = tanhf(acc[mt][nl][e] + qd + S.ds[tl * LDS_ + dd]);      // pm parked here
                     const float de = S.de[tl];
                     dsv = de * vd * (1.f - u * u);
                     dvs[nl] += de * u;
                     dqs[nl] += dsv;
-                    dpm[((long)b * d.Ti + t0 + tl) * A + dd] = dpmv[mt][nl][e] + dsv;
                 }
                 S.ds[tl * LDS_ + dd] = dsv;
             }
@@ -322,6 +324,16 @@ __global__ __launch_bounds__(256) void attn_energies_bwd_mfma(GtAttnDims d, cons
         }
     }
     __syncthreads();                                   // ds complete
+    // dpm += ds as coalesced float4 read-modify-write (the dpm tile was requested at the top)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = threadIdx.x + 256 * i, tl = f >> 5, c4 = f & 31;
+        if (t0 + tl < d.Ti) {
+            const float4 dsv = *reinterpret_cast<const float4*>(&S.ds[tl * LDS_ + 4 * c4]);
+            *reinterpret_cast<float4*>(dpm + ((long)b * d.Ti + t0 + tl) * A + 4 * c4) =
+                make_float4(dpm4[i].x + dsv.x, dpm4[i].y + dsv.y, dpm4[i].z + dsv.z, dpm4[i].w + dsv.w);
+        }
+    }
 
     // G3: dlocf tile (mt = wave>>1, nt = wave&1) = ds[32x128] . Wd[128x32]
     {
