@@ -44,6 +44,15 @@ static bool rows_ok(int B, int Bp) { return B > 0 && Bp >= B && ((Bp <= 64 && Bp
 static hipStream_t g_aux_stream = nullptr;
 static std::vector<hipEvent_t> g_loop_events;
 
+// steps between cross-stream hand-offs for a ring of R buffers (GANTRON_SYNC_EVERY overrides, clamped so that
+// the follower's allowed lag R - k + 1 still covers a burst of k steps)
+static int sync_every(int R) {
+    static const int env = getenv("GANTRON_SYNC_EVERY") ? atoi(getenv("GANTRON_SYNC_EVERY")) : 0;
+    int k = env > 0 ? env : R / 2;
+    if (k > (R + 1) / 2) k = (R + 1) / 2;
+    return k < 1 ? 1 : k;
+}
+
 static int aux_stream(hipStream_t* out) {
     if (g_aux_stream == nullptr) {
         // highest priority: the loop kernels are the critical path, the weight-gradient GEMMs that
@@ -103,27 +112,57 @@ int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
         GT_HIP(hipEventRecord(ev, sA));
         GT_HIP(hipStreamWaitEvent(sB, ev, 0));
     }
-    // events: [1 .. R+1] attention chain done (ring), [R+2 .. 2R+2] decoder chain done (ring)
-    auto evA = [&](int t, hipEvent_t* e) { return loop_event(1 + (size_t)(t % (R + 1)), e); };
-    auto evB = [&](int t, hipEvent_t* e) { return loop_event(2 + R + (size_t)(t % (R + 1)), e); };
+    // Cross-stream hand-offs are batched: an event record or wait costs the stream it is issued on ~6 us of
+    // barrier-packet latency (measured in the kernel trace: the only gaps between back-to-back kernels), and the
+    // attention chain is the critical path.  So chain A records its "context ready" event only every k-th step and
+    // chain B's k steps are issued as one burst behind it; A's wait for ring-slot reuse likewise happens once per
+    // k steps.  k = ring / 2 keeps B's allowed lag (ring - k + 1 steps) above a full burst.
+    const int k = two ? sync_every(R) : 1;
+    const int NE = R + 3;
+    auto recorded = [&](int t) { return t % k == k - 1 || t == a->To - 1; };       // steps after which events are recorded
+    auto cover = [&](int t) { return min((t / k) * k + k - 1, a->To - 1); };       // the recorded step that covers step t
+    auto evA = [&](int t, hipEvent_t* e) { return loop_event(1 + (size_t)((t / k) % NE), e); };
+    auto evB = [&](int t, hipEvent_t* e) { return loop_event(1 + NE + (size_t)((t / k) % NE), e); };
     const float* wpack = nullptr;
     if (a->attn_wpack != nullptr && gt_attn_wpack_elems(d) > 0) {
         GT_TRY(gt_attn_pack_weights(d, a->Wc, a->Wd, a->attn_wpack, sA));
         wpack = a->attn_wpack;
     }
-    for (int t = 0; t < a->To; ++t) {
-        const uint8_t* k1 = a->att_keep ? a->att_keep + (int64_t)t * a->Bp * a->Ha : nullptr;
+    // ---- decoder LSTM chain of one step (stream B): [h_att_t | ctx_t | h_dec_{t-1}] . W2 + bias
+    auto chain_b = [&](int t) -> int {
         const uint8_t* k2 = a->dec_keep ? a->dec_keep + (int64_t)t * a->Bp * a->Hd : nullptr;
         float* hc_t = a->HC + (int64_t)t * a->Bp * hc_ld;
         float* X2t = a->X2 + (int64_t)(t % R) * a->Bp * a->ld2;
         float* X2n = a->X2 + (int64_t)((t + 1) % R) * a->Bp * a->ld2;
+        if (fused2) {
+            GT_TRY(gt_lstm_step_fused(X2t, a->ld2, a->W2g, K2, a->bias2, 0, a->c2 + (int64_t)t * a->Bp * a->Hd, k2, a->p_dec,
+                                      a->gates2 + (int64_t)t * a->Bp * N2, a->c2 + (int64_t)(t + 1) * a->Bp * a->Hd, nullptr,
+                                      X2n + a->Ha + a->E, a->ld2, hc_t, hc_ld, nullptr, 0, a->B, a->Bp, a->Hd, sB));
+        } else {
+            GT_TRY(rec_rows(X2t, a->ld2, a->W2p, partB, a->Bp, N2, K2, a->S2, sB));
+            GT_TRY(gt_lstm_cell_fwd(slabs(partB, a->S2, (int64_t)a->Bp * N2, N2), a->bias2, 0,
+                                    a->c2 + (int64_t)t * a->Bp * a->Hd, nullptr, 0, k2, a->p_dec, nullptr,
+                                    a->gates2 + (int64_t)t * a->Bp * N2, a->c2 + (int64_t)(t + 1) * a->Bp * a->Hd, nullptr,
+                                    X2n + a->Ha + a->E, a->ld2, hc_t, hc_ld, nullptr, 0, a->B, a->Hd, sB));
+        }
+        return 0;
+    };
+    int last_wait_b = -1, batch_start = 0;
+    for (int t = 0; t < a->To; ++t) {
+        const uint8_t* k1 = a->att_keep ? a->att_keep + (int64_t)t * a->Bp * a->Ha : nullptr;
+        float* hc_t = a->HC + (int64_t)t * a->Bp * hc_ld;
+        float* X2t = a->X2 + (int64_t)(t % R) * a->Bp * a->ld2;
         float* X1c = a->X1 + (t & 1) * x1_slot;            // [ctx_{t-1} | h_att_{t-1}]
         float* X1n = a->X1 + ((t + 1) & 1) * x1_slot;      // receives h_att_t (cell) and ctx_t (context kernel)
         // ---- attention chain (stream A)
         if (!fused1) GT_TRY(rec_rows(X1c, a->ld1, a->W1p, a->part, a->Bp, N1, K1, a->S1, sA));
         if (two && t >= R) {     // X2 ring slot t%R was last read by the decoder chain of step t-R
-            GT_TRY(evB(t - R, &ev));
-            GT_HIP(hipStreamWaitEvent(sA, ev, 0));
+            const int c = cover(t - R);
+            if (c != last_wait_b) {
+                GT_TRY(evB(c, &ev));
+                GT_HIP(hipStreamWaitEvent(sA, ev, 0));
+                last_wait_b = c;
+            }
         }
         if (fused1)
             GT_TRY(gt_lstm_step_fused(X1c, a->ld1, a->W1g, K1, a->pre1 + (int64_t)t * a->Bp * N1, N1,
@@ -137,11 +176,11 @@ int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
                                      X1n + a->E, a->ld1, X2t, a->ld2, a->Wq, a->Ha, a->partq, (int64_t)a->Bp * a->Apad, a->B,
                                      a->Bp, a->Ha, a->A, a->Apad, sA));
         else
-        GT_TRY(gt_lstm_cell_fwd(slabs(a->part, a->S1, (int64_t)a->Bp * N1, N1), a->pre1 + (int64_t)t * a->Bp * N1, N1,
-                                a->c1 + (int64_t)t * a->Bp * a->Ha, nullptr, 0, k1, a->p_att, nullptr,
-                                a->gates1 + (int64_t)t * a->Bp * N1, a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha,
-                                a->hatt + (int64_t)t * a->Bp * a->Ha, X1n + a->E, a->ld1, X2t, a->ld2, nullptr, 0,
-                                a->B, a->Ha, sA));
+            GT_TRY(gt_lstm_cell_fwd(slabs(a->part, a->S1, (int64_t)a->Bp * N1, N1), a->pre1 + (int64_t)t * a->Bp * N1, N1,
+                                    a->c1 + (int64_t)t * a->Bp * a->Ha, nullptr, 0, k1, a->p_att, nullptr,
+                                    a->gates1 + (int64_t)t * a->Bp * N1, a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha,
+                                    a->hatt + (int64_t)t * a->Bp * a->Ha, X1n + a->E, a->ld1, X2t, a->ld2, nullptr, 0,
+                                    a->B, a->Ha, sA));
         if (!cq) GT_TRY(rec_rows(X2t, a->ld2, a->Wqp, a->part, a->Bp, a->Apad, a->Ha, a->Sq, sA));
         GT_TRY(gt_attn_energies_fwd_w(d, cq ? slabs(a->partq, a->Ha / 32, (int64_t)a->Bp * a->Apad, a->Apad)
                                             : slabs(a->part, a->Sq, (int64_t)a->Bp * a->Apad, a->Apad),
@@ -150,24 +189,14 @@ int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
         GT_TRY(gt_attn_context_fwd(d, a->energies, a->memory, a->ldE, a->lengths, a->w_hist + (int64_t)(t + 1) * BT,
                                    a->cum_hist + (int64_t)t * BT, a->cum_hist + (int64_t)(t + 1) * BT, X1n, a->ld1,
                                    X2t + a->Ha, a->ld2, hc_t + a->Hd, hc_ld, sA));
-        if (two) {
+        if (!two) {
+            GT_TRY(chain_b(t));
+        } else if (recorded(t)) {
             GT_TRY(evA(t, &ev));
             GT_HIP(hipEventRecord(ev, sA));
             GT_HIP(hipStreamWaitEvent(sB, ev, 0));
-        }
-        // ---- decoder LSTM chain (stream B): [h_att_t | ctx_t | h_dec_{t-1}] . W2 + bias
-        if (fused2) {
-            GT_TRY(gt_lstm_step_fused(X2t, a->ld2, a->W2g, K2, a->bias2, 0, a->c2 + (int64_t)t * a->Bp * a->Hd, k2, a->p_dec,
-                                      a->gates2 + (int64_t)t * a->Bp * N2, a->c2 + (int64_t)(t + 1) * a->Bp * a->Hd, nullptr,
-                                      X2n + a->Ha + a->E, a->ld2, hc_t, hc_ld, nullptr, 0, a->B, a->Bp, a->Hd, sB));
-        } else {
-            GT_TRY(rec_rows(X2t, a->ld2, a->W2p, partB, a->Bp, N2, K2, a->S2, sB));
-            GT_TRY(gt_lstm_cell_fwd(slabs(partB, a->S2, (int64_t)a->Bp * N2, N2), a->bias2, 0,
-                                    a->c2 + (int64_t)t * a->Bp * a->Hd, nullptr, 0, k2, a->p_dec, nullptr,
-                                    a->gates2 + (int64_t)t * a->Bp * N2, a->c2 + (int64_t)(t + 1) * a->Bp * a->Hd, nullptr,
-                                    X2n + a->Ha + a->E, a->ld2, hc_t, hc_ld, nullptr, 0, a->B, a->Hd, sB));
-        }
-        if (two) {
+            for (int s2 = batch_start; s2 <= t; ++s2) GT_TRY(chain_b(s2));
+            batch_start = t + 1;
             GT_TRY(evB(t, &ev));
             GT_HIP(hipEventRecord(ev, sB));
         }
@@ -273,8 +302,13 @@ int gt_decoder_bwd(const GtDecoderBwd* a, void* stream) {
         GT_HIP(hipEventRecord(ev, sA));
         GT_HIP(hipStreamWaitEvent(sB, ev, 0));
     }
-    auto evA = [&](int t, hipEvent_t* e) { return loop_event(1 + (size_t)(t % (R + 1)), e); };
-    auto evB = [&](int t, hipEvent_t* e) { return loop_event(2 + R + (size_t)(t % (R + 1)), e); };
+    // batched cross-stream hand-offs (see gt_decoder_fwd): chain B leads here and records "product ready" only at
+    // steps t % k == 0 (and at the last step of the call); the k attention-chain steps behind it are then issued as
+    // one burst after a single wait.  Chain A records "ring slot free" at steps t % k == 0.
+    const int k = two ? sync_every(R) : 1;
+    const int NE = R + 3;
+    auto evA = [&](int t, hipEvent_t* e) { return loop_event(1 + (size_t)((t / k) % NE), e); };
+    auto evB = [&](int t, hipEvent_t* e) { return loop_event(1 + NE + (size_t)((t / k) % NE), e); };
     auto ringX2 = [&](int t) { return a->partX2 + (int64_t)(t % R) * a->S2 * sX2; };
     const bool bq = a->Wq != nullptr && a->Ha % 16 == 0 && a->E % 4 == 0 && a->N1pad % 4 == 0 && a->N2pad % 4 == 0;
     const int t_hi = (a->t_hi >= a->t_lo && a->t_hi < a->To) ? a->t_hi : a->To - 1;
@@ -284,32 +318,14 @@ int gt_decoder_bwd(const GtDecoderBwd* a, void* stream) {
         GT_TRY(gt_attn_pack_weights(d, a->Wc, a->Wd, a->attn_wpack, sA));
         wpack = a->attn_wpack;
     }
-    for (int t = t_hi; t >= t_lo; --t) {
+    // ---- attention chain of one step (stream A)
+    auto chain_a = [&](int t) -> int {
         const bool last = (t == a->To - 1);
         const uint8_t* k1 = a->att_keep ? a->att_keep + (int64_t)t * a->Bp * a->Ha : nullptr;
-        const uint8_t* k2 = a->dec_keep ? a->dec_keep + (int64_t)t * a->Bp * a->Hd : nullptr;
         const float* dhc_t = a->dHC + (int64_t)t * a->Bp * hc_ld;
-        float* dG2_t = a->dG2 + (int64_t)t * a->Bp * N2;
         float* dG1_t = a->dG1 + (int64_t)t * a->Bp * N1;
         float* dq_t = a->dq_hist + (int64_t)t * a->Bp * a->Apad;
         float* pX2 = ringX2(t);
-        const float* pX2next = ringX2(t + 1);
-        // ---- decoder LSTM chain (stream B, leads): dh = projection grad + recurrent grad from step t+1
-        GT_TRY(gt_lstm_cell_bwd(last ? kNoSlabs : slabs(pX2next + a->Ha + a->E, a->S2, sX2, a->N2pad), kNoSlabs,
-                                kNoSlabs, dhc_t, hc_ld, a->dc2, a->gates2 + (int64_t)t * a->Bp * N2,
-                                a->c2 + (int64_t)(t + 1) * a->Bp * a->Hd, a->c2 + (int64_t)t * a->Bp * a->Hd, k2,
-                                a->p_dec, nullptr, dG2_t, a->dc2, nullptr, a->B, a->Hd, sB));
-        if (two && t + R <= a->To - 1) {   // ring slot t%R was last read by the attention chain of step t+R
-            GT_TRY(evA(t + R, &ev));
-            GT_HIP(hipStreamWaitEvent(sB, ev, 0));
-        }
-        GT_TRY(rec_rows(dG2_t, N2, a->W2Tp, pX2, a->Bp, a->N2pad, N2, a->S2, sB));
-        if (two) {
-            GT_TRY(evB(t, &ev));
-            GT_HIP(hipEventRecord(ev, sB));
-            GT_HIP(hipStreamWaitEvent(sA, ev, 0));
-        }
-        // ---- attention chain (stream A)
         float* dwcat_in = a->dwcat + (int64_t)((t + 1) & 1) * 2 * BT;
         float* dwcat_out = a->dwcat + (int64_t)(t & 1) * 2 * BT;
         GT_TRY(gt_attn_context_bwd(d, slabs(pX2 + a->Ha, a->S2, sX2, a->N2pad),
@@ -318,8 +334,8 @@ int gt_decoder_bwd(const GtDecoderBwd* a, void* stream) {
                                    a->dalign ? a->dalign + (int64_t)t * BT : nullptr,
                                    a->dctx_hist + (int64_t)t * a->B * a->E, a->E, dq_t, a->Apad, a->dw, sA));
         GT_TRY(gt_attn_energies_bwd_w(d, a->dw, a->w_hist + (int64_t)(t + 1) * BT, a->q_hist + (int64_t)t * a->B * a->A,
-                                    a->w_hist + (int64_t)t * BT, a->cum_hist + (int64_t)t * BT, a->pm, a->Wc, a->Wd, a->v,
-                                    a->lengths, dq_t, a->Apad, a->dpm, dwcat_out, a->acc, wpack, sA));
+                                      a->w_hist + (int64_t)t * BT, a->cum_hist + (int64_t)t * BT, a->pm, a->Wc, a->Wd, a->v,
+                                      a->lengths, dq_t, a->Apad, a->dpm, dwcat_out, a->acc, wpack, sA));
         if (bq) {
             // attention LSTM cell backward with dq . Wq computed inside: one dependent launch less per step
             GT_TRY(gt_cell_bwd_query(slabs(pX2, a->S2, sX2, a->N2pad),
@@ -328,7 +344,7 @@ int gt_decoder_bwd(const GtDecoderBwd* a, void* stream) {
                                      a->c1 + (int64_t)t * a->Bp * a->Ha, k1, a->p_att, dG1_t, a->dc1, a->B, a->Bp, a->Ha, a->A,
                                      sA));
         } else {
-        GT_TRY(rec_rows(dq_t, a->Apad, a->WqTp, a->partQ, a->Bp, a->Ha, a->A, a->Sq, sA));
+            GT_TRY(rec_rows(dq_t, a->Apad, a->WqTp, a->partQ, a->Bp, a->Ha, a->A, a->Sq, sA));
             // attention LSTM cell: dh = d(h_att as decoder-LSTM input) + d(query) + recurrent grad from t+1
             GT_TRY(gt_lstm_cell_bwd(slabs(pX2, a->S2, sX2, a->N2pad), slabs(a->partQ, a->Sq, sQ, a->Ha),
                                     last ? kNoSlabs : slabs(a->partX1 + a->E, a->S1, sX1, a->N1pad), nullptr, 0, a->dc1,
@@ -336,12 +352,45 @@ int gt_decoder_bwd(const GtDecoderBwd* a, void* stream) {
                                     a->c1 + (int64_t)t * a->Bp * a->Ha, k1, a->p_att, nullptr, dG1_t, a->dc1, nullptr, a->B,
                                     a->Ha, sA));
         }
-        if (two) {
-            GT_TRY(evA(t, &ev));
-            GT_HIP(hipEventRecord(ev, sA));
+        if (two && t % k == 0) {          // ring slot t%R (and those of the steps above) may be rewritten by chain B
+            hipEvent_t e2;
+            GT_TRY(evA(t, &e2));
+            GT_HIP(hipEventRecord(e2, sA));
         }
-        if (t > 0)
-            GT_TRY(rec_rows(dG1_t, N1, a->W1Tp, a->partX1, a->Bp, a->N1pad, N1, a->S1, sA));
+        if (t > 0) GT_TRY(rec_rows(dG1_t, N1, a->W1Tp, a->partX1, a->Bp, a->N1pad, N1, a->S1, sA));
+        return 0;
+    };
+    int a_next = t_hi, last_wait_a = -1;
+    for (int t = t_hi; t >= t_lo; --t) {
+        const bool last = (t == a->To - 1);
+        const uint8_t* k2 = a->dec_keep ? a->dec_keep + (int64_t)t * a->Bp * a->Hd : nullptr;
+        const float* dhc_t = a->dHC + (int64_t)t * a->Bp * hc_ld;
+        float* dG2_t = a->dG2 + (int64_t)t * a->Bp * N2;
+        float* pX2 = ringX2(t);
+        const float* pX2next = ringX2(t + 1);
+        // ---- decoder LSTM chain (stream B, leads): dh = projection grad + recurrent grad from step t+1
+        GT_TRY(gt_lstm_cell_bwd(last ? kNoSlabs : slabs(pX2next + a->Ha + a->E, a->S2, sX2, a->N2pad), kNoSlabs,
+                                kNoSlabs, dhc_t, hc_ld, a->dc2, a->gates2 + (int64_t)t * a->Bp * N2,
+                                a->c2 + (int64_t)(t + 1) * a->Bp * a->Hd, a->c2 + (int64_t)t * a->Bp * a->Hd, k2,
+                                a->p_dec, nullptr, dG2_t, a->dc2, nullptr, a->B, a->Hd, sB));
+        if (two && t + R <= a->To - 1) {   // ring slot t%R was last read by the attention chain of step t+R
+            const int c = ((t + R) / k) * k;          // the recorded attention-chain step at or below t+R
+            if (c != last_wait_a) {
+                GT_TRY(evA(c, &ev));
+                GT_HIP(hipStreamWaitEvent(sB, ev, 0));
+                last_wait_a = c;
+            }
+        }
+        GT_TRY(rec_rows(dG2_t, N2, a->W2Tp, pX2, a->Bp, a->N2pad, N2, a->S2, sB));
+        if (!two) {
+            GT_TRY(chain_a(t));
+        } else if (t % k == 0 || t == t_lo) {
+            GT_TRY(evB(t, &ev));
+            GT_HIP(hipEventRecord(ev, sB));
+            GT_HIP(hipStreamWaitEvent(sA, ev, 0));
+            for (int s2 = a_next; s2 >= t; --s2) GT_TRY(chain_a(s2));
+            a_next = t - 1;
+        }
     }
     return 0;
 }

@@ -15,6 +15,7 @@ accumulated into a dict of same-shaped tensors.  Stochastic inputs (dropout keep
 noise) are explicit (`rng`), in kernel layout (channels-last, Bp rows per decoder step).
 """
 import math
+import time as _time
 
 import torch
 
@@ -29,11 +30,13 @@ REC_SPLITS_OVERRIDE = int(_os.environ.get("GANTRON_REC_SPLITS", "0"))     # diag
 # 25.5 vs 28.1 us) but every workgroup stages the whole activation matrix (4x the L2->LDS traffic), which slows the
 # kernels of the other chain in the two-stream loop: 69 ms per forward loop instead of 62.  Off by default.
 FUSED_CELL = _os.environ.get('GANTRON_FUSED_CELL', '0') != '0'
+HOST_TIMING = _os.environ.get('GANTRON_HOST_TIMING') == '1'      # diagnostics: host time spent issuing each loop
 CELL_QUERY = _os.environ.get('GANTRON_CELL_QUERY', '1') != '0'    # attention cell + query product in one launch
 HIGH_PRIORITY_BACKWARD = _os.environ.get('GANTRON_HIGH_PRIO', '0') != '0'   # measured: no gain on MI355X
 _HIGH_STREAM = None
 BWD_CHUNKS = int(_os.environ.get("GANTRON_BWD_CHUNKS", "6"))
-DEC_RING = int(_os.environ.get("GANTRON_DEC_RING", "4"))     # 1 = single stream; >1 = two-chain pipelining   # K-splits of the per-step recurrent GEMMs
+DEC_RING = int(_os.environ.get('GANTRON_DEC_RING', '6'))     # ring of hand-off buffers between the two decoder chains;
+                                                             # cross-stream syncs happen every ring/2 steps (loops.hip)
 
 
 def _f32(*shape, device, zero=True):
@@ -410,7 +413,10 @@ class GeneratorEngine:
         for k in ('gates1', 'c1', 'gates2', 'c2', 'hatt', 'HC', 'w_hist', 'cum_hist', 'q_hist'):
             setattr(d, k, ptr(hist[k]))
         PHASES.mark('f.pre_loop')
+        _t0 = _time.perf_counter()
         _run('gt_decoder_fwd', d)
+        if HOST_TIMING:
+            print(f'[host] gt_decoder_fwd issued in {1e3 * (_time.perf_counter() - _t0):.1f} ms (To={To})', flush=True)
         PHASES.mark('f.dec_loop')
         sv.update(hist=hist, pre1=pre1, lens32=lens32, att_keep=att_keep, dec_keep=dec_keep,
                   prenet_keep=pk)
@@ -684,7 +690,10 @@ class GeneratorEngine:
         for ci in reversed(range(n_chunks)):
             lo, hi = bounds[ci], bounds[ci + 1] - 1
             b.t_hi, b.t_lo = hi, lo
+            _t0 = _time.perf_counter()
             _run('gt_decoder_bwd', b)
+            if HOST_TIMING:
+                print(f'[host] gt_decoder_bwd steps {hi}..{lo} issued in {1e3 * (_time.perf_counter() - _t0):.1f} ms', flush=True)
             LEAF.run(lambda lo=lo, hi=hi: leaf_decoder(lo, hi), dHC)
         LEAF.run(lambda: call('gt_attn_acc_reduce', dims, buf['acc'], G[al + 'v.linear_layer.weight'],
                               G[al + 'location_layer.location_dense.linear_layer.weight'],
