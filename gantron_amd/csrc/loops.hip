@@ -87,7 +87,7 @@ int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
                "gt_decoder_fwd: batch %d must be padded to a multiple of 16 (<= 64) or of 64 (got %d)", a->B, a->Bp);
     GT_REQUIRE(a->To > 0 && a->Ti > 0 && a->Ha % 16 == 0 && a->Hd % 16 == 0 && a->Apad % 16 == 0, GT_E_ARG,
                "gt_decoder_fwd: bad dims");
-    GT_REQUIRE(a->ring >= 1 && a->ring <= 8 && (a->ring == 1 || a->part2 != nullptr), GT_E_ARG, "gt_decoder_fwd: ring/part2");
+    GT_REQUIRE(a->ring >= 1 && a->ring <= 32 && (a->ring == 1 || a->part2 != nullptr), GT_E_ARG, "gt_decoder_fwd: ring/part2");
     const int N1 = 4 * a->Ha, N2 = 4 * a->Hd;
     const int K1 = a->E + a->Ha, K2 = a->Ha + a->E + a->Hd;
     const int64_t hc_ld = a->Hd + a->E;
@@ -286,7 +286,7 @@ int gt_decoder_infer(const GtDecoderInfer* q, void* stream) {
 int gt_decoder_bwd(const GtDecoderBwd* a, void* stream) {
     GT_REQUIRE(a != nullptr, GT_E_ARG, "gt_decoder_bwd: NULL");
     GT_REQUIRE(rows_ok(a->B, a->Bp), GT_E_LIMIT, "gt_decoder_bwd: batch padding");
-    GT_REQUIRE(a->ring >= 1 && a->ring <= 8, GT_E_ARG, "gt_decoder_bwd: ring");
+    GT_REQUIRE(a->ring >= 1 && a->ring <= 32, GT_E_ARG, "gt_decoder_bwd: ring");
     const int N1 = 4 * a->Ha, N2 = 4 * a->Hd;
     const int64_t hc_ld = a->Hd + a->E;
     GtAttnDims d; d.B = a->B; d.Ti = a->Ti; d.E = a->E; d.A = a->A; d.F = a->F; d.Kc = a->Kc;

@@ -85,25 +85,21 @@ struct RecW {                             // weight fragments of this wave's hal
 };
 
 // DBG (diagnostics, GANTRON_REC_DEBUG): bit 0 = no weight loads, bit 1 = no MFMAs, bit 2 = no activation staging
-template <int MT, int DBG = 0>
-__global__ __launch_bounds__(REC_THREADS) void rec_gemm_kernel(const float* __restrict__ X, long ldx,
-                                                               const float* __restrict__ Wp,
-                                                               float* __restrict__ part, int N, int KB, int KBS,
-                                                               long xz, long wz, long pz, long ps) {
+// One workgroup of the product: 64 columns starting at column group `cg`, K-slice [kb0, kb1) of 16-wide blocks;
+// `out` is the slab this K-slice writes (row stride N).
+template <int MT, int DBG>
+__device__ __forceinline__ void rec_gemm_body(const float* __restrict__ Xz, long ldx, const float* __restrict__ Wpz,
+                                              float* __restrict__ out_slab, int N, int KB, int kb0, int kb1, int cg) {
     static_assert(MT == 4 || MT == 2 || MT == 1 || MT == 3, "row tiles");
     __shared__ __attribute__((aligned(16))) float Xs[MT * 16 * REC_LD];
     if (DBG & 8) return;                  // diagnostics: pure launch + wave start-up cost
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = wave >> 2;
-    const int s = blockIdx.y, z = blockIdx.z;
-    const int kb0 = s * KBS;
-    const int kb1 = min(KB, kb0 + KBS);
-    int nb = blockIdx.x * 4 + (wave & 3);
+    int nb = cg * 4 + (wave & 3);
     const bool active = nb * 16 < N;      // inactive waves still help staging and join the barriers
     if (!active) nb = 0;
     // this wave's k-blocks of chunk c: kb0 + 8c + 4*half + {0..3}
-    const float4* wp = reinterpret_cast<const float4*>(Wp + (long)z * wz) + ((long)nb * KB + kb0 + REC_HK * half) * 64 + lane;
-    const float* Xz = X + (long)z * xz;
+    const float4* wp = reinterpret_cast<const float4*>(Wpz) + ((long)nb * KB + kb0 + REC_HK * half) * 64 + lane;
 
     f32x4 acc[MT];
 #pragma unroll
@@ -190,8 +186,8 @@ __global__ __launch_bounds__(REC_THREADS) void rec_gemm_kernel(const float* __re
             for (int r = 0; r < 4; ++r) red[(mt * 16 + erow + r) * EP_LD + ecol] += acc[mt][r];
     }
     __syncthreads();
-    float* out = part + (long)z * pz + (long)s * ps + (long)blockIdx.x * 64;
-    const int ncols = min(64, N - (int)blockIdx.x * 64);      // N % 16 == 0: whole float4s
+    float* out = out_slab + (long)cg * 64;
+    const int ncols = min(64, N - cg * 64);      // N % 16 == 0: whole float4s
 #pragma unroll
     for (int i = 0; i < (MT * 16 * 16 + REC_THREADS - 1) / REC_THREADS; ++i) {
         const int f = tid + REC_THREADS * i;
@@ -199,6 +195,38 @@ __global__ __launch_bounds__(REC_THREADS) void rec_gemm_kernel(const float* __re
         if (row < MT * 16 && 4 * c4 < ncols)
             *reinterpret_cast<float4*>(out + (long)row * N + 4 * c4) = *reinterpret_cast<const float4*>(&red[row * EP_LD + 4 * c4]);
     }
+}
+
+template <int MT, int DBG = 0>
+__global__ __launch_bounds__(REC_THREADS) void rec_gemm_kernel(const float* __restrict__ X, long ldx,
+                                                               const float* __restrict__ Wp,
+                                                               float* __restrict__ part, int N, int KB, int KBS,
+                                                               long xz, long wz, long pz, long ps) {
+    const int s = blockIdx.y, z = blockIdx.z;
+    const int kb0 = s * KBS;
+    rec_gemm_body<MT, DBG>(X + (long)z * xz, ldx, Wp + (long)z * wz, part + (long)z * pz + (long)s * ps, N, KB, kb0,
+                           min(KB, kb0 + KBS), blockIdx.x);
+}
+
+// Two independent products with their own shapes in ONE launch (blockIdx.x is linear over both): the decoder loops
+// issue the attention-LSTM and the decoder-LSTM products of a step together, so that they share the device as two
+// co-resident workgroups per CU without any cross-stream synchronisation.
+struct RecProblem {
+    const float* X; long ldx;
+    const float* Wp;
+    float* part; long ps;
+    int N, KB, KBS, groups, splits;
+};
+
+template <int MT>
+__global__ __launch_bounds__(REC_THREADS) void rec_gemm2_kernel(RecProblem p0, RecProblem p1) {
+    const int n0 = p0.groups * p0.splits;
+    const bool second = (int)blockIdx.x >= n0;
+    const RecProblem& p = second ? p1 : p0;
+    const int id = second ? blockIdx.x - n0 : blockIdx.x;
+    const int s = id / p.groups, cg = id - s * p.groups;
+    const int kb0 = s * p.KBS;
+    rec_gemm_body<MT, 0>(p.X, p.ldx, p.Wp, p.part + (long)s * p.ps, p.N, p.KB, kb0, min(p.KB, kb0 + p.KBS), cg);
 }
 
 struct CellFwd {
@@ -498,6 +526,44 @@ extern "C" int gt_rec_gemm(const float* X, int64_t ldx, const float* Wp, float* 
         default: GT_REC(4); break;
     }
 #undef GT_REC
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+static int rec_problem(RecProblem& p, const float* X, int64_t ldx, const float* Wp, float* part, int N, int K, int splits,
+                       int64_t sstride, int mtiles, const char* which) {
+    GT_REQUIRE(X && Wp && part && N > 0 && N % 16 == 0 && K > 0 && splits >= 1, GT_E_ARG, "gt_rec_gemm2: bad problem %s", which);
+    const int KB = cdiv(K, 16);
+    GT_REQUIRE(ldx >= (int64_t)KB * 16 && ldx % 4 == 0 && aligned16(X) && aligned16(Wp) && aligned16(part) && sstride % 4 == 0,
+               GT_E_ALIGN, "gt_rec_gemm2: alignment of problem %s", which);
+    GT_REQUIRE(sstride >= (int64_t)mtiles * 16 * N, GT_E_ARG, "gt_rec_gemm2: slab stride of problem %s", which);
+    const int KBS = cdiv(KB, splits);
+    GT_REQUIRE(cdiv(KB, KBS) == splits, GT_E_ARG, "gt_rec_gemm2: splits=%d leaves empty slabs for K=%d (%s)", splits, K, which);
+    p.X = X; p.ldx = ldx; p.Wp = Wp; p.part = part; p.ps = sstride; p.N = N; p.KB = KB; p.KBS = KBS; p.groups = cdiv(N, 64);
+    p.splits = splits;
+    return 0;
+}
+
+extern "C" int gt_rec_gemm2(const float* X0, int64_t ldx0, const float* Wp0, float* part0, int32_t N0, int32_t K0,
+                            int32_t splits0, int64_t sstride0, const float* X1, int64_t ldx1, const float* Wp1,
+                            float* part1, int32_t N1, int32_t K1, int32_t splits1, int64_t sstride1, int32_t mtiles,
+                            void* stream) {
+    GT_REQUIRE(mtiles >= 1 && mtiles <= 4, GT_E_ARG, "gt_rec_gemm2: mtiles");
+    RecProblem p0, p1;
+    int rc;
+    if ((rc = rec_problem(p0, X0, ldx0, Wp0, part0, N0, K0, splits0, sstride0, mtiles, "0")) != 0) return rc;
+    if ((rc = rec_problem(p1, X1, ldx1, Wp1, part1, N1, K1, splits1, sstride1, mtiles, "1")) != 0) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const double fl = 2.0 * 16 * mtiles * ((double)N0 * K0 + (double)N1 * K1);
+    GtProfScope prof(GT_FAM_REC_GEMM, fl, 4.0 * ((double)N0 * K0 + (double)N1 * K1 + 16.0 * mtiles * (K0 + K1) +
+                                                 16.0 * mtiles * ((double)N0 * splits0 + (double)N1 * splits1)), st);
+    dim3 grid(p0.groups * p0.splits + p1.groups * p1.splits);
+    switch (mtiles) {
+        case 1: hipLaunchKernelGGL((rec_gemm2_kernel<1>), grid, dim3(REC_THREADS), 0, st, p0, p1); break;
+        case 2: hipLaunchKernelGGL((rec_gemm2_kernel<2>), grid, dim3(REC_THREADS), 0, st, p0, p1); break;
+        case 3: hipLaunchKernelGGL((rec_gemm2_kernel<3>), grid, dim3(REC_THREADS), 0, st, p0, p1); break;
+        default: hipLaunchKernelGGL((rec_gemm2_kernel<4>), grid, dim3(REC_THREADS), 0, st, p0, p1); break;
+    }
     GT_LAUNCH_CHECK();
     return 0;
 }

@@ -35,7 +35,7 @@ CELL_QUERY = _os.environ.get('GANTRON_CELL_QUERY', '1') != '0'    # attention ce
 HIGH_PRIORITY_BACKWARD = _os.environ.get('GANTRON_HIGH_PRIO', '0') != '0'   # measured: no gain on MI355X
 _HIGH_STREAM = None
 BWD_CHUNKS = int(_os.environ.get("GANTRON_BWD_CHUNKS", "6"))
-DEC_RING = int(_os.environ.get('GANTRON_DEC_RING', '6'))     # ring of hand-off buffers between the two decoder chains;
+DEC_RING = int(_os.environ.get('GANTRON_DEC_RING', '16'))     # ring of hand-off buffers between the two decoder chains;
                                                              # cross-stream syncs happen every ring/2 steps (loops.hip)
 
 

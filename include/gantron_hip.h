@@ -104,6 +104,14 @@ int gt_rec_gemm(const float* X, int64_t ldx, const float* Wp, float* part, int32
                 int32_t N, int32_t K, int32_t splits, int64_t part_sstride, int32_t nz,
                 int64_t x_zstride, int64_t w_zstride, int64_t part_zstride, void* stream);
 
+/* Two products with their own shapes (both with 16*mtiles rows) in ONE launch: the decoder loops issue the
+ * attention-LSTM and decoder-LSTM products of a step together so that they share the device as co-resident
+ * workgroups without cross-stream synchronisation.  Arguments per problem as in gt_rec_gemm (nz = 1). */
+int gt_rec_gemm2(const float* X0, int64_t ldx0, const float* Wp0, float* part0, int32_t N0, int32_t K0,
+                 int32_t splits0, int64_t sstride0, const float* X1, int64_t ldx1, const float* Wp1,
+                 float* part1, int32_t N1, int32_t K1, int32_t splits1, int64_t sstride1, int32_t mtiles,
+                 void* stream);
+
 /* One whole LSTMCell step forward in a single launch: gates = X.W^T + pre, pointwise cell, dropout, h
  * written to up to three operand buffers (model.py:391-394, 406-409).  Wg is the gate-interleaved packing
  * (gt_pack_rec_weight mode 2) of the (4H, K) weight matching X's column order; pre (row stride ld_pre, 0 = one
@@ -240,7 +248,8 @@ typedef struct GtDecoderFwd {
     float* X2; int64_t ld2;    /* (ring, Bp, ld2) zero-initialised */
     float* part;               /* slab scratch of the attention chain */
     float* part2;              /* slab scratch of the decoder-LSTM chain (ring > 1) */
-    int32_t ring;              /* 1: one stream; 2..8: two-chain pipelining over a ring of X2 buffers */
+    int32_t ring;              /* 1: one stream; 2..32: two-chain pipelining over a ring of X2 buffers, cross-stream
+                                  hand-offs every ring/2 steps */
     float* energies;           /* (B, Ti) */
     float* gates1; float* c1;  /* (To, Bp, 4Ha), (To+1, Bp, Ha) c1[0] = 0 */
     float* gates2; float* c2;  /* (To, Bp, 4Hd), (To+1, Bp, Hd) */

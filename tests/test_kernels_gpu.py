@@ -211,6 +211,25 @@ def test_cell_bwd_query_fused(dev, Bsz, H, A, S):
     close(dcp[:Bsz], (dcell * gf)[:Bsz], rtol=1e-5, atol=1e-5, what='dc_prev')
 
 
+def test_rec_gemm2_two_problems_one_launch(dev):
+    """gt_rec_gemm2: two products of different shapes in one launch == two gt_rec_gemm calls."""
+    from gantron_amd import ops
+    from gantron_amd.engine import pack_rec
+    Bp = 64
+    outs = []
+    args = []
+    for (N, K, S, seed) in ((2048, 4096, 8, 1), (3072, 4096, 5, 2)):
+        W = g(N, K, seed=seed, scale=0.05)
+        X = g(Bp, K, seed=seed + 10)
+        Wp = pack_rec(W.to(dev), N, N, K)
+        part = torch.full((S, Bp, N), float('nan'), device=dev)
+        args += [X.to(dev), K, Wp, part, N, K, S, Bp * N]
+        outs.append((X.double() @ W.double().t(), part))
+    ops.call('gt_rec_gemm2', *args, Bp // 16)
+    for want, part in outs:
+        close(part.sum(0), want, rtol=1e-5, atol=1e-3, what='rec_gemm2')
+
+
 def test_lstm_cell_fwd_bwd(dev):
     from gantron_amd import ops
     B, H, S, p = 5, 48, 3, 0.1
