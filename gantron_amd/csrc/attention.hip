@@ -19,6 +19,8 @@ void gt_launch_attn_energies_bwd_mfma(GtAttnDims d, const float* dw, const float
                                       const float* Wd, const float* v, const int* lengths, float* dq, long ld_dq,
                                       float* dpm, float* dwcat_out, float* acc, const float* wpack, hipStream_t st);
 int gt_attn_wpack_elems_mfma();
+int gt_attn_acc_per_mfma();
+void gt_launch_attn_acc_reduce_mfma(const float* acc, int nwg, float* dv, float* dWd, float* dWc, hipStream_t st);
 void gt_launch_attn_pack_weights(const float* Wc, const float* Wd, float* out, hipStream_t st);
 
 namespace {
@@ -631,8 +633,12 @@ int check_dims(const GtAttnDims& d, const char* who) {
 
 extern "C" int32_t gt_attn_chunks(int32_t Ti) { return cdiv(Ti, CT); }
 
+static bool use_mfma(const GtAttnDims& d) { return d.A == 128 && d.F == 32 && d.Kc == 31 && !getenv("GANTRON_ATTN_VALU"); }
+
 extern "C" int64_t gt_attn_acc_elems(GtAttnDims d) {
-    return (int64_t)d.B * cdiv(d.Ti, CT) * (d.A + d.A * d.F + d.F * 2 * d.Kc);
+    // per workgroup: the logical [dv | dWd | dWc] block, or the matrix-core kernel's register-order block
+    const int per = use_mfma(d) ? gt_attn_acc_per_mfma() : d.A + d.A * d.F + d.F * 2 * d.Kc;
+    return (int64_t)d.B * cdiv(d.Ti, CT) * per;
 }
 
 extern "C" int64_t gt_attn_wpack_elems(GtAttnDims d) {
@@ -783,6 +789,11 @@ extern "C" int gt_attn_acc_reduce(GtAttnDims d, const float* acc, float* dv, flo
     GT_REQUIRE(acc && dv && dWd && dWc, GT_E_ARG, "gt_attn_acc_reduce: NULL pointer");
     const int per = d.A + d.A * d.F + d.F * 2 * d.Kc;
     const int nwg = d.B * cdiv(d.Ti, CT);
+    if (use_mfma(d)) {
+        gt_launch_attn_acc_reduce_mfma(acc, nwg, dv, dWd, dWc, (hipStream_t)stream);
+        GT_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(attn_acc_reduce_kernel, dim3(cdiv(per, 256)), dim3(256), 0, (hipStream_t)stream, acc, nwg, per,
                        d.A, d.A * d.F, dv, dWd, dWc);
     GT_LAUNCH_CHECK();

@@ -26,6 +26,7 @@ constexpr int LDL = 36;    // locf / dlocf rows [tl][f]
 constexpr int LDS_ = 132;  // ds rows [tl][d]
 constexpr int LDG = 66;    // g rows [tl][kk]
 constexpr int WL = 64;     // window row length (32 + 30 used)
+constexpr int PER_MFMA = A + 256 * 16 + 256 * 8;   // accumulator slab of one workgroup in register order
 
 struct SharedM {
     alignas(16) float wc[F * LDC];
@@ -235,8 +236,9 @@ __global__ __launch_bounds__(256) void attn_energies_bwd_mfma(GtAttnDims d, cons
     if (lengths != nullptr && t0 >= lengths[b]) return;      // all-padding chunk: every gradient is zero
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, kq = lane >> 4;
-    constexpr int PER = A + A * F + F * KK;
-    float* acc_wg = acc_slabs + ((long)b * gridDim.x + blockIdx.x) * PER;
+    // this workgroup's accumulator slab in the kernel's own register order (gt_attn_acc_reduce un-permutes it):
+    // [dv: 128][dWd: thread*16 + (ml*2+nt)*4 + e][dWc: thread*8 + nl*4 + e] -> float4 loads / stores
+    float* acc_wg = acc_slabs + ((long)b * gridDim.x + blockIdx.x) * PER_MFMA;
     // every global input is requested here, unconditionally (clamped indices): pm and the dpm accumulator in
     // accumulator layout, this workgroup's dv / dWd / dWc accumulator slab, and the softmax row.  The kernel is
     // then one memory round trip deep instead of five.
@@ -251,18 +253,21 @@ __global__ __launch_bounds__(256) void attn_energies_bwd_mfma(GtAttnDims d, cons
     float old_dv[2], old_wd[2][2][4], old_wc[2][4];
 #pragma unroll
     for (int nl = 0; nl < 2; ++nl) old_dv[nl] = acc_wg[32 * wave + 16 * nl + r];
+    {
+        const float4* pw = reinterpret_cast<const float4*>(acc_wg + A + threadIdx.x * 16);
 #pragma unroll
-    for (int ml = 0; ml < 2; ++ml)
+        for (int ml = 0; ml < 2; ++ml)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < 2; ++nt) {
+                const float4 t = pw[ml * 2 + nt];
+                old_wd[ml][nt][0] = t.x; old_wd[ml][nt][1] = t.y; old_wd[ml][nt][2] = t.z; old_wd[ml][nt][3] = t.w;
+            }
+        const float4* pc = reinterpret_cast<const float4*>(acc_wg + A + A * F + threadIdx.x * 8);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                old_wd[ml][nt][e] = acc_wg[A + (32 * wave + 16 * ml + 4 * kq + e) * F + 16 * nt + r];
-#pragma unroll
-    for (int nl = 0; nl < 2; ++nl) {
-        const int kk = min(16 * (2 * (wave & 1) + nl) + r, KK - 1);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) old_wc[nl][e] = acc_wg[A + A * F + (16 * (wave >> 1) + 4 * kq + e) * KK + kk];
+        for (int nl = 0; nl < 2; ++nl) {
+            const float4 t = pc[nl];
+            old_wc[nl][0] = t.x; old_wc[nl][1] = t.y; old_wc[nl][2] = t.z; old_wc[nl][3] = t.w;
+        }
     }
     // softmax backward: de = w * (dw - sum_t w*dw); the first 256 positions are prefetched, one per thread
     const long ti = (long)b * d.Ti + min((int)threadIdx.x, d.Ti - 1);
@@ -370,13 +375,13 @@ __global__ __launch_bounds__(256) void attn_energies_bwd_mfma(GtAttnDims d, cons
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) c4[ml][nt] = mfma4(a[ml], bb[nt], c4[ml][nt]);
         }
+        float4* pw = reinterpret_cast<float4*>(acc_wd + threadIdx.x * 16);
 #pragma unroll
         for (int ml = 0; ml < 2; ++ml)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    acc_wd[(32 * wave + 16 * ml + 4 * kq + e) * F + 16 * nt + r] = old_wd[ml][nt][e] + c4[ml][nt][e];
+                pw[ml * 2 + nt] = make_float4(old_wd[ml][nt][0] + c4[ml][nt][0], old_wd[ml][nt][1] + c4[ml][nt][1],
+                                              old_wd[ml][nt][2] + c4[ml][nt][2], old_wd[ml][nt][3] + c4[ml][nt][3]);
     }
     __syncthreads();                                   // dlocf complete
     // G5: dWc[f][kk] += dlocf^T . im2col ; wave w: filter tile mt = w>>1, kk tiles nt in {2*(w&1), 2*(w&1)+1}
@@ -409,10 +414,9 @@ __global__ __launch_bounds__(256) void attn_energies_bwd_mfma(GtAttnDims d, cons
         for (int nl = 0; nl < 2; ++nl) {
             const int kk = 16 * (2 * (wave & 1) + nl) + r;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (kk < KK) acc_wc[(16 * mt + 4 * kq + e) * KK + kk] = old_wc[nl][e] + c5[nl][e];
-                S.g[(16 * mt + 4 * kq + e) * LDG + kk] = c6[nl][e];
-            }
+            for (int e = 0; e < 4; ++e) S.g[(16 * mt + 4 * kq + e) * LDG + kk] = c6[nl][e];
+            reinterpret_cast<float4*>(acc_wc + threadIdx.x * 8)[nl] =
+                make_float4(old_wc[nl][0] + c5[nl][0], old_wc[nl][1] + c5[nl][1], old_wc[nl][2] + c5[nl][2], old_wc[nl][3] + c5[nl][3]);
         }
     }
     __syncthreads();                                   // g complete
@@ -449,6 +453,30 @@ void gt_launch_attn_energies_bwd_mfma(GtAttnDims d, const float* dw, const float
                        dq, ld_dq, dpm, dwcat_out, acc, wpack);
 }
 
+__global__ void attn_acc_reduce_mfma_kernel(const float* acc, int nwg, float* dv, float* dWd, float* dWc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= PER_MFMA) return;
+    float s = 0.f;
+    for (int w = 0; w < nwg; ++w) s += acc[(long)w * PER_MFMA + i];
+    if (i < A) { dv[i] += s; return; }
+    int j = i - A;
+    if (j < 256 * 16) {            // dWd: thread*16 + (ml*2 + nt)*4 + e  ->  row 32w + 16ml + 4kq + e, column 16nt + r
+        const int tid = j >> 4, q = j & 15, ml = q >> 3, nt = (q >> 2) & 1, e = q & 3;
+        const int wave = tid >> 6, lane = tid & 63, r = lane & 15, kq = lane >> 4;
+        dWd[(32 * wave + 16 * ml + 4 * kq + e) * F + 16 * nt + r] += s;
+        return;
+    }
+    j -= 256 * 16;                 // dWc: thread*8 + nl*4 + e  ->  filter 16*(wave>>1) + 4kq + e, tap 16*(2*(wave&1)+nl) + r
+    const int tid = j >> 3, q = j & 7, nl = q >> 2, e = q & 3;
+    const int wave = tid >> 6, lane = tid & 63, r = lane & 15, kq = lane >> 4;
+    const int kk = 16 * (2 * (wave & 1) + nl) + r;
+    if (kk < KK) dWc[(16 * (wave >> 1) + 4 * kq + e) * KK + kk] += s;
+}
+
+int gt_attn_acc_per_mfma() { return PER_MFMA; }
+void gt_launch_attn_acc_reduce_mfma(const float* acc, int nwg, float* dv, float* dWd, float* dWc, hipStream_t st) {
+    hipLaunchKernelGGL(attn_acc_reduce_mfma_kernel, dim3((PER_MFMA + 255) / 256), dim3(256), 0, st, acc, nwg, dv, dWd, dWc);
+}
 int gt_attn_wpack_elems_mfma() { return F * LDC + A * LDD; }
 void gt_launch_attn_pack_weights(const float* Wc, const float* Wd, float* out, hipStream_t st) {
     hipLaunchKernelGGL(attn_pack_weights_kernel, dim3(8), dim3(256), 0, st, Wc, Wd, out);
