@@ -573,9 +573,6 @@ class GeneratorEngine:
         hc, nout = Hd + E, n_mel + 1
 
         PHASES.mark(None)
-        # weight-gradient GEMMs issued from here to the end of the decoder loop run UNDER that loop (leaf stream)
-        gentle = ops.splitk_target(ops.SPLITK_OVERLAPPED)
-        gentle.__enter__()
         # ---- PostNet backward (channels-last)
         dmel_cl = _f32(B * To, n_mel, device=dev)
         if dmel is not None:
@@ -589,6 +586,9 @@ class GeneratorEngine:
             call('gt_axpby', dmel_cl, 1.0, dx, 1.0, dmel_cl, B * To * n_mel)
 
         PHASES.mark('b.postnet')
+        # weight-gradient GEMMs issued from here to the end of the decoder loop run UNDER that loop (leaf stream)
+        gentle = ops.splitk_target(ops.SPLITK_OVERLAPPED)
+        gentle.__enter__()
         # ---- projection backward: gradient w.r.t. [h_dec | ctx] of every step
         dout = _f32(To, Bp, nout, device=dev)
         call('gt_permute3', dmel_cl, n_mel, To * n_mel, 1, To, B, n_mel, dout, Bp * nout, nout, 0, 1.0)
