@@ -226,7 +226,7 @@ def main():
         pair(args.warmup + i)
     sync()
     elapsed = time.perf_counter() - t0
-    prof_out = (ctypes.c_double * 40)()
+    prof_out = (ctypes.c_double * 42)()
     _lib.check(lib.gt_prof_end(prof_out), 'gt_prof_end')
     log(f'timed region: {elapsed:.3f} s for {args.steps} pairs')
     if world > 1:
@@ -263,8 +263,11 @@ def main():
     cpu = None
     if rank == 0:
         out = prof_out
-        null_ms = null_us.value * 1e-3          # event-bracket time of an empty kernel (launch latency)
-        # every bracket = kernel execution + the launch latency an empty kernel also shows: subtract it
+        # a bracket = kernel duration (dispatch begin to end, what rocprofv3 reports) + the latency of the two event
+        # packets; that latency, in situ = bracket of an empty kernel on the same busy streams - the empty kernel's own
+        # duration (gt_prof_calibrate: start / stop timestamps of its dispatch)
+        null_bracket_ms = (out[41] / out[40]) if out[40] > 0 else 0.0
+        null_ms = max(null_bracket_ms - null_us.value * 1e-3, 0.0)
         fam = [dict(name=FAMILIES[f], launches=int(out[4 * f]),
                     ms=max(out[4 * f + 1] - null_ms * out[4 * f], 1e-9) if out[4 * f] else 0.0, flops=out[4 * f + 2],
                     bytes=out[4 * f + 3], seen=int(out[32 + f])) for f in range(8)]
@@ -294,7 +297,7 @@ def main():
             pass
         roof.update(kernel=KERNEL_OF[dom['name']], sampled_launches=dom['launches'], sample_stride=PROF_STRIDE,
                     avg_launch_us=avg_ms * 1e3,
-                    event_bracket_null_us=null_us.value,
+                    event_latency_us=null_ms * 1e3, empty_kernel_bracket_us=null_bracket_ms * 1e3, empty_kernel_us=null_us.value,
                     families={r['name']: dict(launches=r['launches'], ms=round(r['ms'], 3), all_launches=r['seen'],
                                               est_ms_per_pair=round(r['est_total_ms'] / args.steps, 2),
                                               tflops=round(r['flops'] / max(r['ms'], 1e-9) / 1e9, 2),

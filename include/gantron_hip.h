@@ -43,14 +43,18 @@ int64_t gt_abi_sizeof(int32_t which);
  * 1 sgemm, 2 attn_energies_fwd, 3 attn_context_fwd, 4 attn_context_bwd, 5 attn_energies_bwd,
  * 6 lstm_cell_fwd, 7 lstm_cell_bwd): out[4f] bracketed launches, out[4f+1] their total ms, out[4f+2]
  * their algorithmic flops, out[4f+3] their algorithmic bytes, and out[32+f] ALL launches of the family
- * issued while profiling (bracketed or not).  `out` is a HOST array of 40 doubles.  Not thread-safe. */
+ * issued while profiling (bracketed or not); with sampling, every 4th bracket is followed by the same bracket
+ * around an EMPTY kernel on the same stream: out[40] their count, out[41] their total ms.  `out` is a HOST array of
+ * 42 doubles.  Not thread-safe.  A bracket = kernel duration (dispatch begin to end) + event latency, so the
+ * duration of a sampled kernel is bracket - (empty-kernel bracket - empty-kernel duration), the latter from
+ * gt_prof_calibrate. */
 int gt_prof_begin(void);
 /* bracket only every stride-th launch of each family (the millisecond-scale sgemm family every
  * max(1, stride/16)-th: its few, very unequal launches need a denser sample and do not feel the bracket) */
 int gt_prof_begin_sampled(int32_t stride);
 int gt_prof_end(double* out);
-/* average event-bracket time (us) of an EMPTY kernel on `stream`: the launch latency every bracket
- * includes on top of the kernel's execution time (HOST pointer out_us) */
+/* duration (us) of the empty calibration kernel itself, from the start / stop timestamps of its own dispatch on the
+ * idle `stream` (HOST pointer out_us) */
 int gt_prof_calibrate(int32_t n, double* out_us, void* stream);
 
 /* ------------------------------------------------------------------------------------------ GEMM
