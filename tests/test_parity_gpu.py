@@ -192,3 +192,67 @@ def test_midsize_against_oracle(dev, case):
         except AssertionError as e:
             bad.append(str(e))
     assert not bad, '\n'.join(bad)
+
+
+def test_full_size_batch_is_consistent_with_its_sub_batch(dev):
+    """Size-independent property at the benchmark's full dimensions (B=64 LJSpeech-shaped batch, E=1024, To up to
+    870): in evaluation mode (BatchNorm running statistics) an utterance's outputs depend only on that utterance, so
+    the first 8 items decoded inside the batch of 64 must equal the same 8 items decoded as their own batch (other
+    row padding Bp, other Ti/To maxima, other workgroup partitioning), and padded positions must carry the
+    reference's fill values (0 / 1e3, model.py:638-641)."""
+    import bench
+    from gantron_amd import ops
+    from gantron_amd.hparams import HParams
+    from gantron_amd.model import Tacotron2
+    hp = HParams('use_labels=False,use_noise=True')
+    torch.manual_seed(0)
+    G = Tacotron2(hp).to(dev).eval()
+    with torch.no_grad():
+        for k, v in G.state_dict().items():
+            if k.endswith('running_mean'):
+                v.copy_(torch.randn_like(v) * 0.05)
+            if k.endswith('running_var'):
+                v.copy_(torch.rand_like(v) * 0.5 + 0.75)
+    batch = bench.ljspeech_shaped_batch(hp, 64, seed=7)
+    text, il, mel, gate, spk, emo, ol = batch
+    To, Ti = mel.shape[2], text.shape[1]
+    g = torch.Generator().manual_seed(3)
+    keeps = [(torch.rand(To, 64, hp.prenet_dim, generator=g) >= 0.5).to(torch.uint8) for _ in range(2)]
+    noise = torch.rand(64, hp.noise_size, generator=g)
+
+    def run(idx):
+        n = len(idx)
+        Bp = ops.roundup(n, 16) if n <= 64 else ops.roundup(n, 64)
+        sub = tuple(t[idx] for t in batch)
+        to, ti = int(sub[6].max()), int(sub[1].max())
+        sub = (sub[0][:, :ti], sub[1], sub[2][:, :, :to].contiguous(), sub[3][:, :to].contiguous(), sub[4], sub[5], sub[6])
+        pk = []
+        for k in keeps:
+            kk = torch.zeros(to, Bp, hp.prenet_dim, dtype=torch.uint8)
+            kk[:, :n] = k[:to, idx]
+            pk.append(kk.to(dev))
+        G.rng_override = dict(prenet_keep=pk, noise=noise[idx].contiguous().to(dev))
+        with torch.no_grad():
+            x, _ = G.parse_batch(sub)
+            out = G(x)
+        return [o.cpu() for o in out], sub
+
+    idx8 = torch.arange(8)
+    full, _ = run(torch.arange(64))
+    small, sub8 = run(idx8)
+    to8, ti8 = small[0].shape[2], small[3].shape[2]
+    for b in range(8):
+        L, Lt = int(ol[b]), int(il[b])
+        close(full[0][b, :, :L], small[0][b, :, :L], rtol=1e-4, atol=1e-5, what=f'mel item {b}')
+        close(full[1][b, :, :L], small[1][b, :, :L], rtol=1e-4, atol=1e-5, what=f'mel_post item {b}')
+        close(full[2][b, :L], small[2][b, :L], rtol=1e-4, atol=1e-5, what=f'gate item {b}')
+        close(full[3][b, :L, :Lt], small[3][b, :L, :Lt], rtol=1e-4, atol=1e-6, what=f'alignment item {b}')
+        if Lt < Ti:
+            assert float(full[3][b, :L, Lt:].abs().max()) == 0.0        # masked encoder positions get no weight
+        if L < To:
+            assert float(full[0][b, :, L:].abs().max()) == 0.0 and float(full[1][b, :, L:].abs().max()) == 0.0
+            assert float(full[2][b, L:].min()) == 1e3
+    # the attention weights of every decoded frame are a distribution over the valid encoder positions
+    sums = full[3].sum(-1)
+    for b in range(64):
+        close(sums[b, :int(ol[b])], torch.ones(int(ol[b])), rtol=1e-5, atol=1e-5, what=f'alignment rows sum to 1 (item {b})')
