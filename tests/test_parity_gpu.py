@@ -142,7 +142,7 @@ def test_full_size_matches_reference_summaries(dev, golden_dir, name):
     assert not bad, '\n'.join(bad)
 
 
-@pytest.mark.parametrize('case', ['ragged5', 'batch70'])
+@pytest.mark.parametrize('case', ['ragged5', 'batch70', 'full_dims_b64', 'full_dims_b20'])
 def test_midsize_against_oracle(dev, case):
     """B=5 (padded to 16 rows) with ragged lengths and To not a multiple of the discriminator window, and
     B=70 (> 64 rows: two 64-row blocks per recurrent launch): HIP path vs the CPU oracle on identical
@@ -154,6 +154,15 @@ def test_midsize_against_oracle(dev, case):
                  'attention_location_kernel_size=9,postnet_embedding_dim=32,noise_size=32,discriminator_dim=32,'
                  'discriminator_window=6')
     in_lens, out_lens = [40, 33, 33, 20, 9], [57, 70, 41, 25, 13]
+    if case.startswith('full_dims'):
+        # the reference's default dimensions (E=1024, 1024-unit LSTMs, attention 128/32/31) at the benchmark's batch
+        # size (64 rows = four 16-row MFMA tiles) and at 20 rows (two tiles), short sequences so that the CPU oracle
+        # finishes in seconds: this is the kernel configuration bench.py runs
+        nb = 64 if case.endswith('b64') else 20
+        hp = HParams('use_labels=False,use_noise=True')
+        g = torch.Generator().manual_seed(11)
+        in_lens = sorted(torch.randint(5, 19, (nb,), generator=g).tolist(), reverse=True)
+        out_lens = torch.randint(21, 27, (nb,), generator=g).tolist()
     if case == 'batch70':
         g = torch.Generator().manual_seed(3)
         in_lens = sorted(torch.randint(3, 15, (70,), generator=g).tolist(), reverse=True)
