@@ -22,6 +22,7 @@ KC, RC, IM2COL_K, IM2COL_R = 0, 1, 2, 3
 SPLITK_EXPOSED = int(_os.environ.get('GANTRON_SPLITK_TARGET', '1024'))
 SPLITK_OVERLAPPED = int(_os.environ.get('GANTRON_SPLITK_OVERLAPPED', '128'))
 SPLITK_TARGET = SPLITK_EXPOSED
+FWD_SPLITK = _os.environ.get('GANTRON_FWD_SPLITK', '1') != '0'
 
 
 class splitk_target:
@@ -87,6 +88,18 @@ def default_split_k(M, N, K, batch=1):
     if tiles >= SPLITK_TARGET or K < 1024:
         return 1
     return max(1, min(-(-SPLITK_TARGET // tiles), K // 512, 64))
+
+
+def forward_split_k(M, N, K):
+    """Split-K for an activation GEMM whose output grid is too small to fill the device (discriminator and encoder
+    convolutions: 88-376 tiles of 128x128): the reduction is split until ~768 workgroups exist, each keeping at
+    least 1024 of K; the output is zero-filled and accumulated with fp32 atomics.  1 = no split."""
+    if not FWD_SPLITK or M <= 64 or N <= 64 or K < 2048:
+        return 1
+    tiles = -(-M // 128) * -(-N // 128)
+    if tiles >= 512:
+        return 1
+    return max(1, min(-(-768 // tiles), K // 1024))
 
 
 def sgemm(A, B, C, M, N, K, ldc=None, bias=None, accumulate=False, split_k=1, batch=1,
@@ -183,17 +196,20 @@ def conv_weight_bwd(W):
 
 def conv1d_fwd(x, Wf, bias, B, T, Cin, Cout, K, dil):
     """Channels-last Conv1d with 'same' padding: x (B*T, Cin) -> (B*T, Cout)."""
-    out = torch.empty(B * T, Cout, device=x.device, dtype=torch.float32)
     pad = dil * (K - 1) // 2
+    sk = forward_split_k(B * T, Cout, K * Cin)
+    out = (torch.zeros if sk > 1 else torch.empty)(B * T, Cout, device=x.device, dtype=torch.float32)
     sgemm(Operand(x, IM2COL_K, T=T, C=Cin, dil=dil, pad=pad), Operand(Wf, KC, ld=K * Cin), out, B * T, Cout, K * Cin,
-          bias=bias)
+          bias=bias, accumulate=sk > 1, split_k=sk)
     return out
 
 
 def conv1d_dx(dy, Wb, B, T, Cin, Cout, K, dil):
-    out = torch.empty(B * T, Cin, device=dy.device, dtype=torch.float32)
     pad = dil * (K - 1) // 2
-    sgemm(Operand(dy, IM2COL_K, T=T, C=Cout, dil=dil, pad=pad), Operand(Wb, KC, ld=K * Cout), out, B * T, Cin, K * Cout)
+    sk = forward_split_k(B * T, Cin, K * Cout)
+    out = (torch.zeros if sk > 1 else torch.empty)(B * T, Cin, device=dy.device, dtype=torch.float32)
+    sgemm(Operand(dy, IM2COL_K, T=T, C=Cout, dil=dil, pad=pad), Operand(Wb, KC, ld=K * Cout), out, B * T, Cin, K * Cout,
+          accumulate=sk > 1, split_k=sk)
     return out
 
 
