@@ -282,3 +282,71 @@ def test_train_loop_on_raw_audio(dev, tmp_path):
     out = tmp_path / 'out'
     T.train(str(out), None, False, 1, 0, 'g', hp, str(wavs) + '/')
     assert os.path.isdir(out)
+
+
+_DP_WORKER = r'''
+import os, sys
+rank, port, root, out = int(sys.argv[1]), sys.argv[2], sys.argv[3], sys.argv[4]
+for p in (root, os.path.join(root, 'tests'), os.path.join(root, 'tests', 'golden')):
+    sys.path.insert(0, p)
+import numpy as np, torch, torch.distributed as dist
+import common
+from gantron_amd.distributed import apply_gradient_allreduce
+from gantron_amd.hparams import HParams
+from gantron_amd.loss_function import Tacotron2Loss
+from gantron_amd.model import Discriminator, Tacotron2
+from gantron_amd.optim import FlatAdam
+from gantron_amd.train_steps import discriminator_step, generator_step
+world = int(sys.argv[5])
+hp = HParams(sys.argv[6])
+dev = torch.device('cuda:0')
+if world > 1:
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', world_size=world, rank=rank)
+torch.manual_seed(7 + 13 * (rank if world > 1 else 0))     # different initial weights per rank: the wrap must broadcast rank 0's
+G, D = Tacotron2(hp).to(dev).train(), Discriminator(hp).to(dev).train()
+g_opt, d_opt = FlatAdam(G, lr=1e-3), FlatAdam(D, lr=1e-3)
+if world > 1:
+    G, D = apply_gradient_allreduce(G), apply_gradient_allreduce(D)
+crit = Tacotron2Loss()
+lens = [([17, 12, 12, 5], [26, 33, 19, 8]), ([15, 9, 6, 4], [31, 22, 14, 9])][rank]
+batch = common.synthetic_batch(hp, lens[0], lens[1], seed=20 + rank)
+G.zero_grad(); D.zero_grad()
+_, gen = generator_step(G, D, g_opt, crit, batch, hp, iteration=0)
+g_grad = G._flat_grad.detach().cpu().numpy().copy()
+discriminator_step(G, D, d_opt, batch, gen, hp)
+d_grad = D._flat_grad.detach().cpu().numpy().copy()
+np.savez(os.path.join(out, f'w{world}_rank{rank}.npz'), g_grad=g_grad, d_grad=d_grad,
+         g_param=G._flat_param.detach().cpu().numpy(), d_param=D._flat_param.detach().cpu().numpy())
+if world > 1:
+    dist.destroy_process_group()
+'''
+
+
+def test_data_parallel_step_two_processes_on_one_gpu(dev, tmp_path):
+    """The distributed training step with world_size 2 (two processes sharing the one GPU of the test box, gloo
+    carrying the CUDA flat gradient buffers): both ranks start from rank 0's weights, and after the generator /
+    discriminator backward every rank holds the MEAN of the two per-rank gradients, hence identical parameters after
+    the optimizer step (reference distributed.py:126-173, train.py:79-91)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'dp_worker.py'
+    script.write_text(_DP_WORKER)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), '29587', root, str(tmp_path), '2', MID], env=env)
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    r0, r1 = np.load(tmp_path / 'w2_rank0.npz'), np.load(tmp_path / 'w2_rank1.npz')
+    for k in ('g_grad', 'd_grad', 'g_param', 'd_param'):
+        close(torch.from_numpy(r0[k]), torch.from_numpy(r1[k]), rtol=1e-6, atol=1e-7, what=f'rank0 vs rank1 {k}')
+    assert float(np.abs(r0['g_grad']).max()) > 0 and float(np.abs(r0['d_grad']).max()) > 0
+    # the same two batches, one process each, from rank 0's initial weights: the mean of their gradients is what the
+    # data-parallel ranks must hold (the discriminator step sees the generator output of the un-averaged first step
+    # in both settings, so the generator gradient is compared)
+    for r in range(2):
+        p = subprocess.Popen([sys.executable, str(script), str(r), '0', root, str(tmp_path), '1', MID], env=env)
+        assert p.wait(timeout=600) == 0
+    s0, s1 = np.load(tmp_path / 'w1_rank0.npz'), np.load(tmp_path / 'w1_rank1.npz')
+    close(torch.from_numpy(r0['g_grad']), torch.from_numpy((s0['g_grad'] + s1['g_grad']) / 2), rtol=1e-4, atol=1e-7,
+          what='averaged generator gradient')
