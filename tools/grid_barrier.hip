@@ -1,0 +1,118 @@
+// Grid-barrier latency probe (development tool for the persistent decoder kernel sketched in DESIGN.md section 7):
+// how long does one all-workgroup barrier through a device-scope atomic counter take on this chip (8 XCDs), for
+// nwg co-resident workgroups?  Every spin is bounded: a lost arrival sets an error flag and the kernel exits.
+//   hipcc --offload-arch=gfx950 -O3 -o grid_barrier grid_barrier.hip && ./grid_barrier
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+__global__ void barrier_kernel(int* ctr, int* err, int rounds, int nwg, float* sink, int payload) {
+    __shared__ float s;
+    float acc = 0.f;
+    for (int r = 0; r < rounds; ++r) {
+        // some work and a store that the other workgroups read after the barrier (release / acquire path)
+        for (int i = 0; i < payload; ++i) acc += __sinf(acc + i);
+        if (threadIdx.x == 0) sink[blockIdx.x] = acc + r;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();                                   // release: publish this workgroup's stores
+            atomicAdd(&ctr[r], 1);
+            long spins = 0;
+            while (__hip_atomic_load(&ctr[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nwg) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > 20000000L) { atomicExch(err, 1); break; }
+            }
+            __threadfence();                                   // acquire
+            s = sink[(blockIdx.x + 1) % nwg];                  // read a neighbour's store
+        }
+        __syncthreads();
+        acc += s * 1e-9f;
+        if (*err) return;
+    }
+    if (threadIdx.x == 0) sink[blockIdx.x] = acc;
+}
+
+// Hierarchical variant: workgroups arrive at a per-XCD counter (blockIdx.x & 7: round-robin placement), the last
+// arrival of each XCD arrives at the global counter, waits for all 8 and then releases its XCD through a per-XCD flag
+// that the other workgroups of the XCD poll.
+__global__ void barrier2_kernel(int* xc, int* gc, int* xf, int* err, int rounds, int nwg, float* sink) {
+    __shared__ float s;
+    float acc = 0.f;
+    const int x = blockIdx.x & 7, per = nwg / 8;
+    for (int r = 0; r < rounds; ++r) {
+        if (threadIdx.x == 0) sink[blockIdx.x] = acc + r;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            const int prev = atomicAdd(&xc[r * 8 + x], 1);
+            long spins = 0;
+            if (prev == per - 1) {
+                atomicAdd(&gc[r], 1);
+                while (__hip_atomic_load(&gc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 8) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > 20000000L) { atomicExch(err, 1); break; }
+                }
+                __hip_atomic_store(&xf[r * 8 + x], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                while (__hip_atomic_load(&xf[r * 8 + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > 20000000L) { atomicExch(err, 1); break; }
+                }
+            }
+            __threadfence();
+            s = sink[(blockIdx.x + 1) % nwg];
+        }
+        __syncthreads();
+        acc += s * 1e-9f;
+        if (*err) return;
+    }
+    if (threadIdx.x == 0) sink[blockIdx.x] = acc;
+}
+
+int main() {
+    const int rounds = 2000;
+    int *ctr, *err;
+    float* sink;
+    hipMalloc(&ctr, rounds * sizeof(int));
+    hipMalloc(&err, sizeof(int));
+    hipMalloc(&sink, 4096 * sizeof(float));
+    for (int nwg : {32, 64, 128, 256, 512}) {
+        for (int threads : {64, 512}) {
+            hipMemset(ctr, 0, rounds * sizeof(int));
+            hipMemset(err, 0, sizeof(int));
+            hipEvent_t e0, e1;
+            hipEventCreate(&e0); hipEventCreate(&e1);
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(barrier_kernel, dim3(nwg), dim3(threads), 0, 0, ctr, err, rounds, nwg, sink, 0);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, e0, e1);
+            int herr = 0;
+            hipMemcpy(&herr, err, sizeof(int), hipMemcpyDeviceToHost);
+            printf("nwg %4d x %3d threads: %.2f us per barrier%s\n", nwg, threads, ms * 1e3 / rounds, herr ? "  (ABORTED: lost arrival)" : "");
+        }
+    }
+    int *xc, *gc, *xf;
+    hipMalloc(&xc, rounds * 8 * sizeof(int));
+    hipMalloc(&gc, rounds * sizeof(int));
+    hipMalloc(&xf, rounds * 8 * sizeof(int));
+    for (int nwg : {64, 128, 256, 512}) {
+        hipMemset(xc, 0, rounds * 8 * sizeof(int));
+        hipMemset(gc, 0, rounds * sizeof(int));
+        hipMemset(xf, 0, rounds * 8 * sizeof(int));
+        hipMemset(err, 0, sizeof(int));
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(barrier2_kernel, dim3(nwg), dim3(64), 0, 0, xc, gc, xf, err, rounds, nwg, sink);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        int herr = 0;
+        hipMemcpy(&herr, err, sizeof(int), hipMemcpyDeviceToHost);
+        printf("hierarchical, nwg %4d: %.2f us per barrier%s\n", nwg, ms * 1e3 / rounds, herr ? "  (ABORTED: lost arrival)" : "");
+    }
+    return 0;
+}
