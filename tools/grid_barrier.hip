@@ -69,6 +69,53 @@ __global__ void barrier2_kernel(int* xc, int* gc, int* xf, int* err, int rounds,
     if (threadIdx.x == 0) sink[blockIdx.x] = acc;
 }
 
+// Flag-array variant (no contended atomics): every workgroup publishes its epoch in its own slot; the first
+// workgroup of each XCD (blockIdx.x < 8) gathers its XCD's slots with one wave-wide load per poll, publishes the
+// XCD's epoch, gathers the 8 XCD epochs the same way and releases its XCD through a flag the others poll.
+__global__ void barrier3_kernel(int* flags, int* gflags, int* rel, int* err, int rounds, int nwg, float* sink) {
+    __shared__ float s;
+    float acc = 0.f;
+    const int x = blockIdx.x & 7, per = nwg / 8, lane = threadIdx.x;
+    for (int r = 0; r < rounds; ++r) {
+        const int e = r + 1;
+        if (threadIdx.x == 0) sink[blockIdx.x] = acc + r;
+        __syncthreads();
+        if (threadIdx.x < 64) {                                   // wave 0
+            long spins = 0;
+            if (lane == 0) {
+                __threadfence();
+                __hip_atomic_store(&flags[blockIdx.x], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (blockIdx.x < 8) {
+                for (;;) {                                         // gather this XCD's arrivals (per <= 64)
+                    const int v = lane < per ? __hip_atomic_load(&flags[x + 8 * lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : e;
+                    if (__all(v >= e)) break;
+                    if (++spins > 20000000L) { if (lane == 0) atomicExch(err, 1); break; }
+                }
+                if (lane == 0) __hip_atomic_store(&gflags[x], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                for (;;) {                                         // gather the 8 XCDs
+                    const int v = lane < 8 ? __hip_atomic_load(&gflags[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : e;
+                    if (__all(v >= e)) break;
+                    if (++spins > 20000000L) { if (lane == 0) atomicExch(err, 1); break; }
+                }
+                if (lane == 0) __hip_atomic_store(&rel[x], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (lane == 0) {
+                while (__hip_atomic_load(&rel[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < e) {
+                    if (++spins > 20000000L) { atomicExch(err, 1); break; }
+                }
+            }
+            if (lane == 0) {
+                __threadfence();
+                s = sink[(blockIdx.x + 1) % nwg];
+            }
+        }
+        __syncthreads();
+        acc += s * 1e-9f;
+        if (*err) return;
+    }
+    if (threadIdx.x == 0) sink[blockIdx.x] = acc;
+}
+
 int main() {
     const int rounds = 2000;
     int *ctr, *err;
@@ -113,6 +160,27 @@ int main() {
         int herr = 0;
         hipMemcpy(&herr, err, sizeof(int), hipMemcpyDeviceToHost);
         printf("hierarchical, nwg %4d: %.2f us per barrier%s\n", nwg, ms * 1e3 / rounds, herr ? "  (ABORTED: lost arrival)" : "");
+    }
+    int *flags, *gflags, *rel;
+    hipMalloc(&flags, 512 * sizeof(int));
+    hipMalloc(&gflags, 8 * sizeof(int));
+    hipMalloc(&rel, 8 * sizeof(int));
+    for (int nwg : {64, 128, 256, 512}) {
+        hipMemset(flags, 0, 512 * sizeof(int));
+        hipMemset(gflags, 0, 8 * sizeof(int));
+        hipMemset(rel, 0, 8 * sizeof(int));
+        hipMemset(err, 0, sizeof(int));
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(barrier3_kernel, dim3(nwg), dim3(64), 0, 0, flags, gflags, rel, err, rounds, nwg, sink);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        int herr = 0;
+        hipMemcpy(&herr, err, sizeof(int), hipMemcpyDeviceToHost);
+        printf("flag array,   nwg %4d: %.2f us per barrier%s\n", nwg, ms * 1e3 / rounds, herr ? "  (ABORTED: lost arrival)" : "");
     }
     return 0;
 }
