@@ -839,3 +839,78 @@ class DiscriminatorEngine:
         dmel = _f32(B, n_mel, T, device=dev, zero=False)
         call('gt_disc_gather_bwd', dy, B, n_mel, T, win, dmel, 0)
         return dmel
+
+
+class LinearDiscriminatorEngine:
+    """LinearDiscriminator.forward + adversarial_loss (reference model.py:543-583): every item is cut into windows of
+    `discriminator_window` frames whose starts advance by window - randint(0, 6) (host RNG, drawn by the caller in
+    the reference's order) plus one final window ending at the item's length; each flattened window (frame-major)
+    goes through 3 x [Linear -> Dropout(.5) -> Tanh] -> Linear(1); the loss is the batch mean of the per-item means."""
+
+    def __init__(self, hp):
+        self.window, self.n_mel = hp.discriminator_window, hp.n_mel_channels
+
+    def forward(self, P, mel, starts, keeps, training=True):
+        """mel (B, n_mel, T) cuda; starts: per item the list of window start frames.  Returns loss (1,), saved."""
+        dev = mel.device
+        B, n_mel, T = mel.shape
+        win = self.window
+        rows, weights = [], []
+        for b, st in enumerate(starts):
+            for s0 in st:
+                rows.extend(range(b * T + s0, b * T + s0 + win))
+            weights.extend([1.0 / (B * len(st))] * len(st))
+        NW = len(weights)
+        idx = torch.tensor(rows, dtype=torch.int32, device=dev)
+        wgt = torch.tensor(weights, dtype=torch.float32, device=dev)
+        frames = _f32(B * T, n_mel, device=dev, zero=False)                 # (b, t) rows of n_mel
+        call('gt_permute3', mel.contiguous(), n_mel * T, 1, T, B, T, n_mel, frames, 0, 0, 0, 1.0)
+        x = _f32(NW, win * n_mel, device=dev, zero=False)
+        call('gt_gather_rows', frames, n_mel, idx, NW * win, n_mel, x, n_mel, 0)
+        sv = dict(B=B, T=T, NW=NW, idx=idx, wgt=wgt, layers=[])
+        for i in range(3):
+            Wt = P[f'discriminator.{i}.module.0.weight']
+            cout, cin = Wt.shape
+            y = ops.linear(x, Wt, NW, cin, cout)
+            keep = keeps[i] if (keeps is not None and training) else None
+            call('gt_bias_act_drop_fwd', y, P[f'discriminator.{i}.module.0.bias'], NW, cout, ACT_TANH, 1, keep, 0.5, y)
+            sv['layers'].append(dict(x=x, y=y, keep=keep))
+            x = y
+        W3 = P['discriminator.3.weight']
+        out = ops.linear(x, W3, NW, W3.shape[1], 1, bias=P['discriminator.3.bias'])
+        sv['h3'], sv['out'] = x, out
+        loss = _f32(1, device=dev)
+        sgemm(Operand(wgt, KC, ld=NW), Operand(out, RC, ld=1), loss, 1, 1, NW)           # sum_w wgt[w] * out[w]
+        return loss, sv
+
+    def backward(self, P, G, sv, dloss, scale=1.0, need_dinput=True, need_dparams=True):
+        B, T, NW = sv['B'], sv['T'], sv['NW']
+        dev = sv['out'].device
+        win, n_mel = self.window, self.n_mel
+        dout = _f32(NW, 1, device=dev, zero=False)
+        call('gt_scale_dev', sv['wgt'], dloss, float(scale), dout, NW, 0)                  # dout[w] = dloss * wgt[w]
+        W3 = P['discriminator.3.weight']
+        c3 = W3.shape[1]
+        if need_dparams:
+            ops.linear_dw(dout, sv['h3'], NW, 1, c3, G['discriminator.3.weight'])
+            acc_add(G['discriminator.3.bias'], ops.col_sums(dout, NW, 1))
+        dy = ops.linear_dx(dout, W3, NW, 1, c3)
+        for i in reversed(range(3)):
+            Wt = P[f'discriminator.{i}.module.0.weight']
+            cout, cin = Wt.shape
+            L = sv['layers'][i]
+            dz = _f32(NW, cout, device=dev, zero=False)
+            call('gt_bias_act_drop_bwd', dy, L['y'], NW, cout, ACT_TANH, 1, L['keep'], 0.5, dz)
+            if need_dparams:
+                ops.linear_dw(dz, L['x'], NW, cout, cin, G[f'discriminator.{i}.module.0.weight'])
+                acc_add(G[f'discriminator.{i}.module.0.bias'], ops.col_sums(dz, NW, cout))
+            if i > 0 or need_dinput:
+                dy = ops.linear_dx(dz, Wt, NW, cout, cin)
+        if not need_dinput:
+            return None
+        # scatter-add the window gradients back to their frames (windows overlap), then to (B, n_mel, T)
+        dframes = _f32(B * T, n_mel, device=dev)
+        call('gt_embedding_bwd', sv['idx'].long(), dy, n_mel, NW * win, n_mel, dframes)
+        dmel = _f32(B, n_mel, T, device=dev, zero=False)
+        call('gt_permute3', dframes, T * n_mel, 1, n_mel, B, n_mel, T, dmel, 0, 0, 0, 1.0)
+        return dmel

@@ -40,3 +40,11 @@ class DiscConv1d(nn.Module):
                          dilation=dilation, bias=bias)
         nn.init.xavier_uniform_(conv.weight, gain=nn.init.calculate_gain('tanh'))
         self.module = nn.Sequential(conv, nn.Dropout(dropout), nn.Tanh())
+
+
+class DiscDense(nn.Module):
+    """Linear -> Dropout(0.5) -> Tanh (reference layers.py:63-74); parameters only, the HIP engine does the arithmetic."""
+
+    def __init__(self, in_dim, out_dim, bias=True, dropout=0.5):
+        super().__init__()
+        self.module = nn.Sequential(nn.Linear(in_dim, out_dim, bias=bias), nn.Dropout(dropout), nn.Tanh())

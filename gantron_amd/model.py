@@ -19,8 +19,8 @@ import torch
 from torch import nn
 
 from . import ops
-from .engine import DiscriminatorEngine, GeneratorEngine
-from .layers import ConvNorm, DiscConv1d, LinearNorm
+from .engine import DiscriminatorEngine, GeneratorEngine, LinearDiscriminatorEngine
+from .layers import ConvNorm, DiscConv1d, DiscDense, LinearNorm
 from .utils import to_gpu
 
 
@@ -319,3 +319,75 @@ class Discriminator(nn.Module):
         _, sv = self.engine.forward(P, mel, lengths, self._keeps(mel.size(0), mel.size(2), mel.device),
                                     training=self.training)
         return sv['out'].view(mel.size(0), -1)
+
+
+class _LinearAdvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, mel, starts, keeps, *params):
+        P = dict(zip(module._param_names, (p.detach() for p in params)))
+        loss, sv = module.engine.forward(P, mel.detach(), starts, keeps, training=module.training)
+        ctx.module, ctx.sv, ctx.P = module, sv, P
+        ctx.need_in = mel.requires_grad
+        ctx.needs = [p.requires_grad for p in params]
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        module, P = ctx.module, ctx.P
+        need_p = any(ctx.needs)
+        G = {k: torch.zeros_like(P[k]) for k in module._param_names} if need_p else None
+        dmel = module.engine.backward(P, G, ctx.sv, dloss.contiguous().view(1), 1.0, need_dinput=ctx.need_in,
+                                      need_dparams=need_p)
+        grads = tuple(G[k] if need else None for k, need in zip(module._param_names, ctx.needs)) if need_p \
+            else (None,) * len(ctx.needs)
+        return (None, dmel, None, None) + grads
+
+
+class LinearDiscriminator(nn.Module):
+    """reference model.py:543-583 (hparams.discriminator_type == 'linear'): windows of `discriminator_window` frames
+    with random overlap (Python's global `random`, drawn in the reference's order) through three DiscDense layers and
+    a Linear(1); the adversarial loss is the batch mean of the per-item window means."""
+
+    def __init__(self, hparams):
+        super().__init__()
+        dd = hparams.discriminator_dim
+        self.discriminator = nn.Sequential(
+            DiscDense(hparams.discriminator_window * hparams.n_mel_channels, dd), DiscDense(dd, dd), DiscDense(dd, dd),
+            nn.Linear(dd, 1))
+        self.n_mel_channels = hparams.n_mel_channels
+        self.windows_size = hparams.discriminator_window
+        self.max_window_overlap = 6
+        self.engine = LinearDiscriminatorEngine(hparams)
+        self._param_names = [k for k, _ in self.named_parameters()]
+        self.dropout_source = DropoutSource(hparams.seed + 1)
+        self.rng_override = None
+
+    def window_starts(self, lengths):
+        """Window start frames per item, consuming random.randint exactly as model.py:571-574 does."""
+        import random
+        starts = []
+        for n in lengths:
+            st, s0 = [], 0
+            while s0 + self.windows_size < n:
+                st.append(s0)
+                s0 += self.windows_size - random.randint(0, self.max_window_overlap)
+            st.append(n - self.windows_size)
+            starts.append(st)
+        return starts
+
+    def adversarial_loss(self, inputs, target_length):
+        """inputs (B, n_mel, T); target_length (B,) (host or device)."""
+        lengths = [int(v) for v in target_length.tolist()]
+        assert min(lengths) >= self.windows_size, 'every item needs at least one full discriminator window'
+        starts = self.window_starts(lengths)
+        keeps = self.rng_override
+        if keeps is None and self.training:
+            nw = sum(len(s) for s in starts)
+            dims = [self.discriminator[i].module[0].out_features for i in range(3)]
+            keeps = [self.dropout_source.keep((nw, c), 0.5, inputs.device) for c in dims]
+        params = [p for _, p in self.named_parameters()]
+        return _LinearAdvFn.apply(self, inputs.contiguous(), starts, keeps, *params)
+
+    def forward(self, inputs):
+        """inputs (NW, window * n_mel) already-cut windows -> (NW, 1) (reference model.py:556-565)."""
+        raise NotImplementedError('call adversarial_loss(); the window-level forward is not part of the training path')

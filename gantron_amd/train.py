@@ -24,7 +24,7 @@ from .data_utils import DeviceBatches, TextAudioCollate, TextAudioLoader, TextMe
 from .distributed import apply_gradient_allreduce, init_distributed, reduce_tensor
 from .hparams import HParams
 from .loss_function import Tacotron2Loss
-from .model import Discriminator, Tacotron2
+from .model import Discriminator, LinearDiscriminator, Tacotron2
 from .optim import FlatAdam
 from .train_steps import discriminator_step, generator_step
 
@@ -49,10 +49,8 @@ def prepare_dataloaders(hparams, wavs_path):
 
 
 def load_model(hparams):
-    if hparams.discriminator_type == 'linear':
-        raise NotImplementedError("discriminator_type='linear' is outside the accelerated path")
     generator = Tacotron2(hparams).cuda()
-    discriminator = Discriminator(hparams).cuda()
+    discriminator = (LinearDiscriminator(hparams) if hparams.discriminator_type == 'linear' else Discriminator(hparams)).cuda()
     if hparams.distributed_run:
         generator = apply_gradient_allreduce(generator)
         discriminator = apply_gradient_allreduce(discriminator)

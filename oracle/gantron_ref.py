@@ -358,6 +358,29 @@ def adversarial_loss(P, mel: Tensor, lengths: Tensor, window: int, disc_keep, tr
 
 
 # ----------------------------------------------------------------------------- losses
+def linear_discriminator_loss(P, mel: Tensor, starts, window: int, keeps, training: bool = True) -> Tensor:
+    """LinearDiscriminator.adversarial_loss (model.py:567-583) with the window starts given (the reference draws them
+    with random.randint; the caller replays the same sequence).  mel (B, n_mel, T); keeps: 3 masks (NW, dim) over the
+    windows of all items in order."""
+    wins = []
+    counts = []
+    for b, st in enumerate(starts):
+        x = mel[b].t()                                   # (T, n_mel)
+        for s0 in st:
+            wins.append(x[s0:s0 + window].flatten())
+        counts.append(len(st))
+    h = torch.stack(wins)
+    for i in range(3):
+        h = h @ P[f'discriminator.{i}.module.0.weight'].t() + P[f'discriminator.{i}.module.0.bias']
+        h = torch.tanh(keep_scale(h, keeps[i] if (keeps is not None and training) else None, 0.5))
+    out = (h @ P['discriminator.3.weight'].t() + P['discriminator.3.bias']).squeeze(1)
+    loss, o = 0.0, 0
+    for n in counts:
+        loss = loss + out[o:o + n].mean()
+        o += n
+    return loss / len(counts)
+
+
 def attention_target(n_chars: int, n_frames: int, width: float = 0.5, sig: float = 3.0) -> Tensor:
     """attention_mask/gaussian, loss_function.py:40-52: row n is exp(-(t-c_n)^2/(width*sig)),
     c_n = n*(n_frames-1)//(n_chars-1) (integer floor)."""

@@ -323,8 +323,41 @@ def inference_case():
     print('wrote', path, os.path.getsize(path) // 1024, 'KiB')
 
 
+def linear_disc_case():
+    """LinearDiscriminator.adversarial_loss (model.py:543-583) on a small configuration: loss, parameter gradients and
+    the gradient w.r.t. the input spectrogram.  Window starts come from Python's global `random` (seeded here; the
+    HIP module and the oracle replay the same sequence); dropout masks are recorded per item and layer."""
+    import random
+    hp_string = 'discriminator_type=linear,n_mel_channels=8,discriminator_window=8,discriminator_dim=16'
+    hp = ref_hparams.HParams(hp_string)
+    torch.manual_seed(4321)
+    D = ref_model.LinearDiscriminator(hp).train()
+    g = torch.Generator().manual_seed(5)
+    lengths = torch.tensor([40, 27, 17])
+    mel = torch.randn(3, 8, 40, generator=g)
+    for b in range(3):
+        mel[b, :, int(lengths[b]):] = 0
+    mel.requires_grad_(True)
+    random.seed(99)
+    inj = Injector(common.MaskStream(404))
+    with inj:
+        loss = D.adversarial_loss(mel, lengths)
+        loss.backward()
+    blob = dict(hparams=np.array(hp_string), mel=mel.detach().numpy(), lengths=lengths.numpy(), random_seed=np.array(99),
+                loss=loss.detach().numpy(), dmel=mel.grad.numpy())
+    blob.update(common.pack_dict('state', {k: v.detach().clone() for k, v in D.state_dict().items()}))
+    blob.update(common.pack_dict('grad', {k: p.grad.clone() for k, p in D.named_parameters()}))
+    for i in range(3):                                   # per layer: the masks of all items, in item order
+        blob[f'keep{i}'] = torch.cat(inj.drops[i::3]).numpy()
+    path = os.path.join(HERE, 'linear_disc.npz')
+    np.savez_compressed(path, **blob)
+    print('wrote', path, os.path.getsize(path) // 1024, 'KiB', 'loss', float(loss))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['tiny', 'ops', 'full', 'vesus', 'allreduce', 'inference']
+    which = sys.argv[1:] or ['tiny', 'ops', 'full', 'vesus', 'allreduce', 'inference', 'linear']
+    if 'linear' in which:
+        linear_disc_case()
     if 'inference' in which:
         inference_case()
     if 'tiny' in which:

@@ -147,3 +147,23 @@ def test_inference_matches_reference(golden_dir, tag, frames):
     for name, t in zip(('mel', 'mel_post', 'gate', 'align'), out):
         assert tuple(t.shape) == tuple(ref[name].shape), name       # gate is (B,T,1) on this path
         _close(t, ref[name], rtol=2e-4, atol=1e-5, what=f'{tag}.{name}')
+
+
+def test_linear_discriminator_matches_reference(golden_dir):
+    """LinearDiscriminator.adversarial_loss of the reference (model.py:543-583): loss, every parameter gradient and
+    the gradient w.r.t. the input spectrogram; the window starts replay the reference's random.randint sequence."""
+    import random
+    from gantron_amd.model import LinearDiscriminator
+    z = _load(golden_dir, 'linear_disc.npz')
+    hp = HParams(str(z['hparams']))
+    P = {k: v.clone().requires_grad_(True) for k, v in common.unpack_dict(z, 'state').items()}
+    mel = torch.from_numpy(z['mel']).clone().requires_grad_(True)
+    random.seed(int(z['random_seed']))
+    starts = LinearDiscriminator(hp).window_starts(z['lengths'].tolist())
+    keeps = [torch.from_numpy(z[f'keep{i}']) for i in range(3)]
+    loss = R.linear_discriminator_loss(P, mel, starts, hp.discriminator_window, keeps)
+    loss.backward()
+    _close(loss.detach(), z['loss'], what='loss')
+    _close(mel.grad, z['dmel'], rtol=2e-4, atol=1e-7, what='d mel')
+    for k, v in common.unpack_dict(z, 'grad').items():
+        _close(P[k].grad, v, rtol=2e-4, atol=1e-7, what=f'grad {k}')

@@ -265,3 +265,24 @@ def test_full_size_batch_is_consistent_with_its_sub_batch(dev):
     sums = full[3].sum(-1)
     for b in range(64):
         close(sums[b, :int(ol[b])], torch.ones(int(ol[b])), rtol=1e-5, atol=1e-5, what=f'alignment rows sum to 1 (item {b})')
+
+
+def test_linear_discriminator_matches_reference_golden(dev, golden_dir):
+    """hparams.discriminator_type == 'linear' (reference model.py:543-583): adversarial loss, every parameter gradient
+    and the gradient w.r.t. the spectrogram through the HIP path, against the reference's own run."""
+    import random
+    from gantron_amd.hparams import HParams
+    from gantron_amd.model import LinearDiscriminator
+    z = np.load(os.path.join(golden_dir, 'linear_disc.npz'))
+    hp = HParams(str(z['hparams']))
+    D = LinearDiscriminator(hp).to(dev).train()
+    D.load_state_dict(common.unpack_dict(z, 'state'))
+    D.rng_override = [torch.from_numpy(z[f'keep{i}']).to(torch.uint8).contiguous().to(dev) for i in range(3)]
+    mel = torch.from_numpy(z['mel']).to(dev).requires_grad_(True)
+    random.seed(int(z['random_seed']))
+    loss = D.adversarial_loss(mel, torch.from_numpy(z['lengths']))
+    loss.backward()
+    close(loss, z['loss'], rtol=1e-4, atol=1e-6, what='loss')
+    close(mel.grad, z['dmel'], rtol=2e-3, atol=1e-7, what='d mel')
+    for k, v in common.unpack_dict(z, 'grad').items():
+        close(dict(D.named_parameters())[k].grad, v, rtol=2e-3, atol=1e-7, what=f'grad {k}')

@@ -350,3 +350,23 @@ def test_data_parallel_step_two_processes_on_one_gpu(dev, tmp_path):
     s0, s1 = np.load(tmp_path / 'w1_rank0.npz'), np.load(tmp_path / 'w1_rank1.npz')
     close(torch.from_numpy(r0['g_grad']), torch.from_numpy((s0['g_grad'] + s1['g_grad']) / 2), rtol=1e-4, atol=1e-7,
           what='averaged generator gradient')
+
+
+def test_steps_with_linear_discriminator(dev):
+    """hparams.discriminator_type = 'linear': the generator step (adversarial gradient into the spectrogram) and the
+    discriminator step run through the same step bodies and produce finite losses and non-zero gradients."""
+    from gantron_amd import train as T
+    from gantron_amd.hparams import HParams
+    from gantron_amd.loss_function import Tacotron2Loss
+    from gantron_amd.model import LinearDiscriminator
+    from gantron_amd.optim import FlatAdam
+    from gantron_amd.train_steps import discriminator_step, generator_step
+    hp = HParams(MID.replace('discriminator_window=6', 'discriminator_window=8') + ',discriminator_type=linear')
+    G, D = T.load_model(hp)
+    assert isinstance(D, LinearDiscriminator)
+    g_opt, d_opt = FlatAdam(G, lr=1e-3), FlatAdam(D, lr=1e-3)
+    batch = common.synthetic_batch(hp, [17, 12, 12, 5], [26, 33, 19, 9], seed=2)
+    losses, gen = generator_step(G.train(), D.train(), g_opt, Tacotron2Loss(), batch, hp, iteration=0)
+    dl = discriminator_step(G, D, d_opt, batch, gen, hp)
+    assert all(torch.isfinite(v).all() for v in losses.values() if v is not None)
+    assert torch.isfinite(dl['total']) and float(D._flat_grad.abs().max()) > 0 and float(G._flat_grad.abs().max()) > 0
