@@ -162,7 +162,12 @@ class ConvBNStack:
             cout, cin, k = W.shape
             bn = f'{self.prefix}.{i}.1'
             Wf = ops.conv_weight_fwd(W)
-            y = ops.conv1d_fwd(x, Wf, P[f'{self.prefix}.{i}.0.conv.bias'], B, T, cin, cout, k, 1)
+            cin_x = x.shape[1]
+            if cin_x != cin:        # input rows carry zero pad columns (the im2col operand needs channels % 4 == 0)
+                Wp = _f32(cout, k, cin_x, device=x.device)
+                Wp[:, :, :cin] = Wf
+                Wf = Wp
+            y = ops.conv1d_fwd(x, Wf, P[f'{self.prefix}.{i}.0.conv.bias'], B, T, cin_x, cout, k, 1)
             rows = B * T
             stats = mi = None
             if training:
@@ -197,7 +202,13 @@ class ConvBNStack:
             x_in = first_input_override if (i == 0 and first_input_override is not None) else s['x']
 
             def leaf(dconv=dconv, x_in=x_in, cin=cin, cout=cout, k=k, i=i):
-                ops.conv1d_dw(dconv, x_in, B, T, cin, cout, k, 1, G[f'{self.prefix}.{i}.0.conv.weight'])
+                gw = G[f'{self.prefix}.{i}.0.conv.weight']
+                if x_in.shape[1] != cin:                # zero-padded input channels: drop their (zero-input) rows
+                    dWp = _f32(cout, x_in.shape[1], k, device=dconv.device)
+                    ops.conv1d_dw(dconv, x_in, B, T, x_in.shape[1], cout, k, 1, dWp)
+                    acc_add(gw, dWp[:, :cin, :].contiguous())
+                else:
+                    ops.conv1d_dw(dconv, x_in, B, T, cin, cout, k, 1, gw)
                 acc_add(G[f'{self.prefix}.{i}.0.conv.bias'], ops.col_sums(dconv, rows, cout))
             LEAF.run(leaf, dconv, x_in)
             if i > 0 or need_dx:
@@ -214,12 +225,18 @@ class GeneratorEngine:
         self.P, self.Ha, self.Hd, self.A = hp.prenet_dim, hp.attention_rnn_dim, hp.decoder_rnn_dim, hp.attention_dim
         self.F, self.Kc = hp.attention_location_n_filters, hp.attention_location_kernel_size
         noise = hp.noise_size if hp.use_noise else 0
-        self.noise = noise
-        self.E = self.enc_dim + noise
         self.vesus = bool(hp.vesus_path)
         self.use_labels = bool(hp.use_labels and hp.vesus_path)
+        # encoder_inputs (hparams.py:102): labels and style noise are extra channels of the first encoder convolution
+        # (model.py:162-170, 649-651) instead of extra columns of the decoder memory (model.py:240-246, 659)
+        self.enc_in = bool(hp.encoder_inputs)
+        self.enc_labels = hp.n_labels if (self.enc_in and self.use_labels) else 0
+        self.enc_noise = noise if self.enc_in else 0
+        self.noise = 0 if self.enc_in else noise
+        self.mem_labels = 5 if (self.use_labels and not self.enc_in) else 0
+        self.E = self.enc_dim + self.noise
         if self.vesus:
-            self.E += hp.speakers_embedding + (5 if self.use_labels else 0)
+            self.E += hp.speakers_embedding + self.mem_labels
         self.enc_stack = ConvBNStack('encoder.convolutions', hp.encoder_n_convolutions,
                                      [ACT_RELU] * hp.encoder_n_convolutions)
         self.post_stack = ConvBNStack('postnet.convolutions', hp.postnet_n_convolutions,
@@ -255,9 +272,18 @@ class GeneratorEngine:
         Bp = sv['Bp']
         H, E, A = self.H, self.E, self.A
         # ---- embedding + encoder convolutions (channels-last rows = (b, t))
-        x = _f32(B * Ti, hp.symbols_embedding_dim, device=dev, zero=False)
-        call('gt_embedding_fwd', text, P['embedding.weight'], B * Ti, hp.symbols_embedding_dim, x,
-             hp.symbols_embedding_dim)
+        D0 = hp.symbols_embedding_dim
+        cin0 = roundup(D0 + self.enc_labels + self.enc_noise, 4)     # channels % 4 == 0 for the im2col operand
+        x = _f32(B * Ti, cin0, device=dev, zero=cin0 > D0)
+        call('gt_embedding_fwd', text, P['embedding.weight'], B * Ti, D0, x, cin0)
+        if cin0 > D0:                                   # [embedded text | labels | style noise | zero pad] per position
+            x3 = x.view(B, Ti, cin0)
+            if self.enc_labels:
+                x3[:, :, D0:D0 + self.enc_labels] = emotions[:, None, :]
+            if self.enc_noise:
+                noise = rng['noise']                    # (B, noise), or (B, Ti, noise) from an inference caller
+                c0 = D0 + self.enc_labels
+                x3[:, :, c0:c0 + self.enc_noise] = noise if noise.dim() == 3 else noise[:, None, :]
         sv['enc_conv'] = []
         x = self.enc_stack.forward(P, x, B, Ti, rng.get('enc_keep'), training, sv['enc_conv'])
         sv['enc_x3'] = x
@@ -307,7 +333,7 @@ class GeneratorEngine:
             call('gt_embedding_fwd', speaker_ids, P['speaker_embedding.weight'], B, se, spk, se)
             memory[:, :, col:col + se] = spk[:, None, :]
             col += se
-            if self.use_labels:
+            if self.mem_labels:
                 memory[:, :, col:col + 5] = emotions[:, None, :]
                 col += 5
             sv['speaker_ids'] = speaker_ids
@@ -768,7 +794,8 @@ class GeneratorEngine:
         PHASES.mark('b.bilstm')
         # ---- encoder convolutions + embedding
         demb = self.enc_stack.backward(P, G, dx3, B, Ti, sv['enc_conv'])
-        call('gt_embedding_bwd', sv['text'], demb, hp.symbols_embedding_dim, B * Ti, hp.symbols_embedding_dim,
+        # demb rows are [d embedded text | d labels | d noise]: only the text columns have a parameter behind them
+        call('gt_embedding_bwd', sv['text'], demb, demb.shape[1], B * Ti, hp.symbols_embedding_dim,
              G['embedding.weight'])
         LEAF.join()
         PHASES.mark('b.enc_conv')

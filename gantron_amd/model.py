@@ -88,13 +88,14 @@ class Postnet(nn.Module):
 class Encoder(nn.Module):
     def __init__(self, hparams):
         super().__init__()
-        if hparams.encoder_inputs:
-            raise NotImplementedError('encoder_inputs=True conditioning is outside the accelerated path')
         dim, k = hparams.encoder_embedding_dim, hparams.encoder_kernel_size
+        extra = 0
+        if hparams.encoder_inputs:                      # labels / style noise enter here (model.py:162-170)
+            extra = (hparams.n_labels if hparams.use_labels else 0) + (hparams.noise_size if hparams.use_noise else 0)
         self.convolutions = nn.ModuleList([
-            nn.Sequential(ConvNorm(dim, dim, kernel_size=k, stride=1, padding=(k - 1) // 2, dilation=1,
-                                   w_init_gain='relu'), nn.BatchNorm1d(dim))
-            for _ in range(hparams.encoder_n_convolutions)])
+            nn.Sequential(ConvNorm(dim + (extra if i == 0 else 0), dim, kernel_size=k, stride=1,
+                                   padding=(k - 1) // 2, dilation=1, w_init_gain='relu'), nn.BatchNorm1d(dim))
+            for i in range(hparams.encoder_n_convolutions)])
         self.lstm = nn.LSTM(dim, dim // 2, 1, batch_first=True, bidirectional=True)
 
 
@@ -127,10 +128,10 @@ class Decoder(nn.Module):
         super().__init__()
         if hparams.n_frames_per_step != 1:
             raise NotImplementedError('n_frames_per_step must be 1 (as in the reference, hparams.py:71)')
-        noise = hparams.noise_size
+        noise = 0 if hparams.encoder_inputs else hparams.noise_size          # model.py:240-246
         din = hparams.encoder_embedding_dim + noise
         if hparams.vesus_path:
-            din += hparams.speakers_embedding + (5 if hparams.use_labels else 0)
+            din += hparams.speakers_embedding + (5 if (hparams.use_labels and not hparams.encoder_inputs) else 0)
         self.decoder_in_dim = din
         self.prenet = Prenet(hparams.n_mel_channels, [hparams.prenet_dim, hparams.prenet_dim])
         self.attention_rnn = nn.LSTMCell(hparams.prenet_dim + din, hparams.attention_rnn_dim)
@@ -217,7 +218,8 @@ class Tacotron2(nn.Module):
     @torch.no_grad()
     def inference(self, text_inputs, style=None, emotions=None, speaker=None):
         """reference model.py:675-723: text (1,Ti) ids or a raw string; style (B,Ti,noise) / (B,1,noise) /
-        (B,noise) or None (drawn U[0,1) as :469 does); emotions (B,5); speaker LongTensor (B,).
+        (B,noise) or None (drawn U[0,1) as :469 does) -- with hparams.encoder_inputs the reference's layout is
+        (B,noise,Ti) / (B,noise,1) (:184-191); emotions (B,5); speaker LongTensor (B,).
         Returns [mel, mel_postnet, gate (B,T,1), alignments] cut at the stop gate."""
         hp = self.hparams
         dev = self.embedding.weight.device
@@ -232,6 +234,8 @@ class Tacotron2(nn.Module):
             if style is None:
                 style = src.uniform((B, hp.noise_size), dev)
             style = style.to(dev).float()
+            if hp.encoder_inputs and style.dim() == 3:  # Encoder.append_noise concatenates on channels: (B, noise, Ti|1)
+                style = style.transpose(1, 2)
             if style.dim() == 3 and style.size(1) == 1:
                 style = style[:, 0]
             style = style.contiguous()

@@ -225,20 +225,29 @@ def generator_forward(P, text: Tensor, text_lengths: Tensor, mels: Tensor, outpu
                       rng: Dict[str, object], speaker_ids: Optional[Tensor] = None,
                       emotions: Optional[Tensor] = None, use_labels: bool = False,
                       training: bool = True, mask_padding: bool = True, new_stats=None,
-                      p_att: float = 0.1, p_dec: float = 0.1):
+                      p_att: float = 0.1, p_dec: float = 0.1, encoder_inputs: bool = False):
     """Tacotron2.forward + parse_output, model.py:632-673.
     rng: dict with 'enc_keep' [3x(B,C,Ti)], 'prenet_keep' [2x(To+1,B,D)], 'att_keep' (To,B,Ha),
-    'dec_keep' (To,B,Hd), 'post_keep' [5x(B,C,To)], 'noise' (B,noise_size) or None."""
+    'dec_keep' (To,B,Hd), 'post_keep' [5x(B,C,To)], 'noise' (B,noise_size) or None.
+    encoder_inputs (hparams.py:102): labels and style noise are concatenated to the embedded text as extra
+    channels of the first encoder convolution (model.py:649-651, 184-191) instead of to the decoder memory."""
     emb = F.embedding(text, P['embedding.weight']).transpose(1, 2)
+    dec_noise = rng.get('noise')
+    if encoder_inputs:
+        if use_labels:
+            emb = torch.cat((emb, emotions[:, :, None].repeat(1, 1, emb.size(-1))), dim=1)
+        if dec_noise is not None:
+            emb = torch.cat((emb, dec_noise[:, :, None].repeat(1, 1, emb.size(-1))), dim=1)
+        dec_noise = None
     enc = encoder_forward(P, emb, text_lengths, rng.get('enc_keep'), training, new_stats)
     if 'speaker_embedding.weight' in P:                                      # model.py:655-663
         spk = F.embedding(speaker_ids, P['speaker_embedding.weight'])[:, None].repeat(1, enc.size(1), 1)
-        if use_labels:
+        if use_labels and not encoder_inputs:
             emo = emotions[:, None].repeat(1, enc.size(1), 1)
             enc = torch.cat((enc, spk, emo), dim=2)
         else:
             enc = torch.cat((enc, spk), dim=2)
-    mel, gate, align = decoder_forward(P, enc, mels, text_lengths, rng.get('noise'),
+    mel, gate, align = decoder_forward(P, enc, mels, text_lengths, dec_noise,
                                        rng['prenet_keep'], rng.get('att_keep'), rng.get('dec_keep'),
                                        p_att, p_dec, training)
     post = postnet_forward(P, mel, rng.get('post_keep'), training, new_stats)
@@ -305,11 +314,19 @@ def decoder_inference(P, memory: Tensor, style: Optional[Tensor], prenet_keep: L
 
 def generator_inference(P, text: Tensor, style: Optional[Tensor], prenet_keep: List[Tensor],
                         speaker: Optional[Tensor] = None, emotions: Optional[Tensor] = None,
-                        gate_threshold: float = 0.5, max_decoder_steps: int = 500):
-    """Tacotron2.inference, model.py:675-723 (encoder_inputs=False): eval-mode encoder without packing
+                        gate_threshold: float = 0.5, max_decoder_steps: int = 500, encoder_inputs: bool = False):
+    """Tacotron2.inference, model.py:675-723: eval-mode encoder without packing
     (Encoder.inference :214-224), memory = [encoder | speaker | emotions | style], free-running decoder,
-    PostNet residual; parse_output without lengths leaves the outputs unmasked."""
+    PostNet residual; parse_output without lengths leaves the outputs unmasked.  With encoder_inputs the
+    emotions and the style (B,noise) are channels of the embedded text instead (:694-701) and the decoder
+    gets neither."""
     emb = F.embedding(text, P['embedding.weight']).transpose(1, 2)
+    if encoder_inputs:
+        if emotions is not None:
+            emb = torch.cat((emb, emotions[:, :, None].repeat(1, 1, emb.size(-1))), dim=1)
+        if style is not None:
+            emb = torch.cat((emb, style[:, :, None].repeat(1, 1, emb.size(-1))), dim=1)
+        style = emotions = None
     lengths = torch.full((text.size(0),), text.size(1), dtype=torch.long)
     enc = encoder_forward(P, emb, lengths, None, training=False)
     if speaker is not None and 'speaker_embedding.weight' in P:
@@ -505,9 +522,13 @@ def init_params(hp, seed: int = 1234) -> (Dict[str, Tensor], Dict[str, Tensor]):
         G[prefix + '.weight'] = torch.ones(c); G[prefix + '.bias'] = torch.zeros(c)
         G[prefix + '.running_mean'] = torch.zeros(c); G[prefix + '.running_var'] = torch.ones(c)
 
+    noise = hp.noise_size if hp.use_noise else 0
+    labels = 5 if (hp.use_labels and hp.vesus_path) else 0
+    enc_in = bool(getattr(hp, 'encoder_inputs', False))                      # model.py:162-170, 240-246
     for i in range(hp.encoder_n_convolutions):
-        G[f'encoder.convolutions.{i}.0.conv.weight'] = xavier((E, E, ks), gain_relu)
-        G[f'encoder.convolutions.{i}.0.conv.bias'] = unif((E,), 1 / math.sqrt(E * ks))
+        cin = E + (((hp.n_labels if labels else 0) + noise) if (enc_in and i == 0) else 0)
+        G[f'encoder.convolutions.{i}.0.conv.weight'] = xavier((E, cin, ks), gain_relu)
+        G[f'encoder.convolutions.{i}.0.conv.bias'] = unif((E,), 1 / math.sqrt(cin * ks))
         bn(f'encoder.convolutions.{i}.1', E)
     H = E // 2
     for sfx in ('', '_reverse'):
@@ -515,10 +536,9 @@ def init_params(hp, seed: int = 1234) -> (Dict[str, Tensor], Dict[str, Tensor]):
         G['encoder.lstm.weight_hh_l0' + sfx] = unif((4 * H, H), 1 / math.sqrt(H))
         G['encoder.lstm.bias_ih_l0' + sfx] = unif((4 * H,), 1 / math.sqrt(H))
         G['encoder.lstm.bias_hh_l0' + sfx] = unif((4 * H,), 1 / math.sqrt(H))
-    noise = hp.noise_size if hp.use_noise else 0
-    D_in = E + noise
+    D_in = E + (0 if enc_in else noise)
     if hp.vesus_path:
-        D_in += hp.speakers_embedding + (5 if hp.use_labels else 0)
+        D_in += hp.speakers_embedding + (0 if enc_in else labels)
         G['speaker_embedding.weight'] = unif((123, hp.speakers_embedding), val)
     n_mel, pd = hp.n_mel_channels, hp.prenet_dim
     G['decoder.prenet.layers.0.linear_layer.weight'] = xavier((pd, n_mel), gain_lin)
@@ -599,7 +619,8 @@ def generator_step_grads(G, Dp, batch, rng, hp, use_attn_loss=True):
     new_stats = {}
     out = generator_forward(Pg, text, in_len, mel_t, out_len, rng, spk, emo,
                             use_labels=bool(hp.use_labels and hp.vesus_path), new_stats=new_stats,
-                            p_att=hp.p_attention_dropout, p_dec=hp.p_decoder_dropout)
+                            p_att=hp.p_attention_dropout, p_dec=hp.p_decoder_dropout,
+                            encoder_inputs=bool(getattr(hp, 'encoder_inputs', False)))
     mel_loss, gate_loss, attn_loss = tacotron_loss(out, mel_t, gate_t, in_len, out_len)
     adv = adversarial_loss(Dp, out[1], out_len, hp.discriminator_window, rng.get('disc_keep'))
     total = mel_loss + gate_loss + adv

@@ -15,6 +15,9 @@ TINY_HPARAMS = ("use_labels=False,use_noise=True,n_mel_channels=8,encoder_embedd
                 "postnet_embedding_dim=16,noise_size=16,discriminator_dim=16,discriminator_window=4")
 FULL_HPARAMS = "use_labels=False,use_noise=True"
 VESUS_HPARAMS = "use_labels=True,use_noise=True,vesus_path=/nonexistent/vesus/"
+# labels + noise fed to the encoder's first convolution instead of the decoder memory (hparams.py:102)
+ENCIN_HPARAMS = (TINY_HPARAMS.replace('use_labels=False', 'use_labels=True') +
+                 ",vesus_path=/nonexistent/vesus/,speakers_embedding=4,encoder_inputs=True")
 
 
 class MaskStream:
@@ -35,9 +38,12 @@ def draw_generator_rng(stream, hp, B, Ti, To, train=True):
     (model.py:197, 275, 104, 393-394/408-409 per step, 148-149)."""
     E = hp.encoder_embedding_dim
     rng = {}
-    rng['enc_keep'] = [stream.keep((B, E, Ti), 0.5) for _ in range(hp.encoder_n_convolutions)]
     noise = hp.noise_size if hp.use_noise else 0
-    rng['noise'] = stream.uniform((B, 1, noise))[:, 0, :] if noise > 0 else None
+    if getattr(hp, 'encoder_inputs', False):       # Encoder.append_noise draws (B, noise, 1) first (model.py:184-187)
+        rng['noise'] = stream.uniform((B, noise, 1))[:, :, 0] if noise > 0 else None
+    rng['enc_keep'] = [stream.keep((B, E, Ti), 0.5) for _ in range(hp.encoder_n_convolutions)]
+    if not getattr(hp, 'encoder_inputs', False):
+        rng['noise'] = stream.uniform((B, 1, noise))[:, 0, :] if noise > 0 else None
     rng['prenet_keep'] = [stream.keep((To + 1, B, hp.prenet_dim), 0.5) for _ in range(2)]
     att, dec = [], []
     for _ in range(To):

@@ -188,6 +188,16 @@ def tiny_case():
     save_full(os.path.join(HERE, 'tiny_pair.npz'), common.TINY_HPARAMS, in_lens, out_lens, res, 101, 11)
 
 
+def encoder_inputs_case():
+    """hparams.encoder_inputs=True with labels + noise (VESUS conditioning): full tensors on the tiny config."""
+    hp, G, D = build(common.ENCIN_HPARAMS)
+    in_lens, out_lens = [7, 5, 4], [11, 9, 6]
+    batch = common.synthetic_batch(hp, in_lens, out_lens, seed=13, vesus=True)
+    res = run_pair(hp, G, D, batch, mask_seed=303)
+    save_full(os.path.join(HERE, 'tiny_encin_pair.npz'), common.ENCIN_HPARAMS, in_lens, out_lens, res, 303, 13,
+              vesus=True)
+
+
 def full_case(name, hp_string, vesus):
     hp, G, D = build(hp_string, weight_seed=2024)
     in_lens, out_lens = [21, 17], [45, 38]
@@ -355,7 +365,9 @@ def linear_disc_case():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['tiny', 'ops', 'full', 'vesus', 'allreduce', 'inference', 'linear']
+    which = sys.argv[1:] or ['tiny', 'ops', 'full', 'vesus', 'allreduce', 'inference', 'linear', 'encin']
+    if 'encin' in which:
+        encoder_inputs_case()
     if 'linear' in which:
         linear_disc_case()
     if 'inference' in which:

@@ -39,8 +39,11 @@ def _run_oracle_pair(z, hp, G, Dp):
     return out, losses, grads, new_stats, dl, dg
 
 
-def test_tiny_pair_matches_reference(golden_dir):
-    z = _load(golden_dir, 'tiny_pair.npz')
+@pytest.mark.parametrize('name', ['tiny_pair.npz', 'tiny_encin_pair.npz'])
+def test_tiny_pair_matches_reference(golden_dir, name):
+    """Every output, loss, gradient and BN buffer of one G step + one D step; tiny_encin_pair.npz is the
+    encoder_inputs=True conditioning (labels + noise into the first encoder convolution) with VESUS speakers."""
+    z = _load(golden_dir, name)
     hp = HParams(str(z['hparams']))
     G = common.unpack_dict(z, 'g_state_before')
     Dp = common.unpack_dict(z, 'd_state')

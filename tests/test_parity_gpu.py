@@ -69,13 +69,18 @@ def run_pair_hip(hp, g_state, d_state, batch, mask_seed, dev, vesus=False):
     return res
 
 
-def test_tiny_pair_matches_reference_golden(dev, golden_dir):
+@pytest.mark.parametrize('name', ['tiny_pair.npz', 'tiny_encin_pair.npz'])
+def test_tiny_pair_matches_reference_golden(dev, golden_dir, name):
+    """tiny_encin_pair.npz: hparams.encoder_inputs=True (labels + style noise as channels of the first encoder
+    convolution, VESUS speaker embedding in the decoder memory)."""
     from gantron_amd.hparams import HParams
-    z = np.load(os.path.join(golden_dir, 'tiny_pair.npz'))
+    z = np.load(os.path.join(golden_dir, name))
     hp = HParams(str(z['hparams']))
-    batch = common.synthetic_batch(hp, z['in_lens'].tolist(), z['out_lens'].tolist(), seed=int(z['batch_seed']))
+    vesus = bool(z['vesus'])
+    batch = common.synthetic_batch(hp, z['in_lens'].tolist(), z['out_lens'].tolist(), seed=int(z['batch_seed']),
+                                   vesus=vesus)
     res = run_pair_hip(hp, common.unpack_dict(z, 'g_state_before'), common.unpack_dict(z, 'd_state'), batch,
-                       int(z['mask_seed']), dev)
+                       int(z['mask_seed']), dev, vesus=vesus)
     for k, v in common.unpack_dict(z, 'out').items():
         close(res['out'][k], v, rtol=1e-3, atol=1e-5, what=f'out.{k}')
     for k, v in common.unpack_dict(z, 'g_loss').items():
@@ -103,7 +108,7 @@ def test_tiny_pair_with_fused_lstm_steps(dev, golden_dir, monkeypatch):
     buffers) must reproduce the same golden outputs and gradients."""
     from gantron_amd import engine
     monkeypatch.setattr(engine, 'FUSED_CELL', True)
-    test_tiny_pair_matches_reference_golden(dev, golden_dir)
+    test_tiny_pair_matches_reference_golden(dev, golden_dir, 'tiny_pair.npz')
 
 
 @pytest.mark.parametrize('name', ['full_pair_summary.npz', 'vesus_pair_summary.npz'])

@@ -225,6 +225,33 @@ def test_inference_batch_against_oracle(dev):
         close(a, b, rtol=1e-3, atol=1e-5, what=f'inference {name}')
 
 
+def test_inference_with_encoder_inputs(dev):
+    """hparams.encoder_inputs=True (labels + style as channels of the first encoder convolution, speaker embedding in
+    the memory): free-running decode against the oracle; the style is passed in the reference's (B, noise, 1) layout."""
+    from gantron_amd.hparams import HParams
+    from gantron_amd.model import Tacotron2
+    from oracle import gantron_ref as R
+    hp = HParams(common.ENCIN_HPARAMS + ',max_decoder_steps=21')
+    Tacotron2(hp)                                   # applies the reference's hparams side effects (model.py:589-591)
+    Gp, _ = R.init_params(hp, seed=8)
+    Gp['decoder.gate_layer.linear_layer.bias'] = torch.full((1,), -30.0)
+    g = torch.Generator().manual_seed(9)
+    B, Ti = 2, 11
+    text = torch.randint(1, hp.n_symbols, (B, Ti), generator=g)
+    style = torch.rand(B, hp.noise_size, generator=g)
+    emotions = torch.eye(5)[torch.tensor([1, 3])]
+    speaker = torch.tensor([4, 7])
+    keeps = [torch.rand(21, B, hp.prenet_dim, generator=g) >= 0.5 for _ in range(2)]
+    G = Tacotron2(hp).to(dev).eval()
+    G.load_state_dict(_with_counters(Gp))
+    G.rng_override = dict(prenet_keep=_pad_keeps(keeps, 21, 16, dev))
+    got = G.inference(text, style=style[:, :, None], emotions=emotions, speaker=speaker)
+    want = R.generator_inference(Gp, text, style, keeps, speaker=speaker, emotions=emotions, max_decoder_steps=21,
+                                 encoder_inputs=True)
+    for name, a, b in zip(('mel', 'mel_post', 'gate', 'align'), got, want):
+        close(a, b, rtol=1e-3, atol=1e-5, what=f'inference(encoder_inputs) {name}')
+
+
 def _write_wavs(root, n, rs, sr=22050):
     from scipy.io import wavfile
     lines = []
