@@ -376,6 +376,53 @@ __global__ __launch_bounds__(256) void log_clamp_kernel(const float* x, long n, 
         out[idx] = logf(fmaxf(x[idx], clip));
 }
 
+// ---- gradient penalty (train.py:32-69) -------------------------------------------------------------------------
+// interpolated[b][c][t] = t < len_b ? alpha_b * real + (1 - alpha_b) * fake : 0      (train.py:36-49)
+__global__ __launch_bounds__(256) void gp_interpolate_kernel(const float* real, const float* fake, const float* alpha,
+                                                             const int64_t* lengths, int B, long CT, int T, float* out) {
+    const long n = (long)B * CT;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / CT);
+        const int t = (int)((idx - (long)b * CT) % T);
+        const float a = alpha[b];
+        out[idx] = t < lengths[b] ? a * real[idx] + (1.f - a) * fake[idx] : 0.f;
+    }
+}
+
+// One workgroup per item: g_b <- masked gradient (train.py:60), n_b = sqrt(sum g_b^2 + 1e-12) (:67),
+// gp += (n_b - 1)^2 / B (:70), and g_b is overwritten with d gp / d g_b = (2 / B) (n_b - 1) / n_b * g_b.
+__global__ __launch_bounds__(256) void gp_norm_kernel(float* g, const int64_t* lengths, int B, long CT, int T, float* gp) {
+    __shared__ float red[16];
+    const int b = blockIdx.x;
+    const int len = (int)lengths[b];
+    float* gb = g + (long)b * CT;
+    float s = 0.f;
+    for (long i = threadIdx.x; i < CT; i += blockDim.x) {
+        const float v = (int)(i % T) < len ? gb[i] : 0.f;
+        s += v * v;
+    }
+    s = block_sum(s, red);
+    const float nb = sqrtf(s + 1e-12f);
+    const float coef = 2.0f / (float)B * (nb - 1.0f) / nb;
+    if (threadIdx.x == 0) atomicAdd(gp, (nb - 1.0f) * (nb - 1.0f) / (float)B);
+    for (long i = threadIdx.x; i < CT; i += blockDim.x) gb[i] = (int)(i % T) < len ? coef * gb[i] : 0.f;
+}
+
+// Second-order terms of a = tanh(m z) (DiscConv1d, layers.py:54-57) for the double backward of the penalty.  With
+// t = da/dz = m (1 - a^2): the first backward computed dz = da * t; given p = d gp / d dz this returns
+// u = d gp / d da = p * t and e = d gp / d z (through t) = p * da * (-2 m a t).
+__global__ __launch_bounds__(256) void tanh_drop_bwd2_kernel(const float* p, const float* da, const float* y, long n,
+                                                             const uint8_t* keep, float scale, float* u, float* e) {
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+        const float m = (keep != nullptr) ? (keep[idx] ? scale : 0.f) : 1.f;
+        const float a = y[idx];
+        const float t = m * (1.f - a * a);
+        const float pv = p[idx];
+        u[idx] = pv * t;
+        e[idx] = pv * da[idx] * (-2.f * m * a * t);
+    }
+}
+
 inline unsigned flat_blocks(long n) { return (unsigned)std::min<long>(std::max<long>(cdiv64(n, 256), 1), 8192); }
 
 }  // namespace
@@ -599,6 +646,32 @@ extern "C" int gt_stft_magnitude(const float* ft, int64_t rows, int32_t cutoff, 
 extern "C" int gt_log_clamp(const float* x, int64_t n, float clip, float* out, void* stream) {
     GT_REQUIRE(x && out && n > 0, GT_E_ARG, "gt_log_clamp: bad argument");
     hipLaunchKernelGGL(log_clamp_kernel, dim3(flat_blocks(n)), dim3(256), 0, ST, x, (long)n, clip, out);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gt_gp_interpolate(const float* real, const float* fake, const float* alpha, const int64_t* lengths,
+                                 int32_t B, int32_t n_mel, int32_t T, float* out, void* stream) {
+    GT_REQUIRE(real && fake && alpha && lengths && out && B > 0 && n_mel > 0 && T > 0, GT_E_ARG, "gt_gp_interpolate: bad argument");
+    const long CT = (long)n_mel * T;
+    hipLaunchKernelGGL(gp_interpolate_kernel, dim3(flat_blocks((long)B * CT)), dim3(256), 0, ST, real, fake, alpha, lengths,
+                       B, CT, T, out);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gt_gp_norm(float* g, const int64_t* lengths, int32_t B, int32_t n_mel, int32_t T, float* gp, void* stream) {
+    GT_REQUIRE(g && lengths && gp && B > 0 && n_mel > 0 && T > 0, GT_E_ARG, "gt_gp_norm: bad argument");
+    hipLaunchKernelGGL(gp_norm_kernel, dim3(B), dim3(256), 0, ST, g, lengths, B, (long)n_mel * T, T, gp);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gt_tanh_drop_bwd2(const float* p, const float* da, const float* y, int64_t rows, int32_t C,
+                                 const uint8_t* keep, float p_drop, float* u, float* e, void* stream) {
+    GT_REQUIRE(p && da && y && u && e && rows > 0 && C > 0, GT_E_ARG, "gt_tanh_drop_bwd2: bad argument");
+    hipLaunchKernelGGL(tanh_drop_bwd2_kernel, dim3(flat_blocks(rows * C)), dim3(256), 0, ST, p, da, y, (long)rows * C, keep,
+                       1.0f / (1.0f - p_drop), u, e);
     GT_LAUNCH_CHECK();
     return 0;
 }

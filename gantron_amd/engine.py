@@ -867,6 +867,75 @@ class DiscriminatorEngine:
         call('gt_disc_gather_bwd', dy, B, n_mel, T, win, dmel, 0)
         return dmel
 
+    def gradient_penalty(self, P, G, real, fake, lengths, alpha, keeps, training=True):
+        """gradient_penalty of train.py:32-69 and its gradient with respect to the discriminator parameters.
+        real, fake (B, n_mel, T) cuda (already cropped to the common T); lengths int64 cuda (B) of the tensor that
+        sets the mask; alpha (B,) cuda U[0,1).  Returns gp (1,) and ADDS d gp / d theta to G.
+
+        The penalty is a function of g = d sum(D(x)) / d x, itself the result of a backward pass, so its parameter
+        gradient is a double backward.  With a_i = tanh(m_i z_i), z_i = conv_i(r_i) + b_i, t_i = m_i (1 - a_i^2):
+          input-gradient pass   dz_i = da_i * t_i,  da_{i-1} = conv_i^T(dz_i),  g = scatter(da_{-1})
+          penalty               v = d gp / d g                                       (gt_gp_norm)
+          up pass   (i = 0..3)  u_0 = gather(v);  p_i = conv_i(u_i);  dW_i += corr(dz_i, u_i);
+                                u_{i+1} = p_i * t_i;  e_i = p_i * da_i * dt_i/dz_i   (gt_tanh_drop_bwd2)
+                                dW_4 += column sums of u_4        (da_3 = rows of W_4)
+          down pass (i = 3..0)  h_3 = e_3;  dW_i += corr(h_i, r_i);  db_i += sum h_i;
+                                h_{i-1} = conv_i^T(h_i) * t_{i-1} + e_{i-1}
+        -- every product is one of the step's own GEMM-backed entries (conv1d_fwd / conv1d_dx / conv1d_dw)."""
+        dev = real.device
+        B, n_mel, T = real.shape
+        win = self.window
+        x = _f32(B, n_mel, T, device=dev, zero=False)
+        call('gt_gp_interpolate', real.contiguous(), fake.contiguous(), alpha, lengths, B, n_mel, T, x)
+        _, sv = self.forward(P, x, lengths, keeps, training)
+        W = sv['W']
+        rows = B * W
+        layers = sv['layers']
+        Wt = [P[f'discriminator.{i}.module.0.weight'] for i in range(4)]
+        Wb = [ops.conv_weight_bwd(w) for w in Wt]
+        W4 = P['discriminator.4.weight']
+        c4 = W4.shape[1]
+        # ---- input-gradient pass with unit upstream on every window (train.py:55-58)
+        ones = torch.ones(rows, 1, device=dev, dtype=torch.float32)
+        da, dz = [None] * 4, [None] * 4
+        da[3] = ops.linear_dx(ones, W4.view(1, -1), rows, 1, c4)
+        for i in reversed(range(4)):
+            cout, ci, k = Wt[i].shape
+            dz[i] = _f32(rows, cout, device=dev, zero=False)
+            call('gt_bias_act_drop_bwd', da[i], layers[i]['y'], rows, cout, ACT_TANH, 1, layers[i]['keep'], 0.5, dz[i])
+            dr = ops.conv1d_dx(dz[i], Wb[i], B, W, ci, cout, k, self.DIL[i])
+            if i > 0:
+                da[i - 1] = dr
+        g = _f32(B, n_mel, T, device=dev, zero=False)
+        call('gt_disc_gather_bwd', dr, B, n_mel, T, win, g, 0)
+        gp = _f32(1, device=dev)
+        call('gt_gp_norm', g, lengths, B, n_mel, T, gp)               # g <- d gp / d g
+        # ---- up pass
+        u = _f32(rows, win * n_mel, device=dev, zero=False)
+        call('gt_disc_gather_fwd', g, B, n_mel, T, win, u)
+        e = [None] * 4
+        for i in range(4):
+            cout, ci, k = Wt[i].shape
+            gw = G[f'discriminator.{i}.module.0.weight']
+            p = ops.conv1d_fwd(u, ops.conv_weight_fwd(Wt[i]), None, B, W, ci, cout, k, self.DIL[i])
+            ops.conv1d_dw(dz[i], u, B, W, ci, cout, k, self.DIL[i], gw)
+            u = _f32(rows, cout, device=dev, zero=False)
+            e[i] = _f32(rows, cout, device=dev, zero=False)
+            call('gt_tanh_drop_bwd2', p, da[i], layers[i]['y'], rows, cout, layers[i]['keep'], 0.5, u, e[i])
+        acc_add(G['discriminator.4.weight'].view(-1), ops.col_sums(u, rows, c4).contiguous())
+        # ---- down pass
+        h = e[3]
+        for i in reversed(range(4)):
+            cout, ci, k = Wt[i].shape
+            ops.conv1d_dw(h, layers[i]['x'], B, W, ci, cout, k, self.DIL[i], G[f'discriminator.{i}.module.0.weight'])
+            acc_add(G[f'discriminator.{i}.module.0.bias'], ops.col_sums(h, rows, cout).contiguous())
+            if i > 0:
+                hr = ops.conv1d_dx(h, Wb[i], B, W, ci, cout, k, self.DIL[i])
+                h = _f32(rows, ci, device=dev, zero=False)
+                call('gt_bias_act_drop_bwd', hr, layers[i - 1]['y'], rows, ci, ACT_TANH, 1, layers[i - 1]['keep'], 0.5, h)
+                acc_add(h, e[i - 1])
+        return gp
+
 
 class LinearDiscriminatorEngine:
     """LinearDiscriminator.forward + adversarial_loss (reference model.py:543-583): every item is cut into windows of

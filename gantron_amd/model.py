@@ -282,6 +282,31 @@ class _AdversarialFn(torch.autograd.Function):
         return (None, dmel, None, None) + grads
 
 
+class _GradientPenaltyFn(torch.autograd.Function):
+    """The penalty and its parameter gradient are computed together (the gradient IS a second backward pass through
+    the discriminator, engine.DiscriminatorEngine.gradient_penalty); backward only scales it by the upstream."""
+
+    @staticmethod
+    def forward(ctx, module, real, fake, lengths, alpha, keeps, *params):
+        P = dict(zip(module._param_names, (p.detach() for p in params)))
+        G = {k: torch.zeros_like(P[k]) for k in module._param_names}
+        gp = module.engine.gradient_penalty(P, G, real.detach(), fake.detach(), lengths, alpha, keeps,
+                                            training=module.training)
+        ctx.G, ctx.names = G, module._param_names
+        ctx.needs = [p.requires_grad for p in params]
+        return gp.view(())
+
+    @staticmethod
+    def backward(ctx, dgp):
+        d = dgp.contiguous().view(1)
+        grads = []
+        for k, need in zip(ctx.names, ctx.needs):
+            if need:
+                ops.call('gt_scale_dev', ctx.G[k], d, 1.0, ctx.G[k], ctx.G[k].numel(), 0)
+            grads.append(ctx.G[k] if need else None)
+        return (None,) * 6 + tuple(grads)
+
+
 class Discriminator(nn.Module):
     def __init__(self, hparams):
         super().__init__()
@@ -314,6 +339,27 @@ class Discriminator(nn.Module):
         params = [p for _, p in self.named_parameters()]
         keeps = self._keeps(inputs.size(0), inputs.size(2), inputs.device)
         return _AdversarialFn.apply(self, inputs.contiguous(), target_length.contiguous().long(), keeps, *params)
+
+    def gradient_penalty(self, real_data, generated_data, real_lengths, generated_lengths):
+        """train.gradient_penalty (reference train.py:32-69) for this discriminator: real/generated (B, n_mel, T);
+        returns a 0-dim tensor whose backward adds d penalty / d theta to the parameters' .grad.
+        rng_override (tests): dict(alpha=(B,) tensor, keeps=[4 keep masks])."""
+        B = real_data.size(0)
+        if real_data.size(2) < generated_data.size(2):                      # train.py:37-44
+            T, lengths = real_data.size(2), real_lengths
+        else:
+            T, lengths = generated_data.size(2), generated_lengths
+        real = real_data[:, :, :T].contiguous().float()
+        fake = generated_data[:, :, :T].contiguous().float()
+        dev = real.device
+        if isinstance(self.rng_override, dict):
+            alpha, keeps = self.rng_override['alpha'], self.rng_override['keeps']
+        else:
+            alpha = self.dropout_source.uniform((B,), dev)
+            keeps = self._keeps(B, T, dev)
+        params = [p for _, p in self.named_parameters()]
+        return _GradientPenaltyFn.apply(self, real, fake, lengths.to(dev).contiguous().long(), alpha.contiguous(),
+                                        keeps, *params)
 
     def forward(self, inputs):
         """inputs (B, T, n_mel) -> (B, W); reference model.py:514-527 (no gradient through this entry)."""

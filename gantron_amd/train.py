@@ -26,7 +26,7 @@ from .hparams import HParams
 from .loss_function import Tacotron2Loss
 from .model import Discriminator, LinearDiscriminator, Tacotron2
 from .optim import FlatAdam
-from .train_steps import discriminator_step, generator_step
+from .train_steps import discriminator_step, generator_step, gradient_penalty  # noqa: F401 (train.py:32)
 
 
 def prepare_dataloaders(hparams, wavs_path):

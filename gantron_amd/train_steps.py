@@ -33,6 +33,13 @@ def generator_step(generator, discriminator, g_optimizer, criterion, batch, hpar
     return losses, [y_pred[1].detach(), x[-1]]
 
 
+def gradient_penalty(discriminator, real_data, generated_data, real_lengths, generated_lengths):
+    """reference train.py:32-69 (same signature); the conv Discriminator implements it on the device."""
+    if not hasattr(discriminator, 'gradient_penalty'):
+        raise NotImplementedError('gradient penalty is implemented for discriminator_type=conv')
+    return discriminator.gradient_penalty(real_data, generated_data, real_lengths, generated_lengths)
+
+
 def discriminator_step(generator, discriminator, d_optimizer, batch, generated, hparams, lr=None):
     """zero_grad -> D(real) - D(fake.detach()) over 2 -> backward (-> all-reduce) -> Adam.
     (The reference calls clip_grad_norm_ BEFORE backward, train.py:326-327: a no-op on zeroed
@@ -49,6 +56,13 @@ def discriminator_step(generator, discriminator, d_optimizer, batch, generated, 
     real_loss = REAL * discriminator.adversarial_loss(real_mel, output_lengths)
     fake_loss = FAKE * discriminator.adversarial_loss(generated_mel.detach(), generated_lengths)
     loss = (real_loss + fake_loss) / 2
+    out = {}
+    # train.py:326-333: clipping (a no-op before backward) takes precedence; the penalty only runs with clipping off
+    if not hparams.clipping_value > 0 and hparams.gradient_penalty_lambda > 0:
+        gp = gradient_penalty(discriminator, real_mel, generated_mel.detach(), output_lengths, generated_lengths)
+        loss = loss + hparams.gradient_penalty_lambda * gp
+        out['gradient_penalty'] = gp.detach()
     loss.backward()
     d_optimizer.step()
-    return dict(total=loss.detach(), real=real_loss.detach(), fake=fake_loss.detach())
+    out.update(total=loss.detach(), real=real_loss.detach(), fake=fake_loss.detach())
+    return out

@@ -416,6 +416,17 @@ int gt_adv_mean_fwd(const float* out, const int64_t* lengths, int32_t B, int32_t
                     float* loss, void* stream);
 int gt_adv_mean_bwd(const float* dloss, const int64_t* lengths, int32_t B, int32_t W,
                     int32_t window, float scale, float* dout, void* stream);
+/* gradient_penalty (train.py:32-69).  gt_gp_interpolate: out[b][c][t] = t < len_b ? alpha_b real + (1 - alpha_b) fake
+ * : 0 (:36-49).  gt_gp_norm: g (B, n_mel, T) = d sum(D(x)) / d x; masks it (:60), adds mean_b (||g_b|| - 1)^2 with
+ * the reference's 1e-12 inside the root (:67-70) to *gp and overwrites g with d gp / d g.  gt_tanh_drop_bwd2: the
+ * second-order terms of a = tanh(dropout(z)) needed to differentiate the input-gradient pass itself
+ * (u = p * t, e = p * da * dt/dz with t = da/dz). */
+int gt_gp_interpolate(const float* real, const float* fake, const float* alpha, const int64_t* lengths,
+                      int32_t B, int32_t n_mel, int32_t T, float* out, void* stream);
+int gt_gp_norm(float* g, const int64_t* lengths, int32_t B, int32_t n_mel, int32_t T, float* gp /* += */,
+               void* stream);
+int gt_tanh_drop_bwd2(const float* p, const float* da, const float* y, int64_t rows, int32_t C,
+                      const uint8_t* keep, float p_drop, float* u, float* e, void* stream);
 
 /* -------------------------------------------------------------------------------------- losses
  * Tacotron2Loss (loss_function.py:10-22): sums[0]=MSE(mel), [1]=MSE(mel_post), [2]=BCE(gate);

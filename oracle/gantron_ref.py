@@ -375,6 +375,28 @@ def adversarial_loss(P, mel: Tensor, lengths: Tensor, window: int, disc_keep, tr
 
 
 # ----------------------------------------------------------------------------- losses
+def gradient_penalty(P, real: Tensor, fake: Tensor, real_len: Tensor, fake_len: Tensor, alpha: Tensor,
+                     window: int, disc_keep, training: bool = True) -> Tensor:
+    """gradient_penalty, train.py:32-69 (WGAN-GP on the conv discriminator): x = alpha real + (1 - alpha) fake cropped
+    to the shorter tensor and zeroed beyond the lengths of that tensor; g = d sum(D(x)) / d x (all windows, dropout
+    on), masked again; mean over items of (sqrt(sum g^2 + 1e-12) - 1)^2.  alpha: (B,) U[0,1)."""
+    B = real.size(0)
+    a = alpha.view(B, 1, 1)
+    if real.size(2) < fake.size(2):
+        x = a * real + (1 - a) * fake[:, :, :real.size(2)]
+        mask = length_mask(real_len)
+    else:
+        x = a * real[:, :, :fake.size(2)] + (1 - a) * fake
+        mask = length_mask(fake_len)
+    mask = mask[:, None, :].expand_as(x)
+    x = x.detach().masked_fill(~mask, 0.0).requires_grad_(True)
+    prob = discriminator_forward(P, x.transpose(1, 2), window, disc_keep, training)
+    g = torch.autograd.grad(prob, x, torch.ones_like(prob), create_graph=True)[0]
+    g = g.masked_fill(~mask, 0.0)
+    norm = torch.sqrt((g.reshape(B, -1) ** 2).sum(dim=1) + 1e-12)
+    return ((norm - 1) ** 2).mean()
+
+
 def linear_discriminator_loss(P, mel: Tensor, starts, window: int, keeps, training: bool = True) -> Tensor:
     """LinearDiscriminator.adversarial_loss (model.py:567-583) with the window starts given (the reference draws them
     with random.randint; the caller replays the same sequence).  mel (B, n_mel, T); keeps: 3 masks (NW, dim) over the

@@ -198,6 +198,37 @@ def encoder_inputs_case():
               vesus=True)
 
 
+def gradient_penalty_case():
+    """train.gradient_penalty (train.py:32-69) on the tiny conv discriminator: the penalty and the gradient of
+    lambda * penalty with respect to every discriminator parameter (double backward through D)."""
+    m = types.ModuleType('wandb')
+    m.log = lambda *a, **k: None
+    sys.modules.setdefault('wandb', m)
+    import train as ref_train
+    ref_train.get_mask_from_lengths = _cpu_mask_from_lengths
+    hp, G, D = build(common.TINY_HPARAMS)
+    out_lens = [11, 9, 6]
+    batch = common.synthetic_batch(hp, [7, 5, 4], out_lens, seed=14)
+    real = batch[2]
+    g = torch.Generator().manual_seed(15)
+    fake = (torch.randn(real.shape, generator=g) * 2.0 - 5.0)
+    lens = torch.tensor(out_lens)
+    lam = 10.0
+    with Injector(common.MaskStream(404)):
+        D.zero_grad()
+        gp = ref_train.gradient_penalty(D, real, fake, lens, lens)
+        (lam * gp).backward()
+    blob = dict(hparams=np.array(common.TINY_HPARAMS), out_lens=np.array(out_lens), mask_seed=np.array(404),
+                real=real.numpy(), fake=fake.numpy(), lam=np.array(lam), gp=gp.detach().numpy())
+    blob.update(common.pack_dict('d_state', {k: v.clone() for k, v in D.state_dict().items()}))
+    # the last bias does not influence d D / d x: autograd leaves its .grad at None, stored as zeros
+    blob.update(common.pack_dict('d_grad', {k: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p))
+                                            for k, p in D.named_parameters()}))
+    path = os.path.join(HERE, 'gradient_penalty.npz')
+    np.savez_compressed(path, **blob)
+    print('wrote', path, os.path.getsize(path) // 1024, 'KiB', 'gp =', float(gp))
+
+
 def full_case(name, hp_string, vesus):
     hp, G, D = build(hp_string, weight_seed=2024)
     in_lens, out_lens = [21, 17], [45, 38]
@@ -365,7 +396,9 @@ def linear_disc_case():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['tiny', 'ops', 'full', 'vesus', 'allreduce', 'inference', 'linear', 'encin']
+    which = sys.argv[1:] or ['tiny', 'ops', 'full', 'vesus', 'allreduce', 'inference', 'linear', 'encin', 'gp']
+    if 'gp' in which:
+        gradient_penalty_case()
     if 'encin' in which:
         encoder_inputs_case()
     if 'linear' in which:

@@ -170,3 +170,23 @@ def test_linear_discriminator_matches_reference(golden_dir):
     _close(mel.grad, z['dmel'], rtol=2e-4, atol=1e-7, what='d mel')
     for k, v in common.unpack_dict(z, 'grad').items():
         _close(P[k].grad, v, rtol=2e-4, atol=1e-7, what=f'grad {k}')
+
+
+def test_gradient_penalty_matches_reference(golden_dir):
+    """train.gradient_penalty (train.py:32-69): the penalty and d(lambda * penalty)/d(every D parameter), i.e. the
+    double backward through the conv discriminator, against the reference's own run."""
+    z = _load(golden_dir, 'gradient_penalty.npz')
+    hp = HParams(str(z['hparams']))
+    Dp = {k: v.clone().requires_grad_(True) for k, v in common.unpack_dict(z, 'd_state').items()}
+    real, fake = torch.from_numpy(z['real']), torch.from_numpy(z['fake'])
+    lens = torch.from_numpy(z['out_lens'])
+    stream = common.MaskStream(int(z['mask_seed']))
+    alpha = stream.uniform((real.size(0), 1, 1)).view(-1)
+    keeps = common.draw_disc_keep(stream, hp, real.size(0), real.size(2))
+    gp = R.gradient_penalty(Dp, real, fake, lens, lens, alpha, hp.discriminator_window, keeps)
+    _close(gp, z['gp'], what='gp')
+    names = list(Dp)
+    grads = torch.autograd.grad(float(z['lam']) * gp, [Dp[k] for k in names], allow_unused=True)
+    ref = common.unpack_dict(z, 'd_grad')
+    for k, g in zip(names, grads):
+        _close(g if g is not None else torch.zeros_like(Dp[k]), ref[k], rtol=2e-4, atol=2e-6, what=f'd_grad.{k}')

@@ -291,3 +291,33 @@ def test_linear_discriminator_matches_reference_golden(dev, golden_dir):
     close(mel.grad, z['dmel'], rtol=2e-3, atol=1e-7, what='d mel')
     for k, v in common.unpack_dict(z, 'grad').items():
         close(dict(D.named_parameters())[k].grad, v, rtol=2e-3, atol=1e-7, what=f'grad {k}')
+
+
+def test_gradient_penalty_matches_reference_golden(dev, golden_dir):
+    """train.gradient_penalty (train.py:32-69) on the device: the penalty and d(lambda * penalty)/d(theta) for every
+    discriminator parameter (a double backward through D) against the reference's own run."""
+    from gantron_amd.hparams import HParams
+    from gantron_amd.model import Discriminator
+    from gantron_amd.train_steps import gradient_penalty
+    z = np.load(os.path.join(golden_dir, 'gradient_penalty.npz'))
+    hp = HParams(str(z['hparams']))
+    D = Discriminator(hp).to(dev).train()
+    D.load_state_dict(common.unpack_dict(z, 'd_state'))
+    real, fake = torch.from_numpy(z['real']).to(dev), torch.from_numpy(z['fake']).to(dev)
+    lens = torch.from_numpy(z['out_lens']).to(dev)
+    stream = common.MaskStream(int(z['mask_seed']))
+    alpha = stream.uniform((real.size(0), 1, 1)).view(-1).to(dev)
+    D.rng_override = dict(alpha=alpha, keeps=kernel_disc_keep(common.draw_disc_keep(stream, hp, real.size(0), real.size(2)), dev))
+    D.zero_grad()
+    gp = gradient_penalty(D, real, fake, lens, lens)
+    (float(z['lam']) * gp).backward()
+    close(gp.detach().cpu(), z['gp'], rtol=1e-3, atol=1e-6, what='gp')
+    bad = []
+    for k, v in common.unpack_dict(z, 'd_grad').items():
+        got = dict(D.named_parameters())[k].grad
+        got = torch.zeros_like(v) if got is None else got.detach().cpu()
+        try:
+            close(got, v, rtol=2e-3, atol=2e-6, what=f'd_grad.{k}')
+        except AssertionError as e:
+            bad.append(str(e))
+    assert not bad, '\n'.join(bad)

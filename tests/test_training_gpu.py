@@ -397,3 +397,25 @@ def test_steps_with_linear_discriminator(dev):
     dl = discriminator_step(G, D, d_opt, batch, gen, hp)
     assert all(torch.isfinite(v).all() for v in losses.values() if v is not None)
     assert torch.isfinite(dl['total']) and float(D._flat_grad.abs().max()) > 0 and float(G._flat_grad.abs().max()) > 0
+
+
+def test_discriminator_step_with_gradient_penalty(dev):
+    """hparams.clipping_value=0, gradient_penalty_lambda=10 (train.py:326-333): the D step adds lambda * penalty; its
+    D-parameter gradient equals the plain step's gradient + lambda * the penalty's gradient (same masks)."""
+    from gantron_amd import train as T
+    from gantron_amd.hparams import HParams
+    from gantron_amd.optim import FlatAdam
+    from gantron_amd.train_steps import discriminator_step
+    grads = {}
+    for lam in (0, 10):
+        hp = HParams(MID + f',clipping_value=0,gradient_penalty_lambda={lam}')
+        G, D = T.load_model(hp)
+        d_opt = FlatAdam(D, lr=0.0)
+        batch = common.synthetic_batch(hp, [17, 12, 12, 5], [26, 33, 19, 9], seed=2)
+        g = torch.Generator().manual_seed(3)
+        fake = (torch.randn(batch[2].shape, generator=g) * 2 - 5).to(dev)
+        out = discriminator_step(G, D.train(), d_opt, batch, [fake, batch[6].to(dev)], hp)
+        assert ('gradient_penalty' in out) == (lam > 0)
+        assert torch.isfinite(out['total'])
+        grads[lam] = D._flat_grad.clone()
+    assert float((grads[10] - grads[0]).abs().max()) > 0
