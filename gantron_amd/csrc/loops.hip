@@ -28,7 +28,11 @@ static const GtSlabs kNoSlabs = {nullptr, 0, 0, 0};
 // Recurrent product for Bp activation rows: up to 64 rows are one launch with Bp/16 row tiles; larger
 // batches (Bp a multiple of 64) use blockIdx.z over 64-row blocks that share the packed weights.
 static int rec_rows(const float* X, int64_t ldx, const float* Wp, float* part, int Bp, int N, int K, int S,
-                    void* stream) {
+                    void* stream, int bf16 = 0) {
+    if (bf16) {         // Wp is a bf16 fragment image (gt_pack_rec_weight_bf16)
+        if (Bp <= 64) return gt_rec_gemm_bf16(X, ldx, Wp, part, Bp / 16, N, K, S, (int64_t)Bp * N, 1, 0, 0, 0, stream);
+        return gt_rec_gemm_bf16(X, ldx, Wp, part, 4, N, K, S, (int64_t)Bp * N, Bp / 64, 64 * ldx, 0, (int64_t)64 * N, stream);
+    }
     if (Bp <= 64) return gt_rec_gemm(X, ldx, Wp, part, Bp / 16, N, K, S, (int64_t)Bp * N, 1, 0, 0, 0, stream);
     return gt_rec_gemm(X, ldx, Wp, part, 4, N, K, S, (int64_t)Bp * N, Bp / 64, 64 * ldx, 0, (int64_t)64 * N, stream);
 }
@@ -97,7 +101,7 @@ int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
     const bool two = R > 1;
     // fused LSTM steps write h into the operand buffer of the NEXT step while other workgroups may still read the
     // current one: X1 ping-pongs between two slots and X2 needs the ring (ring == 1 keeps the two-launch path)
-    const bool fused = two && a->W1g != nullptr && a->W2g != nullptr && a->Ha % 4 == 0 && a->Hd % 4 == 0;
+    const bool fused = !a->bf16 && two && a->W1g != nullptr && a->W2g != nullptr && a->Ha % 4 == 0 && a->Hd % 4 == 0;
     const int64_t x1_slot = fused ? (int64_t)a->Bp * a->ld1 : 0;
     const bool fused1 = fused, fused2 = fused;
     // attention cell + query product as one launch (needs float4-friendly sizes; the fused step supersedes it)
@@ -139,7 +143,7 @@ int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
                                       a->gates2 + (int64_t)t * a->Bp * N2, a->c2 + (int64_t)(t + 1) * a->Bp * a->Hd, nullptr,
                                       X2n + a->Ha + a->E, a->ld2, hc_t, hc_ld, nullptr, 0, a->B, a->Bp, a->Hd, sB));
         } else {
-            GT_TRY(rec_rows(X2t, a->ld2, a->W2p, partB, a->Bp, N2, K2, a->S2, sB));
+            GT_TRY(rec_rows(X2t, a->ld2, a->W2p, partB, a->Bp, N2, K2, a->S2, sB, a->bf16));
             GT_TRY(gt_lstm_cell_fwd(slabs(partB, a->S2, (int64_t)a->Bp * N2, N2), a->bias2, 0,
                                     a->c2 + (int64_t)t * a->Bp * a->Hd, nullptr, 0, k2, a->p_dec, nullptr,
                                     a->gates2 + (int64_t)t * a->Bp * N2, a->c2 + (int64_t)(t + 1) * a->Bp * a->Hd, nullptr,
@@ -155,7 +159,7 @@ int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
         float* X1c = a->X1 + (t & 1) * x1_slot;            // [ctx_{t-1} | h_att_{t-1}]
         float* X1n = a->X1 + ((t + 1) & 1) * x1_slot;      // receives h_att_t (cell) and ctx_t (context kernel)
         // ---- attention chain (stream A)
-        if (!fused1) GT_TRY(rec_rows(X1c, a->ld1, a->W1p, a->part, a->Bp, N1, K1, a->S1, sA));
+        if (!fused1) GT_TRY(rec_rows(X1c, a->ld1, a->W1p, a->part, a->Bp, N1, K1, a->S1, sA, a->bf16));
         if (two && t >= R) {     // X2 ring slot t%R was last read by the decoder chain of step t-R
             const int c = cover(t - R);
             if (c != last_wait_b) {
@@ -256,7 +260,7 @@ int gt_decoder_infer(const GtDecoderInfer* q, void* stream) {
         GT_TRY(gt_bias_act_drop_fwd(q->p2, nullptr, a->Bp, P, 1, 0, q->keep1 + (int64_t)t * a->Bp * P, 0.5f, q->p2, stream));
         GT_TRY(small_linear(q->p2, P, q->W1x, q->ldw1x, q->bias1, pre1, N1, a->Bp, N1, P, stream));
         // decode step (same sequence as gt_decoder_fwd, single stream, single X2 buffer)
-        GT_TRY(rec_rows(a->X1, a->ld1, a->W1p, a->part, a->Bp, N1, K1, a->S1, s));
+        GT_TRY(rec_rows(a->X1, a->ld1, a->W1p, a->part, a->Bp, N1, K1, a->S1, s, a->bf16));
         GT_TRY(gt_lstm_cell_fwd(slabs(a->part, a->S1, (int64_t)a->Bp * N1, N1), pre1, N1,
                                 a->c1 + (int64_t)t * a->Bp * a->Ha, nullptr, 0, nullptr, 0.f, nullptr,
                                 a->gates1 + (int64_t)t * a->Bp * N1, a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha,
@@ -269,7 +273,7 @@ int gt_decoder_infer(const GtDecoderInfer* q, void* stream) {
         GT_TRY(gt_attn_context_fwd(d, a->energies, a->memory, a->ldE, a->lengths, a->w_hist + (int64_t)(t + 1) * BT,
                                    a->cum_hist + (int64_t)t * BT, a->cum_hist + (int64_t)(t + 1) * BT, a->X1, a->ld1,
                                    a->X2 + a->Ha, a->ld2, hc_t + a->Hd, hc_ld, s));
-        GT_TRY(rec_rows(a->X2, a->ld2, a->W2p, a->part, a->Bp, N2, K2, a->S2, s));
+        GT_TRY(rec_rows(a->X2, a->ld2, a->W2p, a->part, a->Bp, N2, K2, a->S2, s, a->bf16));
         GT_TRY(gt_lstm_cell_fwd(slabs(a->part, a->S2, (int64_t)a->Bp * N2, N2), a->bias2, 0,
                                 a->c2 + (int64_t)t * a->Bp * a->Hd, nullptr, 0, nullptr, 0.f, nullptr,
                                 a->gates2 + (int64_t)t * a->Bp * N2, a->c2 + (int64_t)(t + 1) * a->Bp * a->Hd, nullptr,
@@ -357,7 +361,7 @@ int gt_decoder_bwd(const GtDecoderBwd* a, void* stream) {
             GT_TRY(evA(t, &e2));
             GT_HIP(hipEventRecord(e2, sA));
         }
-        if (t > 0) GT_TRY(rec_rows(dG1_t, N1, a->W1Tp, a->partX1, a->Bp, a->N1pad, N1, a->S1, sA));
+        if (t > 0) GT_TRY(rec_rows(dG1_t, N1, a->W1Tp, a->partX1, a->Bp, a->N1pad, N1, a->S1, sA, a->bf16));
         return 0;
     };
     int a_next = t_hi, last_wait_a = -1;
@@ -381,7 +385,7 @@ int gt_decoder_bwd(const GtDecoderBwd* a, void* stream) {
                 last_wait_a = c;
             }
         }
-        GT_TRY(rec_rows(dG2_t, N2, a->W2Tp, pX2, a->Bp, a->N2pad, N2, a->S2, sB));
+        GT_TRY(rec_rows(dG2_t, N2, a->W2Tp, pX2, a->Bp, a->N2pad, N2, a->S2, sB, a->bf16));
         if (!two) {
             GT_TRY(chain_a(t));
         } else if (t % k == 0 || t == t_lo) {

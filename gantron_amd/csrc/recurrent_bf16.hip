@@ -1,0 +1,215 @@
+// bf16-operand variant of the recurrent product (hparams.fp16_run; BASELINE config 3): the weights are packed as
+// bf16 fragments of v_mfma_f32_16x16x32_bf16, the fp32 activations are rounded to bf16 while they are staged through
+// LDS, accumulation and the output slabs stay fp32.
+//
+// At M <= 64 rows the fp32 product is bound by MFMA issue (10 us for N=4096, K=3072); in bf16 the same MFMAs take
+// 1/16 of that, so the kernel is shaped for LATENCY instead: a workgroup's K-slice is at most 4 chunks of 256 and
+// the global loads of the slice -- the wave's weight fragments (16 x 16 B per lane) and the activation rows of the
+// first three chunks (24 float4 per thread; the fourth chunk reuses the first one's registers as soon as that one is
+// in LDS) -- are issued before the first MFMA, then the chunks are converted, published and multiplied in turn.
+// Same decomposition as gt_rec_gemm otherwise: 64 gate columns per workgroup, wave w owns columns [16*(w&3), +16)
+// and the k-blocks of half (w>>2) of every chunk, K split over blockIdx.y into slabs.
+#include <stdint.h>
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int RB_THREADS = 512;
+constexpr int RB_CB = 8;               // 32-wide k-blocks per chunk (256 k)
+constexpr int RB_HB = RB_CB / 2;       // k-blocks per wave per chunk
+constexpr int RB_NCH = 4;              // chunks per K-slice at most (the kernel is instantiated for 1..4)
+constexpr int RB_XR = 3;               // activation chunks held in registers at a time
+constexpr int RB_LD = RB_CB * 32 + 8;  // bf16 per LDS row: 528 B, rows 16 B apart mod 256 B (conflict-free b128 reads)
+
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    const bf16x2 p = {(__bf16)a, (__bf16)b};       // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+    return __builtin_bit_cast(unsigned, p);
+}
+
+// W (N x K, row stride ldw; or K x N when transposed) -> Wp[N/16][KB32][64 lanes][8 bf16]: lane l of block (nb, kb)
+// holds B[k = 32 kb + 8 (l >> 4) + j][column 16 nb + (l & 15)], j = 0..7, zero padded.
+__global__ __launch_bounds__(256) void pack_rec_weight_bf16_kernel(const float* W, long ldw, int transposed, int N,
+                                                                   int n_valid, int K, int KB, uint4* Wp) {
+    const long total = (long)(N / 16) * KB * 64;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        const long blk = idx >> 6;
+        const int kb = (int)(blk % KB), nb = (int)(blk / KB);
+        const int n = nb * 16 + (lane & 15);
+        const int k = kb * 32 + 8 * (lane >> 4);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int kk = k + j;
+            v[j] = (kk < K && n < n_valid) ? (transposed ? W[(long)kk * ldw + n] : W[(long)n * ldw + kk]) : 0.f;
+        }
+        Wp[idx] = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+    }
+}
+
+template <int MT, int NCH>
+__global__ __launch_bounds__(RB_THREADS) void rec_gemm_bf16_kernel(const float* __restrict__ X, long ldx, int kvalid,
+                                                                   const uint4* __restrict__ Wp, float* __restrict__ part,
+                                                                   int N, int KB, int KBS, long xz, long wz, long pz,
+                                                                   long ps) {
+    constexpr int XV = MT * 2;         // float4 per thread per chunk (MT*16 rows x 64 float4 / 512 threads)
+    constexpr int XR = NCH < RB_XR ? NCH : RB_XR;
+    constexpr int EP_LD = 68;
+    static_assert(MT * 16 * RB_LD * 2 >= MT * 16 * EP_LD * 4, "epilogue tile fits the staging buffer");
+    __shared__ __attribute__((aligned(16))) unsigned short Xs[MT * 16 * RB_LD];
+    const int s = blockIdx.y, z = blockIdx.z, cg = blockIdx.x;
+    const int kb0 = s * KBS, kb1 = min(KB, kb0 + KBS);
+    const float* Xz = X + (long)z * xz;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = wave >> 2;
+    int nb = cg * 4 + (wave & 3);
+    const bool active = nb * 16 < N;   // inactive waves (N % 64 != 0) still stage and join the barriers
+    if (!active) nb = 0;
+    const uint4* wp = Wp + (long)z * wz + ((long)nb * KB) * 64 + lane;
+
+    // ---- every load of the slice, issued together.  Out-of-range blocks are clamped to a valid address and
+    // zeroed by a select (a predicated load would put s_waitcnt vmcnt(0) in front of everything behind it).
+    uint4 w[NCH][RB_HB];
+    float4 x[XR][XV];
+    auto xload = [&](float4 (&dst)[XV], int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int f = tid + RB_THREADS * i, row = f >> 6, c4 = f & 63;
+            const int k = (kb0 + c * RB_CB) * 32 + 4 * c4;
+            dst[i] = *reinterpret_cast<const float4*>(Xz + (long)row * ldx + min(k, kvalid - 4));
+        }
+    };
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+        for (int u = 0; u < RB_HB; ++u) {
+            const int kb = kb0 + c * RB_CB + half * RB_HB + u;
+            const uint4 t = wp[(long)min(kb, kb1 - 1) * 64];
+            w[c][u] = kb < kb1 ? t : make_uint4(0u, 0u, 0u, 0u);
+        }
+        if (c < XR) xload(x[c], c);
+    }
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned short* xs = Xs + (lane & 15) * RB_LD + 8 * (lane >> 4) + half * RB_HB * 32;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (kb0 + c * RB_CB < kb1) {   // uniform over the workgroup
+#pragma unroll
+            for (int i = 0; i < XV; ++i) {
+                const int f = tid + RB_THREADS * i, row = f >> 6, c4 = f & 63;
+                // activations beyond the valid columns meet zero weights; the clamped load keeps them finite
+                const float4 xv = x[c % XR][i];
+                *reinterpret_cast<uint2*>(&Xs[row * RB_LD + 4 * c4]) = make_uint2(pack2(xv.x, xv.y), pack2(xv.z, xv.w));
+            }
+            if (c + XR < NCH) xload(x[c % XR], c + XR);      // registers of this chunk are free again
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < RB_HB; ++u) {
+                const bf16x8 b = __builtin_bit_cast(bf16x8, w[c][u]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xs + mt * 16 * RB_LD + u * 32));
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[mt], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- epilogue through LDS: fold the two K-halves, write the slab with full-line float4 stores
+    float* red = reinterpret_cast<float*>(Xs);
+    const int ecol = (wave & 3) * 16 + (lane & 15), erow = 4 * (lane >> 4);
+    if (half == 1) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(mt * 16 + erow + r) * EP_LD + ecol] = acc[mt][r];
+    }
+    __syncthreads();
+    if (half == 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(mt * 16 + erow + r) * EP_LD + ecol] += acc[mt][r];
+    }
+    __syncthreads();
+    float* out = part + (long)z * pz + (long)s * ps + (long)cg * 64;
+    const int ncols = min(64, N - cg * 64);
+#pragma unroll
+    for (int i = 0; i < (MT * 16 * 16 + RB_THREADS - 1) / RB_THREADS; ++i) {
+        const int f = tid + RB_THREADS * i;
+        const int row = f >> 4, c4 = f & 15;
+        if (row < MT * 16 && 4 * c4 < ncols)
+            *reinterpret_cast<float4*>(out + (long)row * N + 4 * c4) = *reinterpret_cast<const float4*>(&red[row * EP_LD + 4 * c4]);
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t gt_rec_weight_bf16_elems(int32_t N, int32_t K) {
+    return (int64_t)(N / 16) * cdiv(K, 32) * 64 * 8;
+}
+
+extern "C" int32_t gt_rec_bf16_min_splits(int32_t K) { return cdiv(cdiv(K, 32), RB_NCH * RB_CB); }
+
+extern "C" int gt_pack_rec_weight_bf16(const float* W, int64_t ldw, int32_t transposed, int32_t N, int32_t n_valid,
+                                       int32_t K, void* Wp, void* stream) {
+    GT_REQUIRE(W && Wp && N > 0 && K > 0 && N % 16 == 0 && n_valid > 0 && n_valid <= N && (transposed == 0 || transposed == 1),
+               GT_E_ARG, "gt_pack_rec_weight_bf16: N=%d must be a multiple of 16 and 0 < n_valid=%d <= N", N, n_valid);
+    GT_REQUIRE(aligned16(Wp), GT_E_ALIGN, "gt_pack_rec_weight_bf16: Wp must be 16-byte aligned");
+    const int KB = cdiv(K, 32);
+    const long total = (long)(N / 16) * KB * 64;
+    const int blocks = (int)std::min<long>(cdiv64(total, 256), 4096);
+    hipLaunchKernelGGL(pack_rec_weight_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, W, (long)ldw,
+                       transposed, N, n_valid, K, KB, reinterpret_cast<uint4*>(Wp));
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gt_rec_gemm_bf16(const float* X, int64_t ldx, const void* Wp, float* part, int32_t mtiles, int32_t N,
+                                int32_t K, int32_t splits, int64_t part_sstride, int32_t nz, int64_t x_zstride,
+                                int64_t w_zstride, int64_t part_zstride, void* stream) {
+    GT_REQUIRE(X && Wp && part, GT_E_ARG, "gt_rec_gemm_bf16: NULL pointer");
+    GT_REQUIRE(mtiles >= 1 && mtiles <= 4 && N > 0 && N % 16 == 0 && K >= 4 && splits >= 1 && nz >= 1, GT_E_ARG,
+               "gt_rec_gemm_bf16: bad sizes mtiles=%d N=%d K=%d splits=%d", mtiles, N, K, splits);
+    const int KB = cdiv(K, 32);
+    const int kvalid = cdiv(K, 16) * 16;        // columns the caller guarantees (zero padded beyond K), as gt_rec_gemm
+    GT_REQUIRE(ldx >= kvalid && ldx % 4 == 0 && aligned16(X) && aligned16(Wp) && x_zstride % 4 == 0 && w_zstride % 8 == 0,
+               GT_E_ALIGN, "gt_rec_gemm_bf16: X needs ldx >= 16*ceil(K/16) (=%d), ldx%%4==0 and 16-byte alignment", kvalid);
+    GT_REQUIRE(part_sstride >= (int64_t)mtiles * 16 * N && aligned16(part) && part_sstride % 4 == 0 && part_zstride % 4 == 0,
+               GT_E_ARG, "gt_rec_gemm_bf16: part slabs too small or misaligned");
+    const int KBS = cdiv(KB, splits);
+    GT_REQUIRE(cdiv(KB, KBS) == splits, GT_E_ARG, "gt_rec_gemm_bf16: splits=%d leaves empty slabs for K=%d", splits, K);
+    GT_REQUIRE(KBS <= RB_NCH * RB_CB, GT_E_ARG, "gt_rec_gemm_bf16: K-slice of %d exceeds %d (use >= %d splits)", KBS * 32,
+               RB_NCH * RB_CB * 32, cdiv(KB, RB_NCH * RB_CB));
+    dim3 grid(cdiv(N, 64), splits, nz);
+    hipStream_t st = (hipStream_t)stream;
+    GtProfScope prof(GT_FAM_REC_GEMM, 2.0 * 16 * mtiles * (double)N * K * nz,
+                     (double)nz * (2.0 * N * K + 4.0 * (16.0 * mtiles * K + 16.0 * mtiles * N * splits)), st);
+    const uint4* wp = reinterpret_cast<const uint4*>(Wp);
+    const int nch = cdiv(KBS, RB_CB);           // chunks of a slice: one instantiation each (all loads issued up front)
+#define GT_RECB(MT, NCH)                                                                                              \
+    hipLaunchKernelGGL((rec_gemm_bf16_kernel<MT, NCH>), grid, dim3(RB_THREADS), 0, st, X, (long)ldx, kvalid, wp, part, N, \
+                       KB, KBS, (long)x_zstride, (long)(w_zstride / 8), (long)part_zstride, (long)part_sstride)
+#define GT_RECB_M(MT)                        \
+    switch (nch) {                           \
+        case 1: GT_RECB(MT, 1); break;       \
+        case 2: GT_RECB(MT, 2); break;       \
+        case 3: GT_RECB(MT, 3); break;       \
+        default: GT_RECB(MT, 4); break;      \
+    }
+    switch (mtiles) {
+        case 1: GT_RECB_M(1); break;
+        case 2: GT_RECB_M(2); break;
+        case 3: GT_RECB_M(3); break;
+        default: GT_RECB_M(4); break;
+    }
+#undef GT_RECB_M
+#undef GT_RECB
+    GT_LAUNCH_CHECK();
+    return 0;
+}

@@ -135,10 +135,34 @@ def rec_splits(N, K, nz=1):
     return best
 
 
+def rec_splits_bf16(N, K):
+    """K-splits of gt_rec_gemm_bf16 (slices of at most 4 chunks of 256 columns, every load of a slice issued up
+    front): rocprofv3 durations at the decoder's shapes fit ~3.4 us fixed + 1.3 us per chunk per workgroup round
+    (256 workgroups a round) + 0.15 us per slab for the consumer."""
+    kb = -(-K // 32)
+    groups = -(-N // 64)
+    best, best_cost = None, None
+    for s in range(int(lib().gt_rec_bf16_min_splits(K)), min(16, kb) + 1):
+        kbs = -(-kb // s)
+        if -(-kb // kbs) != s:
+            continue
+        cost = 3.4 + 1.3 * -(-kbs // 8) * -(-groups * s // 256) + 0.15 * s
+        if best_cost is None or cost < best_cost - 1e-9:
+            best, best_cost = s, cost
+    return best
+
+
 def pack_rec(W2d, N, n_valid, K, transposed=False):
     """Pack a (n_valid x K) [or (K x n_valid) when transposed] matrix for gt_rec_gemm."""
     out = torch.empty(int(lib().gt_rec_weight_elems(N, K)), device=W2d.device, dtype=torch.float32)
     call('gt_pack_rec_weight', W2d, W2d.stride(0), int(transposed), N, n_valid, K, out)
+    return out
+
+
+def pack_rec_bf16(W2d, N, n_valid, K, transposed=False):
+    """Pack a (n_valid x K) [or (K x n_valid) when transposed] matrix as bf16 MFMA fragments for gt_rec_gemm_bf16."""
+    out = torch.empty(int(lib().gt_rec_weight_bf16_elems(N, K)), device=W2d.device, dtype=torch.bfloat16)
+    call('gt_pack_rec_weight_bf16', W2d, W2d.stride(0), int(transposed), N, n_valid, K, out)
     return out
 
 
@@ -237,6 +261,9 @@ class GeneratorEngine:
         self.E = self.enc_dim + self.noise
         if self.vesus:
             self.E += hp.speakers_embedding + self.mem_labels
+        # hparams.fp16_run (the reference's apex path, train.py:246-250): on MI355X the two decoder LSTM products run
+        # with bf16 operands and fp32 accumulation (gt_rec_gemm_bf16); weights, state and every other op stay fp32
+        self.bf16 = bool(getattr(hp, 'fp16_run', False))
         self.enc_stack = ConvBNStack('encoder.convolutions', hp.encoder_n_convolutions,
                                      [ACT_RELU] * hp.encoder_n_convolutions)
         self.post_stack = ConvBNStack('postnet.convolutions', hp.postnet_n_convolutions,
@@ -398,9 +425,13 @@ class GeneratorEngine:
         d.S1, d.S2, d.Sq = rec_splits(4 * Ha, K1), rec_splits(4 * Hd, K2), ops.pick_splits(Ha, 16)
         d.p_att = hp.p_attention_dropout if training else 0.0
         d.p_dec = hp.p_decoder_dropout if training else 0.0
-        fused = FUSED_CELL and Ha % 4 == 0 and Hd % 4 == 0
+        fused = FUSED_CELL and Ha % 4 == 0 and Hd % 4 == 0 and not self.bf16
         keep_t = dict(Wqp=pack_rec(P['decoder.attention_layer.query_layer.linear_layer.weight'], Apad, A, Ha))
-        if fused:
+        if self.bf16:
+            d.bf16 = 1
+            d.S1, d.S2 = rec_splits_bf16(4 * Ha, K1), rec_splits_bf16(4 * Hd, K2)
+            keep_t.update(W1p=pack_rec_bf16(W1cat, 4 * Ha, 4 * Ha, K1), W2p=pack_rec_bf16(W2cat, 4 * Hd, 4 * Hd, K2))
+        elif fused:
             keep_t.update(W1g=pack_gates(W1cat, Ha, K1), W2g=pack_gates(W2cat, Hd, K2))
         else:
             keep_t.update(W1p=pack_rec(W1cat, 4 * Ha, 4 * Ha, K1), W2p=pack_rec(W2cat, 4 * Hd, 4 * Hd, K2))
@@ -515,8 +546,13 @@ class GeneratorEngine:
             B, Bp, Ti, To, E, E, Pd, Ha, Hd, A, Apad, self.F, self.Kc
         d.S1, d.S2, d.Sq = rec_splits(4 * Ha, K1), rec_splits(4 * Hd, K2), ops.pick_splits(Ha, 16)
         d.p_att = d.p_dec = 0.0
-        packed = dict(W1p=pack_rec(W1cat, 4 * Ha, 4 * Ha, K1), W2p=pack_rec(W2cat, 4 * Hd, 4 * Hd, K2),
-                      Wqp=pack_rec(P['decoder.attention_layer.query_layer.linear_layer.weight'], Apad, A, Ha))
+        packed = dict(Wqp=pack_rec(P['decoder.attention_layer.query_layer.linear_layer.weight'], Apad, A, Ha))
+        if self.bf16:
+            d.bf16 = 1
+            d.S1, d.S2 = rec_splits_bf16(4 * Ha, K1), rec_splits_bf16(4 * Hd, K2)
+            packed.update(W1p=pack_rec_bf16(W1cat, 4 * Ha, 4 * Ha, K1), W2p=pack_rec_bf16(W2cat, 4 * Hd, 4 * Hd, K2))
+        else:
+            packed.update(W1p=pack_rec(W1cat, 4 * Ha, 4 * Ha, K1), W2p=pack_rec(W2cat, 4 * Hd, 4 * Hd, K2))
         lens32 = torch.full((B,), Ti, dtype=torch.int32, device=dev)
         ld1, ld2 = roundup(K1, 16), roundup(K2, 16)
         nout, hc = n_mel + 1, Hd + E
@@ -644,13 +680,17 @@ class GeneratorEngine:
         W1cat = torch.cat((W1ih[:, Pd:], W1hh), dim=1).contiguous()
         W2cat = torch.cat((W2ih, W2hh), dim=1).contiguous()
         Wq = P['decoder.attention_layer.query_layer.linear_layer.weight']
-        W1Tp = pack_rec(W1cat, N1pad, K1, 4 * Ha, transposed=True)
-        W2Tp = pack_rec(W2cat, N2pad, K2, 4 * Hd, transposed=True)
+        packT = pack_rec_bf16 if self.bf16 else pack_rec
+        W1Tp = packT(W1cat, N1pad, K1, 4 * Ha, transposed=True)
+        W2Tp = packT(W2cat, N2pad, K2, 4 * Hd, transposed=True)
         WqTp = pack_rec(Wq, Ha, Ha, A, transposed=True)
         b = GtDecoderBwd()
         b.B, b.Bp, b.Ti, b.To, b.E, b.ldE, b.P, b.Ha, b.Hd, b.A, b.Apad, b.F, b.Kc = \
             B, Bp, Ti, To, E, E, Pd, Ha, Hd, A, Apad, self.F, self.Kc
         b.S1, b.S2, b.Sq = rec_splits(N1pad, 4 * Ha), rec_splits(N2pad, 4 * Hd), ops.pick_splits(A, 2)
+        if self.bf16:
+            b.bf16 = 1
+            b.S1, b.S2 = rec_splits_bf16(N1pad, 4 * Ha), rec_splits_bf16(N2pad, 4 * Hd)
         b.N1pad, b.N2pad = N1pad, N2pad
         if CELL_QUERY and Ha % 16 == 0 and E % 4 == 0:
             b.Wq = ptr(P['decoder.attention_layer.query_layer.linear_layer.weight'])

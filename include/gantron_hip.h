@@ -108,6 +108,19 @@ int gt_rec_gemm(const float* X, int64_t ldx, const float* Wp, float* part, int32
                 int32_t N, int32_t K, int32_t splits, int64_t part_sstride, int32_t nz,
                 int64_t x_zstride, int64_t w_zstride, int64_t part_zstride, void* stream);
 
+/* bf16-operand variant (hparams.fp16_run, the reference's apex path train.py:246-250 -> bf16 MFMA with fp32
+ * accumulation on MI355X): the weights are packed as bf16 fragments of v_mfma_f32_16x16x32_bf16
+ * ([N/16][ceil(K/32)][64 lanes][8 bf16], gt_rec_weight_bf16_elems 16-bit elements), the fp32 activations X are
+ * rounded to bf16 (nearest even) inside the kernel, slabs are fp32 as above.  A K-slice may not exceed 1024 columns:
+ * splits >= gt_rec_bf16_min_splits(K).  Strides as in gt_rec_gemm (w_zstride in 16-bit elements, multiple of 8). */
+int64_t gt_rec_weight_bf16_elems(int32_t N, int32_t K);
+int32_t gt_rec_bf16_min_splits(int32_t K);
+int gt_pack_rec_weight_bf16(const float* W, int64_t ldw, int32_t transposed, int32_t N, int32_t n_valid,
+                            int32_t K, void* Wp, void* stream);
+int gt_rec_gemm_bf16(const float* X, int64_t ldx, const void* Wp, float* part, int32_t mtiles, int32_t N,
+                     int32_t K, int32_t splits, int64_t part_sstride, int32_t nz, int64_t x_zstride,
+                     int64_t w_zstride, int64_t part_zstride, void* stream);
+
 /* Two products with their own shapes (both with 16*mtiles rows) in ONE launch: the decoder loops issue the
  * attention-LSTM and decoder-LSTM products of a step together so that they share the device as co-resident
  * workgroups without cross-stream synchronisation.  Arguments per problem as in gt_rec_gemm (nz = 1). */
@@ -262,6 +275,8 @@ typedef struct GtDecoderFwd {
     float* w_hist;             /* (To+1, B, Ti), w_hist[0] = 0 */
     float* cum_hist;           /* (To+1, B, Ti), cum_hist[0] = 0 */
     float* q_hist;             /* (To, B, A) */
+    int32_t bf16;              /* 1: W1p / W2p are gt_pack_rec_weight_bf16 images and the two LSTM products run as
+                                  gt_rec_gemm_bf16 (hparams.fp16_run); needs the unfused path (W1g = W2g = NULL) */
 } GtDecoderFwd;
 
 typedef struct GtDecoderBwd {
@@ -297,6 +312,7 @@ typedef struct GtDecoderBwd {
     int32_t ring;              /* as in GtDecoderFwd */
     int32_t t_hi, t_lo;        /* steps t_hi..t_lo (descending) of this call; t_hi < t_lo = all steps.  State
                                   persists in the buffers, so a loop may be issued in several calls. */
+    int32_t bf16;              /* 1: W1Tp / W2Tp are gt_pack_rec_weight_bf16 images (products run as gt_rec_gemm_bf16) */
 } GtDecoderBwd;
 
 typedef struct GtBiLstm {

@@ -70,10 +70,37 @@ def batch_norm_train(x: Tensor, P: Dict[str, Tensor], prefix: str, training: boo
     return xhat * w[None, :, None] + b[None, :, None]
 
 
+def _bf16(t: Tensor) -> Tensor:
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+class _Bf16Product(torch.autograd.Function):
+    """The arithmetic of the bf16 recurrent products (hparams.fp16_run on the HIP path, gt_rec_gemm_bf16):
+    y = bf16(x) . bf16(W)^T accumulated in fp32; dx = bf16(dy) . bf16(W); the weight gradient stays an fp32 product of
+    the unrounded operands (it is a separate fp32 GEMM over the saved activations)."""
+
+    @staticmethod
+    def forward(ctx, x, W):
+        ctx.save_for_backward(x, W)
+        return _bf16(x) @ _bf16(W).t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        return _bf16(dy) @ _bf16(W), dy.t() @ x
+
+
 def lstm_cell(x: Tensor, h: Tensor, c: Tensor, w_ih: Tensor, w_hh: Tensor,
-              b_ih: Tensor, b_hh: Tensor):
-    """nn.LSTMCell, gate order i,f,g,o (model.py:252-254,261-263)."""
-    gates = x @ w_ih.t() + b_ih + h @ w_hh.t() + b_hh
+              b_ih: Tensor, b_hh: Tensor, bf16_from: Optional[int] = None):
+    """nn.LSTMCell, gate order i,f,g,o (model.py:252-254,261-263).  bf16_from = n: input columns >= n and the
+    recurrent product use bf16 operands (_Bf16Product); columns < n (the Prenet part, a batched fp32 GEMM on the HIP
+    path) stay fp32."""
+    if bf16_from is None:
+        gates = x @ w_ih.t() + b_ih + h @ w_hh.t() + b_hh
+    else:
+        n = bf16_from
+        gates = x[:, :n] @ w_ih[:, :n].t() + b_ih + b_hh + _Bf16Product.apply(
+            torch.cat((x[:, n:], h), dim=1), torch.cat((w_ih[:, n:], w_hh), dim=1))
     i, f, g, o = gates.chunk(4, dim=1)
     c_new = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
     h_new = torch.sigmoid(o) * torch.tanh(c_new)
@@ -157,7 +184,7 @@ def attention_step(P, query: Tensor, memory: Tensor, processed_memory: Tensor,
 def decoder_forward(P, memory: Tensor, mels: Tensor, memory_lengths: Tensor,
                     noise: Optional[Tensor], prenet_keep: List[Tensor],
                     att_keep: Optional[Tensor], dec_keep: Optional[Tensor],
-                    p_att: float = 0.1, p_dec: float = 0.1, training: bool = True):
+                    p_att: float = 0.1, p_dec: float = 0.1, training: bool = True, bf16_products: bool = False):
     """Decoder.forward (teacher forcing), model.py:419-454 with decode() :378-417.
     memory (B,Ti,Eenc); mels (B,n_mel,To); noise (B,noise_size) U[0,1) style vector
     repeated over Ti (model.py:273-279).  Returns mel (B,n_mel,To), gate (B,To),
@@ -184,13 +211,15 @@ def decoder_forward(P, memory: Tensor, mels: Tensor, memory_lengths: Tensor,
     for t in range(To):
         h_a, c_a = lstm_cell(torch.cat((dec_in[t], ctx), -1), h_a, c_a,
                              P['decoder.attention_rnn.weight_ih'], P['decoder.attention_rnn.weight_hh'],
-                             P['decoder.attention_rnn.bias_ih'], P['decoder.attention_rnn.bias_hh'])
+                             P['decoder.attention_rnn.bias_ih'], P['decoder.attention_rnn.bias_hh'],
+                             bf16_from=dec_in.size(2) if bf16_products else None)
         h_a = keep_scale(h_a, att_keep[t] if (training and att_keep is not None) else None, p_att)
         ctx, w = attention_step(P, h_a, memory, pm, w, w_cum, pad)
         w_cum = w_cum + w
         h_d, c_d = lstm_cell(torch.cat((h_a, ctx), -1), h_d, c_d,
                              P['decoder.decoder_rnn.weight_ih'], P['decoder.decoder_rnn.weight_hh'],
-                             P['decoder.decoder_rnn.bias_ih'], P['decoder.decoder_rnn.bias_hh'])
+                             P['decoder.decoder_rnn.bias_ih'], P['decoder.decoder_rnn.bias_hh'],
+                             bf16_from=0 if bf16_products else None)
         h_d = keep_scale(h_d, dec_keep[t] if (training and dec_keep is not None) else None, p_dec)
         hc = torch.cat((h_d, ctx), dim=1)
         mel_out.append(hc @ P['decoder.linear_projection.linear_layer.weight'].t()
@@ -225,7 +254,8 @@ def generator_forward(P, text: Tensor, text_lengths: Tensor, mels: Tensor, outpu
                       rng: Dict[str, object], speaker_ids: Optional[Tensor] = None,
                       emotions: Optional[Tensor] = None, use_labels: bool = False,
                       training: bool = True, mask_padding: bool = True, new_stats=None,
-                      p_att: float = 0.1, p_dec: float = 0.1, encoder_inputs: bool = False):
+                      p_att: float = 0.1, p_dec: float = 0.1, encoder_inputs: bool = False,
+                      bf16_products: bool = False):
     """Tacotron2.forward + parse_output, model.py:632-673.
     rng: dict with 'enc_keep' [3x(B,C,Ti)], 'prenet_keep' [2x(To+1,B,D)], 'att_keep' (To,B,Ha),
     'dec_keep' (To,B,Hd), 'post_keep' [5x(B,C,To)], 'noise' (B,noise_size) or None.
@@ -249,7 +279,7 @@ def generator_forward(P, text: Tensor, text_lengths: Tensor, mels: Tensor, outpu
             enc = torch.cat((enc, spk), dim=2)
     mel, gate, align = decoder_forward(P, enc, mels, text_lengths, dec_noise,
                                        rng['prenet_keep'], rng.get('att_keep'), rng.get('dec_keep'),
-                                       p_att, p_dec, training)
+                                       p_att, p_dec, training, bf16_products)
     post = postnet_forward(P, mel, rng.get('post_keep'), training, new_stats)
     mel_post = mel + post
     if mask_padding and output_lengths is not None:
@@ -642,7 +672,8 @@ def generator_step_grads(G, Dp, batch, rng, hp, use_attn_loss=True):
     out = generator_forward(Pg, text, in_len, mel_t, out_len, rng, spk, emo,
                             use_labels=bool(hp.use_labels and hp.vesus_path), new_stats=new_stats,
                             p_att=hp.p_attention_dropout, p_dec=hp.p_decoder_dropout,
-                            encoder_inputs=bool(getattr(hp, 'encoder_inputs', False)))
+                            encoder_inputs=bool(getattr(hp, 'encoder_inputs', False)),
+                            bf16_products=bool(getattr(hp, 'fp16_run', False)))
     mel_loss, gate_loss, attn_loss = tacotron_loss(out, mel_t, gate_t, in_len, out_len)
     adv = adversarial_loss(Dp, out[1], out_len, hp.discriminator_window, rng.get('disc_keep'))
     total = mel_loss + gate_loss + adv

@@ -116,6 +116,33 @@ def test_rec_gemm(dev, Bsz, N, K, S):
     close(part2.sum(0)[:Bsz, :K], X2[:Bsz].double() @ W.double(), rtol=1e-5, atol=1e-4, what='rec_gemm transposed')
 
 
+@pytest.mark.parametrize('Bsz,N,K,S', [(64, 4096, 3072, 4), (64, 2048, 4096, 8), (5, 128, 40, 1), (33, 192, 1100, 2),
+                                       (64, 4096, 2117, 3)])
+def test_rec_gemm_bf16(dev, Bsz, N, K, S):
+    """gt_rec_gemm_bf16: operands rounded to bf16 (nearest even), fp32 accumulation -- against the fp64 product of the
+    SAME rounded operands (so the check is exact up to accumulation order), plain and transposed packing."""
+    from gantron_amd import ops
+    from gantron_amd.engine import pack_rec_bf16
+    r = lambda t: t.to(torch.bfloat16).double()
+    Bp, ld = ops.roundup(Bsz, 16), ops.roundup(K, 16)
+    W = g(N, K, scale=0.1)
+    X = torch.zeros(Bp, ld)
+    X[:Bsz, :K] = g(Bsz, K, seed=1)
+    Wp = pack_rec_bf16(W.to(dev), N, N, K)
+    part = torch.full((S, Bp, N), float('nan'), device=dev)
+    ops.call('gt_rec_gemm_bf16', X.to(dev), ld, Wp, part, Bp // 16, N, K, S, Bp * N, 1, 0, 0, 0)
+    close(part.sum(0)[:Bsz], r(X[:Bsz, :K]) @ r(W).t(), rtol=1e-5, atol=1e-4, what='rec_gemm_bf16')
+    N2 = ops.roundup(K, 16)
+    WTp = pack_rec_bf16(W.to(dev), N2, K, N, transposed=True)
+    X2 = torch.zeros(Bp, N)
+    X2[:Bsz] = g(Bsz, N, seed=2)
+    from gantron_amd._lib import lib
+    S2 = max(int(lib().gt_rec_bf16_min_splits(N)), 1)
+    part2 = torch.full((S2, Bp, N2), float('nan'), device=dev)
+    ops.call('gt_rec_gemm_bf16', X2.to(dev), N, WTp, part2, Bp // 16, N2, N, S2, Bp * N2, 1, 0, 0, 0)
+    close(part2.sum(0)[:Bsz, :K], r(X2[:Bsz]) @ r(W), rtol=1e-5, atol=1e-4, what='rec_gemm_bf16 transposed')
+
+
 @pytest.mark.parametrize('Bsz,H,K,bias_row', [(64, 1024, 2048, False), (5, 32, 100, True), (33, 64, 333, False), (70, 16, 48, True)])
 def test_lstm_step_fused(dev, Bsz, H, K, bias_row):
     """gt_lstm_step_fused (product + cell + dropout in one launch, gate-interleaved packing) against fp64."""

@@ -43,7 +43,30 @@ def rec(name, N, K, S):
     return part, S
 
 
+def rec_bf16(name, N, K, S):
+    from gantron_amd.engine import pack_rec_bf16
+    W = torch.randn(N, K, device=dev) * 0.05
+    Wp = pack_rec_bf16(W, N, N, K)
+    ld = ops.roundup(K, 16)
+    X = torch.randn(Bp, ld, device=dev)
+    S = max(S, int(lib().gt_rec_bf16_min_splits(K)))
+    kb = -(-K // 32)
+    while -(-kb // -(-kb // S)) != S:
+        S += 1
+    part = torch.empty(S, Bp, N, device=dev)
+    timeit(f'rec_gemm_bf16 {name} N={N} K={K} S={S}', lambda: ops.call('gt_rec_gemm_bf16', X, ld, Wp, part, Bp // 16, N, K, S, Bp * N, 1, 0, 0, 0),
+           flops=2.0 * Bp * N * K, bytes_=2.0 * N * K + 4.0 * (Bp * K + S * Bp * N))
+
+
 splits = [int(x) for x in os.environ.get('SPLITS', '4').split(',')]
+if os.environ.get('BF16'):
+    shapes = {'G1': (4096, 2048), 'G2': (4096, 3072), 'G2T': (3072, 4096), 'G1T': (2048, 4096)}
+    for name, (N, K) in shapes.items():
+        if os.environ.get('ONLY') and os.environ['ONLY'] != name:
+            continue
+        for S in splits:
+            rec_bf16(name, N, K, S)
+    sys.exit(0)
 if os.environ.get('ONLY'):          # e.g. ONLY=G2 under rocprofv3: one shape, so that the stats file is per shape
     shapes = {'G1': (4096, 2048), 'G2': (4096, 3072), 'G2T': (3072, 4096), 'G1T': (2048, 4096)}
     for S in splits:
