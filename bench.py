@@ -157,6 +157,9 @@ def main():
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--fixed-shape', action='store_true', help='nominal Ti=150, To=800 for every item')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--bf16', action='store_true',
+                    help='BASELINE config 3 (hparams.fp16_run): bf16 operands in the decoder LSTM products; NOT the '
+                         'headline metric, the default line is fp32')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -176,7 +179,7 @@ def main():
     from gantron_amd.optim import FlatAdam
     from gantron_amd.train_steps import discriminator_step, generator_step
 
-    hp = HParams(HPARAMS + f',batch_size={args.batch}')
+    hp = HParams(HPARAMS + f',batch_size={args.batch}' + (',fp16_run=True' if args.bf16 else ''))
     # GANTRON_FORCE_DIST=1 exercises the RCCL gradient-averaging path on a single rank (1-GPU boxes)
     use_dist = world > 1 or os.environ.get('GANTRON_FORCE_DIST') == '1'
     if use_dist:
@@ -313,7 +316,8 @@ def main():
         fl = pair_flops(hp, in_lens, out_lens)
         line = dict(metric='mel-frames/sec (gen+disc step) LJSpeech bs=64', value=total_frames * args.steps / elapsed,
                     unit='mel-frames/s', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms,
-                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                    higher_is_better=True, scaling='weak', vs_baseline=None,
+                    dtype='bf16 recurrent products / f32 elsewhere' if args.bf16 else 'f32', data='synthetic',
                     config=dict(workload='Vanilla GANtron (use_labels=False,use_noise=True) LJSpeech-shaped batch=%d fp32, '
                                          'G step + D step pair incl. clip+Adam' % args.batch,
                                 per_gpu_batch=args.batch, global_batch=args.batch * world, Ti_max=Ti, To_max=To,

@@ -135,6 +135,12 @@ def rec_splits(N, K, nz=1):
     return best
 
 
+# chunks per K-slice of the bf16 product.  4 is allowed by the kernel but its 210 VGPRs x 512 threads fill a CU's
+# register file, so nothing of the other chain can share the CU; measured per pair (B=64): 1 chunk 154.5 ms,
+# 2: 150.2, 3: 149.4, 4: 153.1
+BF16_MAX_CHUNKS = int(_os.environ.get('GANTRON_BF16_MAXCH', '3'))
+
+
 def rec_splits_bf16(N, K):
     """K-splits of gt_rec_gemm_bf16 (slices of at most 4 chunks of 256 columns, every load of a slice issued up
     front): rocprofv3 durations at the decoder's shapes fit ~3.4 us fixed + 1.3 us per chunk per workgroup round
@@ -144,7 +150,7 @@ def rec_splits_bf16(N, K):
     best, best_cost = None, None
     for s in range(int(lib().gt_rec_bf16_min_splits(K)), min(16, kb) + 1):
         kbs = -(-kb // s)
-        if -(-kb // kbs) != s:
+        if -(-kb // kbs) != s or -(-kbs // 8) > BF16_MAX_CHUNKS:
             continue
         cost = 3.4 + 1.3 * -(-kbs // 8) * -(-groups * s // 256) + 0.15 * s
         if best_cost is None or cost < best_cost - 1e-9:

@@ -295,7 +295,7 @@ def generator_forward(P, text: Tensor, text_lengths: Tensor, mels: Tensor, outpu
 
 # ----------------------------------------------------------------------------- inference
 def decoder_inference(P, memory: Tensor, style: Optional[Tensor], prenet_keep: List[Tensor],
-                      gate_threshold: float = 0.5, max_decoder_steps: int = 500):
+                      gate_threshold: float = 0.5, max_decoder_steps: int = 500, bf16_products: bool = False):
     """Decoder.inference, model.py:456-497: free-running decode.  The previous mel frame goes back
     through the Prenet (dropout still on, model.py:104), no attention mask (mask=None), no LSTM dropout
     (eval), stop as soon as sigmoid(gate) > gate_threshold (the stopping frame is kept) or after
@@ -322,12 +322,14 @@ def decoder_inference(P, memory: Tensor, style: Optional[Tensor], prenet_keep: L
         x = prenet_forward(P, frame, [k[t] for k in prenet_keep])
         h_a, c_a = lstm_cell(torch.cat((x, ctx), -1), h_a, c_a,
                              P['decoder.attention_rnn.weight_ih'], P['decoder.attention_rnn.weight_hh'],
-                             P['decoder.attention_rnn.bias_ih'], P['decoder.attention_rnn.bias_hh'])
+                             P['decoder.attention_rnn.bias_ih'], P['decoder.attention_rnn.bias_hh'],
+                             bf16_from=x.size(1) if bf16_products else None)
         ctx, w = attention_step(P, h_a, memory, pm, w, w_cum, pad)
         w_cum = w_cum + w
         h_d, c_d = lstm_cell(torch.cat((h_a, ctx), -1), h_d, c_d,
                              P['decoder.decoder_rnn.weight_ih'], P['decoder.decoder_rnn.weight_hh'],
-                             P['decoder.decoder_rnn.bias_ih'], P['decoder.decoder_rnn.bias_hh'])
+                             P['decoder.decoder_rnn.bias_ih'], P['decoder.decoder_rnn.bias_hh'],
+                             bf16_from=0 if bf16_products else None)
         hc = torch.cat((h_d, ctx), dim=1)
         frame = hc @ P['decoder.linear_projection.linear_layer.weight'].t() + P['decoder.linear_projection.linear_layer.bias']
         # (B,1) per step: unlike Decoder.forward (model.py:446), inference does not squeeze the gate, so
@@ -344,7 +346,8 @@ def decoder_inference(P, memory: Tensor, style: Optional[Tensor], prenet_keep: L
 
 def generator_inference(P, text: Tensor, style: Optional[Tensor], prenet_keep: List[Tensor],
                         speaker: Optional[Tensor] = None, emotions: Optional[Tensor] = None,
-                        gate_threshold: float = 0.5, max_decoder_steps: int = 500, encoder_inputs: bool = False):
+                        gate_threshold: float = 0.5, max_decoder_steps: int = 500, encoder_inputs: bool = False,
+                        bf16_products: bool = False):
     """Tacotron2.inference, model.py:675-723: eval-mode encoder without packing
     (Encoder.inference :214-224), memory = [encoder | speaker | emotions | style], free-running decoder,
     PostNet residual; parse_output without lengths leaves the outputs unmasked.  With encoder_inputs the
@@ -363,7 +366,7 @@ def generator_inference(P, text: Tensor, style: Optional[Tensor], prenet_keep: L
         enc = torch.cat((enc, F.embedding(speaker, P['speaker_embedding.weight'])[:, None].repeat(1, enc.size(1), 1)), dim=2)
     if emotions is not None:
         enc = torch.cat((enc, emotions[:, None].repeat(1, enc.size(1), 1)), dim=2)
-    mel, gate, align = decoder_inference(P, enc, style, prenet_keep, gate_threshold, max_decoder_steps)
+    mel, gate, align = decoder_inference(P, enc, style, prenet_keep, gate_threshold, max_decoder_steps, bf16_products)
     mel_post = mel + postnet_forward(P, mel, None, training=False)
     return mel, mel_post, gate, align
 
