@@ -142,17 +142,27 @@ BF16_MAX_CHUNKS = int(_os.environ.get('GANTRON_BF16_MAXCH', '3'))
 
 
 def rec_splits_bf16(N, K):
-    """K-splits of gt_rec_gemm_bf16 (slices of at most 4 chunks of 256 columns, every load of a slice issued up
-    front): rocprofv3 durations at the decoder's shapes fit ~3.4 us fixed + 1.3 us per chunk per workgroup round
-    (256 workgroups a round) + 0.15 us per slab for the consumer."""
+    """K-splits of gt_rec_gemm_bf16 (slices of at most BF16_MAX_CHUNKS chunks of 256 columns, every load of a slice
+    issued up front).  Cost model fitted to rocprofv3 durations at the decoder's shapes: a workgroup round costs
+    ~2.0 us + 1.3 us per chunk; slices of <= 2 chunks need <= 128 VGPRs, so two workgroups share a CU (512 per round,
+    the second 256 at ~0.6 of a round's cost), longer slices run one workgroup per CU (256 per round); 1.4 us of launch
+    + epilogue and 0.15 us per slab for the consumer.  (N=3072, K=4096: 6 splits = 288 workgroups of 3 chunks = two
+    rounds, 12.4 us; 8 splits = 384 workgroups of 2 chunks in one round, 8.0 us; 16 splits = 768 workgroups, 13.9 us.)"""
     kb = -(-K // 32)
     groups = -(-N // 64)
     best, best_cost = None, None
     for s in range(int(lib().gt_rec_bf16_min_splits(K)), min(16, kb) + 1):
         kbs = -(-kb // s)
-        if -(-kb // kbs) != s or -(-kbs // 8) > BF16_MAX_CHUNKS:
+        nch = -(-kbs // 8)
+        if -(-kb // kbs) != s or nch > BF16_MAX_CHUNKS:
             continue
-        cost = 3.4 + 1.3 * -(-kbs // 8) * -(-groups * s // 256) + 0.15 * s
+        wgs, per_round = groups * s, 2.0 + 1.3 * nch
+        cap = 512 if nch <= 2 else 256
+        cost = 1.4 + 0.15 * s
+        while wgs > 0:
+            w = min(wgs, cap)
+            cost += per_round * (1.0 + 0.6 * max(0, w - 256) / 256.0)
+            wgs -= w
         if best_cost is None or cost < best_cost - 1e-9:
             best, best_cost = s, cost
     return best
