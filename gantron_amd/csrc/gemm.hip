@@ -27,7 +27,7 @@ struct GemmDev {
     float* C;
     const float* bias;
     long ldc, a_bs, b_bs, c_bs;
-    int M, N, K, accumulate, split_k, k_per_split;
+    int M, N, K, accumulate, split_k, k_per_split, bf16;
     float alpha;
 };
 
@@ -85,6 +85,23 @@ __device__ __forceinline__ float4 load_rvec(const OpDev& o, const float* base, i
 
 template <int MODE>
 constexpr bool is_ktype() { return MODE == GT_OP_KC || MODE == GT_OP_IM2COL_K; }
+
+// ---- bf16-operand variant (GtGemm.bf16, hparams.fp16_run): the fp32 operands are rounded to bf16 (nearest even)
+// on their way into LDS and multiplied with v_mfma_f32_32x32x16_bf16 (one instruction per 32x32 tile per 16-wide
+// k-tile, 1/16 of the fp32 MFMA time); accumulation, C and the epilogue stay fp32.  The LDS tiles are ROW-major
+// [row][16 k + 8 pad] bf16 (48-byte rows: the 16-byte fragments of 32 consecutive rows fall on distinct bank groups),
+// so that a lane's fragment -- A[row = lane & 31][k = 8 (lane >> 5) + 0..7] -- is one ds_read_b128.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+constexpr int LDH = BK + 8;
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    const bf16x2_t p = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, p);
+}
+__device__ __forceinline__ unsigned short to_bf16(float a) {
+    const __bf16 h = (__bf16)a;
+    return __builtin_bit_cast(unsigned short, h);
+}
 
 // Per-thread loader state for one operand tile of BR rows.
 template <int MODE, int BR>
@@ -158,11 +175,32 @@ struct TileLoader {
             }
         }
     }
+    // bf16 image [row][LDH]: a k-type thread holds 4 consecutive k of one row (one 8-byte store), an r-type thread 4
+    // consecutive rows at one k (four 2-byte stores)
+    __device__ __forceinline__ void store_bf16(unsigned short* S, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            if (is_ktype<MODE>()) {
+                const int rl = (tid & 63) + 64 * i;
+                const int kq = tid >> 6;
+                *reinterpret_cast<uint2*>(&S[rl * LDH + 4 * kq]) =
+                    make_uint2(pack_bf16(reg[i].x, reg[i].y), pack_bf16(reg[i].z, reg[i].w));
+            } else {
+                const int f = tid + 256 * i;
+                const int rq = f % (BR / 4), kl = f / (BR / 4);
+                S[(4 * rq + 0) * LDH + kl] = to_bf16(reg[i].x);
+                S[(4 * rq + 1) * LDH + kl] = to_bf16(reg[i].y);
+                S[(4 * rq + 2) * LDH + kl] = to_bf16(reg[i].z);
+                S[(4 * rq + 3) * LDH + kl] = to_bf16(reg[i].w);
+            }
+        }
+    }
 };
 
-template <int BM, int BN, int AMODE, int BMODE>
+template <int BM, int BN, int AMODE, int BMODE, bool BF = false>
 __global__ __launch_bounds__(256) void sgemm_kernel(GemmDev g) {
     constexpr int LDA = BM + 4, LDB = BN + 4;
+    static_assert((BM + BN) * LDH * 2 <= (BK * LDA + BK * LDB) * 4, "bf16 tiles fit the fp32 staging buffer");
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     __shared__ __attribute__((aligned(16))) float smem[BK * LDA + BK * LDB];
     float* As = smem;
@@ -196,14 +234,35 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmDev g) {
         la.load(g.A, Ab, m0, g.M, kbeg, kend, tid);
         lb.load(g.B, Bb, n0, g.N, kbeg, kend, tid);
     }
+    unsigned short* Ah = reinterpret_cast<unsigned short*>(smem);
+    unsigned short* Bh = Ah + BM * LDH;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        la.store(As, tid);
-        lb.store(Bs, tid);
+        if (BF) {
+            la.store_bf16(Ah, tid);
+            lb.store_bf16(Bh, tid);
+        } else {
+            la.store(As, tid);
+            lb.store(Bs, tid);
+        }
         __syncthreads();
         if (k0 + BK < kend) {
             la.load(g.A, Ab, m0, g.M, k0 + BK, kend, tid);
             lb.load(g.B, Bb, n0, g.N, k0 + BK, kend, tid);
         }
+        if (BF) {
+            bf16x8_t a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(&Ah[(wm0 + 32 * i + (lane & 31)) * LDH + 8 * (lane >> 5)]));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(&Bh[(wn0 + 32 * j + (lane & 31)) * LDH + 8 * (lane >> 5)]));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        } else
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             const int krow = 2 * kk + (lane >> 5);
@@ -245,10 +304,11 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmDev g) {
 template <int BM, int BN>
 int launch_tile(const GemmDev& d, dim3 grid, hipStream_t st) {
     const int am = d.A.mode, bm = d.B.mode;
-#define GT_CASE(AM, BMD)                                                                      \
-    if (am == AM && bm == BMD) {                                                              \
-        hipLaunchKernelGGL((sgemm_kernel<BM, BN, AM, BMD>), grid, dim3(256), 0, st, d);       \
-        return 0;                                                                             \
+#define GT_CASE(AM, BMD)                                                                              \
+    if (am == AM && bm == BMD) {                                                                      \
+        if (d.bf16) hipLaunchKernelGGL((sgemm_kernel<BM, BN, AM, BMD, true>), grid, dim3(256), 0, st, d); \
+        else hipLaunchKernelGGL((sgemm_kernel<BM, BN, AM, BMD>), grid, dim3(256), 0, st, d);         \
+        return 0;                                                                                     \
     }
     GT_CASE(GT_OP_KC, GT_OP_KC)
     GT_CASE(GT_OP_KC, GT_OP_RC)
@@ -305,6 +365,7 @@ extern "C" int gt_sgemm(const GtGemm* g, void* stream) {
     d.a_bs = g->A.batch_stride; d.b_bs = g->B.batch_stride; d.c_bs = g->c_batch_stride;
     d.M = g->M; d.N = g->N; d.K = g->K; d.accumulate = g->accumulate; d.alpha = g->alpha;
     d.split_k = g->split_k;
+    d.bf16 = g->bf16 != 0;
     const int kblocks = cdiv(g->K, BK);
     d.k_per_split = cdiv(kblocks, g->split_k) * BK;
     d.split_k = cdiv(g->K, d.k_per_split);   // drop empty splits

@@ -225,7 +225,7 @@ static GtOperand kc(const float* p, int64_t ld) {
 }
 static int small_linear(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
                         int M, int N, int K, void* stream) {
-    GtGemm g; g.A = kc(X, ldx); g.B = kc(W, ldw); g.C = Y; g.ldc = ldy; g.c_batch_stride = 0; g.bias = bias;
+    GtGemm g = {}; g.A = kc(X, ldx); g.B = kc(W, ldw); g.C = Y; g.ldc = ldy; g.c_batch_stride = 0; g.bias = bias;
     g.M = M; g.N = N; g.K = K; g.batch = 1; g.accumulate = 0; g.split_k = 1; g.alpha = 1.f;
     return gt_sgemm(&g, stream);
 }

@@ -189,6 +189,17 @@ def pack_gates(W2d, H, K):
     return out
 
 
+def _gemm_precision(fn):
+    """Engine entry point: layer GEMMs inside run with bf16 operands when the engine was built with hparams.fp16_run."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        with ops.bf16_gemms(getattr(self, 'bf16', False)):
+            return fn(self, *a, **k)
+    return wrapped
+
+
 class ConvBNStack:
     """[Conv1d(k) -> BatchNorm1d(train) -> act -> dropout] x n over channels-last rows; the encoder
     convolutions (model.py:165-178,196-197) and the PostNet (model.py:113-151)."""
@@ -391,6 +402,7 @@ class GeneratorEngine:
         return memory, mem2, pm
 
     # ------------------------------------------------------------------------------ forward
+    @_gemm_precision
     def forward(self, P, text, in_lens, mels, out_lens, rng, speaker_ids=None, emotions=None, training=True,
                 mask_padding=True):
         """text (B,Ti) int64 cuda; in_lens/out_lens python lists; mels (B,n_mel,To) cuda.
@@ -531,6 +543,7 @@ class GeneratorEngine:
         return (mel, mel_post, gate, align), sv
 
     # ------------------------------------------------------------------------------ inference
+    @_gemm_precision
     def inference(self, P, text, style, prenet_keep, speaker_ids=None, emotions=None, gate_threshold=0.5,
                   max_decoder_steps=500, chunk=32):
         """Tacotron2.inference (model.py:675-723): evaluation-mode encoder (no packing: every row is Ti long),
@@ -626,6 +639,7 @@ class GeneratorEngine:
         return mel, mel_post, gate, align
 
     # ------------------------------------------------------------------------------ backward
+    @_gemm_precision
     def backward(self, P, G, sv, dmel, dmel_post, dgate, dalign):
         """Accumulate parameter gradients into G (dict name -> tensor).  d* are gradients of the four
         outputs (any may be None).  Runs on a high-priority stream so that the latency-bound loop kernels
@@ -798,7 +812,8 @@ class GeneratorEngine:
         dmem = _f32(B, Ti, E, device=dev, zero=False)
         sgemm(Operand(hist['w_hist'], RC, ld=B * Ti, offset=B * Ti, batch_stride=Ti),
               Operand(buf['dctx_hist'], RC, ld=B * E, batch_stride=E), dmem, Ti, E, To, batch=B, c_batch_stride=Ti * E)
-        sgemm(Operand(buf['dpm'], KC, ld=A), Operand(Wmem, RC, ld=E), dmem, B * Ti, E, A, accumulate=True)
+        sgemm(Operand(buf['dpm'], KC, ld=A), Operand(Wmem, RC, ld=E), dmem, B * Ti, E, A, accumulate=True,
+              bf16=ops.BF16_GEMMS)          # input gradient of the memory layer (a layer GEMM)
         LEAF.run(lambda: ops.linear_dw(buf['dpm'], sv['memory'], B * Ti, A, E, G[al + 'memory_layer.linear_layer.weight']), buf['dpm'])
 
         col = 2 * H
@@ -866,7 +881,9 @@ class DiscriminatorEngine:
     def __init__(self, hp):
         self.hp = hp
         self.window, self.n_mel = hp.discriminator_window, hp.n_mel_channels
+        self.bf16 = bool(getattr(hp, 'fp16_run', False))
 
+    @_gemm_precision
     def forward(self, P, mel, lengths, keeps, training=True):
         """mel (B, n_mel, T) cuda; lengths int64 cuda tensor (B).  Returns loss (1,) and saved state."""
         dev = mel.device
@@ -893,6 +910,7 @@ class DiscriminatorEngine:
         sv['out'] = out
         return loss, sv
 
+    @_gemm_precision
     def backward(self, P, G, sv, dloss, scale=1.0, need_dinput=True, need_dparams=True):
         """dloss: (1,) cuda tensor (upstream gradient) or None for 1.  Returns d mel (B, n_mel, T)."""
         B, T, W = sv['B'], sv['T'], sv['W']
@@ -923,6 +941,7 @@ class DiscriminatorEngine:
         call('gt_disc_gather_bwd', dy, B, n_mel, T, win, dmel, 0)
         return dmel
 
+    @_gemm_precision
     def gradient_penalty(self, P, G, real, fake, lengths, alpha, keeps, training=True):
         """gradient_penalty of train.py:32-69 and its gradient with respect to the discriminator parameters.
         real, fake (B, n_mel, T) cuda (already cropped to the common T); lengths int64 cuda (B) of the tensor that
@@ -1001,7 +1020,9 @@ class LinearDiscriminatorEngine:
 
     def __init__(self, hp):
         self.window, self.n_mel = hp.discriminator_window, hp.n_mel_channels
+        self.bf16 = bool(getattr(hp, 'fp16_run', False))
 
+    @_gemm_precision
     def forward(self, P, mel, starts, keeps, training=True):
         """mel (B, n_mel, T) cuda; starts: per item the list of window start frames.  Returns loss (1,), saved."""
         dev = mel.device
@@ -1035,6 +1056,7 @@ class LinearDiscriminatorEngine:
         sgemm(Operand(wgt, KC, ld=NW), Operand(out, RC, ld=1), loss, 1, 1, NW)           # sum_w wgt[w] * out[w]
         return loss, sv
 
+    @_gemm_precision
     def backward(self, P, G, sv, dloss, scale=1.0, need_dinput=True, need_dparams=True):
         B, T, NW = sv['B'], sv['T'], sv['NW']
         dev = sv['out'].device

@@ -40,6 +40,26 @@ class splitk_target:
         SPLITK_TARGET = self.old
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 
+# hparams.fp16_run: the layer GEMMs (linear / conv1d forward, input gradient, weight gradient below) round their
+# operands to bf16 inside gt_sgemm; the engines switch it on for the duration of their entry points.  Raw sgemm()
+# calls stay fp32 unless they ask.
+BF16_GEMMS = False
+
+
+class bf16_gemms:
+    """with ops.bf16_gemms(flag): ... -- layer GEMMs with bf16 operands inside the block."""
+
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global BF16_GEMMS
+        self.old, BF16_GEMMS = BF16_GEMMS, self.on
+
+    def __exit__(self, *exc):
+        global BF16_GEMMS
+        BF16_GEMMS = self.old
+
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
@@ -103,7 +123,7 @@ def forward_split_k(M, N, K):
 
 
 def sgemm(A, B, C, M, N, K, ldc=None, bias=None, accumulate=False, split_k=1, batch=1,
-          c_batch_stride=0, alpha=1.0, c_offset=0):
+          c_batch_stride=0, alpha=1.0, c_offset=0, bf16=False):
     g = GtGemm()
     g.A, g.B = A.c(), B.c()
     g.C = ptr(C, c_offset)
@@ -112,6 +132,7 @@ def sgemm(A, B, C, M, N, K, ldc=None, bias=None, accumulate=False, split_k=1, ba
     g.bias = ptr(bias)
     g.M, g.N, g.K, g.batch = M, N, K, batch
     g.accumulate, g.split_k, g.alpha = int(accumulate), split_k, alpha
+    g.bf16 = int(bool(bf16))
     if split_k > 1 and not accumulate:
         raise ValueError('split_k > 1 accumulates: zero C and pass accumulate=True')
     check(lib().gt_sgemm(ctypes.byref(g), _stream()), 'gt_sgemm')
@@ -151,7 +172,7 @@ def linear(x, W, M, K, N, bias=None, out=None, ldw=None, w_offset=0, ldx=None, x
     if out is None:
         out = torch.empty(M, N, device=x.device, dtype=torch.float32)
     sgemm(Operand(x, KC, ld=ldx or K, offset=x_offset), Operand(W, KC, ld=ldw or K, offset=w_offset), out, M, N, K,
-          bias=bias)
+          bias=bias, bf16=BF16_GEMMS)
     return out
 
 
@@ -159,7 +180,8 @@ def linear_dx(dy, W, M, N, K, out=None, ldw=None, w_offset=0, lddy=None, dy_offs
     """out[M,K] = dy[M,N] @ W[N,K]."""
     if out is None:
         out = torch.empty(M, K, device=dy.device, dtype=torch.float32)
-    sgemm(Operand(dy, KC, ld=lddy or N, offset=dy_offset), Operand(W, RC, ld=ldw or K, offset=w_offset), out, M, K, N)
+    sgemm(Operand(dy, KC, ld=lddy or N, offset=dy_offset), Operand(W, RC, ld=ldw or K, offset=w_offset), out, M, K, N,
+          bf16=BF16_GEMMS)
     return out
 
 
@@ -167,7 +189,7 @@ def linear_dw(dy, x, rows, N, K, dW, lddy=None, dy_offset=0, ldx=None, x_offset=
     """dW[N,K] += dy[rows,N]^T @ x[rows,K]  (split-K over rows when the output grid is small)."""
     sk = default_split_k(N, K, rows)
     sgemm(Operand(dy, RC, ld=lddy or N, offset=dy_offset), Operand(x, RC, ld=ldx or K, offset=x_offset), dW, N, K, rows,
-          ldc=ldc, accumulate=True, split_k=sk, c_offset=c_offset)
+          ldc=ldc, accumulate=True, split_k=sk, c_offset=c_offset, bf16=BF16_GEMMS)
 
 
 def col_sums(x, rows, C):
@@ -200,7 +222,7 @@ def conv1d_fwd(x, Wf, bias, B, T, Cin, Cout, K, dil):
     sk = forward_split_k(B * T, Cout, K * Cin)
     out = (torch.zeros if sk > 1 else torch.empty)(B * T, Cout, device=x.device, dtype=torch.float32)
     sgemm(Operand(x, IM2COL_K, T=T, C=Cin, dil=dil, pad=pad), Operand(Wf, KC, ld=K * Cin), out, B * T, Cout, K * Cin,
-          bias=bias, accumulate=sk > 1, split_k=sk)
+          bias=bias, accumulate=sk > 1, split_k=sk, bf16=BF16_GEMMS)
     return out
 
 
@@ -209,7 +231,7 @@ def conv1d_dx(dy, Wb, B, T, Cin, Cout, K, dil):
     sk = forward_split_k(B * T, Cin, K * Cout)
     out = (torch.zeros if sk > 1 else torch.empty)(B * T, Cin, device=dy.device, dtype=torch.float32)
     sgemm(Operand(dy, IM2COL_K, T=T, C=Cout, dil=dil, pad=pad), Operand(Wb, KC, ld=K * Cout), out, B * T, Cin, K * Cout,
-          accumulate=sk > 1, split_k=sk)
+          accumulate=sk > 1, split_k=sk, bf16=BF16_GEMMS)
     return out
 
 
@@ -219,6 +241,6 @@ def conv1d_dw(dy, x, B, T, Cin, Cout, K, dil, dW):
     tmp = torch.zeros(Cout, K * Cin, device=dy.device, dtype=torch.float32)
     sk = default_split_k(Cout, K * Cin, B * T)
     sgemm(Operand(dy, RC, ld=Cout), Operand(x, IM2COL_R, T=T, C=Cin, dil=dil, pad=pad), tmp, Cout, K * Cin, B * T,
-          accumulate=True, split_k=sk)
+          accumulate=True, split_k=sk, bf16=BF16_GEMMS)
     # tmp[co][k][ci] -> dW[co][ci][k]
     call('gt_permute3', tmp, K * Cin, 1, Cin, Cout, Cin, K, dW, 0, 0, 1, 1.0)

@@ -87,6 +87,8 @@ typedef struct GtGemm {
     int32_t accumulate;         /* 0: C = ..., 1: C += ... */
     int32_t split_k;            /* >= 1; > 1 uses fp32 atomics and therefore always accumulates */
     float alpha;
+    int32_t bf16;               /* 1: operands rounded to bf16 (nearest even) in the tile loader, bf16 MFMA, fp32
+                                   accumulation and output (hparams.fp16_run) */
 } GtGemm;
 
 int gt_sgemm(const GtGemm* g, void* stream);

@@ -74,33 +74,98 @@ def _bf16(t: Tensor) -> Tensor:
     return t.to(torch.bfloat16).to(torch.float32)
 
 
-class _Bf16Product(torch.autograd.Function):
-    """The arithmetic of the bf16 recurrent products (hparams.fp16_run on the HIP path, gt_rec_gemm_bf16):
-    y = bf16(x) . bf16(W)^T accumulated in fp32; dx = bf16(dy) . bf16(W); the weight gradient stays an fp32 product of
-    the unrounded operands (it is a separate fp32 GEMM over the saved activations)."""
+# ---- hparams.fp16_run on the HIP path (BASELINE config 3): bf16 OPERANDS, fp32 accumulation, in
+#   * the layer GEMMs (Linear / Conv1d forward, input gradient and weight gradient: gt_sgemm with GtGemm.bf16),
+#   * the two decoder LSTM products of every step (gt_rec_gemm_bf16) and their input gradients;
+# products that live inside fp32 kernels (BiLSTM recurrence, attention query / location / v, context) stay fp32, but
+# their weight gradients, being layer GEMMs over saved activations, take rounded operands too.  The oracle states
+# exactly that arithmetic, so the *_bf16 parity tests stay operand-for-operand checks.
+_FP16_RUN = False
+
+
+class fp16_run:
+    """with fp16_run(flag): ... -- products below follow the HIP path's hparams.fp16_run arithmetic."""
+
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global _FP16_RUN
+        self.old, _FP16_RUN = _FP16_RUN, self.on
+
+    def __exit__(self, *exc):
+        global _FP16_RUN
+        _FP16_RUN = self.old
+
+
+class _Prod(torch.autograd.Function):
+    """y = x . W^T with per-product operand rounding: r_fwd (forward), r_dx (dx = dy . W), r_dw (dW = dy^T . x)."""
 
     @staticmethod
-    def forward(ctx, x, W):
+    def forward(ctx, x, W, r_fwd, r_dx, r_dw):
         ctx.save_for_backward(x, W)
-        return _bf16(x) @ _bf16(W).t()
+        ctx.flags = (r_dx, r_dw)
+        return (_bf16(x) @ _bf16(W).t()) if r_fwd else (x @ W.t())
 
     @staticmethod
     def backward(ctx, dy):
         x, W = ctx.saved_tensors
-        return _bf16(dy) @ _bf16(W), dy.t() @ x
+        r_dx, r_dw = ctx.flags
+        dy2, x2 = dy.reshape(-1, dy.size(-1)), x.reshape(-1, x.size(-1))
+        dx = (_bf16(dy2) @ _bf16(W)) if r_dx else (dy2 @ W)
+        dW = (_bf16(dy2).t() @ _bf16(x2)) if r_dw else (dy2.t() @ x2)
+        return dx.reshape(x.shape), dW, None, None, None
+
+
+def mm(x: Tensor, W: Tensor, kind: str = 'gemm') -> Tensor:
+    """x . W^T.  kind 'gemm': a layer GEMM (all three products rounded under fp16_run); 'kernel32': forward and input
+    gradient inside an fp32 kernel, weight gradient a layer GEMM; 'rec': a decoder LSTM product (gt_rec_gemm_bf16)."""
+    if not _FP16_RUN:
+        return x @ W.t()
+    if kind == 'kernel32':
+        return _Prod.apply(x, W, False, False, True)
+    return _Prod.apply(x, W, True, True, True)
+
+
+class _Conv(torch.autograd.Function):
+    """Conv1d whose three implicit GEMMs (forward, input gradient, weight gradient) take bf16-rounded operands."""
+
+    @staticmethod
+    def forward(ctx, x, w, padding, dilation):
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (padding, dilation)
+        return F.conv1d(_bf16(x), _bf16(w), None, padding=padding, dilation=dilation)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        padding, dilation = ctx.cfg
+        dyr = _bf16(dy)
+        dx = torch.nn.grad.conv1d_input(x.shape, _bf16(w), dyr, padding=padding, dilation=dilation)
+        dw = torch.nn.grad.conv1d_weight(_bf16(x), w.shape, dyr, padding=padding, dilation=dilation)
+        return dx, dw, None, None
+
+
+def conv1d(x: Tensor, w: Tensor, bias: Optional[Tensor], padding: int = 0, dilation: int = 1) -> Tensor:
+    if not _FP16_RUN:
+        return F.conv1d(x, w, bias, padding=padding, dilation=dilation)
+    y = _Conv.apply(x, w, padding, dilation)
+    return y if bias is None else y + bias[None, :, None]
 
 
 def lstm_cell(x: Tensor, h: Tensor, c: Tensor, w_ih: Tensor, w_hh: Tensor,
-              b_ih: Tensor, b_hh: Tensor, bf16_from: Optional[int] = None):
-    """nn.LSTMCell, gate order i,f,g,o (model.py:252-254,261-263).  bf16_from = n: input columns >= n and the
-    recurrent product use bf16 operands (_Bf16Product); columns < n (the Prenet part, a batched fp32 GEMM on the HIP
-    path) stay fp32."""
+              b_ih: Tensor, b_hh: Tensor, bf16_from: Optional[int] = None, head_fp32: bool = False):
+    """nn.LSTMCell, gate order i,f,g,o (model.py:252-254,261-263).  Default (encoder BiLSTM): the input product is a
+    layer GEMM, the recurrent one runs inside gt_rec_gemm (fp32).  bf16_from = n (decoder cells under fp16_run): input
+    columns < n (the Prenet part, a batched layer GEMM) and columns >= n together with the recurrent product (one
+    gt_rec_gemm_bf16 product) all take bf16 operands."""
     if bf16_from is None:
-        gates = x @ w_ih.t() + b_ih + h @ w_hh.t() + b_hh
+        gates = mm(x, w_ih) + b_ih + mm(h, w_hh, 'kernel32') + b_hh
     else:
         n = bf16_from
-        gates = x[:, :n] @ w_ih[:, :n].t() + b_ih + b_hh + _Bf16Product.apply(
-            torch.cat((x[:, n:], h), dim=1), torch.cat((w_ih[:, n:], w_hh), dim=1))
+        gates = b_ih + b_hh + mm(torch.cat((x[:, n:], h), dim=1), torch.cat((w_ih[:, n:], w_hh), dim=1), 'rec')
+        if n > 0:       # head_fp32: the free-running decoder's per-step Prenet product (fp32 in its C++ loop)
+            gates = gates + (x[:, :n] @ w_ih[:, :n].t() if head_fp32 else mm(x[:, :n], w_ih[:, :n]))
     i, f, g, o = gates.chunk(4, dim=1)
     c_new = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
     h_new = torch.sigmoid(o) * torch.tanh(c_new)
@@ -117,7 +182,7 @@ def encoder_forward(P, embedded: Tensor, lengths: Tensor, enc_keep: Optional[Lis
     n_conv = len([k for k in P if k.startswith('encoder.convolutions.') and k.endswith('.0.conv.weight')])
     for i in range(n_conv):
         w = P[f'encoder.convolutions.{i}.0.conv.weight']
-        x = F.conv1d(x, w, P[f'encoder.convolutions.{i}.0.conv.bias'], padding=(w.size(2) - 1) // 2)
+        x = conv1d(x, w, P[f'encoder.convolutions.{i}.0.conv.bias'], padding=(w.size(2) - 1) // 2)
         x = batch_norm_train(x, P, f'encoder.convolutions.{i}.1', training, new_stats)
         x = keep_scale(F.relu(x), enc_keep[i] if (enc_keep is not None and training) else None, 0.5)
     x = x.transpose(1, 2)  # (B, Ti, C)
@@ -150,12 +215,13 @@ def bilstm_packed(P, x: Tensor, lengths: Tensor) -> Tensor:
 
 
 # ----------------------------------------------------------------------------- decoder
-def prenet_forward(P, x: Tensor, prenet_keep: List[Tensor]) -> Tensor:
-    """Prenet.forward, model.py:102-105: dropout p=.5 is ALWAYS on."""
+def prenet_forward(P, x: Tensor, prenet_keep: List[Tensor], fp32: bool = False) -> Tensor:
+    """Prenet.forward, model.py:102-105: dropout p=.5 is ALWAYS on.  fp32: the free-running decoder computes the
+    Prenet of one frame per step inside its C++ loop with fp32 products whatever hparams.fp16_run says."""
     i = 0
     while f'decoder.prenet.layers.{i}.linear_layer.weight' in P:
-        x = keep_scale(F.relu(x @ P[f'decoder.prenet.layers.{i}.linear_layer.weight'].t()),
-                       prenet_keep[i], 0.5)
+        W = P[f'decoder.prenet.layers.{i}.linear_layer.weight']
+        x = keep_scale(F.relu(x @ W.t() if fp32 else mm(x, W)), prenet_keep[i], 0.5)
         i += 1
     return x
 
@@ -167,7 +233,7 @@ def attention_step(P, query: Tensor, memory: Tensor, processed_memory: Tensor,
     query (B,Ha); memory (B,Ti,E); processed_memory (B,Ti,A); w_prev/w_cum (B,Ti);
     pad_mask True on padded positions."""
     pre = 'decoder.attention_layer.'
-    pq = query @ P[pre + 'query_layer.linear_layer.weight'].t()              # (B, A)
+    pq = mm(query, P[pre + 'query_layer.linear_layer.weight'], 'kernel32')     # (B, A)
     wconv = P[pre + 'location_layer.location_conv.conv.weight']             # (F, 2, K)
     cat = torch.stack((w_prev, w_cum), dim=1)                                # (B, 2, Ti)
     loc = F.conv1d(cat, wconv, None, padding=(wconv.size(2) - 1) // 2)       # (B, F, Ti)
@@ -204,7 +270,7 @@ def decoder_forward(P, memory: Tensor, mels: Tensor, memory_lengths: Tensor,
     h_d = memory.new_zeros(B, Hd); c_d = memory.new_zeros(B, Hd)
     w = memory.new_zeros(B, Ti); w_cum = memory.new_zeros(B, Ti)
     ctx = memory.new_zeros(B, memory.size(2))
-    pm = memory @ P['decoder.attention_layer.memory_layer.linear_layer.weight'].t()
+    pm = mm(memory, P['decoder.attention_layer.memory_layer.linear_layer.weight'])
     pad = ~length_mask(memory_lengths, Ti)
 
     mel_out, gate_out, aligns = [], [], []
@@ -222,9 +288,9 @@ def decoder_forward(P, memory: Tensor, mels: Tensor, memory_lengths: Tensor,
                              bf16_from=0 if bf16_products else None)
         h_d = keep_scale(h_d, dec_keep[t] if (training and dec_keep is not None) else None, p_dec)
         hc = torch.cat((h_d, ctx), dim=1)
-        mel_out.append(hc @ P['decoder.linear_projection.linear_layer.weight'].t()
+        mel_out.append(mm(hc, P['decoder.linear_projection.linear_layer.weight'])
                        + P['decoder.linear_projection.linear_layer.bias'])
-        gate_out.append((hc @ P['decoder.gate_layer.linear_layer.weight'].t()
+        gate_out.append((mm(hc, P['decoder.gate_layer.linear_layer.weight'])
                          + P['decoder.gate_layer.linear_layer.bias']).squeeze(1))
         aligns.append(w)
     aligns = torch.stack(aligns).transpose(0, 1)
@@ -241,7 +307,7 @@ def postnet_forward(P, x: Tensor, post_keep: Optional[List[Tensor]], training: b
     n = len([k for k in P if k.startswith('postnet.convolutions.') and k.endswith('.0.conv.weight')])
     for i in range(n):
         w = P[f'postnet.convolutions.{i}.0.conv.weight']
-        x = F.conv1d(x, w, P[f'postnet.convolutions.{i}.0.conv.bias'], padding=(w.size(2) - 1) // 2)
+        x = conv1d(x, w, P[f'postnet.convolutions.{i}.0.conv.bias'], padding=(w.size(2) - 1) // 2)
         x = batch_norm_train(x, P, f'postnet.convolutions.{i}.1', training, new_stats)
         if i < n - 1:
             x = torch.tanh(x)
@@ -313,17 +379,17 @@ def decoder_inference(P, memory: Tensor, style: Optional[Tensor], prenet_keep: L
     h_d = memory.new_zeros(B, Hd); c_d = memory.new_zeros(B, Hd)
     w = memory.new_zeros(B, Ti); w_cum = memory.new_zeros(B, Ti)
     ctx = memory.new_zeros(B, memory.size(2))
-    pm = memory @ P['decoder.attention_layer.memory_layer.linear_layer.weight'].t()
+    pm = mm(memory, P['decoder.attention_layer.memory_layer.linear_layer.weight'])
     pad = torch.zeros(B, Ti, dtype=torch.bool)
     frame = memory.new_zeros(B, n_mel)
     mel_out, gate_out, aligns = [], [], []
     while True:
         t = len(mel_out)
-        x = prenet_forward(P, frame, [k[t] for k in prenet_keep])
+        x = prenet_forward(P, frame, [k[t] for k in prenet_keep], fp32=True)
         h_a, c_a = lstm_cell(torch.cat((x, ctx), -1), h_a, c_a,
                              P['decoder.attention_rnn.weight_ih'], P['decoder.attention_rnn.weight_hh'],
                              P['decoder.attention_rnn.bias_ih'], P['decoder.attention_rnn.bias_hh'],
-                             bf16_from=x.size(1) if bf16_products else None)
+                             bf16_from=x.size(1) if bf16_products else None, head_fp32=True)
         ctx, w = attention_step(P, h_a, memory, pm, w, w_cum, pad)
         w_cum = w_cum + w
         h_d, c_d = lstm_cell(torch.cat((h_a, ctx), -1), h_d, c_d,
@@ -353,21 +419,22 @@ def generator_inference(P, text: Tensor, style: Optional[Tensor], prenet_keep: L
     PostNet residual; parse_output without lengths leaves the outputs unmasked.  With encoder_inputs the
     emotions and the style (B,noise) are channels of the embedded text instead (:694-701) and the decoder
     gets neither."""
-    emb = F.embedding(text, P['embedding.weight']).transpose(1, 2)
-    if encoder_inputs:
+    with fp16_run(bf16_products):
+        emb = F.embedding(text, P['embedding.weight']).transpose(1, 2)
+        if encoder_inputs:
+            if emotions is not None:
+                emb = torch.cat((emb, emotions[:, :, None].repeat(1, 1, emb.size(-1))), dim=1)
+            if style is not None:
+                emb = torch.cat((emb, style[:, :, None].repeat(1, 1, emb.size(-1))), dim=1)
+            style = emotions = None
+        lengths = torch.full((text.size(0),), text.size(1), dtype=torch.long)
+        enc = encoder_forward(P, emb, lengths, None, training=False)
+        if speaker is not None and 'speaker_embedding.weight' in P:
+            enc = torch.cat((enc, F.embedding(speaker, P['speaker_embedding.weight'])[:, None].repeat(1, enc.size(1), 1)), dim=2)
         if emotions is not None:
-            emb = torch.cat((emb, emotions[:, :, None].repeat(1, 1, emb.size(-1))), dim=1)
-        if style is not None:
-            emb = torch.cat((emb, style[:, :, None].repeat(1, 1, emb.size(-1))), dim=1)
-        style = emotions = None
-    lengths = torch.full((text.size(0),), text.size(1), dtype=torch.long)
-    enc = encoder_forward(P, emb, lengths, None, training=False)
-    if speaker is not None and 'speaker_embedding.weight' in P:
-        enc = torch.cat((enc, F.embedding(speaker, P['speaker_embedding.weight'])[:, None].repeat(1, enc.size(1), 1)), dim=2)
-    if emotions is not None:
-        enc = torch.cat((enc, emotions[:, None].repeat(1, enc.size(1), 1)), dim=2)
-    mel, gate, align = decoder_inference(P, enc, style, prenet_keep, gate_threshold, max_decoder_steps, bf16_products)
-    mel_post = mel + postnet_forward(P, mel, None, training=False)
+            enc = torch.cat((enc, emotions[:, None].repeat(1, enc.size(1), 1)), dim=2)
+        mel, gate, align = decoder_inference(P, enc, style, prenet_keep, gate_threshold, max_decoder_steps, bf16_products)
+        mel_post = mel + postnet_forward(P, mel, None, training=False)
     return mel, mel_post, gate, align
 
 
@@ -389,10 +456,10 @@ def discriminator_forward(P, x: Tensor, window: int, disc_keep: Optional[List[Te
     dil = [1, 2, 2, 2]
     for i in range(4):
         w = P[f'discriminator.{i}.module.0.weight']
-        r = F.conv1d(r, w, P[f'discriminator.{i}.module.0.bias'],
+        r = conv1d(r, w, P[f'discriminator.{i}.module.0.bias'],
                      padding=dil[i] * (w.size(2) - 1) // 2, dilation=dil[i])
         r = torch.tanh(keep_scale(r, disc_keep[i] if (training and disc_keep is not None) else None, 0.5))
-    r = F.conv1d(r, P['discriminator.4.weight'], P['discriminator.4.bias'])
+    r = conv1d(r, P['discriminator.4.weight'], P['discriminator.4.bias'])
     return r.squeeze(1)
 
 
@@ -443,9 +510,9 @@ def linear_discriminator_loss(P, mel: Tensor, starts, window: int, keeps, traini
         counts.append(len(st))
     h = torch.stack(wins)
     for i in range(3):
-        h = h @ P[f'discriminator.{i}.module.0.weight'].t() + P[f'discriminator.{i}.module.0.bias']
+        h = mm(h, P[f'discriminator.{i}.module.0.weight']) + P[f'discriminator.{i}.module.0.bias']
         h = torch.tanh(keep_scale(h, keeps[i] if (keeps is not None and training) else None, 0.5))
-    out = (h @ P['discriminator.3.weight'].t() + P['discriminator.3.bias']).squeeze(1)
+    out = (mm(h, P['discriminator.3.weight']) + P['discriminator.3.bias']).squeeze(1)
     loss, o = 0.0, 0
     for n in counts:
         loss = loss + out[o:o + n].mean()
@@ -663,6 +730,21 @@ def clip_grad_norm(grads: Dict[str, Tensor], max_norm: float) -> Tensor:
     return total
 
 
+def _with_hp_precision(fn):
+    """Run a step function under fp16_run(hp.fp16_run); hp is the positional / keyword argument named `hp`."""
+    import functools
+    import inspect
+    pos = list(inspect.signature(fn).parameters).index('hp')
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        hp = k['hp'] if 'hp' in k else a[pos]
+        with fp16_run(getattr(hp, 'fp16_run', False)):
+            return fn(*a, **k)
+    return wrapped
+
+
+@_with_hp_precision
 def generator_step_grads(G, Dp, batch, rng, hp, use_attn_loss=True):
     """Loss and parameter gradients of one generator step, train.py:361-397.
     batch = (text, in_len, mel, gate, out_len[, speaker_ids, emotions]);
@@ -690,6 +772,7 @@ def generator_step_grads(G, Dp, batch, rng, hp, use_attn_loss=True):
     return [o.detach() for o in out], losses, grads, new_stats
 
 
+@_with_hp_precision
 def discriminator_step_grads(Dp, real_mel, real_len, fake_mel, fake_len, keep_real, keep_fake, hp):
     """Loss and D-parameter gradients of one discriminator step, train.py:302-344:
     loss = (D(real) - D(fake)) / 2 (real=+1, fake=-1, train.py:509-510)."""

@@ -25,20 +25,31 @@ def g(*shape, seed=0, scale=1.0):
 
 
 # ------------------------------------------------------------------------------------- sgemm
-@pytest.mark.parametrize('M,N,K', [(200, 150, 70), (64, 64, 16), (129, 257, 333), (1, 80, 2048), (515, 1, 33)])
-def test_sgemm_kc_kc(dev, M, N, K):
+def rb(t, bf16):
+    """operand as the bf16 variant of gt_sgemm sees it (rounded to nearest even), in fp64"""
+    return t.to(torch.bfloat16).double() if bf16 else t.double()
+
+
+@pytest.mark.parametrize('bf16', [False, True])
+@pytest.mark.parametrize('M,N,K', [(200, 150, 70), (64, 64, 16), (129, 257, 333), (1, 80, 2048), (515, 1, 33), (300, 260, 1000),
+                                   (2000, 1536, 200)])     # the last one runs on 128x128 tiles (>= 192 of them)
+def test_sgemm_kc_kc(dev, M, N, K, bf16):
     from gantron_amd import ops
     A, B, bias = g(M, K), g(N, K, seed=1), g(N, seed=2)
     C = torch.empty(M, N, device=dev)
-    ops.sgemm(ops.Operand(A.to(dev), ops.KC, ld=K), ops.Operand(B.to(dev), ops.KC, ld=K), C, M, N, K, bias=bias.to(dev))
-    close(C, A.double() @ B.double().t() + bias.double(), rtol=1e-5, atol=1e-5, what='sgemm kc/kc')
+    ops.sgemm(ops.Operand(A.to(dev), ops.KC, ld=K), ops.Operand(B.to(dev), ops.KC, ld=K), C, M, N, K, bias=bias.to(dev),
+              bf16=bf16)
+    close(C, rb(A, bf16) @ rb(B, bf16).t() + bias.double(), rtol=1e-5, atol=1e-5, what='sgemm kc/kc')
 
 
-def test_sgemm_modes_accumulate_splitk_batch(dev):
+@pytest.mark.parametrize('bf16', [False, True])
+def test_sgemm_modes_accumulate_splitk_batch(dev, bf16):
     from gantron_amd import ops
+    import functools
     M, N, K = 96, 130, 700
     A, B = g(M, K), g(N, K, seed=1)
-    ref = A.double() @ B.double().t()
+    ref = rb(A, bf16) @ rb(B, bf16).t()
+    ops = type('O', (), {k: getattr(ops, k) for k in ('Operand', 'KC', 'RC')} | {'sgemm': functools.partial(ops.sgemm, bf16=bf16)})
     # RC/RC: both operands stored reduction-major
     C = torch.zeros(M, N, device=dev)
     ops.sgemm(ops.Operand(A.t().contiguous().to(dev), ops.RC, ld=M), ops.Operand(B.t().contiguous().to(dev), ops.RC, ld=N),
@@ -66,29 +77,38 @@ def test_sgemm_modes_accumulate_splitk_batch(dev):
     Apad = torch.cat((torch.zeros(5), Ab.reshape(-1))).to(dev)
     ops.sgemm(ops.Operand(Apad, ops.KC, ld=K, offset=5, batch_stride=M * K),
               ops.Operand(Bb.to(dev), ops.KC, ld=K, batch_stride=N * K), Cb, M, N, K, batch=nb, c_batch_stride=M * N)
-    close(Cb, torch.bmm(Ab.double(), Bb.double().transpose(1, 2)), rtol=1e-5, atol=1e-4, what='batched')
+    close(Cb, torch.bmm(rb(Ab, bf16), rb(Bb, bf16).transpose(1, 2)), rtol=1e-5, atol=1e-4, what='batched')
+    # 128x128 tiles (>= 192 of them), reduction-major operands: the shape class of the weight-gradient GEMMs
+    M2, N2, K2 = 1536, 2000, 150
+    A2, B2 = g(K2, M2, seed=11), g(K2, N2, seed=12)
+    C2 = torch.zeros(M2, N2, device=dev)
+    ops.sgemm(ops.Operand(A2.to(dev), ops.RC, ld=M2), ops.Operand(B2.to(dev), ops.RC, ld=N2), C2, M2, N2, K2)
+    close(C2, rb(A2, bf16).t() @ rb(B2, bf16), rtol=1e-5, atol=1e-4, what='rc/rc 128x128 tiles')
 
 
+@pytest.mark.parametrize('bf16', [False, True])
 @pytest.mark.parametrize('B,T,Cin,Cout,K,dil', [(3, 37, 16, 24, 5, 1), (2, 9, 32, 48, 5, 2), (4, 150, 80, 512, 5, 1)])
-def test_conv1d_fwd_dx_dw(dev, B, T, Cin, Cout, K, dil):
+def test_conv1d_fwd_dx_dw(dev, B, T, Cin, Cout, K, dil, bf16):
+    """bf16: ops.bf16_gemms (hparams.fp16_run) -- every product takes its two operands rounded to bf16, so the
+    reference is the fp64 convolution / gradients of the rounded x, W and dy."""
     from gantron_amd import ops
-    x = g(B, Cin, T).requires_grad_(True)
-    W = g(Cout, Cin, K, seed=1, scale=0.2).requires_grad_(True)
-    bias = g(Cout, seed=2)
-    pad = dil * (K - 1) // 2
-    y = F.conv1d(x.double(), W.double(), bias.double(), padding=pad, dilation=dil)
+    x, W, bias = g(B, Cin, T), g(Cout, Cin, K, seed=1, scale=0.2), g(Cout, seed=2)
     dy = g(B, Cout, T, seed=3)
-    gx, gw = torch.autograd.grad(y, (x, W), dy.double())
-    xcl = x.detach().permute(0, 2, 1).contiguous().view(B * T, Cin).to(dev)
-    Wd = W.detach().to(dev)
-    ycl = ops.conv1d_fwd(xcl, ops.conv_weight_fwd(Wd), bias.to(dev), B, T, Cin, Cout, K, dil)
-    close(ycl.view(B, T, Cout).permute(0, 2, 1), y, rtol=1e-5, atol=1e-4, what='conv fwd')
-    dycl = dy.permute(0, 2, 1).contiguous().view(B * T, Cout).to(dev)
-    dx = ops.conv1d_dx(dycl, ops.conv_weight_bwd(Wd), B, T, Cin, Cout, K, dil)
-    close(dx.view(B, T, Cin).permute(0, 2, 1), gx, rtol=1e-5, atol=1e-4, what='conv dx')
-    dW = torch.zeros(Cout, Cin, K, device=dev)
-    ops.conv1d_dw(dycl, xcl, B, T, Cin, Cout, K, dil, dW)
-    close(dW, gw, rtol=1e-5, atol=1e-4, what='conv dw')
+    pad = dil * (K - 1) // 2
+    xr, Wr = rb(x, bf16).requires_grad_(True), rb(W, bf16).requires_grad_(True)
+    y = F.conv1d(xr, Wr, bias.double(), padding=pad, dilation=dil)
+    gx, gw = torch.autograd.grad(y, (xr, Wr), rb(dy, bf16))
+    xcl = x.permute(0, 2, 1).contiguous().view(B * T, Cin).to(dev)
+    Wd = W.to(dev)
+    with ops.bf16_gemms(bf16):
+        ycl = ops.conv1d_fwd(xcl, ops.conv_weight_fwd(Wd), bias.to(dev), B, T, Cin, Cout, K, dil)
+        close(ycl.view(B, T, Cout).permute(0, 2, 1), y, rtol=1e-5, atol=1e-4, what='conv fwd')
+        dycl = dy.permute(0, 2, 1).contiguous().view(B * T, Cout).to(dev)
+        dx = ops.conv1d_dx(dycl, ops.conv_weight_bwd(Wd), B, T, Cin, Cout, K, dil)
+        close(dx.view(B, T, Cin).permute(0, 2, 1), gx, rtol=1e-5, atol=1e-4, what='conv dx')
+        dW = torch.zeros(Cout, Cin, K, device=dev)
+        ops.conv1d_dw(dycl, xcl, B, T, Cin, Cout, K, dil, dW)
+        close(dW, gw, rtol=1e-5, atol=1e-4, what='conv dw')
 
 
 # ---------------------------------------------------------------------------- recurrent kernels

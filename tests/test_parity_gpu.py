@@ -160,12 +160,17 @@ def test_midsize_against_oracle(dev, case):
                  'attention_location_kernel_size=9,postnet_embedding_dim=32,noise_size=32,discriminator_dim=32,'
                  'discriminator_window=6')
     in_lens, out_lens = [40, 33, 33, 20, 9], [57, 70, 41, 25, 13]
-    # *_bf16: hparams.fp16_run -- the decoder LSTM products take bf16 operands (gt_rec_gemm_bf16); the oracle rounds the
-    # same operands (R._Bf16Product), so the comparison stays a parity check.  A value that lands on the other side of
-    # a bf16 rounding boundary in one of the two implementations moves a product term by 2^-8 relative: tolerances
-    # are 2e-3 / 4e-3 instead of the fp32 path's 1e-3 / 2e-3 (measured: both cases also pass at the fp32 tolerances).
+    # *_bf16: hparams.fp16_run -- the decoder LSTM products (gt_rec_gemm_bf16) and every layer GEMM (GtGemm.bf16) take
+    # bf16 operands; the oracle rounds the same operands (R.fp16_run / R._Prod / R._Conv).  Layer by layer that is an
+    # operand-exact check (1e-7: the kernel tests and test_discriminator_bf16_is_operand_exact below).  Through the
+    # whole generator it cannot be: fp32 summation-order differences of 1e-7 put a few values per layer on the other
+    # side of a bf16 rounding boundary in one of the two implementations, each such flip moves a product term by 2^-8
+    # relative, and 5 BatchNorm layers + 45..70 recurrent steps feed that back.  Measured: outputs within 5.4e-3,
+    # gradients within 2e-2, about HALF the distance between the bf16 and the fp32 oracle -- hence 1e-2 / 4e-2 here
+    # (the fp32 path is held to 1e-3 / 2e-3), and a 2e-5 floor for the conv biases whose gradient is exactly zero.
     bf16 = case.endswith('_bf16')
-    OT, GT = (2e-3, 4e-3) if bf16 else (1e-3, 2e-3)
+    OT, GT = (1e-2, 4e-2) if bf16 else (1e-3, 2e-3)
+    GA = 2e-5 if bf16 else 2e-6
     case = case.replace('_bf16', '')
     if case.startswith('full_dims'):
         # the reference's default dimensions (E=1024, 1024-unit LSTMs, attention 128/32/31) at the benchmark's batch
@@ -203,13 +208,13 @@ def test_midsize_against_oracle(dev, case):
         out32 = R.generator_step_grads(Gp, Dp, (text, il, mel, gate, ol), rng, hp)[0]
         hp.fp16_run = True
         rel = float((res['out']['mel'] - out32[0]).abs().max() / out32[0].abs().max())
-        assert 1e-4 < rel < 3e-2, f'bf16 path vs fp32 oracle: {rel:.3e}'
+        assert 1e-4 < rel < 5e-2, f'bf16 path vs fp32 oracle: {rel:.3e}'
     for k, v in losses.items():
         close(res['g_loss'][k], v, rtol=OT, atol=1e-6, what=f'g_loss.{k}')
     bad = []
     for k, v in grads.items():
         try:
-            close(res['g_grad'][k], v, rtol=GT, atol=2e-6, what=f'g_grad.{k}')
+            close(res['g_grad'][k], v, rtol=GT, atol=GA, what=f'g_grad.{k}')
         except AssertionError as e:
             bad.append(str(e))
     keep_real = common.draw_disc_keep(stream, hp, B, To)
@@ -219,7 +224,7 @@ def test_midsize_against_oracle(dev, case):
         close(res['d_loss'][k], v, rtol=OT, atol=1e-6, what=f'd_loss.{k}')
     for k, v in dg.items():
         try:
-            close(res['d_grad'][k], v, rtol=GT, atol=2e-6, what=f'd_grad.{k}')
+            close(res['d_grad'][k], v, rtol=GT, atol=GA, what=f'd_grad.{k}')
         except AssertionError as e:
             bad.append(str(e))
     assert not bad, '\n'.join(bad)
@@ -338,3 +343,40 @@ def test_gradient_penalty_matches_reference_golden(dev, golden_dir):
         except AssertionError as e:
             bad.append(str(e))
     assert not bad, '\n'.join(bad)
+
+
+@pytest.mark.parametrize('train', [False, True])
+def test_discriminator_bf16_is_operand_exact(dev, train):
+    """hparams.fp16_run on the conv discriminator (4 dilated convolutions + 1x1, no BatchNorm): with the oracle rounding
+    the same GEMM operands to bf16, loss, input gradient and every parameter gradient agree far below the bf16 effect -- the
+    bf16 layer GEMMs (forward, input gradient, weight gradient) compute what the restatement says."""
+    from gantron_amd.hparams import HParams
+    from gantron_amd.model import Discriminator
+    from oracle import gantron_ref as R
+    hp = HParams('use_labels=False,use_noise=True,n_mel_channels=16,discriminator_dim=32,discriminator_window=6,fp16_run=True')
+    _, Dp = R.init_params(hp, seed=3)
+    B, T = 5, 70
+    mel = torch.randn(B, 16, T, generator=torch.Generator().manual_seed(1))
+    lens = torch.tensor([57, 70, 41, 25, 13])
+    keeps = common.draw_disc_keep(common.MaskStream(5), hp, B, T)
+    D = Discriminator(hp).to(dev)
+    D.load_state_dict(Dp)
+    D.train(train)
+    D.rng_override = kernel_disc_keep(keeps, dev) if train else None
+    x = mel.clone().to(dev).requires_grad_(True)
+    loss = D.adversarial_loss(x, lens.to(dev))
+    loss.backward()
+    with R.fp16_run(True):
+        Pd = {k: v.clone().requires_grad_(True) for k, v in Dp.items()}
+        xo = mel.clone().requires_grad_(True)
+        lo = R.adversarial_loss(Pd, xo, lens, hp.discriminator_window, keeps if train else None, training=train)
+        gs = torch.autograd.grad(lo, [xo] + [Pd[k] for k in Pd])
+    # 1e-3 of max-abs: measured 1e-7 .. 2e-4 (one value on a bf16 rounding boundary is enough for the latter); the
+    # bf16 effect itself is ~1e-2
+    close(loss.detach(), lo.detach(), rtol=1e-3, atol=1e-7, what='adv loss')
+    close(x.grad, gs[0], rtol=1e-3, atol=1e-9, what='d adv / d mel')
+    for (k, p), gg in zip(D.named_parameters(), gs[1:]):
+        close(p.grad, gg, rtol=1e-3, atol=1e-9, what=f'd_grad.{k}')
+    with R.fp16_run(False):                     # and it is NOT the fp32 result
+        l32 = R.adversarial_loss(Dp, mel, lens, hp.discriminator_window, keeps if train else None, training=train)
+    assert abs(float(l32) - float(lo)) > 1e-5 * abs(float(lo))

@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gantron_amd import ops
 
 dev = torch.device('cuda:0')
+ops.BF16_GEMMS = bool(os.environ.get('BF16'))      # BF16=1: layer GEMMs with bf16 operands (hparams.fp16_run)
 REPS = int(os.environ.get('REPS', 10))
 
 
