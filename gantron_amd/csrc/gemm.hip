@@ -86,23 +86,6 @@ __device__ __forceinline__ float4 load_rvec(const OpDev& o, const float* base, i
 template <int MODE>
 constexpr bool is_ktype() { return MODE == GT_OP_KC || MODE == GT_OP_IM2COL_K; }
 
-// ---- bf16-operand variant (GtGemm.bf16, hparams.fp16_run): the fp32 operands are rounded to bf16 (nearest even)
-// on their way into LDS and multiplied with v_mfma_f32_32x32x16_bf16 (one instruction per 32x32 tile per 16-wide
-// k-tile, 1/16 of the fp32 MFMA time); accumulation, C and the epilogue stay fp32.  The LDS tiles are ROW-major
-// [row][16 k + 8 pad] bf16 (48-byte rows: the 16-byte fragments of 32 consecutive rows fall on distinct bank groups),
-// so that a lane's fragment -- A[row = lane & 31][k = 8 (lane >> 5) + 0..7] -- is one ds_read_b128.
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-constexpr int LDH = BK + 8;
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
-    const bf16x2_t p = {(__bf16)a, (__bf16)b};
-    return __builtin_bit_cast(unsigned, p);
-}
-__device__ __forceinline__ unsigned short to_bf16(float a) {
-    const __bf16 h = (__bf16)a;
-    return __builtin_bit_cast(unsigned short, h);
-}
-
 // Per-thread loader state for one operand tile of BR rows.
 template <int MODE, int BR>
 struct TileLoader {
@@ -175,32 +158,11 @@ struct TileLoader {
             }
         }
     }
-    // bf16 image [row][LDH]: a k-type thread holds 4 consecutive k of one row (one 8-byte store), an r-type thread 4
-    // consecutive rows at one k (four 2-byte stores)
-    __device__ __forceinline__ void store_bf16(unsigned short* S, int tid) const {
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            if (is_ktype<MODE>()) {
-                const int rl = (tid & 63) + 64 * i;
-                const int kq = tid >> 6;
-                *reinterpret_cast<uint2*>(&S[rl * LDH + 4 * kq]) =
-                    make_uint2(pack_bf16(reg[i].x, reg[i].y), pack_bf16(reg[i].z, reg[i].w));
-            } else {
-                const int f = tid + 256 * i;
-                const int rq = f % (BR / 4), kl = f / (BR / 4);
-                S[(4 * rq + 0) * LDH + kl] = to_bf16(reg[i].x);
-                S[(4 * rq + 1) * LDH + kl] = to_bf16(reg[i].y);
-                S[(4 * rq + 2) * LDH + kl] = to_bf16(reg[i].z);
-                S[(4 * rq + 3) * LDH + kl] = to_bf16(reg[i].w);
-            }
-        }
-    }
 };
 
-template <int BM, int BN, int AMODE, int BMODE, bool BF = false>
+template <int BM, int BN, int AMODE, int BMODE>
 __global__ __launch_bounds__(256) void sgemm_kernel(GemmDev g) {
     constexpr int LDA = BM + 4, LDB = BN + 4;
-    static_assert((BM + BN) * LDH * 2 <= (BK * LDA + BK * LDB) * 4, "bf16 tiles fit the fp32 staging buffer");
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     __shared__ __attribute__((aligned(16))) float smem[BK * LDA + BK * LDB];
     float* As = smem;
@@ -234,35 +196,14 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmDev g) {
         la.load(g.A, Ab, m0, g.M, kbeg, kend, tid);
         lb.load(g.B, Bb, n0, g.N, kbeg, kend, tid);
     }
-    unsigned short* Ah = reinterpret_cast<unsigned short*>(smem);
-    unsigned short* Bh = Ah + BM * LDH;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        if (BF) {
-            la.store_bf16(Ah, tid);
-            lb.store_bf16(Bh, tid);
-        } else {
-            la.store(As, tid);
-            lb.store(Bs, tid);
-        }
+        la.store(As, tid);
+        lb.store(Bs, tid);
         __syncthreads();
         if (k0 + BK < kend) {
             la.load(g.A, Ab, m0, g.M, k0 + BK, kend, tid);
             lb.load(g.B, Bb, n0, g.N, k0 + BK, kend, tid);
         }
-        if (BF) {
-            bf16x8_t a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                a[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(&Ah[(wm0 + 32 * i + (lane & 31)) * LDH + 8 * (lane >> 5)]));
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                b[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(&Bh[(wn0 + 32 * j + (lane & 31)) * LDH + 8 * (lane >> 5)]));
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        } else
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             const int krow = 2 * kk + (lane >> 5);
@@ -301,13 +242,196 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmDev g) {
         }
 }
 
+// =====================================================================================================================
+// bf16-operand variant (GtGemm.bf16, hparams.fp16_run): same contract and operand modes, but the fp32 operands are
+// rounded to bf16 (nearest even) on their way into LDS and multiplied with v_mfma_f32_32x32x16_bf16; accumulation, C
+// and the epilogue stay fp32.  The MFMA work of a tile drops to 1/16, so the kernel is organised around the operand
+// traffic instead: 64-wide k-tiles (one barrier pair per 64 k instead of per 16), ROW-major LDS tiles [row][64 k + 8]
+// bf16 (144-byte rows: the 16-byte fragments of 32 consecutive rows fall on distinct bank groups, a lane's fragment
+// A[row = lane & 31][k = 16 s + 8 (lane >> 5) + 0..7] is one ds_read_b128), k-contiguous operands loaded as 256-byte
+// row segments per 16 threads, reduction-major operands as 4-row x KPT-k register blocks that are transposed in
+// registers and written as one 16-byte (8-byte for 64-row tiles) store per row.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+constexpr int BKH = 64;
+constexpr int LDH = BKH + 8;
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    const bf16x2_t p = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, p);
+}
+
+template <int MODE, int BR>
+struct TileLoaderH {
+    static constexpr int NK = BR / 16;            // k-type: float4 per thread (rows f/16, k-quad f%16)
+    static constexpr int RQ = BR / 4;             // r-type: row quads per tile
+    static constexpr int KPT = BKH / (256 / RQ);  // r-type: consecutive k per thread (8 for 128 rows, 4 for 64)
+    static constexpr int NV = is_ktype<MODE>() ? NK : KPT;
+    float4 reg[NV];
+    int p0[is_ktype<MODE>() ? NK : 1], p1[is_ktype<MODE>() ? NK : 1];   // fixed decomposition of the row index
+    int q0, q1;                                                        // running decomposition of the first k
+
+    __device__ __forceinline__ void init(const OpDev& o, int r0, int kbeg, int tid) {
+        q0 = q1 = 0;
+#pragma unroll
+        for (int i = 0; i < (is_ktype<MODE>() ? NK : 1); ++i) { p0[i] = 0; p1[i] = 0; }
+        if (MODE == GT_OP_IM2COL_K) {
+            const int k = kbeg + 4 * (tid & 15);
+            q0 = k / o.C; q1 = k - q0 * o.C;                      // (tap, c) of this thread's k-quad
+#pragma unroll
+            for (int i = 0; i < NK; ++i) {
+                const int r = r0 + (tid + 256 * i) / 16;
+                p0[i] = r / o.T; p1[i] = r - p0[i] * o.T;         // (b, t) of the row
+            }
+        } else if (MODE == GT_OP_IM2COL_R) {
+            const int r = r0 + 4 * (tid % RQ);
+            p0[0] = r / o.C; p1[0] = r - p0[0] * o.C;             // (tap, c) of the row quad
+            const int k = kbeg + KPT * (tid / RQ);
+            q0 = k / o.T; q1 = k - q0 * o.T;                      // (b, t) of the first k
+        }
+    }
+    __device__ __forceinline__ void load(const OpDev& o, const float* base, int r0, int R, int k0, int K, int tid) {
+        if (is_ktype<MODE>()) {
+            const int k = k0 + 4 * (tid & 15);
+#pragma unroll
+            for (int i = 0; i < NK; ++i)
+                reg[i] = load_kvec<MODE>(o, base, r0 + (tid + 256 * i) / 16, R, k, K, p0[i], p1[i], q0, q1);
+            if (MODE == GT_OP_IM2COL_K) {
+                q1 += BKH;
+                while (q1 >= o.C) { q1 -= o.C; ++q0; }
+            }
+        } else {
+            const int r = r0 + 4 * (tid % RQ);
+            const int k = k0 + KPT * (tid / RQ);
+            int b = q0, t = q1;
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                reg[j] = load_rvec<MODE>(o, base, r, R, k + j, K, p0[0], p1[0], b, t);
+                if (MODE == GT_OP_IM2COL_R) { if (++t >= o.T) { t = 0; ++b; } }
+            }
+            if (MODE == GT_OP_IM2COL_R) {
+                q1 += BKH;
+                while (q1 >= o.T) { q1 -= o.T; ++q0; }
+            }
+        }
+    }
+    __device__ __forceinline__ void store(unsigned short* S, int tid) const {
+        if (is_ktype<MODE>()) {
+#pragma unroll
+            for (int i = 0; i < NK; ++i) {
+                const int f = tid + 256 * i;
+                *reinterpret_cast<uint2*>(&S[(f / 16) * LDH + 4 * (f & 15)]) =
+                    make_uint2(pack_bf16(reg[i].x, reg[i].y), pack_bf16(reg[i].z, reg[i].w));
+            }
+        } else {
+            const int rq = tid % RQ, kc = KPT * (tid / RQ);
+            // reg[j] = rows 4rq..4rq+3 at k = kc + j: per row KPT consecutive k -> one 8 / 16 byte store
+            unsigned short* d = &S[(4 * rq) * LDH + kc];
+            if (KPT == 8) {
+                *reinterpret_cast<uint4*>(d) = make_uint4(pack_bf16(reg[0].x, reg[1].x), pack_bf16(reg[2].x, reg[3].x),
+                                                          pack_bf16(reg[4 % NV].x, reg[5 % NV].x), pack_bf16(reg[6 % NV].x, reg[7 % NV].x));
+                *reinterpret_cast<uint4*>(d + LDH) = make_uint4(pack_bf16(reg[0].y, reg[1].y), pack_bf16(reg[2].y, reg[3].y),
+                                                                pack_bf16(reg[4 % NV].y, reg[5 % NV].y), pack_bf16(reg[6 % NV].y, reg[7 % NV].y));
+                *reinterpret_cast<uint4*>(d + 2 * LDH) = make_uint4(pack_bf16(reg[0].z, reg[1].z), pack_bf16(reg[2].z, reg[3].z),
+                                                                    pack_bf16(reg[4 % NV].z, reg[5 % NV].z), pack_bf16(reg[6 % NV].z, reg[7 % NV].z));
+                *reinterpret_cast<uint4*>(d + 3 * LDH) = make_uint4(pack_bf16(reg[0].w, reg[1].w), pack_bf16(reg[2].w, reg[3].w),
+                                                                    pack_bf16(reg[4 % NV].w, reg[5 % NV].w), pack_bf16(reg[6 % NV].w, reg[7 % NV].w));
+            } else {
+                *reinterpret_cast<uint2*>(d) = make_uint2(pack_bf16(reg[0].x, reg[1].x), pack_bf16(reg[2].x, reg[3].x));
+                *reinterpret_cast<uint2*>(d + LDH) = make_uint2(pack_bf16(reg[0].y, reg[1].y), pack_bf16(reg[2].y, reg[3].y));
+                *reinterpret_cast<uint2*>(d + 2 * LDH) = make_uint2(pack_bf16(reg[0].z, reg[1].z), pack_bf16(reg[2].z, reg[3].z));
+                *reinterpret_cast<uint2*>(d + 3 * LDH) = make_uint2(pack_bf16(reg[0].w, reg[1].w), pack_bf16(reg[2].w, reg[3].w));
+            }
+        }
+    }
+};
+
+template <int BM, int BN, int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void hgemm_kernel(GemmDev g) {
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    __shared__ __attribute__((aligned(16))) unsigned short smem[(BM + BN) * LDH];
+    unsigned short* Ah = smem;
+    unsigned short* Bh = smem + BM * LDH;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int batch = blockIdx.z / g.split_k, kz = blockIdx.z - batch * g.split_k;
+    const int kbeg = kz * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    const float* Ab = g.A.p + (long)batch * g.a_bs;
+    const float* Bb = g.B.p + (long)batch * g.b_bs;
+    float* Cb = g.C + (long)batch * g.c_bs;
+
+    TileLoaderH<AMODE, BM> la;
+    TileLoaderH<BMODE, BN> lb;
+    la.init(g.A, m0, kbeg, tid);
+    lb.init(g.B, n0, kbeg, tid);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+    if (kbeg < kend) {
+        la.load(g.A, Ab, m0, g.M, kbeg, kend, tid);
+        lb.load(g.B, Bb, n0, g.N, kbeg, kend, tid);
+    }
+    const unsigned short* ar = Ah + (wm0 + (lane & 31)) * LDH + 8 * (lane >> 5);
+    const unsigned short* br = Bh + (wn0 + (lane & 31)) * LDH + 8 * (lane >> 5);
+    for (int k0 = kbeg; k0 < kend; k0 += BKH) {
+        la.store(Ah, tid);
+        lb.store(Bh, tid);
+        __syncthreads();
+        if (k0 + BKH < kend) {
+            la.load(g.A, Ab, m0, g.M, k0 + BKH, kend, tid);
+            lb.load(g.B, Bb, n0, g.N, k0 + BKH, kend, tid);
+        }
+#pragma unroll
+        for (int s = 0; s < BKH / 16; ++s) {
+            bf16x8_t a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ar + 32 * i * LDH + 16 * s));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(br + 32 * j * LDH + 16 * s));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // epilogue: as sgemm_kernel (the C/D map of the 32x32 MFMA does not depend on the operand type)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn0 + 32 * j + (lane & 31);
+            if (n >= g.N) continue;
+            const float bias = (g.bias != nullptr && kz == 0) ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= g.M) continue;
+                float* c = Cb + (long)m * g.ldc + n;
+                const float v = g.alpha * acc[i][j][r] + bias;
+                if (g.split_k > 1) atomicAdd(c, v);
+                else if (g.accumulate) *c += v;
+                else *c = v;
+            }
+        }
+}
+
 template <int BM, int BN>
 int launch_tile(const GemmDev& d, dim3 grid, hipStream_t st) {
     const int am = d.A.mode, bm = d.B.mode;
 #define GT_CASE(AM, BMD)                                                                              \
     if (am == AM && bm == BMD) {                                                                      \
-        if (d.bf16) hipLaunchKernelGGL((sgemm_kernel<BM, BN, AM, BMD, true>), grid, dim3(256), 0, st, d); \
-        else hipLaunchKernelGGL((sgemm_kernel<BM, BN, AM, BMD>), grid, dim3(256), 0, st, d);         \
+        if (d.bf16) hipLaunchKernelGGL((hgemm_kernel<BM, BN, AM, BMD>), grid, dim3(256), 0, st, d);    \
+        else hipLaunchKernelGGL((sgemm_kernel<BM, BN, AM, BMD>), grid, dim3(256), 0, st, d);          \
         return 0;                                                                                     \
     }
     GT_CASE(GT_OP_KC, GT_OP_KC)
@@ -366,8 +490,9 @@ extern "C" int gt_sgemm(const GtGemm* g, void* stream) {
     d.M = g->M; d.N = g->N; d.K = g->K; d.accumulate = g->accumulate; d.alpha = g->alpha;
     d.split_k = g->split_k;
     d.bf16 = g->bf16 != 0;
-    const int kblocks = cdiv(g->K, BK);
-    d.k_per_split = cdiv(kblocks, g->split_k) * BK;
+    const int kstep = d.bf16 ? BKH : BK;        // k-tile of the kernel: splits are whole k-tiles
+    const int kblocks = cdiv(g->K, kstep);
+    d.k_per_split = cdiv(kblocks, g->split_k) * kstep;
     d.split_k = cdiv(g->K, d.k_per_split);   // drop empty splits
     hipStream_t st = (hipStream_t)stream;
 
