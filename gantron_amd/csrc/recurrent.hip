@@ -54,8 +54,9 @@ constexpr int REC_THREADS = 512;
 
 template <int MT>
 struct RecChunk {                         // per-thread registers of one activation chunk
-    static constexpr int NV = MT * 16 * REC_CK * 16 / 4 / REC_THREADS;   // float4 per thread (MT=4: 4)
-    float4 v[NV > 0 ? NV : 1];
+    static constexpr int NV = MT * 16 * REC_CK * 16 / 4 / REC_THREADS;   // float4 per thread (= MT)
+    static_assert(NV >= 1, "every thread stages at least one float4 per chunk");
+    float4 v[NV];
     __device__ __forceinline__ void load(const float* X, long ldx, int kb, int kb1, int tid) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -105,26 +106,10 @@ __device__ __forceinline__ void rec_gemm_body(const float* __restrict__ Xz, long
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    RecChunk<MT> xc;
+    RecChunk<MT> xc;                      // MT float4 per thread: MT*16 rows x 32 float4 over 512 threads
     RecW wa, wb;
-    // staging needs MT*16 rows x 32 float4 = MT*512 float4: with MT < 4 only part of the threads take part
-    constexpr int STAGE_THREADS = (RecChunk<MT>::NV > 0) ? REC_THREADS : MT * 128;
-    const bool stager = RecChunk<MT>::NV > 0 || tid < STAGE_THREADS;
-    auto xload = [&](int kb) __attribute__((always_inline)) {
-        if (RecChunk<MT>::NV > 0) { xc.load(Xz, ldx, kb, kb1, tid); return; }
-        if (stager) {
-            const int row = tid / (REC_CK * 4), c4 = tid % (REC_CK * 4);
-            xc.v[0] = (kb + (c4 >> 2) < kb1) ? *reinterpret_cast<const float4*>(Xz + (long)row * ldx + (long)kb * 16 + 4 * c4)
-                                             : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto xstore = [&]() __attribute__((always_inline)) {
-        if (RecChunk<MT>::NV > 0) { xc.store(Xs, tid); return; }
-        if (stager) {
-            const int row = tid / (REC_CK * 4), c4 = tid % (REC_CK * 4);
-            *reinterpret_cast<float4*>(&Xs[row * REC_LD + 4 * c4]) = xc.v[0];
-        }
-    };
+    auto xload = [&](int kb) __attribute__((always_inline)) { xc.load(Xz, ldx, kb, kb1, tid); };
+    auto xstore = [&]() __attribute__((always_inline)) { xc.store(Xs, tid); };
     xload(kb0);
     wa.load(wp, kb0 + REC_HK * half, kb1);
     if (DBG & 1) wb = wa;

@@ -14,7 +14,10 @@ Parameters are passed as a dict {state_dict name: CUDA tensor} in PyTorch layout
 accumulated into a dict of same-shaped tensors.  Stochastic inputs (dropout keep-masks, style
 noise) are explicit (`rng`), in kernel layout (channels-last, Bp rows per decoder step).
 """
+import ctypes
+import functools
 import math
+import os as _os
 import time as _time
 
 import torch
@@ -24,7 +27,7 @@ from .ops import (ACT_NONE, ACT_RELU, ACT_TANH, IM2COL_K, IM2COL_R, KC, RC, Oper
 from ._lib import GtBiLstm, GtDecoderBwd, GtDecoderFwd, GtDecoderInfer, check, lib
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
-import os as _os
+# ---- switches (environment, read once at import; the defaults are the measured-best configuration)
 REC_SPLITS_OVERRIDE = int(_os.environ.get("GANTRON_REC_SPLITS", "0"))     # diagnostics: force the K-split count
 # forward LSTM steps as ONE fused launch (gt_lstm_step_fused).  Stand-alone it beats product + cell (20.4 vs 23.2 us,
 # 25.5 vs 28.1 us) but every workgroup stages the whole activation matrix (4x the L2->LDS traffic), which slows the
@@ -32,8 +35,6 @@ REC_SPLITS_OVERRIDE = int(_os.environ.get("GANTRON_REC_SPLITS", "0"))     # diag
 FUSED_CELL = _os.environ.get('GANTRON_FUSED_CELL', '0') != '0'
 HOST_TIMING = _os.environ.get('GANTRON_HOST_TIMING') == '1'      # diagnostics: host time spent issuing each loop
 CELL_QUERY = _os.environ.get('GANTRON_CELL_QUERY', '1') != '0'    # attention cell + query product in one launch
-HIGH_PRIORITY_BACKWARD = _os.environ.get('GANTRON_HIGH_PRIO', '0') != '0'   # measured: no gain on MI355X
-_HIGH_STREAM = None
 BWD_CHUNKS = int(_os.environ.get("GANTRON_BWD_CHUNKS", "6"))
 DEC_RING = int(_os.environ.get('GANTRON_DEC_RING', '16'))     # ring of hand-off buffers between the two decoder chains;
                                                              # cross-stream syncs happen every ring/2 steps (loops.hip)
@@ -44,7 +45,6 @@ def _f32(*shape, device, zero=True):
 
 
 def _run(name, struct):
-    import ctypes
     check(getattr(lib(), name)(ctypes.byref(struct), ops._stream()), name)
 
 
@@ -191,8 +191,6 @@ def pack_gates(W2d, H, K):
 
 def _gemm_precision(fn):
     """Engine entry point: layer GEMMs inside run with bf16 operands when the engine was built with hparams.fp16_run."""
-    import functools
-
     @functools.wraps(fn)
     def wrapped(self, *a, **k):
         with ops.bf16_gemms(getattr(self, 'bf16', False)):
@@ -642,21 +640,8 @@ class GeneratorEngine:
     @_gemm_precision
     def backward(self, P, G, sv, dmel, dmel_post, dgate, dalign):
         """Accumulate parameter gradients into G (dict name -> tensor).  d* are gradients of the four
-        outputs (any may be None).  Runs on a high-priority stream so that the latency-bound loop kernels
-        win the CUs over the weight-gradient GEMMs of the (normal-priority) leaf stream."""
-        if HIGH_PRIORITY_BACKWARD:
-            global _HIGH_STREAM
-            if _HIGH_STREAM is None:
-                _HIGH_STREAM = torch.cuda.Stream(priority=torch.cuda.Stream.priority_range()[1])
-            outer = torch.cuda.current_stream()
-            _HIGH_STREAM.wait_stream(outer)
-            with torch.cuda.stream(_HIGH_STREAM):
-                self._backward(P, G, sv, dmel, dmel_post, dgate, dalign)
-            outer.wait_stream(_HIGH_STREAM)
-        else:
-            self._backward(P, G, sv, dmel, dmel_post, dgate, dalign)
-
-    def _backward(self, P, G, sv, dmel, dmel_post, dgate, dalign):
+        outputs (any may be None).  (Running the whole backward on a high-priority stream so that the loop kernels win
+        the CUs over the leaf stream's weight-gradient GEMMs was measured: no gain on MI355X.)"""
         hp = self.hp
         B, Bp, Ti, To = sv['B'], sv['Bp'], sv['Ti'], sv['To']
         n_mel, H, E, A, Pd, Ha, Hd = self.n_mel, self.H, self.E, self.A, self.P, self.Ha, self.Hd

@@ -6,13 +6,12 @@ torch is used here for device memory only (allocation, views); all arithmetic is
 kernels.
 """
 import ctypes
+import os as _os
 
 import torch
 
 from . import _lib
 from ._lib import GtAttnDims, GtGemm, GtOperand, GtSlabs, check, lib
-
-import os as _os
 
 KC, RC, IM2COL_K, IM2COL_R = 0, 1, 2, 3
 # Workgroups a weight-gradient GEMM should reach (default_split_k).  Two regimes, both measured on the benchmark
