@@ -167,8 +167,11 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP extension has no CPU fallback)'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # rehearsal on a 1-GPU box (tests/test_training_gpu.py): every rank on device 0 and gloo carrying the CUDA
+    # tensors, so that the N > 1 control flow of this script runs before the driver's multi-GPU launch does
+    dev_index = int(os.environ.get('GANTRON_BENCH_DEVICE', local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
 
     import torch.distributed as dist
     from gantron_amd import _lib
@@ -186,8 +189,12 @@ def main():
         hp.distributed_run = True
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('nccl', init_method='env://', world_size=world, rank=rank,
-                                device_id=dev)
+        backend = os.environ.get('GANTRON_BENCH_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', init_method='env://', world_size=world, rank=rank, device_id=dev)
+        else:
+            hp.dist_backend = backend
+            dist.init_process_group(backend, init_method='env://', world_size=world, rank=rank)
     torch.manual_seed(hp.seed)
     G, D = Tacotron2(hp).to(dev).train(), Discriminator(hp).to(dev).train()
     g_opt = FlatAdam(G, lr=hp.g_learning_rate, weight_decay=hp.weight_decay)

@@ -422,3 +422,23 @@ def test_discriminator_step_with_gradient_penalty(dev):
         assert torch.isfinite(out['total'])
         grads[lam] = D._flat_grad.clone()
     assert float((grads[10] - grads[0]).abs().max()) > 0
+
+
+def test_bench_two_ranks_rehearsal(dev, tmp_path):
+    """bench.py's N > 1 control flow (per-rank batches, barriers, MAX / SUM reductions of the timings, rank 0 printing
+    the one JSON line) on the 1-GPU test box: two ranks share device 0 and gloo carries the CUDA tensors
+    (GANTRON_BENCH_DEVICE / GANTRON_BENCH_BACKEND exist for this rehearsal only; the driver's launch uses RCCL)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GANTRON_BENCH_DEVICE='0', GANTRON_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29611', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1', '--batch', '8']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]                # exactly one JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 1 and d['scaling'] == 'weak' and d['cpu_baseline'] is None
+    assert d['config']['global_batch'] == 16 and d['value'] > 0 and d['roofline'] is not None
