@@ -442,3 +442,31 @@ def test_bench_two_ranks_rehearsal(dev, tmp_path):
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['steps'] == 1 and d['scaling'] == 'weak' and d['cpu_baseline'] is None
     assert d['config']['global_batch'] == 16 and d['value'] > 0 and d['roofline'] is not None
+
+
+def test_bf16_mode_trains_like_fp32(dev):
+    """hparams.fp16_run (bf16 operands in the LSTM products and layer GEMMs, fp32 master weights and accumulation): 10
+    generator+discriminator pairs from the same initial weights, batch and dropout seeds follow the fp32 run -- the
+    generator loss of every step stays within 2 % of the fp32 trajectory and both go down."""
+    from gantron_amd import train as T
+    from gantron_amd.hparams import HParams
+    from gantron_amd.loss_function import Tacotron2Loss
+    from gantron_amd.optim import FlatAdam
+    from gantron_amd.train_steps import discriminator_step, generator_step
+    traj = {}
+    for mode in ('fp32', 'bf16'):
+        hp = HParams(MID + (',fp16_run=True' if mode == 'bf16' else ''))
+        torch.manual_seed(hp.seed)
+        G, D = T.load_model(hp)
+        g_opt, d_opt = FlatAdam(G, lr=1e-3, weight_decay=hp.weight_decay), FlatAdam(D, lr=1e-3, weight_decay=hp.weight_decay)
+        batch = common.synthetic_batch(hp, [17, 12, 12, 5], [26, 33, 19, 9], seed=2)
+        crit = Tacotron2Loss()
+        losses = []
+        for it in range(10):
+            out, gen = generator_step(G.train(), D.train(), g_opt, crit, batch, hp, iteration=it)
+            discriminator_step(G, D, d_opt, batch, gen, hp)
+            losses.append(float(out['total']))
+        traj[mode] = losses
+    a, b = np.array(traj['fp32']), np.array(traj['bf16'])
+    assert np.all(np.isfinite(b)) and b[-1] < b[0] and a[-1] < a[0], (a, b)
+    assert np.max(np.abs(a - b) / np.abs(a)) < 2e-2, (a, b)
