@@ -11,9 +11,17 @@
 #include "common.h"
 
 // matrix-core versions for the reference's default dimensions (attention_mfma.hip)
+void gt_launch_attn_energies_bwd_rec_mfma(GtAttnDims d, const float* dw, const float* w, const float* u, const float* Wc,
+                                          const float* Wd, const float* v, const int* lengths, float* dq, long ld_dq,
+                                          float* dwcat_out, float* de_out, const float* wpack, hipStream_t st);
+void gt_launch_attn_param_grads_mfma(GtAttnDims d, int nsteps, const float* u, const float* de, const float* w_prev,
+                                     const float* w_cum, long step_stride, const float* Wc, const float* Wd,
+                                     const float* v, const int* lengths, float* dpm, float* acc, const float* wpack,
+                                     hipStream_t st);
 void gt_launch_attn_energies_fwd_mfma(GtAttnDims d, GtSlabs qpart, const float* w_prev, const float* w_cum,
                                       const float* pm, const float* Wc, const float* Wd, const float* v,
-                                      const int* lengths, float* q_out, float* energies, const float* wpack, hipStream_t st);
+                                      const int* lengths, float* q_out, float* energies, const float* wpack, hipStream_t st,
+                                      float* u_out);
 void gt_launch_attn_energies_bwd_mfma(GtAttnDims d, const float* dw, const float* w, const float* q,
                                       const float* w_prev, const float* w_cum, const float* pm, const float* Wc,
                                       const float* Wd, const float* v, const int* lengths, float* dq, long ld_dq,
@@ -663,7 +671,17 @@ extern "C" int gt_attn_energies_fwd_w(GtAttnDims d, GtSlabs qpart, const float* 
                                       const float* pm, const float* Wc, const float* Wd, const float* v,
                                       const int32_t* lengths, float* q_out, float* energies, const float* wpack,
                                       void* stream) {
+    return gt_attn_energies_fwd_u(d, qpart, w_prev, w_cum, pm, Wc, Wd, v, lengths, q_out, energies, wpack, nullptr, stream);
+}
+
+extern "C" int32_t gt_attn_hoist_supported(GtAttnDims d) { return use_mfma(d) ? 1 : 0; }
+
+extern "C" int gt_attn_energies_fwd_u(GtAttnDims d, GtSlabs qpart, const float* w_prev, const float* w_cum,
+                                      const float* pm, const float* Wc, const float* Wd, const float* v,
+                                      const int32_t* lengths, float* q_out, float* energies, const float* wpack,
+                                      float* u_out, void* stream) {
     int rc = check_dims(d, "gt_attn_energies_fwd");
+    GT_REQUIRE(u_out == nullptr || use_mfma(d), GT_E_ARG, "gt_attn_energies_fwd_u: u_out needs the (128, 32, 31) dimensions");
     if (rc) return rc;
     GT_REQUIRE(qpart.p && w_prev && w_cum && pm && Wc && Wd && v && energies, GT_E_ARG, "gt_attn_energies_fwd: NULL pointer");
     dim3 grid(cdiv(d.Ti, CT), d.B);
@@ -674,7 +692,7 @@ extern "C" int gt_attn_energies_fwd_w(GtAttnDims d, GtSlabs qpart, const float* 
                        qpart, w_prev, w_cum, pm, Wc, Wd, v, lengths, q_out, energies)
     if (d.A == 128 && d.F == 32 && d.Kc == 31 && !getenv("GANTRON_ATTN_VALU")) {
         gt_launch_attn_energies_fwd_mfma(d, qpart, w_prev, w_cum, pm, Wc, Wd, v, lengths, q_out, energies, wpack,
-                                         (hipStream_t)stream);      // the reference's default hparams
+                                         (hipStream_t)stream, u_out);      // the reference's default hparams
     } else if (d.A == 128 && d.F == 32 && d.Kc == 31) {
         GT_EF(16, 128, 32, 31);
     } else {
@@ -779,6 +797,35 @@ extern "C" int gt_attn_energies_bwd_w(GtAttnDims d, const float* dw, const float
         }
     }
 #undef GT_EB
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gt_attn_energies_bwd_rec(GtAttnDims d, const float* dw, const float* w, const float* u, const float* Wc,
+                                        const float* Wd, const float* v, const int32_t* lengths, float* dq, int64_t ld_dq,
+                                        float* dwcat_out, float* de_out, const float* wpack, void* stream) {
+    int rc = check_dims(d, "gt_attn_energies_bwd_rec");
+    if (rc) return rc;
+    GT_REQUIRE(use_mfma(d), GT_E_ARG, "gt_attn_energies_bwd_rec: needs the (128, 32, 31) dimensions");
+    GT_REQUIRE(dw && w && u && Wc && Wd && v && dq && dwcat_out && de_out, GT_E_ARG, "gt_attn_energies_bwd_rec: NULL pointer");
+    GtProfScope prof(GT_FAM_ATTN_E_BWD, 2.0 * d.B * d.Ti * (double)(d.F * 2 * d.Kc + d.A * d.F + 4 * d.A),
+                     4.0 * d.B * d.Ti * (d.A + 6.0), (hipStream_t)stream);
+    gt_launch_attn_energies_bwd_rec_mfma(d, dw, w, u, Wc, Wd, v, lengths, dq, (long)ld_dq, dwcat_out, de_out, wpack,
+                                         (hipStream_t)stream);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gt_attn_param_grads(GtAttnDims d, int32_t nsteps, const float* u, const float* de, const float* w_prev,
+                                   const float* w_cum, int64_t step_stride, const float* Wc, const float* Wd,
+                                   const float* v, const int32_t* lengths, float* dpm, float* acc, const float* wpack,
+                                   void* stream) {
+    int rc = check_dims(d, "gt_attn_param_grads");
+    if (rc) return rc;
+    GT_REQUIRE(use_mfma(d), GT_E_ARG, "gt_attn_param_grads: needs the (128, 32, 31) dimensions");
+    GT_REQUIRE(nsteps > 0 && u && de && w_prev && w_cum && Wc && Wd && v && dpm && acc, GT_E_ARG, "gt_attn_param_grads: bad argument");
+    gt_launch_attn_param_grads_mfma(d, nsteps, u, de, w_prev, w_cum, (long)step_stride, Wc, Wd, v, lengths, dpm, acc, wpack,
+                                    (hipStream_t)stream);
     GT_LAUNCH_CHECK();
     return 0;
 }

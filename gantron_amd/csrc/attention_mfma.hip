@@ -63,7 +63,7 @@ static_assert((F * LDC) % 4 == 0 && (A * LDD) % 4 == 0 && offsetof(SharedM, wd) 
 
 __device__ __forceinline__ void stage_common(SharedM& S, const GtAttnDims& d, const float* Wc, const float* Wd,
                                              const float* v, const float* w_prev, const float* w_cum, int b, int t0,
-                                             const float* wpack) {
+                                             const float* wpack, bool with_windows = true) {
     if (wpack != nullptr) {
         const float4* src = reinterpret_cast<const float4*>(wpack);
         float4* dst = reinterpret_cast<float4*>(&S.wc[0]);
@@ -81,7 +81,7 @@ __device__ __forceinline__ void stage_common(SharedM& S, const GtAttnDims& d, co
     for (int i = threadIdx.x; i < A * F; i += 256) S.wd[(i >> 5) * LDD + (i & 31)] = Wd[i];
     }
     if (threadIdx.x < A) S.v[threadIdx.x] = v[threadIdx.x];
-    if (threadIdx.x < 2 * WL) {
+    if (with_windows && threadIdx.x < 2 * WL) {
         const int c = threadIdx.x / WL, p = threadIdx.x - c * WL;
         const int t = t0 + p - (KC - 1) / 2;
         const float* src = c == 0 ? w_prev : w_cum;
@@ -153,7 +153,8 @@ __device__ __forceinline__ void dense_tiles(const SharedM& S, int wave, int lane
 __global__ __launch_bounds__(256) void attn_energies_fwd_mfma(GtAttnDims d, GtSlabs qpart, const float* w_prev,
                                                               const float* w_cum, const float* pm, const float* Wc,
                                                               const float* Wd, const float* v, const int* lengths,
-                                                              float* q_out, float* energies, const float* wpack) {
+                                                              float* q_out, float* energies, const float* wpack,
+                                                              float* u_out) {
     __shared__ SharedM S;
     const int b = blockIdx.y, t0 = blockIdx.x * CT;
     if (lengths != nullptr && t0 >= lengths[b]) {      // chunk entirely in the padding: energies are -inf
@@ -201,7 +202,11 @@ __global__ __launch_bounds__(256) void attn_energies_fwd_mfma(GtAttnDims d, GtSl
 #pragma unroll
             for (int nl = 0; nl < 2; ++nl) {
                 const int dd = 32 * wave + 16 * nl + r;
-                sum += S.v[dd] * tanhf(acc[mt][nl][e] + S.q[dd] + S.ds[(16 * mt + 4 * kq + e) * LDS_ + dd]);
+                const float u = tanhf(acc[mt][nl][e] + S.q[dd] + S.ds[(16 * mt + 4 * kq + e) * LDS_ + dd]);
+                sum += S.v[dd] * u;
+                // hoisted backward (gt_attn_param_grads): keep tanh(.) of every step instead of recomputing it
+                if (u_out != nullptr && t0 + 16 * mt + 4 * kq + e < d.Ti)
+                    u_out[((long)b * d.Ti + t0 + 16 * mt + 4 * kq + e) * A + dd] = u;
             }
             sum += __shfl_xor(sum, 1, 64);
             sum += __shfl_xor(sum, 2, 64);
@@ -433,15 +438,305 @@ __global__ __launch_bounds__(256) void attn_energies_bwd_mfma(GtAttnDims d, cons
     }
 }
 
+// ---- hoisted backward ------------------------------------------------------------------------------------------------
+// With the tanh outputs u of every forward step kept (4.9 MB per step at B=64, Ti=150: sized for 288 GB of HBM), the
+// backward loop only needs the RECURRENT terms of the energies backward -- dq and d[w_prev; w_cum] -- and the
+// softmax-backward vector de; the parameter gradients (dv, dWd, dWc) and d(processed memory) are sums over all steps
+// with no consumer inside the loop and are produced by attn_param_grads_mfma in one batched pass per loop chunk.
+__global__ __launch_bounds__(256) void attn_energies_bwd_rec_mfma(GtAttnDims d, const float* dw, const float* w,
+                                                                  const float* u, const float* Wc, const float* Wd,
+                                                                  const float* v, const int* lengths, float* dq, long ld_dq,
+                                                                  float* dwcat_out, float* de_out, const float* wpack) {
+    __shared__ SharedM S;
+    const int b = blockIdx.y, t0 = blockIdx.x * CT;
+    if (lengths != nullptr && t0 >= lengths[b]) {
+        if (threadIdx.x < CT && t0 + threadIdx.x < d.Ti) de_out[(long)b * d.Ti + t0 + threadIdx.x] = 0.f;
+        return;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    float4 u4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = threadIdx.x + 256 * i, tl = f >> 5, c4 = f & 31;
+        u4[i] = *reinterpret_cast<const float4*>(u + ((long)b * d.Ti + min(t0 + tl, d.Ti - 1)) * A + 4 * c4);
+    }
+    const long ti = (long)b * d.Ti + min((int)threadIdx.x, d.Ti - 1);
+    const float w_t = w[ti], dw_t = dw[ti];
+    const long tci = (long)b * d.Ti + min(t0 + (int)(threadIdx.x & (CT - 1)), d.Ti - 1);
+    const float w_c = w[tci], dw_c = dw[tci];
+    stage_common(S, d, Wc, Wd, v, nullptr, nullptr, b, t0, wpack, false);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = threadIdx.x + 256 * i, tl = f >> 5, c4 = f & 31;
+        *reinterpret_cast<float4*>(&S.ds[tl * LDS_ + 4 * c4]) = u4[i];
+    }
+    float part = (int)threadIdx.x < d.Ti ? w_t * dw_t : 0.f;
+    for (int t = threadIdx.x + 256; t < d.Ti; t += 256) part += w[(long)b * d.Ti + t] * dw[(long)b * d.Ti + t];
+    const float dot = block_sum(part, S.red);
+    if (threadIdx.x < CT) {
+        const int t = t0 + threadIdx.x;
+        const float de = (t < d.Ti) ? w_c * (dw_c - dot) : 0.f;
+        S.de[threadIdx.x] = de;
+        if (t < d.Ti) de_out[(long)b * d.Ti + t] = de;
+    }
+    __syncthreads();
+    float dqs[2] = {0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nl = 0; nl < 2; ++nl) {
+            const int dd = 32 * wave + 16 * nl + r;
+            const float vd = S.v[dd];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int tl = 16 * mt + 4 * kq + e;
+                float dsv = 0.f;
+                if (t0 + tl < d.Ti) {
+                    const float uu = S.ds[tl * LDS_ + dd];
+                    dsv = S.de[tl] * vd * (1.f - uu * uu);
+                    dqs[nl] += dsv;
+                }
+                S.ds[tl * LDS_ + dd] = dsv;
+            }
+        }
+#pragma unroll
+    for (int nl = 0; nl < 2; ++nl) {
+        dqs[nl] += __shfl_xor(dqs[nl], 16, 64);
+        dqs[nl] += __shfl_xor(dqs[nl], 32, 64);
+        if (kq == 0) atomicAdd(&dq[(long)b * ld_dq + 32 * wave + 16 * nl + r], dqs[nl]);
+    }
+    __syncthreads();
+    {   // G3: dlocf = ds . Wd
+        const int mt = wave >> 1, nt = wave & 1;
+        f32x4 c3 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s4 = 0; s4 < 8; ++s4) {
+            const int k0 = 16 * s4 + 4 * kq;
+            c3 = mfma4(ld4(&S.ds[(16 * mt + r) * LDS_ + k0]), ld4s(&S.wd[k0 * LDD + 16 * nt + r], LDD), c3);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) S.dlocf[(16 * mt + 4 * kq + e) * LDL + 16 * nt + r] = c3[e];
+    }
+    __syncthreads();
+    {   // G6: g = dlocf . Wc
+        const int mt = wave >> 1;
+        f32x4 c6[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s4 = 0; s4 < 2; ++s4) {
+            const int k0 = 16 * s4 + 4 * kq;
+            const float4 a6 = ld4(&S.dlocf[(16 * mt + r) * LDL + k0]);
+#pragma unroll
+            for (int nl = 0; nl < 2; ++nl) {
+                const int kk = 16 * (2 * (wave & 1) + nl) + r;
+                c6[nl] = mfma4(a6, ld4s(&S.wc[k0 * LDC + kk], LDC), c6[nl]);
+            }
+        }
+#pragma unroll
+        for (int nl = 0; nl < 2; ++nl) {
+            const int kk = 16 * (2 * (wave & 1) + nl) + r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) S.g[(16 * mt + 4 * kq + e) * LDG + kk] = c6[nl][e];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * (CT + KC - 1)) {
+        const int c = threadIdx.x / (CT + KC - 1), p = threadIdx.x - c * (CT + KC - 1);
+        const int t = t0 + p - (KC - 1) / 2;
+        if (t >= 0 && t < d.Ti) {
+            float a = 0.f;
+            const int klo = max(0, p - (CT - 1)), khi = min(KC - 1, p);
+            for (int k = klo; k <= khi; ++k) a += S.g[(p - k) * LDG + c * KC + k];
+            atomicAdd(&dwcat_out[(long)c * d.B * d.Ti + (long)b * d.Ti + t], a);
+        }
+    }
+}
+
+// Parameter gradients of `nsteps` consecutive steps for one (b, 32-position) tile: per step ds = de v (1 - u^2),
+// locf = conv(windows), dlocf = ds . Wd;  dv += de u, dpm += ds, dWd += ds^T . locf, dWc += dlocf^T . im2col, all
+// accumulated in REGISTERS over the steps and added to dpm / the workgroup's accumulator slab once at the end
+// (same slab layout as attn_energies_bwd_mfma, reduced by gt_attn_acc_reduce).
+__global__ __launch_bounds__(256) void attn_param_grads_mfma(GtAttnDims d, int nsteps, const float* u, const float* de,
+                                                             const float* w_prev, const float* w_cum, long step_stride,
+                                                             const float* Wc, const float* Wd, const float* v,
+                                                             const int* lengths, float* dpm, float* acc_slabs,
+                                                             const float* wpack) {
+    __shared__ SharedM S;
+    const int b = blockIdx.y, t0 = blockIdx.x * CT;
+    if (lengths != nullptr && t0 >= lengths[b]) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    const long BTi = (long)d.B * d.Ti;
+    float* acc_wg = acc_slabs + ((long)b * gridDim.x + blockIdx.x) * PER_MFMA;
+    stage_common(S, d, Wc, Wd, v, w_prev, w_cum, b, t0, wpack, false);      // weights once; windows per step below
+    float dv_acc[2] = {0.f, 0.f}, dpm_acc[2][2][4];
+    f32x4 c4[2][2], c5[2];
+#pragma unroll
+    for (int a_ = 0; a_ < 2; ++a_) {
+        c5[a_] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b_ = 0; b_ < 2; ++b_) {
+            c4[a_][b_] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dpm_acc[a_][b_][e] = 0.f;
+        }
+    }
+    // software pipeline: the loads of step s + 1 are issued before the arithmetic of step s
+    float4 u4[4];
+    float de_r = 0.f, win_r = 0.f;
+#define GT_FETCH(STEP)                                                                                              \
+    {                                                                                                               \
+        const float* us = u + (long)(STEP) * BTi * A;                                                               \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                             \
+            const int f = threadIdx.x + 256 * i, tl = f >> 5, c4i = f & 31;                                         \
+            u4[i] = *reinterpret_cast<const float4*>(us + ((long)b * d.Ti + min(t0 + tl, d.Ti - 1)) * A + 4 * c4i);  \
+        }                                                                                                           \
+        de_r = de[(long)(STEP) * BTi + (long)b * d.Ti + min(t0 + (int)(threadIdx.x & (CT - 1)), d.Ti - 1)];         \
+        const int c = (threadIdx.x & 127) / WL, p = (threadIdx.x & 127) - c * WL;                                   \
+        const int t = t0 + p - (KC - 1) / 2;                                                                        \
+        const float* src = (c == 0 ? w_prev : w_cum) + (long)(STEP) * step_stride;                                  \
+        const float wv = src[(long)b * d.Ti + min(max(t, 0), d.Ti - 1)];                                            \
+        win_r = (p < CT + KC - 1 && t >= 0 && t < d.Ti) ? wv : 0.f;                                                 \
+    }
+    GT_FETCH(0)
+    for (int s = 0; s < nsteps; ++s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = threadIdx.x + 256 * i, tl = f >> 5, c4i = f & 31;
+            *reinterpret_cast<float4*>(&S.ds[tl * LDS_ + 4 * c4i]) = u4[i];
+        }
+        if (threadIdx.x < CT) S.de[threadIdx.x] = (t0 + (int)threadIdx.x < d.Ti) ? de_r : 0.f;
+        if (threadIdx.x < 2 * WL) S.win[threadIdx.x / WL][threadIdx.x % WL] = win_r;
+        __syncthreads();
+        if (s + 1 < nsteps) GT_FETCH(s + 1)
+        conv_tile(S, wave, lane);                         // locf (reads win, wc)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nl = 0; nl < 2; ++nl) {
+                const int dd = 32 * wave + 16 * nl + r;
+                const float vd = S.v[dd];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int tl = 16 * mt + 4 * kq + e;
+                    float dsv = 0.f;
+                    if (t0 + tl < d.Ti) {
+                        const float uu = S.ds[tl * LDS_ + dd], dee = S.de[tl];
+                        dsv = dee * vd * (1.f - uu * uu);
+                        dv_acc[nl] += dee * uu;
+                        dpm_acc[mt][nl][e] += dsv;
+                    }
+                    S.ds[tl * LDS_ + dd] = dsv;
+                }
+            }
+        __syncthreads();                                   // ds, locf complete
+        {   // G3: dlocf = ds . Wd
+            const int mt = wave >> 1, nt = wave & 1;
+            f32x4 c3 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s4 = 0; s4 < 8; ++s4) {
+                const int k0 = 16 * s4 + 4 * kq;
+                c3 = mfma4(ld4(&S.ds[(16 * mt + r) * LDS_ + k0]), ld4s(&S.wd[k0 * LDD + 16 * nt + r], LDD), c3);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) S.dlocf[(16 * mt + 4 * kq + e) * LDL + 16 * nt + r] = c3[e];
+        }
+        // G4: dWd rows [32w, 32w+32) += ds^T . locf
+#pragma unroll
+        for (int s4 = 0; s4 < 2; ++s4) {
+            const int k0 = 16 * s4 + 4 * kq;
+            float4 a[2], bb[2];
+#pragma unroll
+            for (int ml = 0; ml < 2; ++ml) a[ml] = ld4s(&S.ds[k0 * LDS_ + 32 * wave + 16 * ml + r], LDS_);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) bb[nt] = ld4s(&S.locf[k0 * LDL + 16 * nt + r], LDL);
+#pragma unroll
+            for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) c4[ml][nt] = mfma4(a[ml], bb[nt], c4[ml][nt]);
+        }
+        __syncthreads();                                   // dlocf complete
+        {   // G5: dWc += dlocf^T . im2col
+            const int mt = wave >> 1;
+#pragma unroll
+            for (int s4 = 0; s4 < 2; ++s4) {
+                const int k0 = 16 * s4 + 4 * kq;
+                const float4 a5 = ld4s(&S.dlocf[k0 * LDL + 16 * mt + r], LDL);
+#pragma unroll
+                for (int nl = 0; nl < 2; ++nl) {
+                    const int kk = 16 * (2 * (wave & 1) + nl) + r;
+                    const float4 b5 = make_float4(im2col(S, k0, kk), im2col(S, k0 + 1, kk), im2col(S, k0 + 2, kk),
+                                                  im2col(S, k0 + 3, kk));
+                    c5[nl] = mfma4(a5, b5, c5[nl]);
+                }
+            }
+        }
+        __syncthreads();                                   // before the next step overwrites ds / win / dlocf
+    }
+#undef GT_FETCH
+    // ---- write-out: dpm tile (+=), accumulator slab (+=) in the register order of attn_energies_bwd_mfma
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nl = 0; nl < 2; ++nl)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int tl = 16 * mt + 4 * kq + e;
+                if (t0 + tl < d.Ti) dpm[((long)b * d.Ti + t0 + tl) * A + 32 * wave + 16 * nl + r] += dpm_acc[mt][nl][e];
+            }
+#pragma unroll
+    for (int nl = 0; nl < 2; ++nl) {
+        dv_acc[nl] += __shfl_xor(dv_acc[nl], 16, 64);
+        dv_acc[nl] += __shfl_xor(dv_acc[nl], 32, 64);
+        if (kq == 0) acc_wg[32 * wave + 16 * nl + r] += dv_acc[nl];
+    }
+    {
+        float4* pw = reinterpret_cast<float4*>(acc_wg + A + threadIdx.x * 16);
+#pragma unroll
+        for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                float4 o = pw[ml * 2 + nt];
+                o.x += c4[ml][nt][0]; o.y += c4[ml][nt][1]; o.z += c4[ml][nt][2]; o.w += c4[ml][nt][3];
+                pw[ml * 2 + nt] = o;
+            }
+        float4* pc = reinterpret_cast<float4*>(acc_wg + A + A * F + threadIdx.x * 8);
+#pragma unroll
+        for (int nl = 0; nl < 2; ++nl) {
+            float4 o = pc[nl];
+            o.x += c5[nl][0]; o.y += c5[nl][1]; o.z += c5[nl][2]; o.w += c5[nl][3];
+            pc[nl] = o;
+        }
+    }
+}
+
 }  // namespace
 
 // entry points used by attention.hip when the dimensions match (128, 32, 31)
 void gt_launch_attn_energies_fwd_mfma(GtAttnDims d, GtSlabs qpart, const float* w_prev, const float* w_cum,
                                       const float* pm, const float* Wc, const float* Wd, const float* v,
-                                      const int* lengths, float* q_out, float* energies, const float* wpack, hipStream_t st) {
+                                      const int* lengths, float* q_out, float* energies, const float* wpack, hipStream_t st,
+                                      float* u_out) {
     dim3 grid(cdiv(d.Ti, CT), d.B);
     hipLaunchKernelGGL(attn_energies_fwd_mfma, grid, dim3(256), 0, st, d, qpart, w_prev, w_cum, pm, Wc, Wd, v, lengths,
-                       q_out, energies, wpack);
+                       q_out, energies, wpack, u_out);
+}
+
+void gt_launch_attn_energies_bwd_rec_mfma(GtAttnDims d, const float* dw, const float* w, const float* u, const float* Wc,
+                                          const float* Wd, const float* v, const int* lengths, float* dq, long ld_dq,
+                                          float* dwcat_out, float* de_out, const float* wpack, hipStream_t st) {
+    dim3 grid(cdiv(d.Ti, CT), d.B);
+    hipLaunchKernelGGL(attn_energies_bwd_rec_mfma, grid, dim3(256), 0, st, d, dw, w, u, Wc, Wd, v, lengths, dq, ld_dq,
+                       dwcat_out, de_out, wpack);
+}
+
+void gt_launch_attn_param_grads_mfma(GtAttnDims d, int nsteps, const float* u, const float* de, const float* w_prev,
+                                     const float* w_cum, long step_stride, const float* Wc, const float* Wd,
+                                     const float* v, const int* lengths, float* dpm, float* acc, const float* wpack,
+                                     hipStream_t st) {
+    dim3 grid(cdiv(d.Ti, CT), d.B);
+    hipLaunchKernelGGL(attn_param_grads_mfma, grid, dim3(256), 0, st, d, nsteps, u, de, w_prev, w_cum, step_stride, Wc, Wd,
+                       v, lengths, dpm, acc, wpack);
 }
 
 void gt_launch_attn_energies_bwd_mfma(GtAttnDims d, const float* dw, const float* w, const float* q,

@@ -186,10 +186,11 @@ int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
                                     a->hatt + (int64_t)t * a->Bp * a->Ha, X1n + a->E, a->ld1, X2t, a->ld2, nullptr, 0,
                                     a->B, a->Ha, sA));
         if (!cq) GT_TRY(rec_rows(X2t, a->ld2, a->Wqp, a->part, a->Bp, a->Apad, a->Ha, a->Sq, sA));
-        GT_TRY(gt_attn_energies_fwd_w(d, cq ? slabs(a->partq, a->Ha / 32, (int64_t)a->Bp * a->Apad, a->Apad)
+        GT_TRY(gt_attn_energies_fwd_u(d, cq ? slabs(a->partq, a->Ha / 32, (int64_t)a->Bp * a->Apad, a->Apad)
                                             : slabs(a->part, a->Sq, (int64_t)a->Bp * a->Apad, a->Apad),
                                       a->w_hist + (int64_t)t * BT, a->cum_hist + (int64_t)t * BT, a->pm, a->Wc, a->Wd, a->v,
-                                      a->lengths, a->q_hist + (int64_t)t * a->B * a->A, a->energies, wpack, sA));
+                                      a->lengths, a->q_hist + (int64_t)t * a->B * a->A, a->energies, wpack,
+                                      a->u_hist ? a->u_hist + (int64_t)t * BT * a->A : nullptr, sA));
         GT_TRY(gt_attn_context_fwd(d, a->energies, a->memory, a->ldE, a->lengths, a->w_hist + (int64_t)(t + 1) * BT,
                                    a->cum_hist + (int64_t)t * BT, a->cum_hist + (int64_t)(t + 1) * BT, X1n, a->ld1,
                                    X2t + a->Ha, a->ld2, hc_t + a->Hd, hc_ld, sA));
@@ -337,9 +338,16 @@ int gt_decoder_bwd(const GtDecoderBwd* a, void* stream) {
                                    a->memory, a->ldE, a->lengths, dwcat_in, a->dcum_acc,
                                    a->dalign ? a->dalign + (int64_t)t * BT : nullptr,
                                    a->dctx_hist + (int64_t)t * a->B * a->E, a->E, dq_t, a->Apad, a->dw, sA));
-        GT_TRY(gt_attn_energies_bwd_w(d, a->dw, a->w_hist + (int64_t)(t + 1) * BT, a->q_hist + (int64_t)t * a->B * a->A,
-                                      a->w_hist + (int64_t)t * BT, a->cum_hist + (int64_t)t * BT, a->pm, a->Wc, a->Wd, a->v,
-                                      a->lengths, dq_t, a->Apad, a->dpm, dwcat_out, a->acc, wpack, sA));
+        if (a->u_hist != nullptr && a->de_hist != nullptr) {
+            // hoisted form: only the recurrent terms here, the sums over steps in gt_attn_param_grads (caller)
+            GT_TRY(gt_attn_energies_bwd_rec(d, a->dw, a->w_hist + (int64_t)(t + 1) * BT, a->u_hist + (int64_t)t * BT * a->A,
+                                            a->Wc, a->Wd, a->v, a->lengths, dq_t, a->Apad, dwcat_out,
+                                            a->de_hist + (int64_t)t * BT, wpack, sA));
+        } else {
+            GT_TRY(gt_attn_energies_bwd_w(d, a->dw, a->w_hist + (int64_t)(t + 1) * BT, a->q_hist + (int64_t)t * a->B * a->A,
+                                          a->w_hist + (int64_t)t * BT, a->cum_hist + (int64_t)t * BT, a->pm, a->Wc, a->Wd, a->v,
+                                          a->lengths, dq_t, a->Apad, a->dpm, dwcat_out, a->acc, wpack, sA));
+        }
         if (bq) {
             // attention LSTM cell backward with dq . Wq computed inside: one dependent launch less per step
             GT_TRY(gt_cell_bwd_query(slabs(pX2, a->S2, sX2, a->N2pad),

@@ -36,6 +36,9 @@ FUSED_CELL = _os.environ.get('GANTRON_FUSED_CELL', '0') != '0'
 HOST_TIMING = _os.environ.get('GANTRON_HOST_TIMING') == '1'      # diagnostics: host time spent issuing each loop
 CELL_QUERY = _os.environ.get('GANTRON_CELL_QUERY', '1') != '0'    # attention cell + query product in one launch
 BWD_CHUNKS = int(_os.environ.get("GANTRON_BWD_CHUNKS", "6"))
+# hoisted attention backward (gt_attn_param_grads): keep tanh(.) of every step (B*Ti*A floats each) so that the loop
+# only computes the recurrent terms of the energies backward
+ATTN_HOIST = _os.environ.get('GANTRON_ATTN_HOIST', '1') != '0'
 DEC_RING = int(_os.environ.get('GANTRON_DEC_RING', '16'))     # ring of hand-off buffers between the two decoder chains;
                                                              # cross-stream syncs happen every ring/2 steps (loops.hip)
 
@@ -495,6 +498,9 @@ class GeneratorEngine:
         d.part2, d.ring = ptr(ws['part2']), DEC_RING
         for k in ('gates1', 'c1', 'gates2', 'c2', 'hatt', 'HC', 'w_hist', 'cum_hist', 'q_hist'):
             setattr(d, k, ptr(hist[k]))
+        if ATTN_HOIST and training and lib().gt_attn_hoist_supported(ops.attn_dims(B, Ti, E, A, self.F, self.Kc)):
+            hist['u_hist'] = _f32(To, B, Ti, A, device=dev, zero=False)
+            d.u_hist = ptr(hist['u_hist'])
         PHASES.mark('f.pre_loop')
         _t0 = _time.perf_counter()
         _run('gt_decoder_fwd', d)
@@ -736,6 +742,15 @@ class GeneratorEngine:
         for k in buf:
             setattr(b, k, ptr(buf[k]))
         b.ring = DEC_RING
+        hoist = 'u_hist' in hist
+        if hoist:
+            # the loop computes dq / d[w_prev; w_cum] / de only; dv, dW_loc and dpm of a finished chunk of steps are
+            # summed on the leaf stream by gt_attn_param_grads (needs the packed [Wc | Wd] image: made here, once)
+            de_hist = _f32(To, B, Ti, device=dev, zero=False)
+            b.u_hist, b.de_hist = ptr(hist['u_hist']), ptr(de_hist)
+            wpack_p = _f32(n_wpack, device=dev, zero=False)
+            call('gt_attn_pack_weights', dims, Wc, Wd, wpack_p)
+            BT = B * Ti
         dG1, dG2 = buf['dG1'], buf['dG2']
         g1ih, g1hh = G['decoder.attention_rnn.weight_ih'], G['decoder.attention_rnn.weight_hh']
         g2ih, g2hh = G['decoder.decoder_rnn.weight_ih'], G['decoder.decoder_rnn.weight_hh']
@@ -775,7 +790,17 @@ class GeneratorEngine:
             _run('gt_decoder_bwd', b)
             if HOST_TIMING:
                 print(f'[host] gt_decoder_bwd steps {hi}..{lo} issued in {1e3 * (_time.perf_counter() - _t0):.1f} ms', flush=True)
+            if hoist:
+                LEAF.run(lambda lo=lo, hi=hi: check(lib().gt_attn_param_grads(
+                    dims, hi - lo + 1, ptr(hist['u_hist'], lo * BT * A), ptr(de_hist, lo * BT), ptr(hist['w_hist'], lo * BT),
+                    ptr(hist['cum_hist'], lo * BT), BT, ptr(Wc), ptr(Wd), ptr(v), ptr(sv['lens32']), ptr(buf['dpm']),
+                    ptr(buf['acc']), ptr(wpack_p), ops._stream()), 'gt_attn_param_grads'), de_hist, wpack_p)
+                if ci == 0:                       # dpm is complete: the main stream reads it after the loop
+                    dpm_ready = torch.cuda.Event()
+                    dpm_ready.record(LEAF.stream if LEAF.enabled else torch.cuda.current_stream())
             LEAF.run(lambda lo=lo, hi=hi: leaf_decoder(lo, hi), dHC)
+        if hoist:
+            torch.cuda.current_stream().wait_event(dpm_ready)
         LEAF.run(lambda: call('gt_attn_acc_reduce', dims, buf['acc'], G[al + 'v.linear_layer.weight'],
                               G[al + 'location_layer.location_dense.linear_layer.weight'],
                               G[al + 'location_layer.location_conv.conv.weight']), buf['acc'])

@@ -229,6 +229,24 @@ int gt_attn_energies_bwd_w(GtAttnDims d, const float* dw, const float* w, const 
                          const float* w_prev, const float* w_cum, const float* pm, const float* Wc,
                          const float* Wd, const float* v, const int32_t* lengths, float* dq,
                          int64_t ld_dq, float* dpm, float* dwcat_out, float* acc, const float* wpack, void* stream);
+/* Hoisted form of the energies backward (dimensions 128/32/31 only, gt_attn_hoist_supported): the forward keeps
+ * u = tanh(.) of every step (gt_attn_energies_fwd_u, u_out (B,Ti,A)), the backward loop computes only the recurrent
+ * terms -- dq, d[w_prev; w_cum] -- and the softmax-backward vector de_out (B,Ti) (gt_attn_energies_bwd_rec), and the
+ * sums over steps that nothing inside the loop consumes -- dv, dWd, dWc into `acc`, d(processed memory) into dpm --
+ * are added by gt_attn_param_grads for `nsteps` consecutive steps at once (u, de advance by B*Ti*A / B*Ti per step,
+ * w_prev / w_cum by step_stride).  Results equal gt_attn_energies_bwd's up to summation order. */
+int32_t gt_attn_hoist_supported(GtAttnDims d);
+int gt_attn_energies_fwd_u(GtAttnDims d, GtSlabs qpart, const float* w_prev, const float* w_cum,
+                           const float* pm, const float* Wc, const float* Wd, const float* v,
+                           const int32_t* lengths, float* q_out, float* energies, const float* wpack,
+                           float* u_out, void* stream);
+int gt_attn_energies_bwd_rec(GtAttnDims d, const float* dw, const float* w, const float* u, const float* Wc,
+                             const float* Wd, const float* v, const int32_t* lengths, float* dq, int64_t ld_dq,
+                             float* dwcat_out, float* de_out, const float* wpack, void* stream);
+int gt_attn_param_grads(GtAttnDims d, int32_t nsteps, const float* u, const float* de, const float* w_prev,
+                        const float* w_cum, int64_t step_stride, const float* Wc, const float* Wd,
+                        const float* v, const int32_t* lengths, float* dpm, float* acc, const float* wpack,
+                        void* stream);
 int64_t gt_attn_acc_elems(GtAttnDims d);     /* size of `acc` (dv | dWd | dWc per workgroup) */
 int gt_attn_acc_reduce(GtAttnDims d, const float* acc, float* dv, float* dWd, float* dWc,
                        void* stream);
@@ -279,6 +297,7 @@ typedef struct GtDecoderFwd {
     float* q_hist;             /* (To, B, A) */
     int32_t bf16;              /* 1: W1p / W2p are gt_pack_rec_weight_bf16 images and the two LSTM products run as
                                   gt_rec_gemm_bf16 (hparams.fp16_run); needs the unfused path (W1g = W2g = NULL) */
+    float* u_hist;             /* NULL or (To, B, Ti, A): tanh outputs of every step for the hoisted backward */
 } GtDecoderFwd;
 
 typedef struct GtDecoderBwd {
@@ -315,6 +334,8 @@ typedef struct GtDecoderBwd {
     int32_t t_hi, t_lo;        /* steps t_hi..t_lo (descending) of this call; t_hi < t_lo = all steps.  State
                                   persists in the buffers, so a loop may be issued in several calls. */
     int32_t bf16;              /* 1: W1Tp / W2Tp are gt_pack_rec_weight_bf16 images (products run as gt_rec_gemm_bf16) */
+    const float* u_hist;       /* both non-NULL: hoisted energies backward (gt_attn_energies_bwd_rec per step; the   */
+    float* de_hist;            /*   caller runs gt_attn_param_grads over the steps afterwards); de_hist (To, B, Ti)  */
 } GtDecoderBwd;
 
 typedef struct GtBiLstm {

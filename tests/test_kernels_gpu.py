@@ -394,6 +394,59 @@ def test_attention_step_fwd_bwd(dev, B, Ti, E, A, Fn, Kc):
     close(dq, torch.autograd.grad(l2, q2)[0], rtol=2e-3, atol=1e-6, what='dq')
 
 
+@pytest.mark.parametrize('B,Ti', [(3, 150), (5, 77), (2, 33)])
+def test_attention_hoisted_backward_equals_in_loop(dev, B, Ti):
+    """gt_attn_energies_fwd_u + gt_attn_energies_bwd_rec per step + ONE gt_attn_param_grads over the steps == the
+    in-loop gt_attn_energies_bwd of every step (itself checked against autograd above): dq, d[w_prev; w_cum] per
+    step, and d(processed memory), dv, dWd, dWc summed over 4 steps."""
+    from gantron_amd import ops
+    from gantron_amd._lib import lib
+    A, Fn, Kc, S = 128, 32, 31, 4
+    d = ops.attn_dims(B, Ti, 64, A, Fn, Kc)
+    assert lib().gt_attn_hoist_supported(d) == 1
+    lens = torch.tensor([Ti, Ti - 7, max(Ti - 20, 3), Ti - 1, 5][:B])
+    lens32 = lens.to(torch.int32).to(dev)
+    Wc, Wd, v = g(Fn, 2, Kc, seed=1, scale=0.3).to(dev), g(A, Fn, seed=2, scale=0.3).to(dev), g(1, A, seed=3, scale=0.5).to(dev)
+    pm = g(B, Ti, A, seed=5, scale=0.5).to(dev)
+    wpack = torch.empty(int(lib().gt_attn_wpack_elems(d)), device=dev)
+    ops.call('gt_attn_pack_weights', d, Wc, Wd, wpack)
+    w_prev = torch.stack([torch.softmax(g(B, Ti, seed=20 + s), 1) for s in range(S)]).to(dev)
+    w_cum = torch.stack([torch.softmax(g(B, Ti, seed=30 + s), 1) * (s + 1) for s in range(S)]).to(dev)
+    q = torch.stack([g(B, A, seed=40 + s) for s in range(S)]).to(dev)
+    dw = torch.stack([g(B, Ti, seed=50 + s, scale=0.3) for s in range(S)]).to(dev)
+    w = torch.empty(S, B, Ti, device=dev)
+    u = torch.full((S, B, Ti, A), float('nan'), device=dev)
+    en = torch.empty(B, Ti, device=dev); q_out = torch.empty(B, A, device=dev)
+    for s in range(S):
+        ops.call('gt_attn_energies_fwd_u', d, ops.slabs(q[s], 1, B * A, A), w_prev[s], w_cum[s], pm, Wc, Wd, v, lens32, q_out, en,
+                 wpack, u[s])
+        w[s] = torch.softmax(en, 1)
+    # in-loop reference
+    dpm0 = torch.zeros(B, Ti, A, device=dev); acc0 = torch.zeros(int(lib().gt_attn_acc_elems(d)), device=dev)
+    dq0 = torch.zeros(S, B, A, device=dev); dwc0 = torch.zeros(S, 2, B, Ti, device=dev)
+    for s in range(S):
+        ops.call('gt_attn_energies_bwd_w', d, dw[s], w[s], q[s], w_prev[s], w_cum[s], pm, Wc, Wd, v, lens32, dq0[s], A, dpm0,
+                 dwc0[s], acc0, wpack)
+    # hoisted
+    dpm1 = torch.zeros(B, Ti, A, device=dev); acc1 = torch.zeros_like(acc0)
+    dq1 = torch.zeros(S, B, A, device=dev); dwc1 = torch.zeros(S, 2, B, Ti, device=dev)
+    de = torch.full((S, B, Ti), float('nan'), device=dev)
+    for s in range(S):
+        ops.call('gt_attn_energies_bwd_rec', d, dw[s], w[s], u[s], Wc, Wd, v, lens32, dq1[s], A, dwc1[s], de[s], wpack)
+    ops.call('gt_attn_param_grads', d, 2, u, de, w_prev, w_cum, B * Ti, Wc, Wd, v, lens32, dpm1, acc1, wpack)       # steps 0-1
+    ops.call('gt_attn_param_grads', d, S - 2, u[2:], de[2:], w_prev[2:], w_cum[2:], B * Ti, Wc, Wd, v, lens32, dpm1, acc1, wpack)
+    close(dq1, dq0, rtol=1e-5, atol=1e-7, what='dq')
+    close(dwc1, dwc0, rtol=1e-5, atol=1e-7, what='d[w_prev; w_cum]')
+    close(dpm1, dpm0, rtol=1e-5, atol=1e-7, what='dpm')
+    outs = []
+    for acc in (acc0, acc1):
+        dv = torch.zeros(1, A, device=dev); dWd = torch.zeros(A, Fn, device=dev); dWc = torch.zeros(Fn, 2, Kc, device=dev)
+        ops.call('gt_attn_acc_reduce', d, acc, dv, dWd, dWc)
+        outs.append((dv, dWd, dWc))
+    for name, a, b in zip(('dv', 'dWd', 'dWc'), outs[1], outs[0]):
+        close(a, b, rtol=1e-5, atol=1e-6, what=name)
+
+
 # ------------------------------------------------------------------------- BN / elementwise
 @pytest.mark.parametrize('rows,C,act', [(300, 24, 1), (1000, 80, 2), (77, 8, 0)])
 def test_bn_act_drop(dev, rows, C, act):
