@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 HPARAMS = 'use_labels=False,use_noise=True'
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (the headline figures with 2:1 sparsity are not used)
 HBM_PEAK_GBS = 8000.0
 FAMILIES = ['rec_gemm', 'sgemm', 'attn_energies_fwd', 'attn_context_fwd', 'attn_context_bwd', 'attn_energies_bwd',
             'lstm_cell_fwd', 'lstm_cell_bwd']
@@ -290,8 +291,8 @@ def main():
         avg_ms = dom['ms'] / max(dom['launches'], 1)
         if dom['name'] in MFMA_BOUND:
             ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12 if dom['ms'] > 0 else 0.0
-            roof = dict(bound='mfma', achieved=ach, peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
-                        frac=ach / FP32_MFMA_PEAK_TFLOPS, traffic=None)
+            peak = BF16_MFMA_PEAK_TFLOPS if args.bf16 else FP32_MFMA_PEAK_TFLOPS     # --bf16: these families run bf16 MFMAs
+            roof = dict(bound='mfma', achieved=ach, peak=peak, unit='TFLOP/s', frac=ach / peak, traffic=None)
         else:
             ach = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9 if dom['ms'] > 0 else 0.0
             roof = dict(bound='hbm', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s', frac=ach / HBM_PEAK_GBS, traffic=None)
