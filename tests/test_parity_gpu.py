@@ -147,7 +147,7 @@ def test_full_size_matches_reference_summaries(dev, golden_dir, name):
     assert not bad, '\n'.join(bad)
 
 
-@pytest.mark.parametrize('case', ['ragged5', 'batch70', 'full_dims_b64', 'full_dims_b20', 'ragged5_bf16',
+@pytest.mark.parametrize('case', ['ragged5', 'batch70', 'full_dims_b64', 'full_dims_b20', 'full_dims_long', 'ragged5_bf16',
                                   'full_dims_b20_bf16'])
 def test_midsize_against_oracle(dev, case):
     """B=5 (padded to 16 rows) with ragged lengths and To not a multiple of the discriminator window, and
@@ -181,6 +181,12 @@ def test_midsize_against_oracle(dev, case):
         g = torch.Generator().manual_seed(11)
         in_lens = sorted(torch.randint(5, 19, (nb,), generator=g).tolist(), reverse=True)
         out_lens = torch.randint(21, 27, (nb,), generator=g).tolist()
+        if case.endswith('long'):
+            # 100+ decoder steps: the backward loop is issued in 3 chunks, each followed by its weight-gradient GEMMs
+            # and its gt_attn_param_grads pass on the leaf stream (the hoisted attention backward), Ti spans two
+            # 32-position attention tiles with ragged lengths
+            nb = 4
+            in_lens, out_lens = [45, 38, 33, 20], [101, 87, 110, 64]
     if case == 'batch70':
         g = torch.Generator().manual_seed(3)
         in_lens = sorted(torch.randint(3, 15, (70,), generator=g).tolist(), reverse=True)
