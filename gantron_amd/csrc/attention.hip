@@ -306,7 +306,10 @@ __global__ __launch_bounds__(256) void attn_context_bwd_kernel(GtAttnDims d, GtS
                                                                float* dw_out) {
     extern __shared__ __attribute__((aligned(16))) float dctx[];   // E floats
     __shared__ float dots[CT];
-    const int b = blockIdx.y, t0 = blockIdx.x * CT;
+    // grid (B, chunks): b is the fast index of the linear workgroup id, so the chunks of one batch row have ids
+    // congruent mod 8 and land on the same XCD -- the 13 K-split slabs of that row's context gradient are then
+    // fetched into one L2 instead of into every XCD that runs one of its chunks
+    const int b = blockIdx.x, chunk = blockIdx.y, t0 = chunk * CT;
     // padded positions carry weight 0: their dw never reaches an energy gradient, so it is set to 0
     // and neither the upstream context gradient nor their memory rows are read
     const int Tv = lengths != nullptr ? min(lengths[b], d.Ti) : d.Ti;
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(256) void attn_context_bwd_kernel(GtAttnDims d, GtS
             g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
         }
         *reinterpret_cast<float4*>(&dctx[e]) = g;
-        if (blockIdx.x == 0 && dctx_out != nullptr) *reinterpret_cast<float4*>(dctx_out + (long)b * ld_dctx_out + e) = g;
+        if (chunk == 0 && dctx_out != nullptr) *reinterpret_cast<float4*>(dctx_out + (long)b * ld_dctx_out + e) = g;
     } else
     for (int e = threadIdx.x; e < d.E; e += blockDim.x) {
         float g = 0.f;
@@ -366,9 +369,9 @@ __global__ __launch_bounds__(256) void attn_context_bwd_kernel(GtAttnDims d, GtS
         if (db.p != nullptr) g += slab_sum(db.p, db.n, db.slab_stride, (long)b * db.ld + e);
         if (dctx_direct != nullptr) g += dctx_direct[(long)b * ld_direct + e];
         dctx[e] = g;
-        if (blockIdx.x == 0 && dctx_out != nullptr) dctx_out[(long)b * ld_dctx_out + e] = g;
+        if (chunk == 0 && dctx_out != nullptr) dctx_out[(long)b * ld_dctx_out + e] = g;
     }
-    if (blockIdx.x == 0 && dq_zero != nullptr)
+    if (chunk == 0 && dq_zero != nullptr)
         for (int i = threadIdx.x; i < d.A; i += blockDim.x) dq_zero[(long)b * ld_dq + i] = 0.f;
     __syncthreads();
     if (NE4 > 0) {
@@ -738,7 +741,7 @@ extern "C" int gt_attn_context_bwd(GtAttnDims d, GtSlabs dctx_a, GtSlabs dctx_b,
     if (rc) return rc;
     GT_REQUIRE(memory && dw_out && ld_mem >= d.E, GT_E_ARG, "gt_attn_context_bwd: bad argument");
     GT_REQUIRE((size_t)d.E * 4 <= 64 * 1024, GT_E_LIMIT, "gt_attn_context_bwd: E too large for LDS");
-    dim3 grid(cdiv(d.Ti, CT), d.B);
+    dim3 grid(d.B, cdiv(d.Ti, CT));
     GtProfScope prof(GT_FAM_ATTN_C_BWD, 2.0 * d.B * d.Ti * (double)d.E, 4.0 * d.B * ((double)d.Ti * d.E + 4.0 * d.E + 6.0 * d.Ti),
                      (hipStream_t)stream);
     const bool vec = (d.E % 4 == 0) && (ld_mem % 4 == 0) && aligned16(memory);

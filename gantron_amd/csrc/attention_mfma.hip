@@ -156,7 +156,9 @@ __global__ __launch_bounds__(256) void attn_energies_fwd_mfma(GtAttnDims d, GtSl
                                                               float* q_out, float* energies, const float* wpack,
                                                               float* u_out) {
     __shared__ SharedM S;
-    const int b = blockIdx.y, t0 = blockIdx.x * CT;
+    // grid (B, chunks): the chunks of a batch row share an XCD (workgroup ids congruent mod 8), so the row's query
+    // slabs are fetched into one L2
+    const int b = blockIdx.x, chunk = blockIdx.y, t0 = chunk * CT;
     if (lengths != nullptr && t0 >= lengths[b]) {      // chunk entirely in the padding: energies are -inf
         if (threadIdx.x < CT && t0 + threadIdx.x < d.Ti) energies[(long)b * d.Ti + t0 + threadIdx.x] = -INFINITY;
         return;
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(256) void attn_energies_fwd_mfma(GtAttnDims d, GtSl
     }
     if (threadIdx.x < A) {
         S.q[threadIdx.x] = qv;
-        if (blockIdx.x == 0 && q_out != nullptr) q_out[(long)b * A + threadIdx.x] = qv;
+        if (chunk == 0 && q_out != nullptr) q_out[(long)b * A + threadIdx.x] = qv;
     }
     __syncthreads();
     conv_tile(S, wave, lane);
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(256) void attn_energies_bwd_rec_mfma(GtAttnDims d, 
                                                                   const float* v, const int* lengths, float* dq, long ld_dq,
                                                                   float* dwcat_out, float* de_out, const float* wpack) {
     __shared__ SharedM S;
-    const int b = blockIdx.y, t0 = blockIdx.x * CT;
+    const int b = blockIdx.x, t0 = blockIdx.y * CT;       // grid (B, chunks), as the forward kernel
     if (lengths != nullptr && t0 >= lengths[b]) {
         if (threadIdx.x < CT && t0 + threadIdx.x < d.Ti) de_out[(long)b * d.Ti + t0 + threadIdx.x] = 0.f;
         return;
@@ -717,7 +719,7 @@ void gt_launch_attn_energies_fwd_mfma(GtAttnDims d, GtSlabs qpart, const float* 
                                       const float* pm, const float* Wc, const float* Wd, const float* v,
                                       const int* lengths, float* q_out, float* energies, const float* wpack, hipStream_t st,
                                       float* u_out) {
-    dim3 grid(cdiv(d.Ti, CT), d.B);
+    dim3 grid(d.B, cdiv(d.Ti, CT));
     hipLaunchKernelGGL(attn_energies_fwd_mfma, grid, dim3(256), 0, st, d, qpart, w_prev, w_cum, pm, Wc, Wd, v, lengths,
                        q_out, energies, wpack, u_out);
 }
@@ -725,7 +727,7 @@ void gt_launch_attn_energies_fwd_mfma(GtAttnDims d, GtSlabs qpart, const float* 
 void gt_launch_attn_energies_bwd_rec_mfma(GtAttnDims d, const float* dw, const float* w, const float* u, const float* Wc,
                                           const float* Wd, const float* v, const int* lengths, float* dq, long ld_dq,
                                           float* dwcat_out, float* de_out, const float* wpack, hipStream_t st) {
-    dim3 grid(cdiv(d.Ti, CT), d.B);
+    dim3 grid(d.B, cdiv(d.Ti, CT));
     hipLaunchKernelGGL(attn_energies_bwd_rec_mfma, grid, dim3(256), 0, st, d, dw, w, u, Wc, Wd, v, lengths, dq, ld_dq,
                        dwcat_out, de_out, wpack);
 }

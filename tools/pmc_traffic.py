@@ -15,6 +15,7 @@ import sys
 FAMILIES = {'rec_gemm_kernel': 'rec_gemm_kernel', 'sgemm_kernel': 'sgemm_kernel',
             'attn_context_fwd_kernel': 'attn_context_fwd_kernel', 'attn_context_bwd_kernel': 'attn_context_bwd_kernel',
             'attn_energies_fwd': 'attn_energies_fwd', 'attn_energies_bwd': 'attn_energies_bwd',
+            'attn_param_grads': 'attn_param_grads', 'rec_gemm_bf16_kernel': 'rec_gemm_bf16_kernel', 'hgemm_kernel': 'hgemm_kernel',
             'lstm_cell_fwd_kernel': 'lstm_cell_fwd_kernel', 'lstm_cell_bwd_kernel': 'lstm_cell_bwd_kernel'}
 
 
