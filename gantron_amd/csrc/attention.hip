@@ -221,6 +221,8 @@ __global__ __launch_bounds__(256) void attn_context_fwd_kernel(GtAttnDims d, con
                                                                long ld_mem, const int* lengths, float* w_out,
                                                                const float* cum_in, float* cum_out, float* c0, long ld0,
                                                                float* c1, long ld1, float* c2, long ld2) {
+    __builtin_amdgcn_s_setprio(3);      // the attention chain is the serial critical path of the decoder loops: its waves
+                                        // issue ahead of the co-resident waves of the other chain and of the leaf GEMMs
     __shared__ float w[MAX_TI];
     __shared__ float red[16];
     __shared__ __attribute__((aligned(16))) float psum[4][256];
@@ -304,6 +306,8 @@ __global__ __launch_bounds__(256) void attn_context_bwd_kernel(GtAttnDims d, GtS
                                                                float* dwcat_in, float* dcum_acc, const float* dw_extern,
                                                                float* dctx_out, long ld_dctx_out, float* dq_zero, long ld_dq,
                                                                float* dw_out) {
+    __builtin_amdgcn_s_setprio(3);      // the attention chain is the serial critical path of the decoder loops: its waves
+                                        // issue ahead of the co-resident waves of the other chain and of the leaf GEMMs
     extern __shared__ __attribute__((aligned(16))) float dctx[];   // E floats
     __shared__ float dots[CT];
     // grid (B, chunks): b is the fast index of the linear workgroup id, so the chunks of one batch row have ids

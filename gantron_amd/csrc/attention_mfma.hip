@@ -155,6 +155,8 @@ __global__ __launch_bounds__(256) void attn_energies_fwd_mfma(GtAttnDims d, GtSl
                                                               const float* Wd, const float* v, const int* lengths,
                                                               float* q_out, float* energies, const float* wpack,
                                                               float* u_out) {
+    __builtin_amdgcn_s_setprio(3);      // the attention chain is the serial critical path of the decoder loops: its waves
+                                        // issue ahead of the co-resident waves of the other chain and of the leaf GEMMs
     __shared__ SharedM S;
     // grid (B, chunks): the chunks of a batch row share an XCD (workgroup ids congruent mod 8), so the row's query
     // slabs are fetched into one L2
@@ -449,6 +451,8 @@ __global__ __launch_bounds__(256) void attn_energies_bwd_rec_mfma(GtAttnDims d, 
                                                                   const float* u, const float* Wc, const float* Wd,
                                                                   const float* v, const int* lengths, float* dq, long ld_dq,
                                                                   float* dwcat_out, float* de_out, const float* wpack) {
+    __builtin_amdgcn_s_setprio(3);      // the attention chain is the serial critical path of the decoder loops: its waves
+                                        // issue ahead of the co-resident waves of the other chain and of the leaf GEMMs
     __shared__ SharedM S;
     const int b = blockIdx.x, t0 = blockIdx.y * CT;       // grid (B, chunks), as the forward kernel
     if (lengths != nullptr && t0 >= lengths[b]) {

@@ -29,6 +29,8 @@ struct CellQuery {
 };
 
 __global__ __launch_bounds__(128) void cell_query_kernel(CellQuery a) {
+    __builtin_amdgcn_s_setprio(3);      // the attention chain is the serial critical path of the decoder loops: its waves
+                                        // issue ahead of the co-resident waves of the other chain and of the leaf GEMMs
     __shared__ __attribute__((aligned(16))) float Xh[16 * CQ_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;          // 2 waves
     const int g = blockIdx.x, row0 = blockIdx.y * 16;
@@ -178,6 +180,8 @@ struct CellBwdQuery {
 };
 
 __global__ __launch_bounds__(64) void cell_bwd_query_kernel(CellBwdQuery a) {
+    __builtin_amdgcn_s_setprio(3);      // the attention chain is the serial critical path of the decoder loops: its waves
+                                        // issue ahead of the co-resident waves of the other chain and of the leaf GEMMs
     __shared__ __attribute__((aligned(16))) float T[16 * CB_LD];
     const int tid = threadIdx.x, lane = tid;
     const int g = blockIdx.x, row0 = blockIdx.y * 16;

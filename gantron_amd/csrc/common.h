@@ -37,6 +37,14 @@ enum { GT_FAM_REC_GEMM = 0, GT_FAM_SGEMM = 1, GT_FAM_ATTN_E_FWD = 2, GT_FAM_ATTN
 extern bool g_gt_prof_on;
 bool gt_prof_sample(int family);      // true for every `stride`-th launch of the family while profiling
 void gt_prof_mark(int family, double flops, double bytes, hipStream_t st, bool begin);
+// internal (not part of the C ABI): recurrent products with raised wave priority for the loops' critical chain
+int gt_rec_gemm_prio(const float* X, int64_t ldx, const float* Wp, float* part, int32_t mtiles, int32_t N, int32_t K,
+                     int32_t splits, int64_t part_sstride, int32_t nz, int64_t x_zstride, int64_t w_zstride,
+                     int64_t part_zstride, int prio, void* stream);
+int gt_rec_gemm_bf16_prio(const float* X, int64_t ldx, const void* Wp, float* part, int32_t mtiles, int32_t N, int32_t K,
+                          int32_t splits, int64_t part_sstride, int32_t nz, int64_t x_zstride, int64_t w_zstride,
+                          int64_t part_zstride, int prio, void* stream);
+
 struct GtProfScope {
     int fam; hipStream_t st; bool on;
     GtProfScope(int family, double flops, double bytes, hipStream_t s)

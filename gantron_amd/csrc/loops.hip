@@ -27,14 +27,16 @@ static const GtSlabs kNoSlabs = {nullptr, 0, 0, 0};
 
 // Recurrent product for Bp activation rows: up to 64 rows are one launch with Bp/16 row tiles; larger
 // batches (Bp a multiple of 64) use blockIdx.z over 64-row blocks that share the packed weights.
+// prio: 1 for the products of the attention chain (the loops' serial critical path): raised wave priority.
 static int rec_rows(const float* X, int64_t ldx, const float* Wp, float* part, int Bp, int N, int K, int S,
-                    void* stream, int bf16 = 0) {
+                    void* stream, int bf16 = 0, int prio = 0) {
     if (bf16) {         // Wp is a bf16 fragment image (gt_pack_rec_weight_bf16)
-        if (Bp <= 64) return gt_rec_gemm_bf16(X, ldx, Wp, part, Bp / 16, N, K, S, (int64_t)Bp * N, 1, 0, 0, 0, stream);
-        return gt_rec_gemm_bf16(X, ldx, Wp, part, 4, N, K, S, (int64_t)Bp * N, Bp / 64, 64 * ldx, 0, (int64_t)64 * N, stream);
+        if (Bp <= 64) return gt_rec_gemm_bf16_prio(X, ldx, Wp, part, Bp / 16, N, K, S, (int64_t)Bp * N, 1, 0, 0, 0, prio, stream);
+        return gt_rec_gemm_bf16_prio(X, ldx, Wp, part, 4, N, K, S, (int64_t)Bp * N, Bp / 64, 64 * ldx, 0, (int64_t)64 * N, prio,
+                                     stream);
     }
-    if (Bp <= 64) return gt_rec_gemm(X, ldx, Wp, part, Bp / 16, N, K, S, (int64_t)Bp * N, 1, 0, 0, 0, stream);
-    return gt_rec_gemm(X, ldx, Wp, part, 4, N, K, S, (int64_t)Bp * N, Bp / 64, 64 * ldx, 0, (int64_t)64 * N, stream);
+    if (Bp <= 64) return gt_rec_gemm_prio(X, ldx, Wp, part, Bp / 16, N, K, S, (int64_t)Bp * N, 1, 0, 0, 0, prio, stream);
+    return gt_rec_gemm_prio(X, ldx, Wp, part, 4, N, K, S, (int64_t)Bp * N, Bp / 64, 64 * ldx, 0, (int64_t)64 * N, prio, stream);
 }
 static bool rows_ok(int B, int Bp) { return B > 0 && Bp >= B && ((Bp <= 64 && Bp % 16 == 0) || Bp % 64 == 0); }
 
@@ -46,6 +48,9 @@ static bool rows_ok(int B, int Bp) { return B > 0 && Bp >= B && ((Bp <= 64 && Bp
 // is latency-bound at ~1 wave per SIMD, so two kernels in flight fill each other's bubbles.
 // Hand-offs use a ring of `ring` buffers (X2 forward, partX2 backward) and HIP events.
 static hipStream_t g_aux_stream = nullptr;
+// wave issue priorities (s_setprio) inside the two-chain loops: the attention chain is the serial critical path (3),
+// the decoder-LSTM chain comes next (2), the weight-gradient GEMMs of the leaf stream keep the default (0)
+static const int kPrioA = 3, kPrioB = 2;
 static std::vector<hipEvent_t> g_loop_events;
 
 // steps between cross-stream hand-offs for a ring of R buffers (GANTRON_SYNC_EVERY overrides, clamped so that
@@ -143,7 +148,7 @@ int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
                                       a->gates2 + (int64_t)t * a->Bp * N2, a->c2 + (int64_t)(t + 1) * a->Bp * a->Hd, nullptr,
                                       X2n + a->Ha + a->E, a->ld2, hc_t, hc_ld, nullptr, 0, a->B, a->Bp, a->Hd, sB));
         } else {
-            GT_TRY(rec_rows(X2t, a->ld2, a->W2p, partB, a->Bp, N2, K2, a->S2, sB, a->bf16));
+            GT_TRY(rec_rows(X2t, a->ld2, a->W2p, partB, a->Bp, N2, K2, a->S2, sB, a->bf16, two ? kPrioB : 0));
             GT_TRY(gt_lstm_cell_fwd(slabs(partB, a->S2, (int64_t)a->Bp * N2, N2), a->bias2, 0,
                                     a->c2 + (int64_t)t * a->Bp * a->Hd, nullptr, 0, k2, a->p_dec, nullptr,
                                     a->gates2 + (int64_t)t * a->Bp * N2, a->c2 + (int64_t)(t + 1) * a->Bp * a->Hd, nullptr,
@@ -159,7 +164,7 @@ int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
         float* X1c = a->X1 + (t & 1) * x1_slot;            // [ctx_{t-1} | h_att_{t-1}]
         float* X1n = a->X1 + ((t + 1) & 1) * x1_slot;      // receives h_att_t (cell) and ctx_t (context kernel)
         // ---- attention chain (stream A)
-        if (!fused1) GT_TRY(rec_rows(X1c, a->ld1, a->W1p, a->part, a->Bp, N1, K1, a->S1, sA, a->bf16));
+        if (!fused1) GT_TRY(rec_rows(X1c, a->ld1, a->W1p, a->part, a->Bp, N1, K1, a->S1, sA, a->bf16, two ? kPrioA : 0));
         if (two && t >= R) {     // X2 ring slot t%R was last read by the decoder chain of step t-R
             const int c = cover(t - R);
             if (c != last_wait_b) {
@@ -369,7 +374,7 @@ int gt_decoder_bwd(const GtDecoderBwd* a, void* stream) {
             GT_TRY(evA(t, &e2));
             GT_HIP(hipEventRecord(e2, sA));
         }
-        if (t > 0) GT_TRY(rec_rows(dG1_t, N1, a->W1Tp, a->partX1, a->Bp, a->N1pad, N1, a->S1, sA, a->bf16));
+        if (t > 0) GT_TRY(rec_rows(dG1_t, N1, a->W1Tp, a->partX1, a->Bp, a->N1pad, N1, a->S1, sA, a->bf16, two ? kPrioA : 0));
         return 0;
     };
     int a_next = t_hi, last_wait_a = -1;
@@ -393,7 +398,7 @@ int gt_decoder_bwd(const GtDecoderBwd* a, void* stream) {
                 last_wait_a = c;
             }
         }
-        GT_TRY(rec_rows(dG2_t, N2, a->W2Tp, pX2, a->Bp, a->N2pad, N2, a->S2, sB, a->bf16));
+        GT_TRY(rec_rows(dG2_t, N2, a->W2Tp, pX2, a->Bp, a->N2pad, N2, a->S2, sB, a->bf16, two ? kPrioB : 0));
         if (!two) {
             GT_TRY(chain_a(t));
         } else if (t % k == 0 || t == t_lo) {

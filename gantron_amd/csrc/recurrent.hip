@@ -186,7 +186,11 @@ template <int MT, int DBG = 0>
 __global__ __launch_bounds__(REC_THREADS) void rec_gemm_kernel(const float* __restrict__ X, long ldx,
                                                                const float* __restrict__ Wp,
                                                                float* __restrict__ part, int N, int KB, int KBS,
-                                                               long xz, long wz, long pz, long ps) {
+                                                               long xz, long wz, long pz, long ps, int prio) {
+    // issue priority of the waves: 3 = the loops' critical (attention) chain, 2 = the other chain, 0 = everything else
+    if (prio == 3) __builtin_amdgcn_s_setprio(3);
+    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
     const int s = blockIdx.y, z = blockIdx.z;
     const int kb0 = s * KBS;
     rec_gemm_body<MT, DBG>(X + (long)z * xz, ldx, Wp + (long)z * wz, part + (long)z * pz + (long)s * ps, N, KB, kb0,
@@ -462,6 +466,15 @@ extern "C" int gt_pack_gates(const float* W, int64_t ldw, int32_t H, int32_t K, 
 extern "C" int gt_rec_gemm(const float* X, int64_t ldx, const float* Wp, float* part, int32_t mtiles,
                            int32_t N, int32_t K, int32_t splits, int64_t part_sstride, int32_t nz,
                            int64_t x_zstride, int64_t w_zstride, int64_t part_zstride, void* stream) {
+    return gt_rec_gemm_prio(X, ldx, Wp, part, mtiles, N, K, splits, part_sstride, nz, x_zstride, w_zstride, part_zstride, 0,
+                            stream);
+}
+
+// prio != 0: the waves run at raised issue priority (s_setprio): used by the decoder loops for the products of the
+// attention chain, which is the serial critical path, while the other chain's kernels share the CUs
+int gt_rec_gemm_prio(const float* X, int64_t ldx, const float* Wp, float* part, int32_t mtiles, int32_t N, int32_t K,
+                     int32_t splits, int64_t part_sstride, int32_t nz, int64_t x_zstride, int64_t w_zstride,
+                     int64_t part_zstride, int prio, void* stream) {
     GT_REQUIRE(X && Wp && part, GT_E_ARG, "gt_rec_gemm: NULL pointer");
     GT_REQUIRE(mtiles >= 1 && mtiles <= 4 && N > 0 && N % 16 == 0 && K > 0 && splits >= 1 && nz >= 1, GT_E_ARG,
                "gt_rec_gemm: bad sizes mtiles=%d N=%d K=%d splits=%d", mtiles, N, K, splits);
@@ -484,12 +497,12 @@ extern "C" int gt_rec_gemm(const float* X, int64_t ldx, const float* Wp, float* 
     static const int lds_pad = getenv("GANTRON_REC_LDS_PAD") ? atoi(getenv("GANTRON_REC_LDS_PAD")) : 0;
 #define GT_REC(MT)                                                                                    \
     hipLaunchKernelGGL((rec_gemm_kernel<MT>), grid, dim3(REC_THREADS), lds_pad, st, X, (long)ldx, Wp, part, N, KB, \
-                       KBS, (long)x_zstride, (long)w_zstride, (long)part_zstride, (long)part_sstride)
+                       KBS, (long)x_zstride, (long)w_zstride, (long)part_zstride, (long)part_sstride, prio)
     static const int dbg = getenv("GANTRON_REC_DEBUG") ? atoi(getenv("GANTRON_REC_DEBUG")) : 0;
     if (dbg && mtiles == 4) {   // diagnostic variants (wrong results by construction)
 #define GT_RECD(D)                                                                                       \
     hipLaunchKernelGGL((rec_gemm_kernel<4, D>), grid, dim3(REC_THREADS), lds_pad, st, X, (long)ldx, Wp, part, N, KB,  \
-                       KBS, (long)x_zstride, (long)w_zstride, (long)part_zstride, (long)part_sstride)
+                       KBS, (long)x_zstride, (long)w_zstride, (long)part_zstride, (long)part_sstride, prio)
         switch (dbg) {
             case 1: GT_RECD(1); break;
             case 2: GT_RECD(2); break;

@@ -54,7 +54,11 @@ template <int MT, int NCH>
 __global__ __launch_bounds__(RB_THREADS) void rec_gemm_bf16_kernel(const float* __restrict__ X, long ldx, int kvalid,
                                                                    const uint4* __restrict__ Wp, float* __restrict__ part,
                                                                    int N, int KB, int KBS, long xz, long wz, long pz,
-                                                                   long ps) {
+                                                                   long ps, int prio) {
+    // issue priority of the waves: 3 = the loops' critical (attention) chain, 2 = the other chain, 0 = everything else
+    if (prio == 3) __builtin_amdgcn_s_setprio(3);
+    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
     constexpr int XV = MT * 2;         // float4 per thread per chunk (MT*16 rows x 64 float4 / 512 threads)
     constexpr int XR = NCH < RB_XR ? NCH : RB_XR;
     constexpr int EP_LD = 68;
@@ -173,6 +177,13 @@ extern "C" int gt_pack_rec_weight_bf16(const float* W, int64_t ldw, int32_t tran
 extern "C" int gt_rec_gemm_bf16(const float* X, int64_t ldx, const void* Wp, float* part, int32_t mtiles, int32_t N,
                                 int32_t K, int32_t splits, int64_t part_sstride, int32_t nz, int64_t x_zstride,
                                 int64_t w_zstride, int64_t part_zstride, void* stream) {
+    return gt_rec_gemm_bf16_prio(X, ldx, Wp, part, mtiles, N, K, splits, part_sstride, nz, x_zstride, w_zstride, part_zstride, 0,
+                                 stream);
+}
+
+int gt_rec_gemm_bf16_prio(const float* X, int64_t ldx, const void* Wp, float* part, int32_t mtiles, int32_t N, int32_t K,
+                          int32_t splits, int64_t part_sstride, int32_t nz, int64_t x_zstride, int64_t w_zstride,
+                          int64_t part_zstride, int prio, void* stream) {
     GT_REQUIRE(X && Wp && part, GT_E_ARG, "gt_rec_gemm_bf16: NULL pointer");
     GT_REQUIRE(mtiles >= 1 && mtiles <= 4 && N > 0 && N % 16 == 0 && K >= 4 && splits >= 1 && nz >= 1, GT_E_ARG,
                "gt_rec_gemm_bf16: bad sizes mtiles=%d N=%d K=%d splits=%d", mtiles, N, K, splits);
@@ -194,7 +205,7 @@ extern "C" int gt_rec_gemm_bf16(const float* X, int64_t ldx, const void* Wp, flo
     const int nch = cdiv(KBS, RB_CB);           // chunks of a slice: one instantiation each (all loads issued up front)
 #define GT_RECB(MT, NCH)                                                                                              \
     hipLaunchKernelGGL((rec_gemm_bf16_kernel<MT, NCH>), grid, dim3(RB_THREADS), 0, st, X, (long)ldx, kvalid, wp, part, N, \
-                       KB, KBS, (long)x_zstride, (long)(w_zstride / 8), (long)part_zstride, (long)part_sstride)
+                       KB, KBS, (long)x_zstride, (long)(w_zstride / 8), (long)part_zstride, (long)part_sstride, prio)
 #define GT_RECB_M(MT)                        \
     switch (nch) {                           \
         case 1: GT_RECB(MT, 1); break;       \
