@@ -40,8 +40,11 @@ def prepare_dataloaders(hparams, wavs_path):
     else:
         trainset, train_collate = TextAudioLoader(hparams.training_files, hparams, wavs_path), TextAudioCollate()
     sampler = DistributedSampler(trainset) if hparams.distributed_run else None
+    # one loader process, as in the reference (train.py:107-110), but kept alive across epochs: re-spawning it (and
+    # re-importing torch in it) at every epoch start costs seconds, i.e. percents of an LJSpeech epoch at this step rate
     train_loader = DataLoader(trainset, num_workers=1, shuffle=sampler is None, sampler=sampler,
-                              batch_size=hparams.batch_size, pin_memory=True, drop_last=True, collate_fn=train_collate)
+                              batch_size=hparams.batch_size, pin_memory=True, drop_last=True, collate_fn=train_collate,
+                              persistent_workers=True)
     if not hparams.load_mel_from_disk:
         from .stft import TacotronSTFT
         train_loader = DeviceBatches(train_loader, TacotronSTFT(*trainset._stft_args).cuda())
