@@ -11,6 +11,9 @@ clip, Adam) followed by the body of its discriminator step (train.py:302-360) on
 with the cached generator output.  Inputs are resident on the device before the timed region.
 Multi-GPU: one process per GPU, each with its own batch (weak scaling), flat-buffer gradient
 all-reduce over RCCL after every backward.  Rank 0 prints ONE JSON line.
+
+    python bench.py --bf16        # BASELINE config 3 (hparams.fp16_run), a separate, explicitly labelled line
+    python bench.py --batch 128   # BASELINE config 5's batch size
 """
 import argparse
 import ctypes
@@ -159,8 +162,8 @@ def main():
     ap.add_argument('--fixed-shape', action='store_true', help='nominal Ti=150, To=800 for every item')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--bf16', action='store_true',
-                    help='BASELINE config 3 (hparams.fp16_run): bf16 operands in the decoder LSTM products; NOT the '
-                         'headline metric, the default line is fp32')
+                    help='BASELINE config 3 (hparams.fp16_run): bf16 operands in the decoder LSTM products and the layer '
+                         'GEMMs, fp32 accumulation and master weights; NOT the headline metric, the default line is fp32')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -325,7 +328,7 @@ def main():
         line = dict(metric='mel-frames/sec (gen+disc step) LJSpeech bs=64', value=total_frames * args.steps / elapsed,
                     unit='mel-frames/s', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms,
                     higher_is_better=True, scaling='weak', vs_baseline=None,
-                    dtype='bf16 recurrent products / f32 elsewhere' if args.bf16 else 'f32', data='synthetic',
+                    dtype='bf16 operands (LSTM products, layer GEMMs) / f32 accumulation and elsewhere' if args.bf16 else 'f32', data='synthetic',
                     config=dict(workload='Vanilla GANtron (use_labels=False,use_noise=True) LJSpeech-shaped batch=%d fp32, '
                                          'G step + D step pair incl. clip+Adam' % args.batch,
                                 per_gpu_batch=args.batch, global_batch=args.batch * world, Ti_max=Ti, To_max=To,
