@@ -9,6 +9,8 @@
 // K = To*B) and d(memory) (batched W^T . dctx).  Inside the loop only the recurrent products
 // ([ctx|h] . W) remain, as weight-streaming small-M MFMA kernels (recurrent.hip).
 #include <stdlib.h>
+#include <map>
+#include <mutex>
 #include <vector>
 #include "common.h"
 
@@ -47,11 +49,31 @@ static bool rows_ok(int B, int Bp) { return B > 0 && Bp >= B && ((Bp <= 64 && Bp
 // auxiliary stream; backward the roles swap (the decoder-LSTM chain leads).  Every kernel of the loop
 // is latency-bound at ~1 wave per SIMD, so two kernels in flight fill each other's bubbles.
 // Hand-offs use a ring of `ring` buffers (X2 forward, partX2 backward) and HIP events.
-static hipStream_t g_aux_stream = nullptr;
 // wave issue priorities (s_setprio) inside the two-chain loops: the attention chain is the serial critical path (3),
 // the decoder-LSTM chain comes next (2), the weight-gradient GEMMs of the leaf stream keep the default (0)
 static const int kPrioA = 3, kPrioB = 2;
-static std::vector<hipEvent_t> g_loop_events;
+
+// Auxiliary stream and hand-off events are per DEVICE (one process may drive several GPUs) and guarded by a mutex that
+// a loop call holds while it issues its launches: the forward loop (Python main thread) and the backward loop
+// (autograd's backward thread) of one device can therefore never interleave their event records.
+struct LoopCtx {
+    std::mutex mu;
+    hipStream_t aux = nullptr;
+    std::vector<hipEvent_t> events;
+};
+static std::mutex g_ctx_mu;
+static std::map<int, LoopCtx*> g_ctx;
+
+static int loop_ctx(LoopCtx** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    GT_REQUIRE(e == hipSuccess, (int)e, "decoder loop: hipGetDevice failed");
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    auto it = g_ctx.find(dev);
+    if (it == g_ctx.end()) it = g_ctx.emplace(dev, new LoopCtx()).first;
+    *out = it->second;
+    return 0;
+}
 
 // steps between cross-stream hand-offs for a ring of R buffers (GANTRON_SYNC_EVERY overrides, clamped so that
 // the follower's allowed lag R - k + 1 still covers a burst of k steps)
@@ -62,33 +84,156 @@ static int sync_every(int R) {
     return k < 1 ? 1 : k;
 }
 
-static int aux_stream(hipStream_t* out) {
-    if (g_aux_stream == nullptr) {
+static int aux_stream(LoopCtx* c, hipStream_t* out) {
+    if (c->aux == nullptr) {
         // highest priority: the loop kernels are the critical path, the weight-gradient GEMMs that
         // share the device (leaf stream, normal priority) should only fill what they leave idle
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        hipError_t e = hipStreamCreateWithPriority(&g_aux_stream, hipStreamNonBlocking, hi);
+        hipError_t e = hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, hi);
         GT_REQUIRE(e == hipSuccess, (int)e, "decoder loop: cannot create the auxiliary stream");
     }
-    *out = g_aux_stream;
+    *out = c->aux;
     return 0;
 }
-static int loop_event(size_t i, hipEvent_t* out) {
-    while (g_loop_events.size() <= i) {
+static int loop_event(LoopCtx* c, size_t i, hipEvent_t* out) {
+    while (c->events.size() <= i) {
         hipEvent_t ev;
         hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
         GT_REQUIRE(e == hipSuccess, (int)e, "decoder loop: cannot create an event");
-        g_loop_events.push_back(ev);
+        c->events.push_back(ev);
     }
-    *out = g_loop_events[i];
+    *out = c->events[i];
     return 0;
 }
+// On every exit of a two-stream loop -- the error returns included -- `stream` is made to wait for whatever was issued
+// on the auxiliary stream, so that the caller never recycles buffers that auxiliary-stream kernels still use.
+struct AuxJoin {
+    LoopCtx* c; hipStream_t main, aux; bool on;
+    ~AuxJoin() {
+        if (!on) return;
+        hipEvent_t ev;
+        if (loop_event(c, 0, &ev) != 0) return;
+        if (hipEventRecord(ev, aux) == hipSuccess) (void)hipStreamWaitEvent(main, ev, 0);
+    }
+};
 #define GT_HIP(call)                                                                              \
     do {                                                                                          \
         hipError_t e__ = (call);                                                                  \
         GT_REQUIRE(e__ == hipSuccess, (int)e__, "%s failed: %s", #call, hipGetErrorString(e__)); \
     } while (0)
+
+static GtOperand op_kc(const float* p, int64_t ld) {
+    GtOperand o; o.p = p; o.mode = GT_OP_KC; o.T = o.C = o.dil = o.pad = 0; o.ld = ld; o.batch_stride = 0; return o;
+}
+static GtOperand op_rc(const float* p, int64_t ld) {
+    GtOperand o = op_kc(p, ld); o.mode = GT_OP_RC; return o;
+}
+// C[M,N] (=|+=) A[M,K] . B(n,k) (+ bias) through the tiled MFMA GEMM (bf16 operands when the loop runs in that mode)
+static int block_gemm(GtOperand A, GtOperand B, const float* bias, float* C, int64_t ldc, int M, int N, int K, int accumulate,
+                      int bf16, void* stream) {
+    GtGemm g = {}; g.A = A; g.B = B; g.C = C; g.ldc = ldc; g.c_batch_stride = 0; g.bias = bias;
+    g.M = M; g.N = N; g.K = K; g.batch = 1; g.accumulate = accumulate; g.split_k = 1; g.alpha = 1.f; g.bf16 = bf16;
+    return gt_sgemm(&g, stream);
+}
+static int block_steps(int blk) {
+    static const int env = getenv("GANTRON_DEC_BLK") ? atoi(getenv("GANTRON_DEC_BLK")) : 0;
+    const int b = env > 0 ? env : (blk > 0 ? blk : 32);
+    return b < 1 ? 1 : b;
+}
+
+// ---- hoisted decoder-LSTM input product (GtDecoderFwd::W2hp) ---------------------------------------------------------
+// The attention chain (stream A) never reads the decoder LSTM, so it simply runs ahead: per block of `blk` steps it
+// leaves [h_att_t | ctx_t] rows in the X2 history, one tiled GEMM on stream B turns them into the decoder LSTM's input
+// pre-activations of the whole block, and stream B then walks the block with the small recurrent product
+// h_dec_{t-1} . W2hh^T (+ cell).  No ring, no back-pressure: A waits for B only at the very end.
+static int decoder_fwd_hoisted(const GtDecoderFwd* a, void* stream) {
+    GT_REQUIRE(a->W2ih && a->pre2 && a->Xh && a->X2 && a->part2 && a->ldw2 >= a->Ha + a->E && a->ld2 >= a->Ha + a->E &&
+                   a->ldh >= 16 * cdiv(a->Hd, 16) && a->ldh % 4 == 0, GT_E_ARG, "gt_decoder_fwd: hoisted mode needs W2ih, pre2, Xh, X2 history, part2");
+    const int N1 = 4 * a->Ha, N2 = 4 * a->Hd;
+    const int K1 = a->E + a->Ha;
+    const int64_t hc_ld = a->Hd + a->E;
+    GtAttnDims d; d.B = a->B; d.Ti = a->Ti; d.E = a->E; d.A = a->A; d.F = a->F; d.Kc = a->Kc;
+    const int64_t BT = (int64_t)a->B * a->Ti;
+    const bool two = a->ring > 1;
+    const bool cq = a->Wq != nullptr && a->partq != nullptr && a->Ha % 32 == 0 && a->ld1 % 4 == 0 && a->ld2 % 4 == 0 &&
+                    a->E % 4 == 0;
+    hipStream_t sA = (hipStream_t)stream, sB = sA;
+    hipEvent_t ev;
+    LoopCtx* ctx = nullptr;
+    GT_TRY(loop_ctx(&ctx));
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    AuxJoin join{ctx, sA, sB, false};
+    if (two) {
+        GT_TRY(aux_stream(ctx, &sB));
+        GT_TRY(loop_event(ctx, 0, &ev));
+        GT_HIP(hipEventRecord(ev, sA));
+        GT_HIP(hipStreamWaitEvent(sB, ev, 0));
+        join.aux = sB; join.on = true;
+    }
+    const float* wpack = nullptr;
+    if (a->attn_wpack != nullptr && gt_attn_wpack_elems(d) > 0) {
+        GT_TRY(gt_attn_pack_weights(d, a->Wc, a->Wd, a->attn_wpack, sA));
+        wpack = a->attn_wpack;
+    }
+    const int blk = block_steps(a->blk);
+    const int64_t xa_step = (int64_t)a->Bp * a->ld2;
+    int nblock = 0;
+    for (int t0 = 0; t0 < a->To;) {
+        // the last `blk` steps go in quarter blocks: what stream B still has to do after A's last step is exposed
+        const int len = (a->To - t0 <= blk) ? max(blk / 4, 1) : blk;
+        const int t1 = min(a->To, t0 + len);
+        // ---- attention chain (stream A), steps t0 .. t1-1
+        for (int t = t0; t < t1; ++t) {
+            const uint8_t* k1 = a->att_keep ? a->att_keep + (int64_t)t * a->Bp * a->Ha : nullptr;
+            float* hc_t = a->HC + (int64_t)t * a->Bp * hc_ld;
+            float* XAt = a->X2 + (int64_t)t * xa_step;         // [h_att_t | ctx_t]
+            GT_TRY(rec_rows(a->X1, a->ld1, a->W1p, a->part, a->Bp, N1, K1, a->S1, sA, a->bf16, two ? kPrioA : 0));
+            if (cq)      // cell + query projection in one launch
+                GT_TRY(gt_cell_query_fwd(slabs(a->part, a->S1, (int64_t)a->Bp * N1, N1), a->pre1 + (int64_t)t * a->Bp * N1, N1,
+                                         a->c1 + (int64_t)t * a->Bp * a->Ha, k1, a->p_att, a->gates1 + (int64_t)t * a->Bp * N1,
+                                         a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha, a->hatt + (int64_t)t * a->Bp * a->Ha,
+                                         a->X1 + a->E, a->ld1, XAt, a->ld2, a->Wq, a->Ha, a->partq, (int64_t)a->Bp * a->Apad, a->B,
+                                         a->Bp, a->Ha, a->A, a->Apad, sA));
+            else {
+                GT_TRY(gt_lstm_cell_fwd(slabs(a->part, a->S1, (int64_t)a->Bp * N1, N1), a->pre1 + (int64_t)t * a->Bp * N1, N1,
+                                        a->c1 + (int64_t)t * a->Bp * a->Ha, nullptr, 0, k1, a->p_att, nullptr,
+                                        a->gates1 + (int64_t)t * a->Bp * N1, a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha,
+                                        a->hatt + (int64_t)t * a->Bp * a->Ha, a->X1 + a->E, a->ld1, XAt, a->ld2, nullptr, 0,
+                                        a->B, a->Ha, sA));
+                GT_TRY(rec_rows(XAt, a->ld2, a->Wqp, a->part, a->Bp, a->Apad, a->Ha, a->Sq, sA));
+            }
+            GT_TRY(gt_attn_energies_fwd_u(d, cq ? slabs(a->partq, a->Ha / 32, (int64_t)a->Bp * a->Apad, a->Apad)
+                                                : slabs(a->part, a->Sq, (int64_t)a->Bp * a->Apad, a->Apad),
+                                          a->w_hist + (int64_t)t * BT, a->cum_hist + (int64_t)t * BT, a->pm, a->Wc, a->Wd, a->v,
+                                          a->lengths, a->q_hist + (int64_t)t * a->B * a->A, a->energies, wpack,
+                                          a->u_hist ? a->u_hist + (int64_t)t * BT * a->A : nullptr, sA));
+            GT_TRY(gt_attn_context_fwd(d, a->energies, a->memory, a->ldE, a->lengths, a->w_hist + (int64_t)(t + 1) * BT,
+                                       a->cum_hist + (int64_t)t * BT, a->cum_hist + (int64_t)(t + 1) * BT, a->X1, a->ld1,
+                                       XAt + a->Ha, a->ld2, hc_t + a->Hd, hc_ld, sA));
+        }
+        if (two) {
+            GT_TRY(loop_event(ctx, 1 + (size_t)(nblock % 32), &ev));
+            GT_HIP(hipEventRecord(ev, sA));
+            GT_HIP(hipStreamWaitEvent(sB, ev, 0));
+        }
+        // ---- decoder LSTM (stream B): input pre-activations of the block, then its recurrence
+        GT_TRY(block_gemm(op_kc(a->X2 + (int64_t)t0 * xa_step, a->ld2), op_kc(a->W2ih, a->ldw2), a->bias2,
+                          a->pre2 + (int64_t)t0 * a->Bp * N2, N2, (t1 - t0) * a->Bp, N2, a->Ha + a->E, 0, a->bf16, sB));
+        for (int t = t0; t < t1; ++t) {
+            const uint8_t* k2 = a->dec_keep ? a->dec_keep + (int64_t)t * a->Bp * a->Hd : nullptr;
+            float* hc_t = a->HC + (int64_t)t * a->Bp * hc_ld;
+            GT_TRY(rec_rows(a->Xh, a->ldh, a->W2hp, a->part2, a->Bp, N2, a->Hd, a->S2, sB, a->bf16, two ? kPrioB : 0));
+            GT_TRY(gt_lstm_cell_fwd(slabs(a->part2, a->S2, (int64_t)a->Bp * N2, N2), a->pre2 + (int64_t)t * a->Bp * N2, N2,
+                                    a->c2 + (int64_t)t * a->Bp * a->Hd, nullptr, 0, k2, a->p_dec, nullptr,
+                                    a->gates2 + (int64_t)t * a->Bp * N2, a->c2 + (int64_t)(t + 1) * a->Bp * a->Hd, nullptr,
+                                    a->Xh, a->ldh, hc_t, hc_ld, nullptr, 0, a->B, a->Hd, sB));
+        }
+        t0 = t1;
+        ++nblock;
+    }
+    return 0;       // AuxJoin: `stream` waits for stream B
+}
 
 int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
     GT_REQUIRE(a != nullptr, GT_E_ARG, "gt_decoder_fwd: NULL");
@@ -97,6 +242,7 @@ int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
     GT_REQUIRE(a->To > 0 && a->Ti > 0 && a->Ha % 16 == 0 && a->Hd % 16 == 0 && a->Apad % 16 == 0, GT_E_ARG,
                "gt_decoder_fwd: bad dims");
     GT_REQUIRE(a->ring >= 1 && a->ring <= 32 && (a->ring == 1 || a->part2 != nullptr), GT_E_ARG, "gt_decoder_fwd: ring/part2");
+    if (a->W2hp != nullptr) return decoder_fwd_hoisted(a, stream);
     const int N1 = 4 * a->Ha, N2 = 4 * a->Hd;
     const int K1 = a->E + a->Ha, K2 = a->Ha + a->E + a->Hd;
     const int64_t hc_ld = a->Hd + a->E;
@@ -115,11 +261,16 @@ int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
     hipStream_t sA = (hipStream_t)stream, sB = sA;
     float* partB = two ? a->part2 : a->part;
     hipEvent_t ev;
+    LoopCtx* ctx = nullptr;
+    GT_TRY(loop_ctx(&ctx));
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    AuxJoin join{ctx, sA, sB, false};
     if (two) {
-        GT_TRY(aux_stream(&sB));
-        GT_TRY(loop_event(0, &ev));
+        GT_TRY(aux_stream(ctx, &sB));
+        GT_TRY(loop_event(ctx, 0, &ev));
         GT_HIP(hipEventRecord(ev, sA));
         GT_HIP(hipStreamWaitEvent(sB, ev, 0));
+        join.aux = sB; join.on = true;
     }
     // Cross-stream hand-offs are batched: an event record or wait costs the stream it is issued on ~6 us of
     // barrier-packet latency (measured in the kernel trace: the only gaps between back-to-back kernels), and the
@@ -130,8 +281,8 @@ int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
     const int NE = R + 3;
     auto recorded = [&](int t) { return t % k == k - 1 || t == a->To - 1; };       // steps after which events are recorded
     auto cover = [&](int t) { return min((t / k) * k + k - 1, a->To - 1); };       // the recorded step that covers step t
-    auto evA = [&](int t, hipEvent_t* e) { return loop_event(1 + (size_t)((t / k) % NE), e); };
-    auto evB = [&](int t, hipEvent_t* e) { return loop_event(1 + NE + (size_t)((t / k) % NE), e); };
+    auto evA = [&](int t, hipEvent_t* e) { return loop_event(ctx, 1 + (size_t)((t / k) % NE), e); };
+    auto evB = [&](int t, hipEvent_t* e) { return loop_event(ctx, 1 + NE + (size_t)((t / k) % NE), e); };
     const float* wpack = nullptr;
     if (a->attn_wpack != nullptr && gt_attn_wpack_elems(d) > 0) {
         GT_TRY(gt_attn_pack_weights(d, a->Wc, a->Wd, a->attn_wpack, sA));
@@ -211,10 +362,7 @@ int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
             GT_HIP(hipEventRecord(ev, sB));
         }
     }
-    if (two) {      // join: everything issued on the auxiliary stream is ordered before later work on `stream`
-        GT_TRY(evB(a->To - 1, &ev));
-        GT_HIP(hipStreamWaitEvent(sA, ev, 0));
-    }
+    // join (AuxJoin): everything issued on the auxiliary stream is ordered before later work on `stream`
     return 0;
 }
 
@@ -293,10 +441,120 @@ int gt_decoder_infer(const GtDecoderInfer* q, void* stream) {
     return 0;
 }
 
+// ---- hoisted decoder-LSTM input gradient (GtDecoderBwd::W2hTp): the mirror of decoder_fwd_hoisted ---------------------
+// The decoder-LSTM chain (stream B) leads and carries only d h_dec through its per-step product dG2_t . W2hh; after a
+// block of steps ONE tiled GEMM produces d[h_att_t | ctx_t] = dG2_t . W2ih for the whole block (dXA), and the attention
+// chain (stream A) then walks the block.  Across the calls of a chunked backward (t_hi / t_lo) stream B keeps running
+// ahead: it is synchronised with `stream` once, at the first call.
+static int decoder_bwd_hoisted(const GtDecoderBwd* a, void* stream) {
+    const int N1 = 4 * a->Ha, N2 = 4 * a->Hd;
+    const int Hdpad = 16 * cdiv(a->Hd, 16);
+    GT_REQUIRE(a->W2ih && a->dXA && a->partXh && a->ldw2 >= a->Ha + a->E && a->ldxa >= a->Ha + a->E && a->ldxa % 4 == 0, GT_E_ARG,
+               "gt_decoder_bwd: hoisted mode needs W2ih, dXA (ldxa %% 4 == 0) and partXh");
+    const int64_t hc_ld = a->Hd + a->E;
+    GtAttnDims d; d.B = a->B; d.Ti = a->Ti; d.E = a->E; d.A = a->A; d.F = a->F; d.Kc = a->Kc;
+    const int64_t BT = (int64_t)a->B * a->Ti;
+    const int64_t sX1 = (int64_t)a->Bp * a->N1pad, sXh = (int64_t)a->Bp * Hdpad, sQ = (int64_t)a->Bp * a->Ha;
+    const bool two = a->ring > 1;
+    const bool bq = a->Wq != nullptr && a->Ha % 16 == 0 && a->E % 4 == 0 && a->N1pad % 4 == 0;
+    const int t_hi = (a->t_hi >= a->t_lo && a->t_hi < a->To) ? a->t_hi : a->To - 1;
+    const int t_lo = (a->t_hi >= a->t_lo && a->t_lo >= 0 && a->t_hi < a->To) ? a->t_lo : 0;
+    hipStream_t sA = (hipStream_t)stream, sB = sA;
+    hipEvent_t ev;
+    LoopCtx* ctx = nullptr;
+    GT_TRY(loop_ctx(&ctx));
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    AuxJoin join{ctx, sA, sB, false};
+    if (two) {
+        GT_TRY(aux_stream(ctx, &sB));
+        if (t_hi == a->To - 1) {        // first call of a backward pass: the inputs (dHC ...) were produced on `stream`
+            GT_TRY(loop_event(ctx, 0, &ev));
+            GT_HIP(hipEventRecord(ev, sA));
+            GT_HIP(hipStreamWaitEvent(sB, ev, 0));
+        }
+        join.aux = sB; join.on = true;
+    }
+    const float* wpack = nullptr;
+    if (a->attn_wpack != nullptr && gt_attn_wpack_elems(d) > 0) {
+        GT_TRY(gt_attn_pack_weights(d, a->Wc, a->Wd, a->attn_wpack, sA));
+        wpack = a->attn_wpack;
+    }
+    const int blk = block_steps(a->blk);
+    int nblock = 0;
+    for (int b1 = t_hi; b1 >= t_lo;) {
+        // the very first blocks of a backward pass are short: stream A idles until stream B has finished one
+        const int len = (t_hi == a->To - 1 && nblock < 2) ? max(blk / 4, 1) : blk;
+        const int b0 = max(t_lo, b1 - len + 1);
+        // ---- decoder LSTM chain (stream B, leads), steps b1 .. b0
+        for (int t = b1; t >= b0; --t) {
+            const bool last = (t == a->To - 1);
+            const uint8_t* k2 = a->dec_keep ? a->dec_keep + (int64_t)t * a->Bp * a->Hd : nullptr;
+            const float* dhc_t = a->dHC + (int64_t)t * a->Bp * hc_ld;
+            float* dG2_t = a->dG2 + (int64_t)t * a->Bp * N2;
+            GT_TRY(gt_lstm_cell_bwd(last ? kNoSlabs : slabs(a->partXh, a->S2, sXh, Hdpad), kNoSlabs, kNoSlabs, dhc_t, hc_ld,
+                                    a->dc2, a->gates2 + (int64_t)t * a->Bp * N2, a->c2 + (int64_t)(t + 1) * a->Bp * a->Hd,
+                                    a->c2 + (int64_t)t * a->Bp * a->Hd, k2, a->p_dec, nullptr, dG2_t, a->dc2, nullptr, a->B,
+                                    a->Hd, sB));
+            if (t > 0) GT_TRY(rec_rows(dG2_t, N2, a->W2hTp, a->partXh, a->Bp, Hdpad, N2, a->S2, sB, a->bf16, two ? kPrioB : 0));
+        }
+        GT_TRY(block_gemm(op_kc(a->dG2 + (int64_t)b0 * a->Bp * N2, N2), op_rc(a->W2ih, a->ldw2), nullptr,
+                          a->dXA + (int64_t)b0 * a->Bp * a->ldxa, a->ldxa, (b1 - b0 + 1) * a->Bp, a->Ha + a->E, N2, 0, a->bf16, sB));
+        if (two) {
+            GT_TRY(loop_event(ctx, 1 + (size_t)(nblock % 32), &ev));
+            GT_HIP(hipEventRecord(ev, sB));
+            GT_HIP(hipStreamWaitEvent(sA, ev, 0));
+        }
+        // ---- attention chain (stream A), steps b1 .. b0
+        for (int t = b1; t >= b0; --t) {
+            const bool last = (t == a->To - 1);
+            const uint8_t* k1 = a->att_keep ? a->att_keep + (int64_t)t * a->Bp * a->Ha : nullptr;
+            const float* dhc_t = a->dHC + (int64_t)t * a->Bp * hc_ld;
+            const float* dXA_t = a->dXA + (int64_t)t * a->Bp * a->ldxa;
+            float* dG1_t = a->dG1 + (int64_t)t * a->Bp * N1;
+            float* dq_t = a->dq_hist + (int64_t)t * a->Bp * a->Apad;
+            float* dwcat_in = a->dwcat + (int64_t)((t + 1) & 1) * 2 * BT;
+            float* dwcat_out = a->dwcat + (int64_t)(t & 1) * 2 * BT;
+            GT_TRY(gt_attn_context_bwd(d, slabs(dXA_t + a->Ha, 1, 0, a->ldxa),
+                                       last ? kNoSlabs : slabs(a->partX1, a->S1, sX1, a->N1pad), dhc_t + a->Hd, hc_ld,
+                                       a->memory, a->ldE, a->lengths, dwcat_in, a->dcum_acc,
+                                       a->dalign ? a->dalign + (int64_t)t * BT : nullptr,
+                                       a->dctx_hist + (int64_t)t * a->B * a->E, a->E, dq_t, a->Apad, a->dw, sA));
+            if (a->u_hist != nullptr && a->de_hist != nullptr) {
+                GT_TRY(gt_attn_energies_bwd_rec(d, a->dw, a->w_hist + (int64_t)(t + 1) * BT, a->u_hist + (int64_t)t * BT * a->A,
+                                                a->Wc, a->Wd, a->v, a->lengths, dq_t, a->Apad, dwcat_out,
+                                                a->de_hist + (int64_t)t * BT, wpack, sA));
+            } else {
+                GT_TRY(gt_attn_energies_bwd_w(d, a->dw, a->w_hist + (int64_t)(t + 1) * BT, a->q_hist + (int64_t)t * a->B * a->A,
+                                              a->w_hist + (int64_t)t * BT, a->cum_hist + (int64_t)t * BT, a->pm, a->Wc, a->Wd, a->v,
+                                              a->lengths, dq_t, a->Apad, a->dpm, dwcat_out, a->acc, wpack, sA));
+            }
+            if (bq) {
+                GT_TRY(gt_cell_bwd_query(slabs(dXA_t, 1, 0, a->ldxa),
+                                         last ? kNoSlabs : slabs(a->partX1 + a->E, a->S1, sX1, a->N1pad), dq_t, a->Apad, a->Wq,
+                                         a->Ha, a->dc1, a->gates1 + (int64_t)t * a->Bp * N1, a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha,
+                                         a->c1 + (int64_t)t * a->Bp * a->Ha, k1, a->p_att, dG1_t, a->dc1, a->B, a->Bp, a->Ha, a->A,
+                                         sA));
+            } else {
+                GT_TRY(rec_rows(dq_t, a->Apad, a->WqTp, a->partQ, a->Bp, a->Ha, a->A, a->Sq, sA));
+                GT_TRY(gt_lstm_cell_bwd(slabs(dXA_t, 1, 0, a->ldxa), slabs(a->partQ, a->Sq, sQ, a->Ha),
+                                        last ? kNoSlabs : slabs(a->partX1 + a->E, a->S1, sX1, a->N1pad), nullptr, 0, a->dc1,
+                                        a->gates1 + (int64_t)t * a->Bp * N1, a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha,
+                                        a->c1 + (int64_t)t * a->Bp * a->Ha, k1, a->p_att, nullptr, dG1_t, a->dc1, nullptr, a->B,
+                                        a->Ha, sA));
+            }
+            if (t > 0) GT_TRY(rec_rows(dG1_t, N1, a->W1Tp, a->partX1, a->Bp, a->N1pad, N1, a->S1, sA, a->bf16, two ? kPrioA : 0));
+        }
+        b1 = b0 - 1;
+        ++nblock;
+    }
+    return 0;
+}
+
 int gt_decoder_bwd(const GtDecoderBwd* a, void* stream) {
     GT_REQUIRE(a != nullptr, GT_E_ARG, "gt_decoder_bwd: NULL");
     GT_REQUIRE(rows_ok(a->B, a->Bp), GT_E_LIMIT, "gt_decoder_bwd: batch padding");
     GT_REQUIRE(a->ring >= 1 && a->ring <= 32, GT_E_ARG, "gt_decoder_bwd: ring");
+    if (a->W2hTp != nullptr) return decoder_bwd_hoisted(a, stream);
     const int N1 = 4 * a->Ha, N2 = 4 * a->Hd;
     const int64_t hc_ld = a->Hd + a->E;
     GtAttnDims d; d.B = a->B; d.Ti = a->Ti; d.E = a->E; d.A = a->A; d.F = a->F; d.Kc = a->Kc;
@@ -306,19 +564,24 @@ int gt_decoder_bwd(const GtDecoderBwd* a, void* stream) {
     const bool two = R > 1;
     hipStream_t sA = (hipStream_t)stream, sB = sA;
     hipEvent_t ev;
+    LoopCtx* ctx = nullptr;
+    GT_TRY(loop_ctx(&ctx));
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    AuxJoin join{ctx, sA, sB, false};
     if (two) {
-        GT_TRY(aux_stream(&sB));
-        GT_TRY(loop_event(0, &ev));
+        GT_TRY(aux_stream(ctx, &sB));
+        GT_TRY(loop_event(ctx, 0, &ev));
         GT_HIP(hipEventRecord(ev, sA));
         GT_HIP(hipStreamWaitEvent(sB, ev, 0));
+        join.aux = sB; join.on = true;
     }
     // batched cross-stream hand-offs (see gt_decoder_fwd): chain B leads here and records "product ready" only at
     // steps t % k == 0 (and at the last step of the call); the k attention-chain steps behind it are then issued as
     // one burst after a single wait.  Chain A records "ring slot free" at steps t % k == 0.
     const int k = two ? sync_every(R) : 1;
     const int NE = R + 3;
-    auto evA = [&](int t, hipEvent_t* e) { return loop_event(1 + (size_t)((t / k) % NE), e); };
-    auto evB = [&](int t, hipEvent_t* e) { return loop_event(1 + NE + (size_t)((t / k) % NE), e); };
+    auto evA = [&](int t, hipEvent_t* e) { return loop_event(ctx, 1 + (size_t)((t / k) % NE), e); };
+    auto evB = [&](int t, hipEvent_t* e) { return loop_event(ctx, 1 + NE + (size_t)((t / k) % NE), e); };
     auto ringX2 = [&](int t) { return a->partX2 + (int64_t)(t % R) * a->S2 * sX2; };
     const bool bq = a->Wq != nullptr && a->Ha % 16 == 0 && a->E % 4 == 0 && a->N1pad % 4 == 0 && a->N2pad % 4 == 0;
     const int t_hi = (a->t_hi >= a->t_lo && a->t_hi < a->To) ? a->t_hi : a->To - 1;

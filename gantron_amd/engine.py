@@ -41,6 +41,10 @@ BWD_CHUNKS = int(_os.environ.get("GANTRON_BWD_CHUNKS", "6"))
 ATTN_HOIST = _os.environ.get('GANTRON_ATTN_HOIST', '1') != '0'
 DEC_RING = int(_os.environ.get('GANTRON_DEC_RING', '16'))     # ring of hand-off buffers between the two decoder chains;
                                                              # cross-stream syncs happen every ring/2 steps (loops.hip)
+# hoisted decoder-LSTM input product (GtDecoderFwd.W2hp / GtDecoderBwd.W2hTp): [h_att | ctx] . W2ih of a block of steps
+# is one tiled GEMM, only h_dec . W2hh stays in the per-step loops
+HOIST2 = _os.environ.get('GANTRON_HOIST2', '1') != '0'
+DEC_BLK = int(_os.environ.get('GANTRON_DEC_BLK', '32'))       # steps per block in that mode
 
 
 def _f32(*shape, device, zero=True):
@@ -446,7 +450,7 @@ class GeneratorEngine:
         # ---- decoder loop
         K1, K2 = E + Ha, Ha + E + Hd
         W1cat = torch.cat((W1ih[:, Pd:], W1hh), dim=1).contiguous()
-        W2cat = torch.cat((W2ih, W2hh), dim=1).contiguous()
+        W2cat = None if (HOIST2 and not FUSED_CELL) else torch.cat((W2ih, W2hh), dim=1).contiguous()
         Apad = roundup(A, 16)
         d = GtDecoderFwd()
         d.B, d.Bp, d.Ti, d.To, d.E, d.ldE, d.P, d.Ha, d.Hd, d.A, d.Apad, d.F, d.Kc = \
@@ -455,8 +459,16 @@ class GeneratorEngine:
         d.p_att = hp.p_attention_dropout if training else 0.0
         d.p_dec = hp.p_decoder_dropout if training else 0.0
         fused = FUSED_CELL and Ha % 4 == 0 and Hd % 4 == 0 and not self.bf16
+        hoist2 = HOIST2 and not FUSED_CELL
         keep_t = dict(Wqp=pack_rec(P['decoder.attention_layer.query_layer.linear_layer.weight'], Apad, A, Ha))
-        if self.bf16:
+        if hoist2:
+            pack = pack_rec_bf16 if self.bf16 else pack_rec
+            split = rec_splits_bf16 if self.bf16 else rec_splits
+            d.bf16 = int(self.bf16)
+            d.S1, d.S2 = split(4 * Ha, K1), split(4 * Hd, Hd)
+            keep_t.update(W1p=pack(W1cat, 4 * Ha, 4 * Ha, K1), W2hp=pack(W2hh, 4 * Hd, 4 * Hd, Hd),
+                          W2ih=W2ih if W2ih.is_contiguous() else W2ih.contiguous())
+        elif self.bf16:
             d.bf16 = 1
             d.S1, d.S2 = rec_splits_bf16(4 * Ha, K1), rec_splits_bf16(4 * Hd, K2)
             keep_t.update(W1p=pack_rec_bf16(W1cat, 4 * Ha, 4 * Ha, K1), W2p=pack_rec_bf16(W2cat, 4 * Hd, 4 * Hd, K2))
@@ -467,7 +479,9 @@ class GeneratorEngine:
         lens32 = torch.tensor(in_lens, dtype=torch.int32, device=dev)
         ld1, ld2 = (int(lib().gt_fused_k_padded(K1)), int(lib().gt_fused_k_padded(K2))) if fused else \
             (roundup(K1, 16), roundup(K2, 16))
-        ws = dict(X1=_f32(2, Bp, ld1, device=dev), X2=_f32(DEC_RING, Bp, ld2, device=dev),
+        if hoist2:
+            ld2 = roundup(Ha + E, 16)           # X2 is the (To, Bp, ld2) history of [h_att_t | ctx_t]
+        ws = dict(X1=_f32(2, Bp, ld1, device=dev), X2=_f32(To if hoist2 else DEC_RING, Bp, ld2, device=dev),
                   part=_f32(max(d.S1 * Bp * 4 * Ha, d.S2 * Bp * 4 * Hd, d.Sq * Bp * Apad), device=dev, zero=False),
                   part2=_f32(d.S2 * Bp * 4 * Hd, device=dev, zero=False),
                   energies=_f32(B, Ti, device=dev, zero=False))
@@ -498,6 +512,11 @@ class GeneratorEngine:
         d.part2, d.ring = ptr(ws['part2']), DEC_RING
         for k in ('gates1', 'c1', 'gates2', 'c2', 'hatt', 'HC', 'w_hist', 'cum_hist', 'q_hist'):
             setattr(d, k, ptr(hist[k]))
+        if hoist2:
+            ldh = roundup(Hd, 16)
+            ws['Xh'] = _f32(Bp, ldh, device=dev)
+            d.W2hp, d.W2ih, d.ldw2 = ptr(keep_t['W2hp']), ptr(keep_t['W2ih']), keep_t['W2ih'].stride(0)
+            d.pre2, d.Xh, d.ldh, d.blk = ptr(hist['gates2']), ptr(ws['Xh']), ldh, DEC_BLK
         if ATTN_HOIST and training and lib().gt_attn_hoist_supported(ops.attn_dims(B, Ti, E, A, self.F, self.Kc)):
             hist['u_hist'] = _f32(To, B, Ti, A, device=dev, zero=False)
             d.u_hist = ptr(hist['u_hist'])
@@ -699,11 +718,14 @@ class GeneratorEngine:
         W1ih, W1hh = P['decoder.attention_rnn.weight_ih'], P['decoder.attention_rnn.weight_hh']
         W2ih, W2hh = P['decoder.decoder_rnn.weight_ih'], P['decoder.decoder_rnn.weight_hh']
         W1cat = torch.cat((W1ih[:, Pd:], W1hh), dim=1).contiguous()
-        W2cat = torch.cat((W2ih, W2hh), dim=1).contiguous()
+        W2cat = None if (HOIST2 and not FUSED_CELL) else torch.cat((W2ih, W2hh), dim=1).contiguous()
         Wq = P['decoder.attention_layer.query_layer.linear_layer.weight']
         packT = pack_rec_bf16 if self.bf16 else pack_rec
+        hoist2 = HOIST2 and not FUSED_CELL
+        Hdpad = roundup(Hd, 16)
         W1Tp = packT(W1cat, N1pad, K1, 4 * Ha, transposed=True)
-        W2Tp = packT(W2cat, N2pad, K2, 4 * Hd, transposed=True)
+        W2Tp = None if hoist2 else packT(W2cat, N2pad, K2, 4 * Hd, transposed=True)
+        W2hTp = packT(W2hh, Hdpad, Hd, 4 * Hd, transposed=True) if hoist2 else None
         WqTp = pack_rec(Wq, Ha, Ha, A, transposed=True)
         b = GtDecoderBwd()
         b.B, b.Bp, b.Ti, b.To, b.E, b.ldE, b.P, b.Ha, b.Hd, b.A, b.Apad, b.F, b.Kc = \
@@ -712,6 +734,8 @@ class GeneratorEngine:
         if self.bf16:
             b.bf16 = 1
             b.S1, b.S2 = rec_splits_bf16(N1pad, 4 * Ha), rec_splits_bf16(N2pad, 4 * Hd)
+        if hoist2:
+            b.S2 = (rec_splits_bf16 if self.bf16 else rec_splits)(Hdpad, 4 * Hd)
         b.N1pad, b.N2pad = N1pad, N2pad
         if CELL_QUERY and Ha % 16 == 0 and E % 4 == 0:
             b.Wq = ptr(P['decoder.attention_layer.query_layer.linear_layer.weight'])
@@ -731,8 +755,14 @@ class GeneratorEngine:
                    dc1=_f32(Bp, Ha, device=dev), dc2=_f32(Bp, Hd, device=dev), dwcat=_f32(2, 2, B, Ti, device=dev),
                    dcum_acc=_f32(B, Ti, device=dev), dq_hist=_f32(To, Bp, Apad, device=dev),
                    dw=_f32(B, Ti, device=dev, zero=False),
-                   partX1=_f32(b.S1, Bp, N1pad, device=dev), partX2=_f32(DEC_RING, b.S2, Bp, N2pad, device=dev),
+                   partX1=_f32(b.S1, Bp, N1pad, device=dev),
+                   partX2=None if hoist2 else _f32(DEC_RING, b.S2, Bp, N2pad, device=dev),
                    partQ=_f32(b.Sq, Bp, Ha, device=dev))
+        if hoist2:
+            ldxa = roundup(Ha + E, 4)
+            W2ih_c = W2ih if W2ih.is_contiguous() else W2ih.contiguous()
+            buf.update(dXA=_f32(To, Bp, ldxa, device=dev, zero=False), partXh=_f32(b.S2, Bp, Hdpad, device=dev))
+            b.W2hTp, b.W2ih, b.ldw2, b.ldxa, b.blk = ptr(W2hTp), ptr(W2ih_c), W2ih_c.stride(0), ldxa, DEC_BLK
         b.memory, b.pm, b.Wc, b.Wd, b.v = ptr(sv['memory']), ptr(sv['pm']), ptr(Wc), ptr(Wd), ptr(v)
         b.lengths = ptr(sv['lens32'])
         b.att_keep, b.dec_keep = ptr(sv['att_keep']), ptr(sv['dec_keep'])

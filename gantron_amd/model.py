@@ -172,8 +172,8 @@ class Tacotron2(nn.Module):
         """reference model.py:617-630.  Lengths additionally stay on the host (python lists) so the
         engine never synchronises on them (the reference calls .item()/.cpu() instead)."""
         text_padded, input_lengths, mel_padded, gate_padded, speaker_ids, emotions, output_lengths = batch
-        self._host_lens = (input_lengths.tolist(), output_lengths.tolist())
-        max_len = int(max(self._host_lens[0]))
+        host_in, host_out = input_lengths.tolist(), output_lengths.tolist()
+        max_len = int(max(host_in))
         text_padded = to_gpu(text_padded).long()
         input_lengths = to_gpu(input_lengths).long()
         speaker_ids = to_gpu(speaker_ids).long()
@@ -181,6 +181,9 @@ class Tacotron2(nn.Module):
         gate_padded = to_gpu(gate_padded).float()
         emotions = to_gpu(emotions).float()
         output_lengths = to_gpu(output_lengths).long()
+        # the host copies travel WITH the device tensors they describe (forward() reads them back from the very
+        # tensor objects it is handed, and falls back to .tolist() for tensors that did not come from here)
+        input_lengths._gt_host, output_lengths._gt_host = host_in, host_out
         return ((text_padded, input_lengths, mel_padded, max_len, speaker_ids, emotions, output_lengths),
                 (mel_padded, gate_padded))
 
@@ -203,10 +206,13 @@ class Tacotron2(nn.Module):
 
     def forward(self, inputs):
         text, text_lengths, mels, max_len, speaker_ids, emotions, output_lengths = inputs
-        host = getattr(self, '_host_lens', None)
-        if host is None or len(host[0]) != text.size(0):
-            host = (text_lengths.tolist(), output_lengths.tolist())
-        in_lens, out_lens = host
+        # lengths as python lists: the copies parse_batch attached to these very tensors, else one device read
+        in_lens = getattr(text_lengths, '_gt_host', None)
+        out_lens = getattr(output_lengths, '_gt_host', None)
+        if in_lens is None or len(in_lens) != text.size(0):
+            in_lens = text_lengths.tolist()
+        if out_lens is None or len(out_lens) != text.size(0):
+            out_lens = output_lengths.tolist()
         rng = self.rng_override if self.rng_override is not None else \
             self.draw_rng(text.size(0), text.size(1), mels.size(2), text.device)
         params = [p for _, p in self.named_parameters()]

@@ -298,6 +298,19 @@ typedef struct GtDecoderFwd {
     int32_t bf16;              /* 1: W1p / W2p are gt_pack_rec_weight_bf16 images and the two LSTM products run as
                                   gt_rec_gemm_bf16 (hparams.fp16_run); needs the unfused path (W1g = W2g = NULL) */
     float* u_hist;             /* NULL or (To, B, Ti, A): tanh outputs of every step for the hoisted backward */
+    /* Hoisted decoder-LSTM input product (W2hp != NULL).  Of [h_att_t | ctx_t | h_dec_{t-1}] . W2 only the h_dec
+     * part is on the decoder LSTM's recurrence; the attention chain never reads the decoder LSTM.  So the attention
+     * chain runs `blk` steps ahead, [h_att | ctx] . W2ih^T + bias2 of those steps is ONE tiled GEMM (M = blk*Bp rows)
+     * into pre2, and the per-step product shrinks to h_dec . W2hh^T (a third of the weights and flops).  In this mode
+     * X2 is a HISTORY (To, Bp, ld2) of [h_att_t | ctx_t] rows (ld2 >= Ha+E, zero-initialised), W2p / ring slots are
+     * unused, S2 counts the K-splits of the h_dec product and part2 holds S2 slabs of (Bp, 4Hd). */
+    const float* W2hp;         /* packed [4Hd] x [Hd] (gt_pack_rec_weight, or the bf16 image when bf16 = 1) */
+    const float* W2ih;         /* decoder_rnn.weight_ih (4Hd, Ha+E), PyTorch layout, rows ldw2 apart */
+    int64_t ldw2;
+    float* pre2;               /* (To, Bp, 4Hd); may alias gates2 (the cell reads its pre-activations before it
+                                  writes the gate values of the same elements) */
+    float* Xh; int64_t ldh;    /* (Bp, ldh >= 16*ceil(Hd/16)) zero-initialised: h_dec operand of the per-step product */
+    int32_t blk;               /* steps per block (hand-off granularity between the two chains); <= 0: 32 */
 } GtDecoderFwd;
 
 typedef struct GtDecoderBwd {
@@ -336,6 +349,16 @@ typedef struct GtDecoderBwd {
     int32_t bf16;              /* 1: W1Tp / W2Tp are gt_pack_rec_weight_bf16 images (products run as gt_rec_gemm_bf16) */
     const float* u_hist;       /* both non-NULL: hoisted energies backward (gt_attn_energies_bwd_rec per step; the   */
     float* de_hist;            /*   caller runs gt_attn_param_grads over the steps afterwards); de_hist (To, B, Ti)  */
+    /* Hoisted decoder-LSTM input gradient (W2hTp != NULL), the mirror of GtDecoderFwd's hoisted mode: the decoder-LSTM
+     * chain leads and only carries d h_dec (per-step product dG2_t . W2hh, N = Hd); d[h_att_t | ctx_t] = dG2_t . W2ih
+     * of a block of steps is ONE tiled GEMM into dXA before the attention chain runs those steps.  W2Tp, partX2 and
+     * the ring are unused; S2 counts the K-splits of the d h_dec product. */
+    const float* W2hTp;        /* packed [Hdpad = 16*ceil(Hd/16)] x [4Hd] (transpose of W2hh; bf16 image when bf16 = 1) */
+    const float* W2ih;         /* decoder_rnn.weight_ih (4Hd, Ha+E), rows ldw2 apart */
+    int64_t ldw2;
+    float* dXA; int64_t ldxa;  /* (To, Bp, ldxa >= Ha+E, ldxa % 4 == 0): [d h_att_t | d ctx_t] from the decoder LSTM */
+    float* partXh;             /* (S2, Bp, Hdpad) zero-initialised */
+    int32_t blk;               /* steps per block; <= 0: 32 */
 } GtDecoderBwd;
 
 typedef struct GtBiLstm {

@@ -148,7 +148,8 @@ def test_full_size_matches_reference_summaries(dev, golden_dir, name):
 
 
 @pytest.mark.parametrize('case', ['ragged5', 'batch70', 'full_dims_b64', 'full_dims_b20', 'full_dims_long', 'ragged5_bf16',
-                                  'full_dims_b20_bf16'])
+                                  'full_dims_b20_bf16', 'full_dims_b64_t200', 'vesus_b64', 'vesus_b128_bf16',
+                                  'full_dims_b64_bf16'])
 def test_midsize_against_oracle(dev, case):
     """B=5 (padded to 16 rows) with ragged lengths and To not a multiple of the discriminator window, and
     B=70 (> 64 rows: two 64-row blocks per recurrent launch): HIP path vs the CPU oracle on identical
@@ -172,6 +173,24 @@ def test_midsize_against_oracle(dev, case):
     OT, GT = (1e-2, 4e-2) if bf16 else (1e-3, 2e-3)
     GA = 2e-5 if bf16 else 2e-6
     case = case.replace('_bf16', '')
+    vesus = case.startswith('vesus')
+    if vesus:
+        # BASELINE configs 4 / 5: VESUS conditioning (labels + speaker embedding + style noise in the decoder memory:
+        # E = 1093, so the recurrent products run with K = 1349 / 2117 / 1093-wide rows, padded inside the kernels) at
+        # the reference's default dimensions; B = 64 rows in fp32, B = 128 (two 64-row blocks per launch) in bf16
+        nb = 128 if case.endswith('b128') else 64
+        hp = HParams(common.VESUS_HPARAMS + (',fp16_run=True' if bf16 else ''))
+        g = torch.Generator().manual_seed(13)
+        in_lens = sorted(torch.randint(4, 17, (nb,), generator=g).tolist(), reverse=True)
+        out_lens = torch.randint(20, 27, (nb,), generator=g).tolist()
+    if case == 'full_dims_b64_t200':
+        # 64 rows x up to 200 decoder steps at the reference's dimensions, Ti up to 50 (two attention tiles): several
+        # blocks of the hoisted decoder-LSTM GEMMs, three chunks of the backward loop with their leaf-stream passes
+        hp = HParams('use_labels=False,use_noise=True')
+        g = torch.Generator().manual_seed(17)
+        in_lens = sorted(torch.randint(12, 51, (64,), generator=g).tolist(), reverse=True)
+        out_lens = torch.randint(96, 201, (64,), generator=g).tolist()
+        case = 'done'
     if case.startswith('full_dims'):
         # the reference's default dimensions (E=1024, 1024-unit LSTMs, attention 128/32/31) at the benchmark's batch
         # size (64 rows = four 16-row MFMA tiles) and at 20 rows (two tiles), short sequences so that the CPU oracle
@@ -193,19 +212,20 @@ def test_midsize_against_oracle(dev, case):
         out_lens = torch.randint(6, 23, (70,), generator=g).tolist()
     if bf16 and not hp.fp16_run:
         hp.fp16_run = True
-    batch = common.synthetic_batch(hp, in_lens, out_lens, seed=5)
+    batch = common.synthetic_batch(hp, in_lens, out_lens, seed=5, vesus=vesus)
     Gp, Dp = R.init_params(hp, seed=3)
     for k in list(Gp):
         if k.endswith('running_var'):
             Gp[k.replace('running_var', 'num_batches_tracked')] = torch.zeros((), dtype=torch.long)
-    res = run_pair_hip(hp, Gp, Dp, batch, 77, dev)
+    res = run_pair_hip(hp, Gp, Dp, batch, 77, dev, vesus=vesus)
     text, il, mel, gate, spk, emo, ol = batch
     stream = common.MaskStream(77)
     B, Ti, To = len(in_lens), max(in_lens), max(out_lens)
     rng = common.draw_generator_rng(stream, hp, B, Ti, To)
     rng['disc_keep'] = common.draw_disc_keep(stream, hp, B, To)
     Gp = {k: v for k, v in Gp.items() if not k.endswith('num_batches_tracked')}
-    out, losses, grads, new_stats = R.generator_step_grads(Gp, Dp, (text, il, mel, gate, ol), rng, hp)
+    obatch = (text, il, mel, gate, ol, spk.long(), emo) if vesus else (text, il, mel, gate, ol)
+    out, losses, grads, new_stats = R.generator_step_grads(Gp, Dp, obatch, rng, hp)
     for name, t in zip(('mel', 'mel_post', 'gate', 'align'), out):
         close(res['out'][name], t, rtol=OT, atol=1e-5, what=f'out.{name}')
     if bf16 and case == 'ragged5':
@@ -426,10 +446,11 @@ def test_full_size_training_step_is_schedule_invariant(dev, monkeypatch):
     monkeypatch.setattr(engine, 'BWD_CHUNKS', 1)
     monkeypatch.setattr(engine, 'ATTN_HOIST', False)
     monkeypatch.setattr(engine, 'CELL_QUERY', False)
+    monkeypatch.setattr(engine, 'HOIST2', False)
     monkeypatch.setattr(engine.LEAF, 'enabled', False)
     out0, g0 = run()
     monkeypatch.undo()
-    assert engine.DEC_RING > 1 and engine.BWD_CHUNKS > 1 and engine.ATTN_HOIST and engine.LEAF.enabled
+    assert engine.DEC_RING > 1 and engine.BWD_CHUNKS > 1 and engine.ATTN_HOIST and engine.LEAF.enabled and engine.HOIST2
     out1, g1 = run()
     for name, a, b in zip(('mel', 'mel_post', 'gate', 'align'), out1, out0):
         close(a, b, rtol=1e-4, atol=1e-6, what=f'out.{name}')

@@ -66,6 +66,33 @@ def test_eval_mode_forward_matches_oracle(dev):
             close(v, Gp[k], rtol=0, atol=0, what=k)
 
 
+def test_forward_uses_the_lengths_it_is_given(dev):
+    """x1 = parse_batch(b1); parse_batch(b2); model(x1) must run with b1's lengths (the reference derives every mask
+    from the tensors inside `inputs`, model.py:644-673), and hand-built inputs without parse_batch work as well."""
+    from gantron_amd.hparams import HParams
+    from gantron_amd.model import Tacotron2
+    hp = HParams(MID)
+    b1 = common.synthetic_batch(hp, [21, 18, 7], [30, 41, 12], seed=9)
+    b2 = common.synthetic_batch(hp, [21, 9, 5], [41, 20, 33], seed=10)       # same B, Ti, To: other lengths
+    torch.manual_seed(0)
+    G = Tacotron2(hp).to(dev).eval()
+    rng = common.draw_generator_rng(common.MaskStream(3), hp, 3, 21, 41)
+    G.rng_override = kernel_rng(rng, 3, dev)
+    with torch.no_grad():
+        x1, _ = G.parse_batch(b1)
+        want = [o.clone() for o in G(x1)]
+        x1b, _ = G.parse_batch(b1)
+        G.parse_batch(b2)                               # a later parse must not leak into x1b
+        got = G(x1b)
+        hand = tuple(t.clone() if torch.is_tensor(t) else t for t in x1)    # fresh tensors: no host copies attached
+        got2 = G(hand)
+        other = G(G.parse_batch(b2)[0])
+    for name, a, b, c in zip(('mel', 'mel_post', 'gate', 'align'), got, want, got2):
+        close(a, b, rtol=0, atol=0, what=f'{name} after a second parse_batch')
+        close(c, b, rtol=0, atol=0, what=f'{name} from hand-built inputs')
+    assert float((other[2] - want[2]).abs().max()) > 1.0        # b2's lengths really give another padding mask
+
+
 def test_three_optimizer_steps_track_the_oracle(dev):
     """G,D,G schedule with Adam + clipping: losses of every step and the final parameters agree with the
     oracle driven by the same masks (train.py:361-423, 302-360)."""
