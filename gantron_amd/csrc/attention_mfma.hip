@@ -175,8 +175,27 @@ __global__ __launch_bounds__(256) void attn_energies_fwd_mfma(GtAttnDims d, GtSl
         const int f = threadIdx.x + 256 * i, tl = f >> 5, c4 = f & 31;
         pm4[i] = *reinterpret_cast<const float4*>(pm + ((long)b * d.Ti + min(t0 + tl, d.Ti - 1)) * A + 4 * c4);
     }
+    // query = sum of the slabs of the query product (up to H/16 = 64 of them).  Vector form: thread (sg, c4) takes slabs
+    // sg, sg + 8, ... at channels 4 c4 .. 4 c4 + 3, so that ALL slab loads of the workgroup are in flight together (one
+    // memory round trip); the 8 partial rows are folded through LDS (S.g is free in the forward kernel).
+    const bool qvec = ((qpart.ld | qpart.slab_stride) & 3) == 0 && (reinterpret_cast<uintptr_t>(qpart.p) & 15) == 0;
     float qv = 0.f;
-    {   // query = sum of the K-split slabs of the query product (all loads in flight together)
+    if (qvec) {
+        const int sg = threadIdx.x >> 5, c4 = threadIdx.x & 31;
+        const float* qp = qpart.p + (long)b * qpart.ld + 4 * c4;
+        float4 qa = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int base = 0; base < qpart.n; base += 64) {
+            float4 t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = *reinterpret_cast<const float4*>(qp + (long)min(base + sg + 8 * j, qpart.n - 1) * qpart.slab_stride);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float w = base + sg + 8 * j < qpart.n ? 1.f : 0.f;
+                qa.x += w * t[j].x; qa.y += w * t[j].y; qa.z += w * t[j].z; qa.w += w * t[j].w;
+            }
+        }
+        *reinterpret_cast<float4*>(&S.g[sg * A + 4 * c4]) = qa;
+    } else {
         const float* qp = qpart.p + (long)b * qpart.ld + (threadIdx.x & (A - 1));
 #pragma unroll 8
         for (int s2 = 0; s2 < qpart.n; ++s2) qv += qp[(long)s2 * qpart.slab_stride];
@@ -186,6 +205,14 @@ __global__ __launch_bounds__(256) void attn_energies_fwd_mfma(GtAttnDims d, GtSl
     for (int i = 0; i < 4; ++i) {
         const int f = threadIdx.x + 256 * i, tl = f >> 5, c4 = f & 31;
         *reinterpret_cast<float4*>(&S.ds[tl * LDS_ + 4 * c4]) = pm4[i];
+    }
+    if (qvec) {
+        __syncthreads();
+        if (threadIdx.x < A) {
+            qv = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qv += S.g[j * A + threadIdx.x];
+        }
     }
     if (threadIdx.x < A) {
         S.q[threadIdx.x] = qv;

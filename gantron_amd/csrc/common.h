@@ -58,15 +58,17 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0;
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
-// sum of `n` (<= 16) partial slabs at element index idx (slab s lives at p + s*stride).  The loads are
+// sum of `n` partial slabs (16 per trip) at element index idx (slab s lives at p + s*stride).  The loads are
 // issued together (guarded full unroll): a runtime-bounded loop would expose one memory latency per slab.
 __device__ __forceinline__ float slab_sum(const float* p, int n, int64_t stride, int64_t idx) {
-    float v[16];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) v[s] = (s < n) ? p[(int64_t)s * stride + idx] : 0.f;
     float acc = 0.f;
+    for (int base = 0; base < n; base += 16) {        // one trip for n <= 16
+        float v[16];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) acc += v[s];
+        for (int s = 0; s < 16; ++s) v[s] = (base + s < n) ? p[(int64_t)(base + s) * stride + idx] : 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc += v[s];
+    }
     return acc;
 }
 

@@ -178,6 +178,13 @@ static int decoder_fwd_hoisted(const GtDecoderFwd* a, void* stream) {
     }
     const int blk = block_steps(a->blk);
     const int64_t xa_step = (int64_t)a->Bp * a->ld2;
+    // fused product + cell (+ query) launches: fp32, float4-friendly sizes
+    const bool fusedA = a->W1c != nullptr && a->counters1 != nullptr && !a->bf16 && cq && a->Ha % 16 == 0;
+    const bool fusedB = a->W2hc != nullptr && a->counters2 != nullptr && !a->bf16 && a->Hd % 16 == 0 && (a->Hd + a->E) % 4 == 0;
+    GT_REQUIRE((a->W1c == nullptr || fusedA) && (a->W2hc == nullptr || fusedB), GT_E_ARG,
+               "gt_decoder_fwd: W1c / W2hc need fp32, Wq + partq, Ha %% 32 == 0, Hd %% 16 == 0, E %% 4 == 0 and their counters");
+    const int64_t x1_slot = fusedA ? (int64_t)a->Bp * a->ld1 : 0;      // operand ping-pong (see GtDecoderFwd::W1c)
+    const int64_t xh_slot = fusedB ? (int64_t)a->Bp * a->ldh : 0;
     int nblock = 0;
     for (int t0 = 0; t0 < a->To;) {
         // the last `blk` steps go in quarter blocks: what stream B still has to do after A's last step is exposed
@@ -188,28 +195,38 @@ static int decoder_fwd_hoisted(const GtDecoderFwd* a, void* stream) {
             const uint8_t* k1 = a->att_keep ? a->att_keep + (int64_t)t * a->Bp * a->Ha : nullptr;
             float* hc_t = a->HC + (int64_t)t * a->Bp * hc_ld;
             float* XAt = a->X2 + (int64_t)t * xa_step;         // [h_att_t | ctx_t]
-            GT_TRY(rec_rows(a->X1, a->ld1, a->W1p, a->part, a->Bp, N1, K1, a->S1, sA, a->bf16, two ? kPrioA : 0));
-            if (cq)      // cell + query projection in one launch
-                GT_TRY(gt_cell_query_fwd(slabs(a->part, a->S1, (int64_t)a->Bp * N1, N1), a->pre1 + (int64_t)t * a->Bp * N1, N1,
-                                         a->c1 + (int64_t)t * a->Bp * a->Ha, k1, a->p_att, a->gates1 + (int64_t)t * a->Bp * N1,
-                                         a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha, a->hatt + (int64_t)t * a->Bp * a->Ha,
-                                         a->X1 + a->E, a->ld1, XAt, a->ld2, a->Wq, a->Ha, a->partq, (int64_t)a->Bp * a->Apad, a->B,
-                                         a->Bp, a->Ha, a->A, a->Apad, sA));
-            else {
-                GT_TRY(gt_lstm_cell_fwd(slabs(a->part, a->S1, (int64_t)a->Bp * N1, N1), a->pre1 + (int64_t)t * a->Bp * N1, N1,
-                                        a->c1 + (int64_t)t * a->Bp * a->Ha, nullptr, 0, k1, a->p_att, nullptr,
-                                        a->gates1 + (int64_t)t * a->Bp * N1, a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha,
-                                        a->hatt + (int64_t)t * a->Bp * a->Ha, a->X1 + a->E, a->ld1, XAt, a->ld2, nullptr, 0,
-                                        a->B, a->Ha, sA));
-                GT_TRY(rec_rows(XAt, a->ld2, a->Wqp, a->part, a->Bp, a->Apad, a->Ha, a->Sq, sA));
+            float* X1c = a->X1 + (t & 1) * x1_slot;            // [ctx_{t-1} | h_att_{t-1}]
+            float* X1n = a->X1 + ((t + 1) & 1) * x1_slot;      // receives h_att_t (cell) and ctx_t (context kernel)
+            if (fusedA) {       // product + cell + dropout + query slabs: one launch
+                GT_TRY(gt_rec_cell_fwd(X1c, a->ld1, a->W1c, a->part, a->counters1, a->Bp, a->B, a->Ha, K1, a->S1,
+                                       a->pre1 + (int64_t)t * a->Bp * N1, N1, a->c1 + (int64_t)t * a->Bp * a->Ha, k1, a->p_att,
+                                       a->gates1 + (int64_t)t * a->Bp * N1, a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha,
+                                       a->hatt + (int64_t)t * a->Bp * a->Ha, X1n + a->E, a->ld1, XAt, a->ld2, nullptr, 0, a->Wq,
+                                       a->Ha, a->partq, (int64_t)a->Bp * a->Apad, a->A, a->Apad, two ? kPrioA : 0, sA));
+            } else {
+                GT_TRY(rec_rows(X1c, a->ld1, a->W1p, a->part, a->Bp, N1, K1, a->S1, sA, a->bf16, two ? kPrioA : 0));
+                if (cq)      // cell + query projection in one launch
+                    GT_TRY(gt_cell_query_fwd(slabs(a->part, a->S1, (int64_t)a->Bp * N1, N1), a->pre1 + (int64_t)t * a->Bp * N1, N1,
+                                             a->c1 + (int64_t)t * a->Bp * a->Ha, k1, a->p_att, a->gates1 + (int64_t)t * a->Bp * N1,
+                                             a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha, a->hatt + (int64_t)t * a->Bp * a->Ha,
+                                             X1n + a->E, a->ld1, XAt, a->ld2, a->Wq, a->Ha, a->partq, (int64_t)a->Bp * a->Apad, a->B,
+                                             a->Bp, a->Ha, a->A, a->Apad, sA));
+                else {
+                    GT_TRY(gt_lstm_cell_fwd(slabs(a->part, a->S1, (int64_t)a->Bp * N1, N1), a->pre1 + (int64_t)t * a->Bp * N1, N1,
+                                            a->c1 + (int64_t)t * a->Bp * a->Ha, nullptr, 0, k1, a->p_att, nullptr,
+                                            a->gates1 + (int64_t)t * a->Bp * N1, a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha,
+                                            a->hatt + (int64_t)t * a->Bp * a->Ha, X1n + a->E, a->ld1, XAt, a->ld2, nullptr, 0,
+                                            a->B, a->Ha, sA));
+                    GT_TRY(rec_rows(XAt, a->ld2, a->Wqp, a->part, a->Bp, a->Apad, a->Ha, a->Sq, sA));
+                }
             }
-            GT_TRY(gt_attn_energies_fwd_u(d, cq ? slabs(a->partq, a->Ha / 32, (int64_t)a->Bp * a->Apad, a->Apad)
+            GT_TRY(gt_attn_energies_fwd_u(d, cq ? slabs(a->partq, a->Ha / (fusedA ? 16 : 32), (int64_t)a->Bp * a->Apad, a->Apad)
                                                 : slabs(a->part, a->Sq, (int64_t)a->Bp * a->Apad, a->Apad),
                                           a->w_hist + (int64_t)t * BT, a->cum_hist + (int64_t)t * BT, a->pm, a->Wc, a->Wd, a->v,
                                           a->lengths, a->q_hist + (int64_t)t * a->B * a->A, a->energies, wpack,
                                           a->u_hist ? a->u_hist + (int64_t)t * BT * a->A : nullptr, sA));
             GT_TRY(gt_attn_context_fwd(d, a->energies, a->memory, a->ldE, a->lengths, a->w_hist + (int64_t)(t + 1) * BT,
-                                       a->cum_hist + (int64_t)t * BT, a->cum_hist + (int64_t)(t + 1) * BT, a->X1, a->ld1,
+                                       a->cum_hist + (int64_t)t * BT, a->cum_hist + (int64_t)(t + 1) * BT, X1n, a->ld1,
                                        XAt + a->Ha, a->ld2, hc_t + a->Hd, hc_ld, sA));
         }
         if (two) {
@@ -223,11 +240,20 @@ static int decoder_fwd_hoisted(const GtDecoderFwd* a, void* stream) {
         for (int t = t0; t < t1; ++t) {
             const uint8_t* k2 = a->dec_keep ? a->dec_keep + (int64_t)t * a->Bp * a->Hd : nullptr;
             float* hc_t = a->HC + (int64_t)t * a->Bp * hc_ld;
-            GT_TRY(rec_rows(a->Xh, a->ldh, a->W2hp, a->part2, a->Bp, N2, a->Hd, a->S2, sB, a->bf16, two ? kPrioB : 0));
+            float* Xhc = a->Xh + (t & 1) * xh_slot;
+            float* Xhn = a->Xh + ((t + 1) & 1) * xh_slot;
+            if (fusedB) {
+                GT_TRY(gt_rec_cell_fwd(Xhc, a->ldh, a->W2hc, a->part2, a->counters2, a->Bp, a->B, a->Hd, a->Hd, a->S2,
+                                       a->pre2 + (int64_t)t * a->Bp * N2, N2, a->c2 + (int64_t)t * a->Bp * a->Hd, k2, a->p_dec,
+                                       a->gates2 + (int64_t)t * a->Bp * N2, a->c2 + (int64_t)(t + 1) * a->Bp * a->Hd, nullptr,
+                                       Xhn, a->ldh, hc_t, hc_ld, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, two ? kPrioB : 0, sB));
+                continue;
+            }
+            GT_TRY(rec_rows(Xhc, a->ldh, a->W2hp, a->part2, a->Bp, N2, a->Hd, a->S2, sB, a->bf16, two ? kPrioB : 0));
             GT_TRY(gt_lstm_cell_fwd(slabs(a->part2, a->S2, (int64_t)a->Bp * N2, N2), a->pre2 + (int64_t)t * a->Bp * N2, N2,
                                     a->c2 + (int64_t)t * a->Bp * a->Hd, nullptr, 0, k2, a->p_dec, nullptr,
                                     a->gates2 + (int64_t)t * a->Bp * N2, a->c2 + (int64_t)(t + 1) * a->Bp * a->Hd, nullptr,
-                                    a->Xh, a->ldh, hc_t, hc_ld, nullptr, 0, a->B, a->Hd, sB));
+                                    Xhn, a->ldh, hc_t, hc_ld, nullptr, 0, a->B, a->Hd, sB));
         }
         t0 = t1;
         ++nblock;

@@ -27,6 +27,9 @@ __global__ __launch_bounds__(256) void pack_rec_weight_kernel(const float* W, lo
         const int nb = (int)(blk / KB);
         int n = nb * 16 + (lane & 15);
         if (transposed == 2) n = (n & 3) * (N / 4) + (n >> 2);
+        // mode 3 (gt_rec_cell_fwd): packed column 64*cg + 16*gate + u holds gate `gate` of hidden unit 16*cg + u, so
+        // that a workgroup's 64 columns are the four gates of 16 units (wave & 3 = gate)
+        if (transposed == 3) n = ((n >> 4) & 3) * (N / 4) + (n >> 6) * 16 + (n & 15);
         const int k = kb * 16 + 4 * (lane >> 4);
         float4 v;
         float* vv = reinterpret_cast<float*>(&v);
@@ -88,12 +91,17 @@ struct RecW {                             // weight fragments of this wave's hal
 // DBG (diagnostics, GANTRON_REC_DEBUG): bit 0 = no weight loads, bit 1 = no MFMAs, bit 2 = no activation staging
 // One workgroup of the product: 64 columns starting at column group `cg`, K-slice [kb0, kb1) of 16-wide blocks;
 // `out` is the slab this K-slice writes (row stride N).
+constexpr int EP_LD = 68;                 // epilogue tile row stride: 4 rows apart = 16 banks apart, conflict-free scalar writes
+
+// Product of one workgroup: 64 columns starting at column group `cg`, K-slice [kb0, kb1).  Returns (after a barrier)
+// the folded [MT*16 rows][64 columns] tile in LDS, row stride EP_LD; the LDS array has MT*16*REC_LD floats, of which
+// the tile uses the first MT*16*EP_LD.
 template <int MT, int DBG>
-__device__ __forceinline__ void rec_gemm_body(const float* __restrict__ Xz, long ldx, const float* __restrict__ Wpz,
-                                              float* __restrict__ out_slab, int N, int KB, int kb0, int kb1, int cg) {
+__device__ __forceinline__ float* rec_gemm_tile(const float* __restrict__ Xz, long ldx, const float* __restrict__ Wpz,
+                                                int N, int KB, int kb0, int kb1, int cg) {
     static_assert(MT == 4 || MT == 2 || MT == 1 || MT == 3, "row tiles");
     __shared__ __attribute__((aligned(16))) float Xs[MT * 16 * REC_LD];
-    if (DBG & 8) return;                  // diagnostics: pure launch + wave start-up cost
+    if (DBG & 8) return Xs;               // diagnostics: pure launch + wave start-up cost
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = wave >> 2;
     int nb = cg * 4 + (wave & 3);
@@ -153,7 +161,6 @@ __device__ __forceinline__ void rec_gemm_body(const float* __restrict__ Xz, long
     // Epilogue through LDS (Xs is free after the last barrier): the two K-halves are folded into a row-major
     // [row][64 columns] tile so that the slab is written with full-line float4 stores by all 8 waves (the MFMA
     // C layout would give 16 scalar stores of 64-byte pieces per lane, by half of the waves only).
-    constexpr int EP_LD = 68;             // 4 rows apart = 16 banks apart: the scalar tile writes are conflict free
     static_assert(MT * 16 * EP_LD <= MT * 16 * REC_LD, "epilogue tile fits the staging buffer");
     float* red = Xs;
     const int ecol = (wave & 3) * 16 + (lane & 15), erow = 4 * (lane >> 4);
@@ -171,6 +178,15 @@ __device__ __forceinline__ void rec_gemm_body(const float* __restrict__ Xz, long
             for (int r = 0; r < 4; ++r) red[(mt * 16 + erow + r) * EP_LD + ecol] += acc[mt][r];
     }
     __syncthreads();
+    return red;
+}
+
+template <int MT, int DBG>
+__device__ __forceinline__ void rec_gemm_body(const float* __restrict__ Xz, long ldx, const float* __restrict__ Wpz,
+                                              float* __restrict__ out_slab, int N, int KB, int kb0, int kb1, int cg) {
+    const float* red = rec_gemm_tile<MT, DBG>(Xz, ldx, Wpz, N, KB, kb0, kb1, cg);
+    if (DBG & 8) return;
+    const int tid = threadIdx.x;
     float* out = out_slab + (long)cg * 64;
     const int ncols = min(64, N - cg * 64);      // N % 16 == 0: whole float4s
 #pragma unroll
@@ -216,6 +232,209 @@ __global__ __launch_bounds__(REC_THREADS) void rec_gemm2_kernel(RecProblem p0, R
     const int s = id / p.groups, cg = id - s * p.groups;
     const int kb0 = s * p.KBS;
     rec_gemm_body<MT, 0>(p.X, p.ldx, p.Wp, p.part + (long)s * p.ps, p.N, p.KB, kb0, min(p.KB, kb0 + p.KBS), cg);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused recurrent product + LSTM cell (+ attention query projection): gt_rec_cell_fwd.
+// The K-splits of one 64-column group (= the four gates of 16 hidden units, packing mode 3) meet INSIDE the launch:
+// every split writes its partial tile as a slab with write-through (sc1) 16-byte stores, drains them, and draws a
+// ticket from the group's counter; the workgroup that draws the last ticket adds the other slabs (sc1 loads, which
+// bypass its CU's L1) to the tile it still holds in LDS and runs the cell for its 16 units x all rows: gates, cell
+// state, dropout, the h scatter into the next operands -- and, for the attention LSTM, its share of the query
+// projection h . Wq^T as one more slab.  This is the hand-off form "sc1 stores, every storing wave drained, one
+// agent-scope atomic add per workgroup, the last adder loads with sc1 loads" of MI355X_MICROARCH.md (section
+// visibility): no fence, no spinning, no assumption about placement or dispatch order.  It replaces the dependent
+// launch of the cell kernel (launch + slab round trip, ~8 us) by ~3 us of epilogue in the last workgroup per group.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct RecCellEpi {
+    const float* pre; long ld_pre;        // (rows, 4H) gate pre-activations [i | f | g | o] (PyTorch gate order), added
+    const float* c_prev; float* c_out;    // (rows, H)
+    const uint8_t* keep; float scale;     // dropout on h (or NULL)
+    float* gates;                         // (rows, 4H) gate values saved for the backward pass (may alias `pre`)
+    float* h_raw; float* h0; long ld0; float* h1; long ld1; float* h2; long ld2;     // h destinations (NULL = skip)
+    const float* Wq; long ldwq;           // query_layer weight (A, H) or NULL
+    float* qpart; long q_sstride;         // query slab of column group cg at qpart + cg * q_sstride, rows of Apad
+    unsigned* counters;                   // (row blocks, N/64) tickets, zero-initialised ONCE by the caller
+    int B, H, A, Apad, S;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rc_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+
+template <int MT>
+__global__ __launch_bounds__(REC_THREADS) void rec_cell_kernel(const float* __restrict__ X, long ldx,
+                                                               const float* __restrict__ Wp, float* part, int N, int KB,
+                                                               int KBS, long xz, long pz, long ps, int prio, RecCellEpi e) {
+    if (prio == 3) __builtin_amdgcn_s_setprio(3);
+    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+    const int cg = blockIdx.x, s = blockIdx.y, z = blockIdx.z;
+    const int kb0 = s * KBS;
+    float* red = rec_gemm_tile<MT, 0>(X + (long)z * xz, ldx, Wp, N, KB, kb0, min(KB, kb0 + KBS), cg);
+    constexpr int ROWS = MT * 16;
+    constexpr int NV = (ROWS * 16 + REC_THREADS - 1) / REC_THREADS;        // float4 of the tile per thread
+    float* lds_h = red + ROWS * EP_LD;             // [ROWS][20] h tile for the query product (inside the staging array)
+    unsigned* lds_ticket = reinterpret_cast<unsigned*>(red + ROWS * EP_LD + ROWS * 20);
+    static_assert(ROWS * EP_LD + ROWS * 20 + 4 <= ROWS * REC_LD, "epilogue scratch fits the staging buffer");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = 64 * z;                       // first batch row of this row block
+    float* slab0 = part + (long)z * pz + (long)cg * 64;                    // slab 0 of this column group
+    if (e.S > 1) {
+        // ---- publish this K-slice's tile (write-through), then draw a ticket
+        const __amdgpu_buffer_rsrc_t wr = rc_rsrc(slab0 + (long)s * ps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int f = tid + REC_THREADS * i;
+            const int row = f >> 4, c4 = f & 15;
+            if (row < ROWS) {
+                const float4 v = *reinterpret_cast<const float4*>(&red[row * EP_LD + 4 * c4]);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), wr, (int)(((long)row * N + 4 * c4) * 4), 0, 16);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // EVERY storing wave drains its stores
+        __syncthreads();
+        if (tid == 0)
+            *lds_ticket = __hip_atomic_fetch_add(e.counters + (long)z * gridDim.x + cg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if ((*lds_ticket % (unsigned)e.S) != (unsigned)(e.S - 1)) return;       // not the last K-slice of this group
+    }
+    // ---- last arriver: inputs of the cell are requested together with the other K-slices' slabs
+    const bool cell_thread = tid < ROWS * 4;
+    const int crow = tid >> 2, uq = tid & 3;
+    const int m = row0 + crow;                     // batch row
+    const int u = 16 * cg + 4 * uq;                // first of this thread's 4 hidden units
+    const bool live = cell_thread && m < e.B;
+    const long cidx = (long)m * e.H + u;
+    float4 pre4[4], cp = make_float4(0.f, 0.f, 0.f, 0.f);
+    uchar4 kp = make_uchar4(1, 1, 1, 1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pre4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        if (e.pre != nullptr) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pre4[q] = *reinterpret_cast<const float4*>(e.pre + (long)m * e.ld_pre + q * e.H + u);
+        }
+        cp = *reinterpret_cast<const float4*>(e.c_prev + cidx);
+        if (e.keep != nullptr) kp = *reinterpret_cast<const uchar4*>(e.keep + cidx);
+    }
+    // query weights of this wave's column blocks: B operand of the 16x16x4 MFMA, lane supplies Wq[n = lane & 15][k..k+3]
+    float4 wq[2];
+    const int ncb = e.Wq != nullptr ? e.Apad / 16 : 0;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        wq[sl] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int cb = wave + 8 * sl;
+        if (cb < ncb) {
+            const int ch = min(cb * 16 + (lane & 15), e.A - 1);
+            const float4 t = *reinterpret_cast<const float4*>(e.Wq + (long)ch * e.ldwq + 16 * cg + 4 * (lane >> 4));
+            if (cb * 16 + (lane & 15) < e.A) wq[sl] = t;
+        }
+    }
+    if (e.S > 1) {
+        const __amdgpu_buffer_rsrc_t rd = rc_rsrc(slab0);
+        float4 acc[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s0 = 0; s0 < e.S; s0 += 4) {       // four slabs in flight per pass
+            float4 t[4][NV];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // slabs beyond S and this workgroup's own (still in LDS) are replaced by a re-read of slab 0 and masked
+                const int sj = s0 + j;
+                const bool use = sj < e.S && sj != s;
+                const long base = (long)(use ? sj : 0) * ps;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const int f = min(tid + REC_THREADS * i, ROWS * 16 - 1);
+                    const int row = f >> 4, c4 = f & 15;
+                    t[j][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rd, (int)((base + (long)row * N + 4 * c4) * 4), 0, 16));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int sj = s0 + j;
+                const float w = (sj < e.S && sj != s) ? 1.f : 0.f;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    acc[i].x += w * t[j][i].x; acc[i].y += w * t[j][i].y; acc[i].z += w * t[j][i].z; acc[i].w += w * t[j][i].w;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int f = tid + REC_THREADS * i;
+            const int row = f >> 4, c4 = f & 15;
+            if (row < ROWS) {
+                float4* d = reinterpret_cast<float4*>(&red[row * EP_LD + 4 * c4]);
+                float4 v = *d;
+                v.x += acc[i].x; v.y += acc[i].y; v.z += acc[i].z; v.w += acc[i].w;
+                *d = v;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- cell: thread = (row, 4 units); tile column 16*gate + unit
+    float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        float4 gv[4], cn;
+        float* gvf = reinterpret_cast<float*>(&gv[0]);
+        const float* cpf = reinterpret_cast<const float*>(&cp);
+        float* cnf = reinterpret_cast<float*>(&cn);
+        float* hvf = reinterpret_cast<float*>(&hv);
+        const unsigned char* kpf = reinterpret_cast<const unsigned char*>(&kp);
+        float gi[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 t = *reinterpret_cast<const float4*>(&red[crow * EP_LD + 16 * q + 4 * uq]);
+            gi[4 * q + 0] = t.x + pre4[q].x; gi[4 * q + 1] = t.y + pre4[q].y;
+            gi[4 * q + 2] = t.z + pre4[q].z; gi[4 * q + 3] = t.w + pre4[q].w;
+        }
+#pragma unroll
+        for (int el = 0; el < 4; ++el) {
+            const float ig = sigmoidf_(gi[0 * 4 + el]), fg = sigmoidf_(gi[1 * 4 + el]);
+            const float gg = tanhf(gi[2 * 4 + el]), og = sigmoidf_(gi[3 * 4 + el]);
+            gvf[0 * 4 + el] = ig; gvf[1 * 4 + el] = fg; gvf[2 * 4 + el] = gg; gvf[3 * 4 + el] = og;
+            const float c = fg * cpf[el] + ig * gg;
+            cnf[el] = c;
+            float h = og * tanhf(c);
+            if (e.keep != nullptr) h *= kpf[el] ? e.scale : 0.f;
+            hvf[el] = h;
+        }
+        if (e.gates != nullptr) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(e.gates + (long)m * 4 * e.H + q * e.H + u) = gv[q];
+        }
+        *reinterpret_cast<float4*>(e.c_out + cidx) = cn;
+        if (e.h_raw != nullptr) *reinterpret_cast<float4*>(e.h_raw + cidx) = hv;
+        if (e.h0 != nullptr) *reinterpret_cast<float4*>(e.h0 + (long)m * e.ld0 + u) = hv;
+        if (e.h1 != nullptr) *reinterpret_cast<float4*>(e.h1 + (long)m * e.ld1 + u) = hv;
+        if (e.h2 != nullptr) *reinterpret_cast<float4*>(e.h2 + (long)m * e.ld2 + u) = hv;
+    }
+    if (ncb == 0) return;
+    // ---- query slab of this column group: [ROWS x 16 units] . [16 x Apad]
+    if (cell_thread) *reinterpret_cast<float4*>(&lds_h[crow * 20 + 4 * uq]) = hv;       // rows beyond the batch: zeros
+    __syncthreads();
+    float* qout = e.qpart + (long)cg * e.q_sstride;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        const int cb = wave + 8 * sl;
+        if (cb >= ncb) break;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const float4 x = *reinterpret_cast<const float4*>(&lds_h[(16 * mt + (lane & 15)) * 20 + 4 * (lane >> 4)]);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, wq[sl].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, wq[sl].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, wq[sl].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, wq[sl].w, acc, 0, 0, 0);
+            // C layout: column n = lane & 15, rows 4*(lane>>4) + r
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                qout[(long)(row0 + 16 * mt + 4 * (lane >> 4) + r) * e.Apad + cb * 16 + (lane & 15)] = acc[r];
+        }
+    }
 }
 
 struct CellFwd {
@@ -524,6 +743,66 @@ int gt_rec_gemm_prio(const float* X, int64_t ldx, const float* Wp, float* part, 
         default: GT_REC(4); break;
     }
 #undef GT_REC
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+// packing for gt_rec_cell_fwd (mode 3): W is the (4H x K) LSTM weight in PyTorch gate order
+extern "C" int gt_pack_rec_cell_weight(const float* W, int64_t ldw, int32_t H, int32_t K, float* Wp, void* stream) {
+    GT_REQUIRE(W && Wp && H > 0 && H % 16 == 0 && K > 0, GT_E_ARG, "gt_pack_rec_cell_weight: H=%d must be a multiple of 16", H);
+    GT_REQUIRE(aligned16(Wp), GT_E_ALIGN, "gt_pack_rec_cell_weight: Wp must be 16-byte aligned");
+    const int N = 4 * H, KB = cdiv(K, 16);
+    const long total = (long)(N / 16) * KB * 64;
+    const int blocks = (int)std::min<long>(cdiv64(total, 256), 4096);
+    hipLaunchKernelGGL(pack_rec_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, W, (long)ldw, 3, N, N, K, KB, Wp);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gt_rec_cell_fwd(const float* X, int64_t ldx, const float* Wp, float* part, uint32_t* counters, int32_t Bp,
+                               int32_t B, int32_t H, int32_t K, int32_t splits, const float* pre, int64_t ld_pre,
+                               const float* c_prev, const uint8_t* keep, float p_drop, float* gates, float* c_out,
+                               float* h_raw, float* h0, int64_t ld0, float* h1, int64_t ld1, float* h2, int64_t ld2,
+                               const float* Wq, int64_t ldwq, float* qpart, int64_t q_sstride, int32_t A, int32_t Apad,
+                               int32_t prio, void* stream) {
+    GT_REQUIRE(X && Wp && part && counters && c_prev && c_out, GT_E_ARG, "gt_rec_cell_fwd: NULL pointer");
+    GT_REQUIRE(B > 0 && Bp >= B && ((Bp <= 64 && Bp % 16 == 0) || Bp % 64 == 0) && H > 0 && H % 16 == 0 && K > 0 && splits >= 1 &&
+                   splits <= 16, GT_E_ARG, "gt_rec_cell_fwd: bad sizes B=%d Bp=%d H=%d K=%d splits=%d", B, Bp, H, K, splits);
+    GT_REQUIRE(p_drop >= 0.f && p_drop < 1.f, GT_E_ARG, "gt_rec_cell_fwd: p_drop");
+    const int N = 4 * H, KB = cdiv(K, 16);
+    GT_REQUIRE(ldx >= (int64_t)KB * 16 && ldx % 4 == 0 && aligned16(X) && aligned16(Wp) && aligned16(part), GT_E_ALIGN,
+               "gt_rec_cell_fwd: X needs ldx >= 16*ceil(K/16), ldx %% 4 == 0 and 16-byte alignment");
+    auto ok4 = [](const void* p, int64_t ld) { return p == nullptr || (aligned16(p) && ld % 4 == 0); };
+    GT_REQUIRE(ok4(pre, ld_pre) && aligned16(c_prev) && (keep == nullptr || (((uintptr_t)keep) & 3) == 0) && ok4(gates, 0) &&
+                   aligned16(c_out) && ok4(h_raw, 0) && ok4(h0, ld0) && ok4(h1, ld1) && ok4(h2, ld2) && ok4(Wq, ldwq),
+               GT_E_ALIGN, "gt_rec_cell_fwd: every pointer must be 16-byte aligned with leading dimensions %% 4 == 0");
+    if (Wq != nullptr)
+        GT_REQUIRE(qpart && A > 0 && Apad >= A && Apad % 16 == 0 && Apad <= 256 && q_sstride >= (int64_t)Bp * Apad, GT_E_LIMIT,
+                   "gt_rec_cell_fwd: attention_dim %d (padded %d) must fit 16 column blocks", A, Apad);
+    const int KBS = cdiv(KB, splits);
+    GT_REQUIRE(cdiv(KB, KBS) == splits, GT_E_ARG, "gt_rec_cell_fwd: splits=%d leaves empty slabs for K=%d", splits, K);
+    const int mt = Bp <= 64 ? Bp / 16 : 4, nz = Bp <= 64 ? 1 : Bp / 64;
+    RecCellEpi e;
+    e.pre = pre; e.ld_pre = ld_pre; e.c_prev = c_prev; e.c_out = c_out; e.keep = keep; e.scale = 1.0f / (1.0f - p_drop);
+    e.gates = gates; e.h_raw = h_raw; e.h0 = h0; e.ld0 = ld0; e.h1 = h1; e.ld1 = ld1; e.h2 = h2; e.ld2 = ld2;
+    e.Wq = Wq; e.ldwq = ldwq; e.qpart = qpart; e.q_sstride = q_sstride; e.counters = counters;
+    e.B = B; e.H = H; e.A = A; e.Apad = Apad; e.S = splits;
+    dim3 grid(N / 64, splits, nz);
+    hipStream_t st = (hipStream_t)stream;
+    GtProfScope prof(GT_FAM_REC_GEMM, 2.0 * Bp * (double)N * K + (Wq ? 2.0 * Bp * (double)H * A : 0.0),
+                     4.0 * ((double)N * K + (double)Bp * K + (double)Bp * N * (splits > 1 ? 2 * splits - 1 : 0) +
+                            (double)B * H * 12), st);
+    const long ps = (long)Bp * N;
+#define GT_RC(MT)                                                                                                      \
+    hipLaunchKernelGGL((rec_cell_kernel<MT>), grid, dim3(REC_THREADS), 0, st, X, (long)ldx, Wp, part, N, KB, KBS,        \
+                       (long)(64 * ldx), (long)64 * N, ps, prio, e)
+    switch (mt) {
+        case 1: GT_RC(1); break;
+        case 2: GT_RC(2); break;
+        case 3: GT_RC(3); break;
+        default: GT_RC(4); break;
+    }
+#undef GT_RC
     GT_LAUNCH_CHECK();
     return 0;
 }

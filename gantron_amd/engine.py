@@ -44,6 +44,8 @@ DEC_RING = int(_os.environ.get('GANTRON_DEC_RING', '16'))     # ring of hand-off
 # hoisted decoder-LSTM input product (GtDecoderFwd.W2hp / GtDecoderBwd.W2hTp): [h_att | ctx] . W2ih of a block of steps
 # is one tiled GEMM, only h_dec . W2hh stays in the per-step loops
 HOIST2 = _os.environ.get('GANTRON_HOIST2', '1') != '0'
+# fused product + cell (+ query) launches of the forward loop (gt_rec_cell_fwd): 1 = attention LSTM, 2 = decoder LSTM, 3 = both
+REC_CELL = int(_os.environ.get('GANTRON_REC_CELL', '3'))
 DEC_BLK = int(_os.environ.get('GANTRON_DEC_BLK', '32'))       # steps per block in that mode
 
 
@@ -186,6 +188,13 @@ def pack_rec_bf16(W2d, N, n_valid, K, transposed=False):
     """Pack a (n_valid x K) [or (K x n_valid) when transposed] matrix as bf16 MFMA fragments for gt_rec_gemm_bf16."""
     out = torch.empty(int(lib().gt_rec_weight_bf16_elems(N, K)), device=W2d.device, dtype=torch.bfloat16)
     call('gt_pack_rec_weight_bf16', W2d, W2d.stride(0), int(transposed), N, n_valid, K, out)
+    return out
+
+
+def pack_rec_cell(W2d, H, K):
+    """Pack a (4H x K) LSTM weight for gt_rec_cell_fwd (a workgroup's 64 columns = the four gates of 16 hidden units)."""
+    out = torch.empty(int(lib().gt_rec_weight_elems(4 * H, K)), device=W2d.device, dtype=torch.float32)
+    call('gt_pack_rec_cell_weight', W2d, W2d.stride(0), H, K, out)
     return out
 
 
@@ -466,8 +475,12 @@ class GeneratorEngine:
             split = rec_splits_bf16 if self.bf16 else rec_splits
             d.bf16 = int(self.bf16)
             d.S1, d.S2 = split(4 * Ha, K1), split(4 * Hd, Hd)
-            keep_t.update(W1p=pack(W1cat, 4 * Ha, 4 * Ha, K1), W2hp=pack(W2hh, 4 * Hd, 4 * Hd, Hd),
-                          W2ih=W2ih if W2ih.is_contiguous() else W2ih.contiguous())
+            # fused product + cell launches (gt_rec_cell_fwd) take their own packing
+            use_c1 = not self.bf16 and bool(REC_CELL & 1) and CELL_QUERY and Ha % 32 == 0 and E % 4 == 0
+            use_c2 = not self.bf16 and bool(REC_CELL & 2) and Hd % 16 == 0 and (Hd + E) % 4 == 0
+            keep_t['W2ih'] = W2ih if W2ih.is_contiguous() else W2ih.contiguous()
+            keep_t['W1c' if use_c1 else 'W1p'] = pack_rec_cell(W1cat, Ha, K1) if use_c1 else pack(W1cat, 4 * Ha, 4 * Ha, K1)
+            keep_t['W2hc' if use_c2 else 'W2hp'] = pack_rec_cell(W2hh, Hd, Hd) if use_c2 else pack(W2hh, 4 * Hd, 4 * Hd, Hd)
         elif self.bf16:
             d.bf16 = 1
             d.S1, d.S2 = rec_splits_bf16(4 * Ha, K1), rec_splits_bf16(4 * Hd, K2)
@@ -500,7 +513,7 @@ class GeneratorEngine:
             d.attn_wpack = ptr(ws['attn_wpack'])
         if CELL_QUERY and Ha % 32 == 0 and E % 4 == 0:
             Wq = P['decoder.attention_layer.query_layer.linear_layer.weight']
-            ws['partq'] = _f32(Ha // 32, Bp, Apad, device=dev, zero=False)
+            ws['partq'] = _f32(Ha // 16, Bp, Apad, device=dev, zero=False)      # Ha/32 slabs, Ha/16 with gt_rec_cell_fwd
             d.Wq, d.partq = ptr(Wq), ptr(ws['partq'])
         d.Wc = ptr(P[al + 'location_layer.location_conv.conv.weight'])
         d.Wd = ptr(P[al + 'location_layer.location_dense.linear_layer.weight'])
@@ -514,9 +527,17 @@ class GeneratorEngine:
             setattr(d, k, ptr(hist[k]))
         if hoist2:
             ldh = roundup(Hd, 16)
-            ws['Xh'] = _f32(Bp, ldh, device=dev)
-            d.W2hp, d.W2ih, d.ldw2 = ptr(keep_t['W2hp']), ptr(keep_t['W2ih']), keep_t['W2ih'].stride(0)
+            ws['Xh'] = _f32(2, Bp, ldh, device=dev)
+            # W2hp only tells the loop to run in hoisted mode when the fused launch carries the product
+            d.W2hp, d.W2ih, d.ldw2 = ptr(keep_t.get('W2hp', keep_t.get('W2hc'))), ptr(keep_t['W2ih']), keep_t['W2ih'].stride(0)
             d.pre2, d.Xh, d.ldh, d.blk = ptr(hist['gates2']), ptr(ws['Xh']), ldh, DEC_BLK
+            nzb = Bp // 64 if Bp > 64 else 1
+            if use_c1:
+                ws['counters1'] = torch.zeros(nzb * (Ha // 16), dtype=torch.int32, device=dev)
+                d.W1c, d.counters1 = ptr(keep_t['W1c']), ptr(ws['counters1'])
+            if use_c2:
+                ws['counters2'] = torch.zeros(nzb * (Hd // 16), dtype=torch.int32, device=dev)
+                d.W2hc, d.counters2 = ptr(keep_t['W2hc']), ptr(ws['counters2'])
         if ATTN_HOIST and training and lib().gt_attn_hoist_supported(ops.attn_dims(B, Ti, E, A, self.F, self.Kc)):
             hist['u_hist'] = _f32(To, B, Ti, A, device=dev, zero=False)
             d.u_hist = ptr(hist['u_hist'])

@@ -110,6 +110,26 @@ int gt_rec_gemm(const float* X, int64_t ldx, const float* Wp, float* part, int32
                 int32_t N, int32_t K, int32_t splits, int64_t part_sstride, int32_t nz,
                 int64_t x_zstride, int64_t w_zstride, int64_t part_zstride, void* stream);
 
+/* Fused recurrent product + LSTM cell (model.py:391-394 / 406-409) (+ the attention query projection, model.py:56):
+ * ONE launch for  gates = X . W^T (+ pre);  i,f,g,o;  c' = f c + i g;  h = dropout(o tanh c')  [;  q_slab = h . Wq^T].
+ * Wp comes from gt_pack_rec_cell_weight (the columns of a workgroup are the four gates of 16 hidden units, H % 16 == 0,
+ * gt_rec_weight_elems(4H, K) floats).  K is split over `splits` workgroups per column group; they exchange partial
+ * tiles through `part` (splits x Bp x 4H floats, any content) with write-through stores and a ticket per column group
+ * in `counters` ((Bp > 64 ? Bp/64 : 1) x H/16 uint32, zero-initialised ONCE; the kernel keeps them consistent from
+ * launch to launch as long as `splits` does not change); the workgroup drawing a group's last ticket runs the cell for
+ * its 16 units.  pre (Bp, 4H) holds the hoisted part of the pre-activations in PyTorch gate order (may be NULL);
+ * gates (Bp, 4H, PyTorch gate order) may alias pre; h goes to h_raw (Bp, H) and to up to three strided destinations;
+ * rows >= B are neither read nor written.  Wq (A, H) != NULL: every column group also writes its share of the query
+ * projection as slab cg of qpart (H/16 slabs of (Bp, Apad), q_sstride apart) for gt_attn_energies_fwd*.
+ * prio: wave issue priority 0..3 (s_setprio). */
+int gt_pack_rec_cell_weight(const float* W, int64_t ldw, int32_t H, int32_t K, float* Wp, void* stream);
+int gt_rec_cell_fwd(const float* X, int64_t ldx, const float* Wp, float* part, uint32_t* counters, int32_t Bp,
+                    int32_t B, int32_t H, int32_t K, int32_t splits, const float* pre, int64_t ld_pre,
+                    const float* c_prev, const uint8_t* keep, float p_drop, float* gates, float* c_out,
+                    float* h_raw, float* h0, int64_t ld0, float* h1, int64_t ld1, float* h2, int64_t ld2,
+                    const float* Wq, int64_t ldwq, float* qpart, int64_t q_sstride, int32_t A, int32_t Apad,
+                    int32_t prio, void* stream);
+
 /* bf16-operand variant (hparams.fp16_run, the reference's apex path train.py:246-250 -> bf16 MFMA with fp32
  * accumulation on MI355X): the weights are packed as bf16 fragments of v_mfma_f32_16x16x32_bf16
  * ([N/16][ceil(K/32)][64 lanes][8 bf16], gt_rec_weight_bf16_elems 16-bit elements), the fp32 activations X are
@@ -311,6 +331,14 @@ typedef struct GtDecoderFwd {
                                   writes the gate values of the same elements) */
     float* Xh; int64_t ldh;    /* (Bp, ldh >= 16*ceil(Hd/16)) zero-initialised: h_dec operand of the per-step product */
     int32_t blk;               /* steps per block (hand-off granularity between the two chains); <= 0: 32 */
+    /* Fused product + cell launches (gt_rec_cell_fwd) inside the hoisted mode, fp32 only.  W1c != NULL: the attention
+     * LSTM step is ONE launch (product, cell, dropout, h scatter, query slabs): X1 must hold two (Bp, ld1) slots (the
+     * cell writes the next step's operand while other workgroups still read this step's), partq Ha/16 slabs.
+     * W2hc != NULL: the same for the decoder LSTM's h_dec product; Xh then holds two (Bp, ldh) slots. */
+    const float* W1c;          /* gt_pack_rec_cell_weight of [4Ha] x [ctx(E) | h_att(Ha)] */
+    const float* W2hc;         /* gt_pack_rec_cell_weight of [4Hd] x [Hd] */
+    uint32_t* counters1;       /* (Bp > 64 ? Bp/64 : 1) x Ha/16 tickets, zero-initialised */
+    uint32_t* counters2;       /* ... x Hd/16 */
 } GtDecoderFwd;
 
 typedef struct GtDecoderBwd {

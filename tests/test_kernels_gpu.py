@@ -229,6 +229,56 @@ def test_cell_query_fused(dev, Bsz, H, A, S):
     assert torch.isfinite(qpart).all()                   # every slab element was written
 
 
+@pytest.mark.parametrize('Bsz,H,K,S,A', [(64, 1024, 2048, 4, 128), (5, 32, 100, 2, 8), (70, 64, 333, 3, 40), (64, 1024, 1024, 4, 0),
+                                         (33, 48, 50, 1, 24), (64, 1024, 3072, 6, 0)])
+def test_rec_cell_fused(dev, Bsz, H, K, S, A):
+    """gt_rec_cell_fwd = gt_rec_gemm + gt_lstm_cell_fwd (+ the query projection) in ONE launch: the K-splits of a
+    column group meet through write-through slabs and a ticket, the last one runs the cell.  Three launches in a
+    row on the same workspace (the tickets carry over from launch to launch), each with fresh inputs."""
+    from gantron_amd import ops
+    from gantron_amd._lib import lib
+    p = 0.1
+    Bp = ops.roundup(Bsz, 16) if Bsz <= 64 else ops.roundup(Bsz, 64)
+    Apad = ops.roundup(max(A, 1), 16)
+    ld = ops.roundup(K, 16) + 16
+    S = ops.pick_splits(K, S)
+    W = g(4 * H, K, scale=0.1)
+    Wp = torch.empty(int(lib().gt_rec_weight_elems(4 * H, K)), device=dev)
+    ops.call('gt_pack_rec_cell_weight', W.to(dev), K, H, K, Wp)
+    Wq = g(max(A, 1), H, seed=4, scale=0.1)
+    part = torch.full((S, Bp, 4 * H), float('nan'), device=dev)
+    counters = torch.zeros((Bp // 64 if Bp > 64 else 1) * (H // 16), dtype=torch.int32, device=dev)
+    for rep in range(3):
+        X = torch.zeros(Bp, ld)
+        X[:Bsz, :K] = g(Bsz, K, seed=10 + rep)
+        pre = g(Bp, 4 * H, seed=20 + rep, scale=0.5)
+        c_prev = g(Bp, H, seed=30 + rep)
+        keep = (torch.rand(Bp, H, generator=torch.Generator().manual_seed(40 + rep)) >= p)
+        gates_in = (X[:Bsz, :K].double() @ W.double().t() + pre[:Bsz].double())
+        i, f, gg, o = gates_in.chunk(4, dim=1)
+        c = torch.sigmoid(f) * c_prev[:Bsz].double() + torch.sigmoid(i) * torch.tanh(gg)
+        h = torch.sigmoid(o) * torch.tanh(c) * keep[:Bsz].double() / (1 - p)
+        gates = pre.clone().to(dev)                      # in place: the gate values overwrite the pre-activations
+        c_out = torch.zeros(Bp, H, device=dev); h_raw = torch.zeros(Bp, H, device=dev)
+        h0 = torch.zeros(Bp, H + 8, device=dev); h1 = torch.zeros(Bp, H, device=dev)
+        qpart = torch.full((H // 16, Bp, Apad), float('nan'), device=dev)
+        ops.call('gt_rec_cell_fwd', X.to(dev), ld, Wp, part, counters, Bp, Bsz, H, K, S, gates, 4 * H, c_prev.to(dev),
+                 keep.to(torch.uint8).to(dev), p, gates, c_out, h_raw, ops.ptr(h0, 4), H + 8, h1, H, None, 0,
+                 Wq.to(dev) if A else None, H, qpart if A else None, Bp * Apad, A, Apad, 3)
+        close(c_out[:Bsz], c, rtol=1e-5, atol=2e-5, what=f'c (launch {rep})')
+        close(h_raw[:Bsz], h, rtol=1e-5, atol=2e-5, what=f'h (launch {rep})')
+        close(h0[:Bsz, 4:4 + H], h, rtol=1e-5, atol=2e-5, what='h strided')
+        close(h1[:Bsz], h, rtol=1e-5, atol=2e-5, what='h second destination')
+        close(gates[:Bsz], torch.cat((torch.sigmoid(i), torch.sigmoid(f), torch.tanh(gg), torch.sigmoid(o)), 1), rtol=1e-5,
+              atol=2e-5, what='gates')
+        if Bsz < Bp:
+            assert float(c_out[Bsz:].abs().max()) == 0.0 and float(h1[Bsz:].abs().max()) == 0.0      # pad rows untouched
+        if A:
+            close(qpart.sum(0)[:Bsz, :A], h @ Wq.double().t(), rtol=1e-5, atol=2e-5, what='query')
+            assert torch.isfinite(qpart).all()               # every slab element was written
+    assert int(counters.min()) == int(counters.max()) == (3 * S if S > 1 else 0)      # one ticket per workgroup and launch
+
+
 @pytest.mark.parametrize('Bsz,H,A,S', [(64, 1024, 128, 6), (5, 32, 8, 2), (70, 64, 40, 3)])
 def test_cell_bwd_query_fused(dev, Bsz, H, A, S):
     """gt_cell_bwd_query = gt_lstm_cell_bwd whose dh also receives dq . Wq computed inside the kernel."""
