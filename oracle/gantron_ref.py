@@ -536,7 +536,7 @@ def attention_loss(align: Tensor, in_len: Tensor, out_len: Tensor) -> Tensor:
     total = 0
     for b in range(align.size(0)):
         ni, no = int(in_len[b]), int(out_len[b])
-        total = total + F.binary_cross_entropy(align[b].T[:ni, :no], attention_target(ni, no))
+        total = total + F.binary_cross_entropy(align[b].T[:ni, :no], attention_target(ni, no).to(align.dtype))
     return total / align.size(0)
 
 

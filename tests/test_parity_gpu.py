@@ -235,19 +235,34 @@ def test_midsize_against_oracle(dev, case):
         hp.fp16_run = True
         rel = float((res['out']['mel'] - out32[0]).abs().max() / out32[0].abs().max())
         assert 1e-4 < rel < 5e-2, f'bf16 path vs fp32 oracle: {rel:.3e}'
+    # adversarial terms are means of discriminator outputs of both signs (and d_loss.total a difference of two of
+    # them): their error is bounded by the size of the terms, not of the result
+    adv_atol = 5e-4 if bf16 else 1e-6
     for k, v in losses.items():
-        close(res['g_loss'][k], v, rtol=OT, atol=1e-6, what=f'g_loss.{k}')
+        close(res['g_loss'][k], v, rtol=OT, atol=adv_atol if k == 'adv' else 1e-6, what=f'g_loss.{k}')
     bad = []
     for k, v in grads.items():
         try:
-            close(res['g_grad'][k], v, rtol=GT, atol=GA, what=f'g_grad.{k}')
+            if k.startswith(('encoder.convolutions.', 'embedding.')) and v.numel() > 1 and B * Ti >= 1024:
+                # ReLU-threshold sensitivity: with B*Ti*512 pre-activations per encoder block, a few lie within fp32
+                # rounding of zero and fall on the other side of the ReLU for another summation order (tools/
+                # convstack_probe.py counts them against float64).  One such element moves one channel's slice of the
+                # weight gradients below it by percents of the tensor's max-abs while every other entry agrees to
+                # 1e-5: these tensors are held to a relative L2 error instead, with a loose max-abs bound
+                got = res['g_grad'][k].double()
+                l2 = float((got - v.double()).norm() / (v.double().norm() + 1e-30))
+                assert l2 <= (5e-2 if bf16 else 2e-3), f'g_grad.{k}: relative L2 error {l2:.3e}'
+                close(got, v, rtol=0.3 if bf16 else 6e-2, atol=GA, what=f'g_grad.{k}')
+            else:
+                close(res['g_grad'][k], v, rtol=GT, atol=GA, what=f'g_grad.{k}')
         except AssertionError as e:
             bad.append(str(e))
     keep_real = common.draw_disc_keep(stream, hp, B, To)
     keep_fake = common.draw_disc_keep(stream, hp, B, To)
     dl, dg = R.discriminator_step_grads(Dp, mel, ol, out[1], ol, keep_real, keep_fake, hp)
+    d_scale = max(float(dl['real'].abs()), float(dl['fake'].abs()))
     for k, v in dl.items():
-        close(res['d_loss'][k], v, rtol=OT, atol=1e-6, what=f'd_loss.{k}')
+        close(res['d_loss'][k], v, rtol=OT, atol=max(adv_atol, OT * d_scale if k == 'total' else 0.0), what=f'd_loss.{k}')
     for k, v in dg.items():
         try:
             close(res['d_grad'][k], v, rtol=GT, atol=GA, what=f'd_grad.{k}')
