@@ -6,8 +6,9 @@ Differences that come with the MI355X design:
   copy stream, ONE batched STFT-mel per batch on the GPU, double-buffered so batch i+1 is staged while
   batch i trains).  `TextMelLoader` keeps the reference's per-item behaviour (mel per item through the
   HIP STFT in the main process, or `load_mel_from_disk=True`) and is what validation uses;
-* wav files are decoded with scipy (16-bit PCM or float); files whose rate differs from
-  `hparams.sampling_rate` are rejected instead of resampled (librosa/resampy are not in the image).
+* wav files are decoded with scipy (8/16/32-bit PCM or float); files whose rate differs from
+  `hparams.sampling_rate` are resampled by `resample()` (a Kaiser-windowed polyphase filter with resampy's
+  kaiser_best parameters: the reference's librosa/resampy are not in the image, so this step is parity-unpinned).
 """
 import random
 
@@ -47,19 +48,37 @@ def load_vesus(filename, wavs_path, split='|', use_labels='one', use_text=True):
     return items, speakers, emotions
 
 
+def resample(x, sr_in, sr_out):
+    """Band-limited rate conversion for files that are not at hparams.sampling_rate.  The reference gets this from
+    librosa.load -> resampy 0.2.2 'kaiser_best' (utils.py:27-31), third-party code that is not in its tree: this is a
+    polyphase Kaiser-windowed sinc filter with resampy's published kaiser_best parameters (beta 14.7697, roll-off
+    0.9476, 64 zero crossings) through scipy.signal.resample_poly -- the same design, not bit-identical (parity
+    unpinned); the parity and benchmark inputs are generated at the target rate and never come here."""
+    from math import gcd
+    from scipy.signal import firwin, resample_poly
+    g = gcd(int(sr_in), int(sr_out))
+    up, down = int(sr_out) // g, int(sr_in) // g
+    zeros, beta, rolloff = 64, 14.769656459379492, 0.9475632
+    half = zeros * max(up, down)
+    h = firwin(2 * half + 1, rolloff / max(up, down), window=('kaiser', beta))
+    return resample_poly(x.astype(np.float64), up, down, window=h).astype(np.float32)
+
+
 def load_wav_to_torch(full_path, sampling_rate=22050):
     """reference utils.py:27-31 (librosa.load -> float32 in [-1, 1], peak-normalised only if it clips)."""
     from scipy.io import wavfile
     sr, data = wavfile.read(full_path)
-    if sr != sampling_rate:
-        raise ValueError(f'{full_path}: sampling rate {sr} != {sampling_rate} (resampling is not available)')
     if data.dtype == np.int16:
         data = data.astype(np.float32) / 32768.0
     elif data.dtype == np.int32:
         data = data.astype(np.float32) / 2147483648.0
+    elif data.dtype == np.uint8:
+        data = (data.astype(np.float32) - 128.0) / 128.0
     data = data.astype(np.float32)
     if data.ndim > 1:
         data = data.mean(axis=1)
+    if sr != sampling_rate:
+        data = resample(data, sr, sampling_rate)
     peak = max(abs(float(data.min())), abs(float(data.max())))
     if peak > 1:
         data = data / peak
@@ -101,6 +120,13 @@ class TextMelLoader(torch.utils.data.Dataset):
             assert mel.size(0) == self.n_mel_channels, \
                 'Mel dimension mismatch: given {}, expected {}'.format(mel.size(0), self.n_mel_channels)
             return mel
+        if torch.utils.data.get_worker_info() is not None:
+            # reference data_utils.py:51-58 runs its CPU STFT inside the (forked) worker; a HIP context does not survive
+            # a fork, and this package has no CPU arithmetic path on purpose
+            raise RuntimeError('TextMelLoader.get_mel on raw audio needs the GPU and cannot run inside a DataLoader worker: '
+                               'use num_workers=0, or TextAudioLoader + TextAudioCollate + DeviceBatches (what train.py does: '
+                               'workers decode wav + text, the main process runs one batched STFT-mel per batch on the '
+                               'device), or precomputed mels with load_mel_from_disk=True')
         audio = load_wav_to_torch(filename, self.sampling_rate).unsqueeze(0)
         return self._stft_module().mel_spectrogram(audio.cuda()).squeeze(0).cpu()
 

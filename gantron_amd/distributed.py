@@ -33,15 +33,33 @@ def _tick(on):
     return time.perf_counter()
 
 
-def _average_flat(module):
-    flat = module._flat_grad
-    dist.all_reduce(flat)
-    world = dist.get_world_size()
+def _scale(flat, world):
     if flat.is_cuda:
         from . import ops
         ops.call('gt_scale_dev', flat, None, 1.0 / world, flat, flat.numel(), 0)
     else:
         flat.div_(world)          # gloo wiring tests on the CPU
+
+
+def _average_flat(module):
+    """SUM all-reduce of the flat gradient buffer, then 1/world.  Ranges that a bucket already put on the wire while
+    the backward pass was still running (module._early_buckets) are only waited for."""
+    flat = module._flat_grad
+    early = getattr(module, '_early_buckets', None) or []
+    module._early_buckets = []
+    covered = sorted((b, e) for b, e, _ in early)
+    pos, rest = 0, []
+    for b, e in covered:
+        if b > pos:
+            rest.append((pos, b))
+        pos = max(pos, e)
+    if pos < flat.numel():
+        rest.append((pos, flat.numel()))
+    for b, e in rest:
+        dist.all_reduce(flat[b:e])
+    for _, _, work in early:
+        work.wait()                # the current stream waits for the side-stream collective
+    _scale(flat, dist.get_world_size())
 
 
 def apply_gradient_allreduce(module):
@@ -51,8 +69,11 @@ def apply_gradient_allreduce(module):
         dist.broadcast(buf, 0)
 
     timing = os.environ.get('GANTRON_DIST_TIMING') == '1'      # diagnostics: synchronising per-phase timer
+    overlap = os.environ.get('GANTRON_DIST_OVERLAP', '1') != '0'
+    state = {'queued': False, 'comm': None}
 
     def allreduce_params():
+        state['queued'] = False
         if not getattr(module, 'needs_reduction', False):
             return
         module.needs_reduction = False
@@ -60,9 +81,13 @@ def apply_gradient_allreduce(module):
         t0 = _tick(timing)
         for name, p in module.named_parameters():
             if p.grad is None:
-                views[name].zero_()
+                if not getattr(module, '_direct_grads', False):
+                    views[name].zero_()
             elif p.grad.data_ptr() != views[name].data_ptr():     # autograd handed back its own tensor
-                views[name].copy_(p.grad)
+                if getattr(module, '_direct_grads', False):
+                    views[name].add_(p.grad)                      # the buffer already holds the engine's share
+                else:
+                    views[name].copy_(p.grad)
                 p.grad = views[name]
             # else: the gradient was accumulated in place in the flat buffer already
         t1 = _tick(timing)
@@ -73,11 +98,34 @@ def apply_gradient_allreduce(module):
                   f'({module._flat_grad.numel() * 4 / 1e6:.1f} MB)', flush=True)
 
     def allreduce_hook(*unused):
-        Variable._execution_engine.queue_callback(allreduce_params)
+        if not state['queued']:        # one end-of-backward callback per backward pass (distributed.py:163-167)
+            state['queued'] = True
+            Variable._execution_engine.queue_callback(allreduce_params)
 
     for p in module.parameters():
         if p.requires_grad:
             p.register_hook(allreduce_hook)
+    # model.py's autograd nodes write gradients straight into the flat buffer (optim.enable_direct_grads): autograd
+    # never sees them, so no parameter hook fires -- the nodes call this instead
+    module._after_backward = allreduce_hook
+
+    def bucket_ready(prefix, event):
+        """engine.GeneratorEngine.backward: the gradients under `prefix` are final once `event` has happened.  Their
+        slice of the flat buffer goes on the wire now, from a side stream, while the decoder loop is still running."""
+        if not (overlap and getattr(module, '_direct_grads', False) and module._flat_grad.is_cuda):
+            return
+        from .optim import flat_range
+        rng = flat_range(module, prefix)
+        if rng is None:
+            return
+        if state['comm'] is None:
+            state['comm'] = torch.cuda.Stream()
+        comm = state['comm']
+        comm.wait_event(event)
+        with torch.cuda.stream(comm):
+            work = dist.all_reduce(module._flat_grad[rng[0]:rng[1]], async_op=True)
+        module.__dict__.setdefault('_early_buckets', []).append((rng[0], rng[1], work))
+    module._bucket_ready = bucket_ready
 
     def set_needs_reduction(mod, inputs, output):
         mod.needs_reduction = True

@@ -684,9 +684,22 @@ class GeneratorEngine:
 
     # ------------------------------------------------------------------------------ backward
     @_gemm_precision
-    def backward(self, P, G, sv, dmel, dmel_post, dgate, dalign):
+    def backward(self, P, G, sv, dmel, dmel_post, dgate, dalign, on_ready=None):
+        """Generator backward (see _backward).  Whatever happens inside -- a GantronHipError from a loop call included --
+        the split-K target of the overlapped region is restored and the leaf stream is joined before the buffers it
+        reads can be recycled."""
+        target = ops.SPLITK_TARGET
+        try:
+            return self._backward(P, G, sv, dmel, dmel_post, dgate, dalign, on_ready)
+        finally:
+            ops.SPLITK_TARGET = target
+            LEAF.join()
+
+    def _backward(self, P, G, sv, dmel, dmel_post, dgate, dalign, on_ready=None):
         """Accumulate parameter gradients into G (dict name -> tensor).  d* are gradients of the four
-        outputs (any may be None).  (Running the whole backward on a high-priority stream so that the loop kernels win
+        outputs (any may be None).  on_ready(prefix, event): called when the gradients of every parameter under
+        `prefix` are final, `event` being recorded behind the last kernel that writes them (the data-parallel wrapper
+        starts that bucket's all-reduce while the decoder loop still runs).  (Running the whole backward on a high-priority stream so that the loop kernels win
         the CUs over the leaf stream's weight-gradient GEMMs was measured: no gain on MI355X.)"""
         hp = self.hp
         B, Bp, Ti, To = sv['B'], sv['Bp'], sv['Ti'], sv['To']
@@ -709,6 +722,16 @@ class GeneratorEngine:
             call('gt_axpby', dmel_cl, 1.0, dx, 1.0, dmel_cl, B * To * n_mel)
 
         PHASES.mark('b.postnet')
+        if on_ready is not None and dmel_post is not None:
+            # the PostNet's gradients are complete long before the decoder loop ends: weight gradients come off the leaf
+            # stream, BatchNorm gradients off this one
+            ev = torch.cuda.Event()
+            if LEAF.enabled and LEAF.stream is not None:
+                LEAF.stream.wait_stream(torch.cuda.current_stream())
+                ev.record(LEAF.stream)
+            else:
+                ev.record(torch.cuda.current_stream())
+            on_ready('postnet.', ev)
         # weight-gradient GEMMs issued from here to the end of the decoder loop run UNDER that loop (leaf stream)
         gentle = ops.splitk_target(ops.SPLITK_OVERLAPPED)
         gentle.__enter__()
@@ -972,13 +995,15 @@ class DiscriminatorEngine:
         return loss, sv
 
     @_gemm_precision
-    def backward(self, P, G, sv, dloss, scale=1.0, need_dinput=True, need_dparams=True):
-        """dloss: (1,) cuda tensor (upstream gradient) or None for 1.  Returns d mel (B, n_mel, T)."""
+    def backward(self, P, G, sv, dloss, scale=1.0, need_dinput=True, need_dparams=True, dout=None):
+        """dloss: (1,) cuda tensor (upstream gradient of the adversarial loss) or None for 1; alternatively dout
+        (B*W, 1): the gradient of the per-window outputs themselves (Discriminator.forward).  Returns d mel (B, n_mel, T)."""
         B, T, W = sv['B'], sv['T'], sv['W']
         dev = sv['out'].device
         win, n_mel = self.window, self.n_mel
-        dout = _f32(B * W, 1, device=dev, zero=False)
-        call('gt_adv_mean_bwd', dloss, sv['lengths'], B, W, win, float(scale), dout)
+        if dout is None:
+            dout = _f32(B * W, 1, device=dev, zero=False)
+            call('gt_adv_mean_bwd', dloss, sv['lengths'], B, W, win, float(scale), dout)
         W4 = P['discriminator.4.weight']
         c4 = W4.shape[1]
         if need_dparams:
@@ -1083,6 +1108,44 @@ class LinearDiscriminatorEngine:
         self.window, self.n_mel = hp.discriminator_window, hp.n_mel_channels
         self.bf16 = bool(getattr(hp, 'fp16_run', False))
 
+    def layers_forward(self, P, x, keeps, training):
+        """The dense chain on already-cut windows x (NW, window*n_mel) -> (NW, 1) (LinearDiscriminator.forward)."""
+        NW = x.shape[0]
+        layers = []
+        for i in range(3):
+            Wt = P[f'discriminator.{i}.module.0.weight']
+            cout, cin = Wt.shape
+            y = ops.linear(x, Wt, NW, cin, cout)
+            keep = keeps[i] if (keeps is not None and training) else None
+            call('gt_bias_act_drop_fwd', y, P[f'discriminator.{i}.module.0.bias'], NW, cout, ACT_TANH, 1, keep, 0.5, y)
+            layers.append(dict(x=x, y=y, keep=keep))
+            x = y
+        W3 = P['discriminator.3.weight']
+        out = ops.linear(x, W3, NW, W3.shape[1], 1, bias=P['discriminator.3.bias'])
+        return out, dict(NW=NW, layers=layers, h3=x, out=out)
+
+    def layers_backward(self, P, G, sv, dout, need_dinput=True, need_dparams=True):
+        """dout (NW, 1) -> gradient of the windows (NW, window*n_mel) (or None); parameter gradients are added to G."""
+        NW = sv['NW']
+        W3 = P['discriminator.3.weight']
+        c3 = W3.shape[1]
+        if need_dparams:
+            ops.linear_dw(dout, sv['h3'], NW, 1, c3, G['discriminator.3.weight'])
+            acc_add(G['discriminator.3.bias'], ops.col_sums(dout, NW, 1))
+        dy = ops.linear_dx(dout, W3, NW, 1, c3)
+        for i in reversed(range(3)):
+            Wt = P[f'discriminator.{i}.module.0.weight']
+            cout, cin = Wt.shape
+            L = sv['layers'][i]
+            dz = _f32(NW, cout, device=dout.device, zero=False)
+            call('gt_bias_act_drop_bwd', dy, L['y'], NW, cout, ACT_TANH, 1, L['keep'], 0.5, dz)
+            if need_dparams:
+                ops.linear_dw(dz, L['x'], NW, cout, cin, G[f'discriminator.{i}.module.0.weight'])
+                acc_add(G[f'discriminator.{i}.module.0.bias'], ops.col_sums(dz, NW, cout))
+            if i > 0 or need_dinput:
+                dy = ops.linear_dx(dz, Wt, NW, cout, cin)
+        return dy if need_dinput else None
+
     @_gemm_precision
     def forward(self, P, mel, starts, keeps, training=True):
         """mel (B, n_mel, T) cuda; starts: per item the list of window start frames.  Returns loss (1,), saved."""
@@ -1101,18 +1164,8 @@ class LinearDiscriminatorEngine:
         call('gt_permute3', mel.contiguous(), n_mel * T, 1, T, B, T, n_mel, frames, 0, 0, 0, 1.0)
         x = _f32(NW, win * n_mel, device=dev, zero=False)
         call('gt_gather_rows', frames, n_mel, idx, NW * win, n_mel, x, n_mel, 0)
-        sv = dict(B=B, T=T, NW=NW, idx=idx, wgt=wgt, layers=[])
-        for i in range(3):
-            Wt = P[f'discriminator.{i}.module.0.weight']
-            cout, cin = Wt.shape
-            y = ops.linear(x, Wt, NW, cin, cout)
-            keep = keeps[i] if (keeps is not None and training) else None
-            call('gt_bias_act_drop_fwd', y, P[f'discriminator.{i}.module.0.bias'], NW, cout, ACT_TANH, 1, keep, 0.5, y)
-            sv['layers'].append(dict(x=x, y=y, keep=keep))
-            x = y
-        W3 = P['discriminator.3.weight']
-        out = ops.linear(x, W3, NW, W3.shape[1], 1, bias=P['discriminator.3.bias'])
-        sv['h3'], sv['out'] = x, out
+        out, sv = self.layers_forward(P, x, keeps, training)
+        sv.update(B=B, T=T, idx=idx, wgt=wgt)
         loss = _f32(1, device=dev)
         sgemm(Operand(wgt, KC, ld=NW), Operand(out, RC, ld=1), loss, 1, 1, NW)           # sum_w wgt[w] * out[w]
         return loss, sv
@@ -1124,23 +1177,7 @@ class LinearDiscriminatorEngine:
         win, n_mel = self.window, self.n_mel
         dout = _f32(NW, 1, device=dev, zero=False)
         call('gt_scale_dev', sv['wgt'], dloss, float(scale), dout, NW, 0)                  # dout[w] = dloss * wgt[w]
-        W3 = P['discriminator.3.weight']
-        c3 = W3.shape[1]
-        if need_dparams:
-            ops.linear_dw(dout, sv['h3'], NW, 1, c3, G['discriminator.3.weight'])
-            acc_add(G['discriminator.3.bias'], ops.col_sums(dout, NW, 1))
-        dy = ops.linear_dx(dout, W3, NW, 1, c3)
-        for i in reversed(range(3)):
-            Wt = P[f'discriminator.{i}.module.0.weight']
-            cout, cin = Wt.shape
-            L = sv['layers'][i]
-            dz = _f32(NW, cout, device=dev, zero=False)
-            call('gt_bias_act_drop_bwd', dy, L['y'], NW, cout, ACT_TANH, 1, L['keep'], 0.5, dz)
-            if need_dparams:
-                ops.linear_dw(dz, L['x'], NW, cout, cin, G[f'discriminator.{i}.module.0.weight'])
-                acc_add(G[f'discriminator.{i}.module.0.bias'], ops.col_sums(dz, NW, cout))
-            if i > 0 or need_dinput:
-                dy = ops.linear_dx(dz, Wt, NW, cout, cin)
+        dy = self.layers_backward(P, G, sv, dout, need_dinput, need_dparams)
         if not need_dinput:
             return None
         # scatter-add the window gradients back to their frames (windows overlap), then to (B, n_mel, T)

@@ -52,6 +52,27 @@ def _named_tensors(module):
     return names, tensors
 
 
+def _direct(module):
+    return getattr(module, '_direct_grads', False) and getattr(module, '_grad_views', None) is not None
+
+
+def _publish_direct(module):
+    """After an in-place accumulation into the flat gradient buffer: every p.grad is its view of that buffer (a gradient
+    another autograd node left in a tensor of its own is folded in), then the data-parallel wrapper -- which cannot rely
+    on parameter hooks here, autograd never sees these gradients -- is told that a backward pass produced gradients."""
+    views = module._grad_views
+    for name, p in module.named_parameters():
+        v = views[name]
+        if p.grad is None:
+            p.grad = v
+        elif p.grad.data_ptr() != v.data_ptr():
+            v.add_(p.grad)
+            p.grad = v
+    hook = getattr(module, '_after_backward', None)
+    if hook is not None:
+        hook()
+
+
 class _GeneratorFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, text, in_lens, mels, out_lens, rng, speaker_ids, emotions, *params):
@@ -66,6 +87,12 @@ class _GeneratorFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dmel, dpost, dgate, dalign):
         module, P = ctx.module, ctx.P
+        if _direct(module) and all(ctx.needs):
+            # gradients are accumulated in place in the flat gradient buffer (optim.enable_direct_grads)
+            module.engine.backward(P, module._grad_views, ctx.sv, dmel, dpost, dgate, dalign,
+                                   on_ready=getattr(module, '_bucket_ready', None))
+            _publish_direct(module)
+            return (None,) * (8 + len(ctx.needs))
         G = {k: torch.zeros_like(P[k]) for k in module._param_names}
         module.engine.backward(P, G, ctx.sv, dmel, dpost, dgate, dalign)
         grads = tuple(G[k] if need else None for k, need in zip(module._param_names, ctx.needs))
@@ -280,9 +307,13 @@ class _AdversarialFn(torch.autograd.Function):
     def backward(ctx, dloss):
         module, P = ctx.module, ctx.P
         need_p = any(ctx.needs)
-        G = {k: torch.zeros_like(P[k]) for k in module._param_names} if need_p else None
+        direct = need_p and all(ctx.needs) and _direct(module)
+        G = module._grad_views if direct else ({k: torch.zeros_like(P[k]) for k in module._param_names} if need_p else None)
         dmel = module.engine.backward(P, G, ctx.sv, dloss.contiguous().view(1), 1.0, need_dinput=ctx.need_in,
                                       need_dparams=need_p)
+        if direct:
+            _publish_direct(module)
+            return (None, dmel, None, None) + (None,) * len(ctx.needs)
         grads = tuple(G[k] if need else None for k, need in zip(module._param_names, ctx.needs)) if need_p \
             else (None,) * len(ctx.needs)
         return (None, dmel, None, None) + grads
@@ -311,6 +342,31 @@ class _GradientPenaltyFn(torch.autograd.Function):
                 ops.call('gt_scale_dev', ctx.G[k], d, 1.0, ctx.G[k], ctx.G[k].numel(), 0)
             grads.append(ctx.G[k] if need else None)
         return (None,) * 6 + tuple(grads)
+
+
+class _DiscForwardFn(torch.autograd.Function):
+    """Discriminator.forward as one autograd node: mel (B, n_mel, T) -> (B, W) window outputs."""
+
+    @staticmethod
+    def forward(ctx, module, mel, keeps, *params):
+        P = dict(zip(module._param_names, (p.detach() for p in params)))
+        lengths = torch.full((mel.size(0),), mel.size(2), dtype=torch.int64, device=mel.device)
+        _, sv = module.engine.forward(P, mel.detach(), lengths, keeps, training=module.training)
+        ctx.module, ctx.sv, ctx.P = module, sv, P
+        ctx.need_in = mel.requires_grad
+        ctx.needs = [p.requires_grad for p in params]
+        return sv['out'].view(mel.size(0), -1).clone()
+
+    @staticmethod
+    def backward(ctx, dout):
+        module, P = ctx.module, ctx.P
+        need_p = any(ctx.needs)
+        G = {k: torch.zeros_like(P[k]) for k in module._param_names} if need_p else None
+        dmel = module.engine.backward(P, G, ctx.sv, None, 1.0, need_dinput=ctx.need_in, need_dparams=need_p,
+                                      dout=dout.contiguous().view(-1, 1))
+        grads = tuple(G[k] if need else None for k, need in zip(module._param_names, ctx.needs)) if need_p \
+            else (None,) * len(ctx.needs)
+        return (None, dmel, None) + grads
 
 
 class Discriminator(nn.Module):
@@ -368,13 +424,12 @@ class Discriminator(nn.Module):
                                         keeps, *params)
 
     def forward(self, inputs):
-        """inputs (B, T, n_mel) -> (B, W); reference model.py:514-527 (no gradient through this entry)."""
+        """inputs (B, T, n_mel) -> (B, W) per-window outputs; reference model.py:514-527.  Differentiable with respect
+        to the input and the parameters (train.gradient_penalty, train.py:52-58, differentiates exactly this call)."""
+        params = [p for _, p in self.named_parameters()]
         mel = inputs.transpose(1, 2).contiguous()
-        P = {k: v.detach() for k, v in self.named_parameters()}
-        lengths = torch.full((mel.size(0),), mel.size(2), dtype=torch.int64, device=mel.device)
-        _, sv = self.engine.forward(P, mel, lengths, self._keeps(mel.size(0), mel.size(2), mel.device),
-                                    training=self.training)
-        return sv['out'].view(mel.size(0), -1)
+        keeps = self._keeps(mel.size(0), mel.size(2), mel.device)
+        return _DiscForwardFn.apply(self, mel, keeps, *params)
 
 
 class _LinearAdvFn(torch.autograd.Function):
@@ -391,12 +446,43 @@ class _LinearAdvFn(torch.autograd.Function):
     def backward(ctx, dloss):
         module, P = ctx.module, ctx.P
         need_p = any(ctx.needs)
-        G = {k: torch.zeros_like(P[k]) for k in module._param_names} if need_p else None
+        direct = need_p and all(ctx.needs) and _direct(module)
+        G = module._grad_views if direct else ({k: torch.zeros_like(P[k]) for k in module._param_names} if need_p else None)
         dmel = module.engine.backward(P, G, ctx.sv, dloss.contiguous().view(1), 1.0, need_dinput=ctx.need_in,
                                       need_dparams=need_p)
+        if direct:
+            _publish_direct(module)
+            return (None, dmel, None, None) + (None,) * len(ctx.needs)
         grads = tuple(G[k] if need else None for k, need in zip(module._param_names, ctx.needs)) if need_p \
             else (None,) * len(ctx.needs)
         return (None, dmel, None, None) + grads
+
+
+class _LinearFwdFn(torch.autograd.Function):
+    """LinearDiscriminator.forward as one autograd node: windows (NW, window*n_mel) -> (NW, 1)."""
+
+    @staticmethod
+    def forward(ctx, module, x, keeps, *params):
+        from . import ops as _ops
+        P = dict(zip(module._param_names, (p.detach() for p in params)))
+        with _ops.bf16_gemms(module.engine.bf16):
+            out, sv = module.engine.layers_forward(P, x.detach(), keeps, module.training)
+        ctx.module, ctx.sv, ctx.P = module, sv, P
+        ctx.need_in = x.requires_grad
+        ctx.needs = [p.requires_grad for p in params]
+        return out.clone()
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import ops as _ops
+        module, P = ctx.module, ctx.P
+        need_p = any(ctx.needs)
+        G = {k: torch.zeros_like(P[k]) for k in module._param_names} if need_p else None
+        with _ops.bf16_gemms(module.engine.bf16):
+            dx = module.engine.layers_backward(P, G, ctx.sv, dout.contiguous(), need_dinput=ctx.need_in, need_dparams=need_p)
+        grads = tuple(G[k] if need else None for k, need in zip(module._param_names, ctx.needs)) if need_p \
+            else (None,) * len(ctx.needs)
+        return (None, dx, None) + grads
 
 
 class LinearDiscriminator(nn.Module):
@@ -445,5 +531,11 @@ class LinearDiscriminator(nn.Module):
         return _LinearAdvFn.apply(self, inputs.contiguous(), starts, keeps, *params)
 
     def forward(self, inputs):
-        """inputs (NW, window * n_mel) already-cut windows -> (NW, 1) (reference model.py:556-565)."""
-        raise NotImplementedError('call adversarial_loss(); the window-level forward is not part of the training path')
+        """inputs (NW, window * n_mel) already-cut windows (frame-major) -> (NW, 1); reference model.py:556-565.
+        Differentiable with respect to the windows and the parameters."""
+        keeps = self.rng_override
+        if keeps is None and self.training:
+            dims = [self.discriminator[i].module[0].out_features for i in range(3)]
+            keeps = [self.dropout_source.keep((inputs.size(0), c), 0.5, inputs.device) for c in dims]
+        params = [p for _, p in self.named_parameters()]
+        return _LinearFwdFn.apply(self, inputs.contiguous().float(), keeps, *params)

@@ -41,10 +41,35 @@ def flatten_module(module):
     return flat, grad
 
 
+def enable_direct_grads(module):
+    """The autograd nodes of model.py then ACCUMULATE parameter gradients straight into the flat gradient buffer and
+    point every p.grad at its view of it: no per-backward zero-filled gradient tensors, no copy into the flat buffer
+    before the optimizer step or the all-reduce.  Because the buffer is the only home of the gradients, zeroing it is
+    part of zero_grad(): the module's zero_grad is rebound accordingly."""
+    flatten_module(module)
+    if getattr(module, '_direct_grads', False):
+        return
+    module._direct_grads = True
+
+    def zero_grad(set_to_none=True):
+        module._flat_grad.zero_()
+        for p in module.parameters():
+            p.grad = None
+    module.zero_grad = zero_grad
+
+
+def flat_range(module, prefix):
+    """[begin, end) of the flat buffers covered by the parameters whose names start with `prefix` (contiguous when the
+    prefix names a sub-module)."""
+    hits = [(o, o + -(-n // 4) * 4) for k, o, n in module._flat_layout if k.startswith(prefix)]
+    return (min(h[0] for h in hits), max(h[1] for h in hits)) if hits else None
+
+
 class FlatAdam:
     def __init__(self, module, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         self.module = module
         self.flat, self.grad = flatten_module(module)
+        enable_direct_grads(module)
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
         self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)]

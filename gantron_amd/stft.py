@@ -69,7 +69,13 @@ class TacotronSTFT(nn.Module):
 
     def _magnitude_rows(self, y):
         """y (B, n) cuda -> (B*frames, cutoff) magnitudes, frames = n // hop + 1."""
-        assert y.is_cuda and y.dim() == 2
+        if not y.is_cuda:
+            # no CPU fallback by design: the windowed DFT is a HIP GEMM.  A forked DataLoader worker cannot own a HIP
+            # context, so raw audio is turned into mels in the MAIN process (data_utils.TextAudioLoader -> DeviceBatches)
+            raise RuntimeError('TacotronSTFT runs on the GPU only (no CPU path): call it from the main process with CUDA '
+                               'tensors -- inside DataLoader workers use data_utils.TextAudioLoader + DeviceBatches (raw '
+                               'audio out of the worker, one batched STFT-mel on the device) or load_mel_from_disk=True')
+        assert y.dim() == 2
         B, n = y.shape
         N, hop, cut = self.filter_length, self.hop_length, self.cutoff
         frames = n // hop + 1

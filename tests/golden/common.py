@@ -132,3 +132,39 @@ def pack_dict(prefix, d):
 def unpack_dict(npz, prefix):
     pre = prefix + '/'
     return {k[len(pre):]: torch.from_numpy(np.asarray(npz[k])) for k in npz.files if k.startswith(pre)}
+
+
+# ---- loader / collate fixture (loader_collate.npz): a small dataset both the reference and the repo read
+LOADER_TEXTS = ['Printing, in the only sense with which we are at present concerned,',
+                'differs from most if not from all the arts and crafts represented in the Exhibition',
+                'Mr. Smith and Dr. Jones met Mrs. Brown; "quoted" text -- dashes?',
+                'in being comparatively modern.',
+                'Hello!',
+                'For although the Chinese took impressions from wood blocks engraved in relief for centuries',
+                'produced the block books, which were the immediate predecessors of the true printed book,',
+                'A b c']
+VESUS_TEXTS = ['I am happy today.', 'Leave me alone!', 'What a day.']
+
+
+def write_loader_dataset(root, n_mel=8, seed=3):
+    """Writes mels (.npy, load_mel_from_disk) and two filelists under `root`; returns (lj_list, vesus_list)."""
+    import os
+    g = torch.Generator().manual_seed(seed)
+    os.makedirs(os.path.join(root, 'mels'), exist_ok=True)
+    os.makedirs(os.path.join(root, 'vesus', 'Happy'), exist_ok=True)
+    os.makedirs(os.path.join(root, 'vesus', 'Angry'), exist_ok=True)
+    lj = os.path.join(root, 'lj.txt')
+    with open(lj, 'w') as f:
+        for i, t in enumerate(LOADER_TEXTS):
+            frames = int(torch.randint(5, 40, (1,), generator=g))
+            np.save(os.path.join(root, 'mels', f'a{i}.npy'), torch.randn(n_mel, frames, generator=g).numpy())
+            f.write(f'mels/a{i}.npy|{t}\n')
+    ve = os.path.join(root, 'vesus.txt')
+    with open(ve, 'w') as f:
+        for i, t in enumerate(VESUS_TEXTS):
+            emo = 'Happy' if i % 2 == 0 else 'Angry'
+            frames = int(torch.randint(5, 40, (1,), generator=g))
+            np.save(os.path.join(root, 'vesus', emo, f'v{i}.npy'), torch.randn(n_mel, frames, generator=g).numpy())
+            votes = ', '.join(str(v) for v in torch.rand(5, generator=g).round(decimals=2).tolist())
+            f.write(f'vesus/{emo}/v{i}.npy|{t}|{i + 3}|{votes}\n')
+    return lj, ve

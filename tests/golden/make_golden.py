@@ -395,8 +395,42 @@ def linear_disc_case():
     print('wrote', path, os.path.getsize(path) // 1024, 'KiB', 'loss', float(loss))
 
 
+def loader_collate_case():
+    """The reference's TextMelLoader (text front-end, seeded index shuffle, load_mel_from_disk, VESUS speakers/labels)
+    and TextMelCollate (data_utils.py:13-131) on a small dataset both sides can build (common.write_loader_dataset)."""
+    import tempfile
+    import data_utils as ref_data
+    out = {}
+    for tag, hp_extra in (('lj', ''), ('vesus', ',vesus_path=ROOT/,use_intended_labels=True'),
+                          ('vesus_multi', ',vesus_path=ROOT/,use_intended_labels=False')):
+        with tempfile.TemporaryDirectory() as root:
+            lj, ve = common.write_loader_dataset(root)
+            hp = ref_hparams.HParams(('use_labels=True,use_noise=True,n_mel_channels=8,load_mel_from_disk=True,seed=77'
+                                      + hp_extra).replace('ROOT', root))
+            ds = ref_data.TextMelLoader([lj, ve], hp, root + '/')
+            items = [ds[i] for i in range(len(ds))]
+            batch = ref_data.TextMelCollate(1)(items[:5] if tag == 'lj' else items)
+            out[f'{tag}/idx'] = np.asarray(ds.idx)
+            out[f'{tag}/n'] = np.asarray(len(ds))
+            for i, it in enumerate(items):
+                out[f'{tag}/text{i}'] = it[0].numpy()
+                if len(it) == 4:
+                    out[f'{tag}/speaker{i}'] = np.asarray(int(it[2]))
+                    out[f'{tag}/emotions{i}'] = it[3].numpy()
+            names = ('text_padded', 'input_lengths', 'mel_padded', 'gate_padded', 'speaker_ids', 'emotions', 'output_lengths')
+            for nme, t in zip(names, batch):
+                if tag == 'lj' and nme in ('speaker_ids', 'emotions'):
+                    continue                     # uninitialised memory in the reference when the items carry no labels
+                out[f'{tag}/batch/{nme}'] = t.numpy()
+    path = os.path.join(HERE, 'loader_collate.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, os.path.getsize(path) // 1024, 'KiB')
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['tiny', 'ops', 'full', 'vesus', 'allreduce', 'inference', 'linear', 'encin', 'gp']
+    which = sys.argv[1:] or ['tiny', 'ops', 'full', 'vesus', 'allreduce', 'inference', 'linear', 'encin', 'gp', 'loader']
+    if 'loader' in which:
+        loader_collate_case()
     if 'gp' in which:
         gradient_penalty_case()
     if 'encin' in which:

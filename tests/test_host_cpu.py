@@ -6,6 +6,7 @@ import os
 import re
 import subprocess
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -171,3 +172,87 @@ def test_flat_adam_state_dict_uses_torch_adam_layout():
         assert float(sd['state'][i]['step']) == float(st['step'])
     ref2 = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-6)
     ref2.load_state_dict(sd)                     # and back: the reference's optimizer accepts our dict
+
+
+def test_multiproc_launcher_env_and_supervision(tmp_path):
+    """gantron_amd.multiproc: every rank gets the torchrun environment plus the reference's --n_gpus/--rank/--group_name
+    flags (reference multiproc.py:13-20), ranks > 0 log to files, and a failing rank stops the job instead of leaving
+    the others hanging."""
+    import subprocess
+    script = tmp_path / 'worker.py'
+    script.write_text(
+        'import os, sys, time\n'
+        'rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])\n'
+        'assert f"--rank={rank}" in sys.argv and f"--n_gpus={world}" in sys.argv, sys.argv\n'
+        'assert os.environ["MASTER_ADDR"] == "127.0.0.1" and os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"\n'
+        'print("worker", rank, "of", world, flush=True)\n'
+        'if "--fail" in sys.argv and rank == 1:\n'
+        '    sys.exit(7)\n'
+        'if "--fail" in sys.argv:\n'
+        '    time.sleep(60)\n')
+    base = [sys.executable, '-m', 'gantron_amd.multiproc', '--gpus', '2', '--log-dir', str(tmp_path / 'logs'), str(script)]
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run(base, env=env, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    assert 'worker 0 of 2' in r.stdout
+    logs = list((tmp_path / 'logs').glob('*_rank1.log'))
+    assert len(logs) == 1 and 'worker 1 of 2' in logs[0].read_text()
+    t0 = time.time()
+    r = subprocess.run(base + ['--fail'], env=env, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 7 and time.time() - t0 < 30, (r.returncode, r.stderr)
+
+
+@pytest.mark.parametrize('tag', ['lj', 'vesus', 'vesus_multi'])
+def test_loader_and_collate_match_the_reference(golden_dir, tmp_path, tag):
+    """TextMelLoader (text front-end, seeded shuffle, mels from disk, VESUS speakers / labels) and TextMelCollate against
+    loader_collate.npz, which tests/golden/make_golden.py produced by running the reference's own classes
+    (data_utils.py:13-131) on the same small dataset (common.write_loader_dataset)."""
+    import common
+    from gantron_amd.data_utils import TextMelCollate, TextMelLoader
+    from gantron_amd.hparams import HParams
+    z = np.load(os.path.join(golden_dir, 'loader_collate.npz'))
+    root = str(tmp_path)
+    lj, ve = common.write_loader_dataset(root)
+    extra = {'lj': '', 'vesus': f',vesus_path={root}/,use_intended_labels=True',
+             'vesus_multi': f',vesus_path={root}/,use_intended_labels=False'}[tag]
+    hp = HParams('use_labels=True,use_noise=True,n_mel_channels=8,load_mel_from_disk=True,seed=77' + extra)
+    ds = TextMelLoader([lj, ve], hp, root + '/')
+    assert len(ds) == int(z[f'{tag}/n'])
+    assert list(ds.idx) == z[f'{tag}/idx'].tolist()
+    items = [ds[i] for i in range(len(ds))]
+    for i, it in enumerate(items):
+        assert it[0].tolist() == z[f'{tag}/text{i}'].tolist(), f'text ids of item {i}'
+        if tag != 'lj':
+            assert int(it[2]) == int(z[f'{tag}/speaker{i}'])
+            np.testing.assert_allclose(it[3].numpy(), z[f'{tag}/emotions{i}'])
+    batch = TextMelCollate(1)(items[:5] if tag == 'lj' else items)
+    names = ('text_padded', 'input_lengths', 'mel_padded', 'gate_padded', 'speaker_ids', 'emotions', 'output_lengths')
+    for nme, t in zip(names, batch):
+        key = f'{tag}/batch/{nme}'
+        if key in z.files:
+            assert tuple(t.shape) == z[key].shape and str(t.dtype).replace('torch.', '') == str(z[key].dtype), (nme, t.dtype, z[key].dtype)
+            np.testing.assert_array_equal(t.numpy(), z[key], err_msg=nme)
+
+
+def test_stft_refuses_to_run_without_the_gpu():
+    """There is no CPU arithmetic path: TacotronSTFT on a CPU tensor (e.g. inside a forked DataLoader worker, where the
+    reference runs its CPU STFT, data_utils.py:51-58) fails loudly and names the device data path instead."""
+    from gantron_amd.stft import TacotronSTFT
+    with pytest.raises(RuntimeError, match='DeviceBatches'):
+        TacotronSTFT().mel_spectrogram(torch.zeros(1, 4096))
+
+
+def test_load_wav_resamples_other_rates(tmp_path):
+    """load_wav_to_torch (reference utils.py:27-31 = librosa.load(path, sr)): a 44.1 kHz and a 16 kHz file come back at
+    22 050 Hz with the tone preserved (band-limited conversion; the filter itself is third-party, parity unpinned)."""
+    from scipy.io import wavfile
+    from gantron_amd.data_utils import load_wav_to_torch
+    for sr in (44100, 16000, 22050):
+        t = np.arange(sr) / sr                      # one second
+        x = (0.5 * np.sin(2 * np.pi * 440.0 * t)).astype(np.float32)
+        path = str(tmp_path / f'tone_{sr}.wav')
+        wavfile.write(path, sr, (x * 32767).astype(np.int16))
+        y = load_wav_to_torch(path, 22050).numpy()
+        assert abs(len(y) - 22050) <= 1 and y.dtype == np.float32
+        ref = 0.5 * np.sin(2 * np.pi * 440.0 * np.arange(len(y)) / 22050)
+        assert np.abs(y[2000:-2000] - ref[2000:-2000]).max() < 2e-3, sr
