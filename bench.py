@@ -13,7 +13,9 @@ Multi-GPU: one process per GPU, each with its own batch (weak scaling), flat-buf
 all-reduce over RCCL after every backward.  Rank 0 prints ONE JSON line.
 
     python bench.py --bf16        # BASELINE config 3 (hparams.fp16_run), a separate, explicitly labelled line
-    python bench.py --batch 128   # BASELINE config 5's batch size
+    python bench.py --vesus       # BASELINE config 4: VESUS labels + speakers + noise (E = 1093), 50/50 LJ / VESUS-shaped mix
+    python bench.py --merged      # BASELINE config 5: merged-filelist length mix, batch 128, bf16 (implies both)
+    python bench.py --batch 128   # any of the above at another per-GPU batch size
 """
 import argparse
 import ctypes
@@ -34,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HPARAMS = 'use_labels=False,use_noise=True'
+VESUS_HPARAMS = 'use_labels=True,use_noise=True,vesus_path=/synthetic/vesus/'      # E = 512 + 64 + 5 + 512 = 1093
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (the headline figures with 2:1 sparsity are not used)
 HBM_PEAK_GBS = 8000.0
@@ -47,19 +50,29 @@ MFMA_BOUND = {'rec_gemm', 'sgemm'}
 PROF_STRIDE = 64
 
 
-def ljspeech_shaped_batch(hp, B, seed, fixed=False):
-    """SURVEY.md 8(d): Ti ~ round(clip(N(100,33),12,187)), To = clip(round(5.66 Ti + N(0,25)),96,870),
-    sorted by Ti descending; ids uniform [1,147]; mel ~ N(-5.5,2.2) clipped to [-11.52, 2]."""
-    rs = np.random.default_rng(seed)
-    if fixed:
-        ti = np.full(B, 150)
-        to = np.full(B, 800)
-    else:
-        ti = np.rint(np.clip(rs.normal(100, 33, B), 12, 187)).astype(int)
-        to = np.clip(np.rint(5.66 * ti + rs.normal(0, 25, B)), 96, 870).astype(int)
+def _lj_lengths(rs, n):
+    ti = np.rint(np.clip(rs.normal(100, 33, n), 12, 187)).astype(int)
+    to = np.clip(np.rint(5.66 * ti + rs.normal(0, 25, n)), 96, 870).astype(int)
+    return ti, to
+
+
+def _vesus_lengths(rs, n):
+    ti = np.rint(np.clip(rs.normal(15.7, 7, n), 3, 38)).astype(int)
+    to = np.clip(np.rint(7 * ti + rs.normal(40, 15, n)), 40, 400).astype(int)
+    return ti, to
+
+
+def _short_lengths(rs, n):
+    """CREMA-D / RAVDESS-shaped items of the merged mix (config 5): 2-4 s clips with one short sentence."""
+    ti = np.rint(np.clip(rs.normal(25, 8, n), 8, 50)).astype(int)
+    to = np.clip(np.rint(rs.normal(255, 45, n)), 150, 400).astype(int)
+    return ti, to
+
+
+def _assemble(hp, rs, ti, to, spk, emo):
     order = np.argsort(-ti, kind='stable')
-    ti, to = ti[order], to[order]
-    Ti, To = int(ti.max()), int(to.max())
+    ti, to, spk, emo = ti[order], to[order], spk[order], emo[order]
+    B, Ti, To = len(ti), int(ti.max()), int(to.max())
     text = torch.zeros(B, Ti, dtype=torch.long)
     mel = torch.zeros(B, hp.n_mel_channels, To)
     gate = torch.zeros(B, To)
@@ -68,16 +81,61 @@ def ljspeech_shaped_batch(hp, B, seed, fixed=False):
         m = np.clip(rs.normal(-5.5, 2.2, (hp.n_mel_channels, to[b])), -11.52, 2.0)
         mel[b, :, :to[b]] = torch.from_numpy(m).float()
         gate[b, to[b] - 1:] = 1
-    return (text, torch.from_numpy(ti).long(), mel, gate, torch.zeros(B), torch.zeros(B, 5),
+    return (text, torch.from_numpy(ti).long(), mel, gate, torch.from_numpy(spk).float(), torch.from_numpy(emo).float(),
             torch.from_numpy(to).long())
+
+
+def ljspeech_shaped_batch(hp, B, seed, fixed=False):
+    """SURVEY.md 8(d): Ti ~ round(clip(N(100,33),12,187)), To = clip(round(5.66 Ti + N(0,25)),96,870),
+    sorted by Ti descending; ids uniform [1,147]; mel ~ N(-5.5,2.2) clipped to [-11.52, 2]."""
+    rs = np.random.default_rng(seed)
+    if fixed:
+        ti, to = np.full(B, 150), np.full(B, 800)
+    else:
+        ti, to = _lj_lengths(rs, B)
+    return _assemble(hp, rs, ti, to, np.zeros(B), np.zeros((B, 5)))
+
+
+def vesus_shaped_batch(hp, B, seed):
+    """50/50 mix of LJSpeech-shaped items (speaker 0, labels 0 -- what the reference's loader
+    gives LJ items, data_utils.py:27-28) and VESUS-shaped items (Ti ~ clip(N(15.7,7),3,38), To = clip(round(7 Ti +
+    N(40,15)),40,400), speaker 1..10, one-hot 'intended' label, utils.py:118-119)."""
+    rs = np.random.default_rng(seed)
+    n_lj = B // 2
+    t1, o1 = _lj_lengths(rs, n_lj)
+    t2, o2 = _vesus_lengths(rs, B - n_lj)
+    spk = np.concatenate([np.zeros(n_lj), rs.integers(1, 11, B - n_lj)])
+    emo = np.concatenate([np.zeros((n_lj, 5)), np.eye(5)[rs.integers(0, 5, B - n_lj)]])
+    return _assemble(hp, rs, np.concatenate([t1, t2]), np.concatenate([o1, o2]), spk, emo)
+
+
+def merged_shaped_batch(hp, B, seed):
+    """Config 5 (LJSpeech + VESUS + CREMA-D + RAVDESS merged filelists).  The reference trainer only reads the LJ and the
+    VESUS filelist (data_utils.py:21-30) and the CREMA-D / RAVDESS lists carry no transcripts, so this is a LENGTH mix
+    defined here: 1/2 LJSpeech-shaped, 1/4 VESUS-shaped, 1/4 CREMA-D / RAVDESS-shaped short clips, all
+    with the VESUS conditioning path (speaker ids up to 122 = the embedding's 123 rows, one-hot labels)."""
+    rs = np.random.default_rng(seed)
+    n1, n2 = B // 2, B // 4
+    n3 = B - n1 - n2
+    t1, o1 = _lj_lengths(rs, n1)
+    t2, o2 = _vesus_lengths(rs, n2)
+    t3, o3 = _short_lengths(rs, n3)
+    spk = np.concatenate([np.zeros(n1), rs.integers(1, 11, n2), rs.integers(11, 123, n3)])
+    emo = np.concatenate([np.zeros((n1, 5)), np.eye(5)[rs.integers(0, 5, n2)], np.eye(5)[rs.integers(0, 5, n3)]])
+    return _assemble(hp, rs, np.concatenate([t1, t2, t3]), np.concatenate([o1, o2, o3]), spk, emo)
 
 
 def pair_flops(hp, in_lens, out_lens):
     """Algorithmic FLOPs of one G+D pair on the padded shapes."""
     B, Ti, To = len(in_lens), max(in_lens), max(out_lens)
     E = hp.encoder_embedding_dim + (hp.noise_size if hp.use_noise else 0)
+    if hp.vesus_path:
+        E += hp.speakers_embedding + (5 if hp.use_labels else 0)
     enc = 3932160 * B * Ti + 1572864 * sum(in_lens)
-    dec = B * To * (22317056 + 7232 * Ti) + 128 * E * B * Ti + 86016 * B * (To + 1)
+    # decoder MACs per (item, step): two gate GEMMs + projection + query + per-position attention terms (SURVEY 8d:
+    # 22 317 056 + 7 232 Ti at E = 1024, 22 888 392 + 7 301 Ti at E = 1093)
+    per_step = {1024: 22317056, 1093: 22888392}.get(E, 4096 * (256 + E + 1024) + 4096 * (1024 + E + 1024) + 81 * (1024 + E) + 128 * 1024)
+    dec = B * To * (per_step + (1984 + 4096 + 128 + E) * Ti) + 128 * E * B * Ti + 86016 * B * (To + 1)
     post = 4341760 * B * To
     W = To // 20 + (1 if To % 20 else 0)
     disc = 12329040 * B * W
@@ -101,8 +159,8 @@ def log(msg):
 
 
 def cpu_sample_batch(hp, B=8):
-    """The bounded CPU-baseline sample: an LJSpeech-shaped batch clipped to <= 200 frames / 50 characters
-    per item (also timed against the real reference in the build container, tests/golden/time_reference.py)."""
+    """A bounded LJSpeech-shaped sample (<= 200 frames / 50 characters per item): tests/golden/time_reference.py times
+    the real reference against the oracle on it in the build container (the oracle must not be slower than ~1.1x)."""
     text, il, mel, gate, _, _, ol = ljspeech_shaped_batch(hp, B, seed=99)
     ol = torch.clamp(ol, max=200)
     il = torch.clamp(il, max=50)
@@ -114,16 +172,18 @@ def cpu_sample_batch(hp, B=8):
     return text.contiguous(), il, mel, gate, ol
 
 
-def cpu_baseline(seconds_budget=20.0):
-    """The CPU oracle (oracle/gantron_ref.py, a restatement of the reference pinned by its golden
-    vectors) timed on the host cores for one G+D pair of a bounded LJSpeech-shaped sample."""
+def cpu_baseline(seconds_budget=45.0):
+    """The CPU oracle (oracle/gantron_ref.py, a restatement of the reference pinned by its golden vectors) timed on the
+    host cores for G+D pairs of BASELINE config 1's shape: vanilla GANtron, an LJSpeech-shaped batch of 8, UNCLIPPED
+    (Ti up to 187 characters, To up to 870 frames), fp32.  One warm-up pair, then as many timed pairs as fit the budget
+    (at least one); the sample string says how many."""
     from gantron_amd.hparams import HParams
     from oracle import gantron_ref as R
     sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
     import common
     hp = HParams(HPARAMS)
     B = 8
-    text, il, mel, gate, ol = cpu_sample_batch(hp, B)
+    text, il, mel, gate, _, _, ol = ljspeech_shaped_batch(hp, B, seed=99)
     Ti, To = text.shape[1], mel.shape[2]
     torch.set_num_threads(host_threads())
     Gp, Dp = R.init_params(hp, seed=1)
@@ -139,18 +199,19 @@ def cpu_baseline(seconds_budget=20.0):
     t0 = time.perf_counter()
     pair()
     first = time.perf_counter() - t0
-    log(f'cpu baseline: first pair {first:.2f} s on {torch.get_num_threads()} threads')
-    reps = max(1, min(3, int(seconds_budget / max(first, 1e-3)) - 1))
+    log(f'cpu baseline: warm-up pair {first:.2f} s on {torch.get_num_threads()} threads')
+    reps = max(1, min(3, int((seconds_budget - first) / max(first, 1e-3))))
     times = []
     for _ in range(reps):
         t0 = time.perf_counter()
         pair()
         times.append(time.perf_counter() - t0)
-    t = float(np.median(times)) if times else first
+    t = float(np.median(times))
     frames = int(ol.sum())
     return dict(value=frames / t, unit='mel-frames/s', cores=torch.get_num_threads(), kind='port',
-                sample=f'oracle/gantron_ref.py G+D pair, B={B}, Ti<={Ti}, To<={To} ({frames} valid frames), '
-                       f'{t:.2f} s per pair, median of {max(len(times), 1)}')
+                sample=f'BASELINE config 1 shape: oracle/gantron_ref.py G+D pair (incl. clip), vanilla, fp32, LJSpeech-shaped '
+                       f'B={B} unclipped (Ti<={Ti}, To<={To}, {frames} valid frames); 1 warm-up + {len(times)} timed pair(s), '
+                       f'median {t:.2f} s per pair')
 
 
 def main():
@@ -164,7 +225,17 @@ def main():
     ap.add_argument('--bf16', action='store_true',
                     help='BASELINE config 3 (hparams.fp16_run): bf16 operands in the decoder LSTM products and the layer '
                          'GEMMs, fp32 accumulation and master weights; NOT the headline metric, the default line is fp32')
+    ap.add_argument('--vesus', action='store_true',
+                    help='BASELINE config 4: VESUS labels + speaker embedding + noise (E = 1093), 50/50 LJ / VESUS-shaped mix')
+    ap.add_argument('--merged', action='store_true',
+                    help='BASELINE config 5: merged-filelist length mix with the VESUS conditioning; implies --batch 128 --bf16 '
+                         'unless given otherwise')
     args = ap.parse_args()
+    if args.merged:
+        args.vesus = True
+        if '--batch' not in sys.argv:
+            args.batch = 128
+        args.bf16 = True
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -186,7 +257,7 @@ def main():
     from gantron_amd.optim import FlatAdam
     from gantron_amd.train_steps import discriminator_step, generator_step
 
-    hp = HParams(HPARAMS + f',batch_size={args.batch}' + (',fp16_run=True' if args.bf16 else ''))
+    hp = HParams((VESUS_HPARAMS if args.vesus else HPARAMS) + f',batch_size={args.batch}' + (',fp16_run=True' if args.bf16 else ''))
     # GANTRON_FORCE_DIST=1 exercises the RCCL gradient-averaging path on a single rank (1-GPU boxes)
     use_dist = world > 1 or os.environ.get('GANTRON_FORCE_DIST') == '1'
     if use_dist:
@@ -206,11 +277,17 @@ def main():
     if use_dist:
         G, D = apply_gradient_allreduce(G), apply_gradient_allreduce(D)
     crit = Tacotron2Loss()
-    batch = ljspeech_shaped_batch(hp, args.batch, seed=1234 + rank, fixed=args.fixed_shape)
+    if args.merged:
+        batch = merged_shaped_batch(hp, args.batch, seed=1234 + rank)
+    elif args.vesus:
+        batch = vesus_shaped_batch(hp, args.batch, seed=1234 + rank)
+    else:
+        batch = ljspeech_shaped_batch(hp, args.batch, seed=1234 + rank, fixed=args.fixed_shape)
     # lengths stay on the host, as they are when a DataLoader produces the batch (no per-step D2H sync)
     batch = tuple(t if i in (1, 6) else t.to(dev) for i, t in enumerate(batch))
     in_lens, out_lens = batch[1].tolist(), batch[6].tolist()
     frames = sum(out_lens)
+    _lib.check(_lib.lib().gt_prof_set_context_rows(sum(in_lens)), 'gt_prof_set_context_rows')
 
     def pair(it):
         _, generated = generator_step(G, D, g_opt, crit, batch, hp, iteration=it)
@@ -272,6 +349,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         g_s, d_s = float(t[0]), float(t[1])
 
+    # ---- data-parallel evidence: backend, world size, and whether every rank holds the SAME averaged generator gradient
+    # after a step (sum and sum of squares of the flat gradient buffer, gathered from all ranks)
+    dist_info = None
+    if use_dist:
+        fg = G._flat_grad.double()
+        mine = torch.stack([fg.sum(), (fg * fg).sum()]).to(dev)
+        allc = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allc, mine)
+        allc = torch.stack(allc).cpu()
+        dist_info = dict(backend=dist.get_backend(), world_size=dist.get_world_size(),
+                         flat_grad_mb=G._flat_grad.numel() * 4 / 1e6,
+                         grad_checksum=[float(allc[0, 0]), float(allc[0, 1])],
+                         grad_checksum_equal_on_all_ranks=bool((allc == allc[0:1]).all()))
+
     # ---- roofline of the dominant kernel family from the sampled brackets of the timed region
     roof = None
     cpu = None
@@ -329,8 +420,10 @@ def main():
                     unit='mel-frames/s', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms,
                     higher_is_better=True, scaling='weak', vs_baseline=None,
                     dtype='bf16 operands (LSTM products, layer GEMMs) / f32 accumulation and elsewhere' if args.bf16 else 'f32', data='synthetic',
-                    config=dict(workload='Vanilla GANtron (use_labels=False,use_noise=True) LJSpeech-shaped batch=%d fp32, '
-                                         'G step + D step pair incl. clip+Adam' % args.batch,
+                    config=dict(workload=('merged-filelist length mix (LJ + VESUS + CREMA-D/RAVDESS-shaped), VESUS conditioning E=1093, '
+                                          if args.merged else 'VESUS labels+noise (E=1093), 50/50 LJSpeech/VESUS-shaped mix, ' if args.vesus
+                                          else 'Vanilla GANtron (use_labels=False,use_noise=True) LJSpeech-shaped ') +
+                                         'batch=%d %s, G step + D step pair incl. clip+Adam' % (args.batch, 'bf16' if args.bf16 else 'fp32'),
                                 per_gpu_batch=args.batch, global_batch=args.batch * world, Ti_max=Ti, To_max=To,
                                 valid_frames_per_rank=frames, padded_frames_per_rank=args.batch * To,
                                 parallelism='dp%d' % world, pair_tflop=fl / 1e12,
@@ -338,7 +431,7 @@ def main():
                                 g_step_ms=g_s * 1e3, d_step_ms=d_s * 1e3,
                                 schedule_2g1d_frames_per_s=2 * total_frames / (2 * g_s + d_s),
                                 pair_mfma_frac=fl / (elapsed / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS),
-                    roofline=roof, cpu_baseline=cpu)
+                    roofline=roof, cpu_baseline=cpu, dist=dist_info)
         print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()

@@ -33,6 +33,7 @@ extern "C" int64_t gt_abi_sizeof(int32_t which) {
 #include <vector>
 #include <hip/hip_ext.h>
 bool g_gt_prof_on = false;
+double g_gt_prof_ctx_rows = 0.0;      // valid memory rows of the batch (gt_prof_set_context_rows), 0 = charge B*Ti
 namespace {
 struct ProfRec { int fam; double flops, bytes; hipEvent_t e0, e1; };
 std::vector<ProfRec> g_recs;
@@ -81,6 +82,12 @@ static long g_prof_count[GT_FAM_COUNT];
 bool gt_prof_sample(int family) {
     const int stride = family == GT_FAM_SGEMM ? (g_prof_stride >= 16 ? g_prof_stride / 16 : 1) : g_prof_stride;
     return (g_prof_count[family]++ % stride) == 0;
+}
+
+extern "C" int gt_prof_set_context_rows(int64_t valid_rows) {
+    GT_REQUIRE(valid_rows >= 0, GT_E_ARG, "gt_prof_set_context_rows: negative");
+    g_gt_prof_ctx_rows = (double)valid_rows;
+    return 0;
 }
 
 extern "C" int gt_prof_begin(void) { return gt_prof_begin_sampled(1); }

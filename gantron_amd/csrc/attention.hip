@@ -724,7 +724,9 @@ extern "C" int gt_attn_context_fwd(GtAttnDims d, const float* energies, const fl
     GT_REQUIRE(energies && memory && w_out && ld_mem >= d.E, GT_E_ARG, "gt_attn_context_fwd: bad argument");
     GT_REQUIRE(cum_out == nullptr || cum_in != nullptr, GT_E_ARG, "gt_attn_context_fwd: cum_in missing");
     dim3 grid(cdiv(d.E, 256), d.B);
-    GtProfScope prof(GT_FAM_ATTN_C_FWD, 2.0 * d.B * d.Ti * (double)d.E, 4.0 * d.B * ((double)d.Ti * d.E + 3.0 * d.E + 4.0 * d.Ti),
+    // the kernels skip padded memory rows: charge the rows they really read when the caller has told us how many
+    const double ctx_rows = g_gt_prof_ctx_rows > 0.0 ? g_gt_prof_ctx_rows : (double)d.B * d.Ti;
+    GtProfScope prof(GT_FAM_ATTN_C_FWD, 2.0 * ctx_rows * (double)d.E, 4.0 * (ctx_rows * d.E + d.B * (3.0 * d.E + 4.0 * d.Ti)),
                      (hipStream_t)stream);
     const bool vec = (d.E % 4 == 0) && (ld_mem % 4 == 0) && aligned16(memory);
     if (vec)
@@ -746,8 +748,9 @@ extern "C" int gt_attn_context_bwd(GtAttnDims d, GtSlabs dctx_a, GtSlabs dctx_b,
     GT_REQUIRE(memory && dw_out && ld_mem >= d.E, GT_E_ARG, "gt_attn_context_bwd: bad argument");
     GT_REQUIRE((size_t)d.E * 4 <= 64 * 1024, GT_E_LIMIT, "gt_attn_context_bwd: E too large for LDS");
     dim3 grid(d.B, cdiv(d.Ti, CT));
-    GtProfScope prof(GT_FAM_ATTN_C_BWD, 2.0 * d.B * d.Ti * (double)d.E, 4.0 * d.B * ((double)d.Ti * d.E + 4.0 * d.E + 6.0 * d.Ti),
-                     (hipStream_t)stream);
+    const double ctx_rows = g_gt_prof_ctx_rows > 0.0 ? g_gt_prof_ctx_rows : (double)d.B * d.Ti;
+    GtProfScope prof(GT_FAM_ATTN_C_BWD, 2.0 * ctx_rows * (double)d.E,
+                     4.0 * (ctx_rows * d.E + d.B * ((1.0 + dctx_a.n + dctx_b.n) * d.E + 6.0 * d.Ti)), (hipStream_t)stream);
     const bool vec = (d.E % 4 == 0) && (ld_mem % 4 == 0) && aligned16(memory);
     auto sl4 = [](const GtSlabs& sl) { return sl.p == nullptr || (aligned16(sl.p) && sl.ld % 4 == 0 && sl.slab_stride % 4 == 0); };
     const bool vec_slabs = sl4(dctx_a) && sl4(dctx_b) && (dctx_direct == nullptr || (aligned16(dctx_direct) && ld_direct % 4 == 0)) &&

@@ -49,6 +49,9 @@ int64_t gt_abi_sizeof(int32_t which);
  * duration of a sampled kernel is bracket - (empty-kernel bracket - empty-kernel duration), the latter from
  * gt_prof_calibrate. */
 int gt_prof_begin(void);
+/* the attention context kernels skip padded memory rows: tell the profiler how many rows of the current batch are valid
+ * (sum of the memory lengths) so that their algorithmic bytes are charged for what they read; 0 = charge B*Ti */
+int gt_prof_set_context_rows(int64_t valid_rows);
 /* bracket only every stride-th launch of each family (the millisecond-scale sgemm family every
  * max(1, stride/16)-th: its few, very unequal launches need a denser sample and do not feel the bracket) */
 int gt_prof_begin_sampled(int32_t stride);

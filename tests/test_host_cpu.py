@@ -151,6 +151,15 @@ def test_bench_helpers():
     fixed = bench.ljspeech_shaped_batch(hp, 64, seed=0, fixed=True)
     fl = bench.pair_flops(hp, fixed[1].tolist(), fixed[6].tolist())
     assert abs(fl / 1e12 - 9.38) < 0.05          # 9.38 TFLOP per pair at B=64, 150/800
+    # config 4 / 5 workloads: VESUS conditioning (E = 1093), mixed lengths, sorted by text length, labels only on non-LJ items
+    hv = HParams(bench.VESUS_HPARAMS)
+    for gen, B in ((bench.vesus_shaped_batch, 64), (bench.merged_shaped_batch, 128)):
+        text, il, mel, gate, spk, emo, ol = gen(hv, B, seed=5)
+        assert text.shape[0] == B and il.tolist() == sorted(il.tolist(), reverse=True)
+        assert int(spk.max()) <= 122 and ((spk == 0) == (emo.sum(1) == 0)).all() and int((spk == 0).sum()) == B // 2
+        assert all(float(gate[b, int(ol[b]) - 1]) == 1 and (int(ol[b]) < 2 or float(gate[b, int(ol[b]) - 2]) == 0) for b in range(B))
+    fixed_v = bench.ljspeech_shaped_batch(hv, 64, seed=0, fixed=True)
+    assert abs(bench.pair_flops(hv, fixed_v[1].tolist(), fixed_v[6].tolist()) / 1e12 - 9.56) < 0.05   # 9.56 at E=1093
 
 
 def test_flat_adam_state_dict_uses_torch_adam_layout():

@@ -356,9 +356,12 @@ from gantron_amd.optim import FlatAdam
 from gantron_amd.train_steps import discriminator_step, generator_step
 world = int(sys.argv[5])
 hp = HParams(sys.argv[6])
-dev = torch.device('cuda:0')
+backend = sys.argv[7] if len(sys.argv) > 7 else 'gloo'
+dev = torch.device('cuda', rank if backend == 'nccl' else 0)       # RCCL: one GPU per rank; gloo rehearsal: both on device 0
+torch.cuda.set_device(dev)
 if world > 1:
-    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', world_size=world, rank=rank)
+    kw = dict(device_id=dev) if backend == 'nccl' else {}
+    dist.init_process_group(backend, init_method=f'tcp://127.0.0.1:{port}', world_size=world, rank=rank, **kw)
 torch.manual_seed(7 + 13 * (rank if world > 1 else 0))     # different initial weights per rank: the wrap must broadcast rank 0's
 G, D = Tacotron2(hp).to(dev).train(), Discriminator(hp).to(dev).train()
 g_opt, d_opt = FlatAdam(G, lr=1e-3), FlatAdam(D, lr=1e-3)
@@ -397,6 +400,28 @@ def test_data_parallel_step_two_processes_on_one_gpu(dev, tmp_path):
     r0, r1 = np.load(tmp_path / 'w2_rank0.npz'), np.load(tmp_path / 'w2_rank1.npz')
     for k in ('g_grad', 'd_grad', 'g_param', 'd_param'):
         close(torch.from_numpy(r0[k]), torch.from_numpy(r1[k]), rtol=1e-6, atol=1e-7, what=f'rank0 vs rank1 {k}')
+    assert float(np.abs(r0['g_grad']).max()) > 0 and float(np.abs(r0['d_grad']).max()) > 0
+
+
+def test_data_parallel_step_rccl_two_gpus(tmp_path):
+    """The same experiment over RCCL ('nccl' backend), one process per GPU: runs wherever two MI355X are visible and skips
+    itself on a one-GPU box.  Besides rank 0 == rank 1 it checks that the averaged gradient IS the mean of the two
+    single-process gradients (ranks re-run alone, world_size 1, from rank 0's initial weights)."""
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs (RCCL all-reduce between two ranks)')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'dp_worker.py'
+    script.write_text(_DP_WORKER)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), '29589', root, str(tmp_path), '2', MID, 'nccl'], env=env)
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    r0, r1 = np.load(tmp_path / 'w2_rank0.npz'), np.load(tmp_path / 'w2_rank1.npz')
+    for k in ('g_grad', 'd_grad', 'g_param', 'd_param'):
+        close(torch.from_numpy(r0[k]), torch.from_numpy(r1[k]), rtol=1e-6, atol=1e-7, what=f'RCCL rank0 vs rank1 {k}')
     assert float(np.abs(r0['g_grad']).max()) > 0 and float(np.abs(r0['d_grad']).max()) > 0
     # the same two batches, one process each, from rank 0's initial weights: the mean of their gradients is what the
     # data-parallel ranks must hold (the discriminator step sees the generator output of the un-averaged first step
@@ -468,6 +493,7 @@ def test_bench_two_ranks_rehearsal(dev, tmp_path):
     assert len(lines) == 1, out.stdout[-2000:]                # exactly one JSON line, from rank 0
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['steps'] == 1 and d['scaling'] == 'weak' and d['cpu_baseline'] is None
+    assert d['dist']['backend'] == 'gloo' and d['dist']['world_size'] == 2 and d['dist']['grad_checksum_equal_on_all_ranks']
     assert d['config']['global_batch'] == 16 and d['value'] > 0 and d['roofline'] is not None
 
 
