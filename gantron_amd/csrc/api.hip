@@ -79,7 +79,10 @@ void gt_prof_mark(int family, double flops, double bytes, hipStream_t st, bool b
 static int g_prof_stride = 1;
 static long g_prof_count[GT_FAM_COUNT];
 
+bool g_gt_capturing = false;          // a decoder loop is being captured into a hipGraph: no timing brackets inside it
+
 bool gt_prof_sample(int family) {
+    if (g_gt_capturing) { g_prof_count[family]++; return false; }
     const int stride = family == GT_FAM_SGEMM ? (g_prof_stride >= 16 ? g_prof_stride / 16 : 1) : g_prof_stride;
     return (g_prof_count[family]++ % stride) == 0;
 }

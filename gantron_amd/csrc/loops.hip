@@ -9,6 +9,7 @@
 // K = To*B) and d(memory) (batched W^T . dctx).  Inside the loop only the recurrent products
 // ([ctx|h] . W) remain, as weight-streaming small-M MFMA kernels (recurrent.hip).
 #include <stdlib.h>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -123,6 +124,48 @@ struct AuxJoin {
         GT_REQUIRE(e__ == hipSuccess, (int)e__, "%s failed: %s", #call, hipGetErrorString(e__)); \
     } while (0)
 
+// ---- hipGraph replay of a whole loop call (GANTRON_GRAPH=1; BASELINE config 5 names it) --------------------------------
+// The launches of a loop call -- both streams, their hand-off events included -- are captured once into a graph and the
+// graph is replayed whenever a call arrives with byte-identical arguments (same buffers, same sizes: the steady state of a
+// training run whose allocator hands back the same blocks).  Host issue time drops from ~19 ms to one graph launch; what
+// it does to the GPU-side duration is recorded in DESIGN.md (the loops are bound by dependent-kernel latency, not by issue).
+static int graph_mode() {
+    static const int v = getenv("GANTRON_GRAPH") ? atoi(getenv("GANTRON_GRAPH")) : 0;
+    return v;
+}
+struct GraphEntry { std::vector<unsigned char> key; hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; };
+static std::vector<GraphEntry> g_graphs;
+static std::mutex g_graphs_mu;
+
+static int run_graphed(const void* args, size_t nbytes, hipStream_t stream, const std::function<int()>& issue) {
+    std::lock_guard<std::mutex> lk(g_graphs_mu);
+    std::vector<unsigned char> key((const unsigned char*)args, (const unsigned char*)args + nbytes);
+    key.insert(key.end(), (const unsigned char*)&stream, (const unsigned char*)&stream + sizeof(stream));
+    for (auto& g : g_graphs)
+        if (g.key == key) {
+            GT_HIP(hipGraphLaunch(g.exec, stream));
+            return 0;
+        }
+    if (g_graphs.size() >= 16) {               // new shapes / buffers: drop the old graphs (nothing of them may still run)
+        GT_HIP(hipStreamSynchronize(stream));
+        for (auto& g : g_graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+        g_graphs.clear();
+    }
+    GraphEntry e;
+    e.key = key;
+    GT_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
+    g_gt_capturing = true;
+    const int rc = issue();
+    g_gt_capturing = false;
+    hipError_t ce = hipStreamEndCapture(stream, &e.graph);
+    GT_REQUIRE(rc == 0, rc, "decoder loop: a launch failed during graph capture (%s)", gt_last_error_string());
+    GT_REQUIRE(ce == hipSuccess && e.graph != nullptr, (int)ce, "decoder loop: hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+    GT_HIP(hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0));
+    GT_HIP(hipGraphLaunch(e.exec, stream));
+    g_graphs.push_back(e);
+    return 0;
+}
+
 static GtOperand op_kc(const float* p, int64_t ld) {
     GtOperand o; o.p = p; o.mode = GT_OP_KC; o.T = o.C = o.dil = o.pad = 0; o.ld = ld; o.batch_stride = 0; return o;
 }
@@ -130,11 +173,19 @@ static GtOperand op_rc(const float* p, int64_t ld) {
     GtOperand o = op_kc(p, ld); o.mode = GT_OP_RC; return o;
 }
 // C[M,N] (=|+=) A[M,K] . B(n,k) (+ bias) through the tiled MFMA GEMM (bf16 operands when the loop runs in that mode)
+static int polite_lds() {
+    static const int v = getenv("GANTRON_POLITE_LDS") ? atoi(getenv("GANTRON_POLITE_LDS")) : 0;
+    return v;
+}
 static int block_gemm(GtOperand A, GtOperand B, const float* bias, float* C, int64_t ldc, int M, int N, int K, int accumulate,
                       int bf16, void* stream) {
     GtGemm g = {}; g.A = A; g.B = B; g.C = C; g.ldc = ldc; g.c_batch_stride = 0; g.bias = bias;
     g.M = M; g.N = N; g.K = K; g.batch = 1; g.accumulate = accumulate; g.split_k = 1; g.alpha = 1.f; g.bf16 = bf16;
-    return gt_sgemm(&g, stream);
+    // the block GEMMs run underneath the attention chain: leave room for its kernels on every CU (gt_sgemm_set_polite)
+    const int old = gt_sgemm_set_polite(polite_lds());
+    const int rc = gt_sgemm(&g, stream);
+    (void)gt_sgemm_set_polite(old < 0 ? 0 : old);
+    return rc;
 }
 static int block_steps(int blk) {
     static const int env = getenv("GANTRON_DEC_BLK") ? atoi(getenv("GANTRON_DEC_BLK")) : 0;
@@ -268,7 +319,11 @@ int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
     GT_REQUIRE(a->To > 0 && a->Ti > 0 && a->Ha % 16 == 0 && a->Hd % 16 == 0 && a->Apad % 16 == 0, GT_E_ARG,
                "gt_decoder_fwd: bad dims");
     GT_REQUIRE(a->ring >= 1 && a->ring <= 32 && (a->ring == 1 || a->part2 != nullptr), GT_E_ARG, "gt_decoder_fwd: ring/part2");
-    if (a->W2hp != nullptr) return decoder_fwd_hoisted(a, stream);
+    if (a->W2hp != nullptr) {
+        if (graph_mode() && !g_gt_capturing)
+            return run_graphed(a, sizeof(*a), (hipStream_t)stream, [&]() { return decoder_fwd_hoisted(a, stream); });
+        return decoder_fwd_hoisted(a, stream);
+    }
     const int N1 = 4 * a->Ha, N2 = 4 * a->Hd;
     const int K1 = a->E + a->Ha, K2 = a->Ha + a->E + a->Hd;
     const int64_t hc_ld = a->Hd + a->E;
@@ -493,7 +548,8 @@ static int decoder_bwd_hoisted(const GtDecoderBwd* a, void* stream) {
     AuxJoin join{ctx, sA, sB, false};
     if (two) {
         GT_TRY(aux_stream(ctx, &sB));
-        if (t_hi == a->To - 1) {        // first call of a backward pass: the inputs (dHC ...) were produced on `stream`
+        if (t_hi == a->To - 1 || g_gt_capturing) {   // first call of a backward pass: the inputs (dHC ...) were produced on
+                                                     // `stream`; under capture every call forks the auxiliary stream anew
             GT_TRY(loop_event(ctx, 0, &ev));
             GT_HIP(hipEventRecord(ev, sA));
             GT_HIP(hipStreamWaitEvent(sB, ev, 0));
@@ -580,7 +636,11 @@ int gt_decoder_bwd(const GtDecoderBwd* a, void* stream) {
     GT_REQUIRE(a != nullptr, GT_E_ARG, "gt_decoder_bwd: NULL");
     GT_REQUIRE(rows_ok(a->B, a->Bp), GT_E_LIMIT, "gt_decoder_bwd: batch padding");
     GT_REQUIRE(a->ring >= 1 && a->ring <= 32, GT_E_ARG, "gt_decoder_bwd: ring");
-    if (a->W2hTp != nullptr) return decoder_bwd_hoisted(a, stream);
+    if (a->W2hTp != nullptr) {
+        if (graph_mode() && !g_gt_capturing)
+            return run_graphed(a, sizeof(*a), (hipStream_t)stream, [&]() { return decoder_bwd_hoisted(a, stream); });
+        return decoder_bwd_hoisted(a, stream);
+    }
     const int N1 = 4 * a->Ha, N2 = 4 * a->Hd;
     const int64_t hc_ld = a->Hd + a->E;
     GtAttnDims d; d.B = a->B; d.Ti = a->Ti; d.E = a->E; d.A = a->A; d.F = a->F; d.Kc = a->Kc;

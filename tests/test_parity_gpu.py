@@ -493,10 +493,10 @@ def test_full_size_training_step_is_schedule_invariant(dev, monkeypatch):
     backward entirely inside the loop, separate cell and query launches: the code path the small-size oracle tests
     pin -- against the benchmark's schedule (two-chain pipelining over a ring of 16 buffers with batched hand-offs,
     6 backward chunks with leaf-stream GEMMs, hoisted attention gradients, fused cell+query kernels).  Differences are
-    summation order only: 1e-3 of each tensor's max-abs, except the encoder convolution / embedding gradients, which at
-    this size are small residuals of three BatchNorm backwards (the batch statistics remove most of the incoming
-    gradient) and differ by up to 1.2e-2 between two runs of the SAME single-stream schedule (order of the fp32
-    atomics in the split-K reductions): 3e-2 there."""
+    summation order only: 1e-3 of each tensor's max-abs.  (With split-K atomics in the encoder's forward convolutions
+    two runs of the SAME schedule differ by up to 1.2e-2 in the encoder gradients: a pre-activation within rounding of
+    the ReLU threshold lands on either side depending on the order of the atomics.  Both runs here therefore use the
+    deterministic forward, GANTRON_FWD_SPLITK=0.)"""
     import bench
     from gantron_amd import engine
     from gantron_amd.hparams import HParams
@@ -520,6 +520,11 @@ def test_full_size_training_step_is_schedule_invariant(dev, monkeypatch):
         torch.cuda.synchronize()
         return [o.detach().clone() for o in out], {k: p.grad.detach().clone() for k, p in G.named_parameters()}
 
+    # deterministic activations in BOTH runs (no split-K atomics in the forward / input-gradient convolutions): the two
+    # schedules then see bit-identical encoder pre-activations, no ReLU mask can differ, and a race in the leaf-stream /
+    # two-chain schedule cannot hide behind atomic-order noise -- every tensor is held to 1e-3
+    from gantron_amd import ops
+    monkeypatch.setattr(ops, 'FWD_SPLITK', False)
     monkeypatch.setattr(engine, 'DEC_RING', 1)
     monkeypatch.setattr(engine, 'BWD_CHUNKS', 1)
     monkeypatch.setattr(engine, 'ATTN_HOIST', False)
@@ -528,15 +533,15 @@ def test_full_size_training_step_is_schedule_invariant(dev, monkeypatch):
     monkeypatch.setattr(engine.LEAF, 'enabled', False)
     out0, g0 = run()
     monkeypatch.undo()
+    monkeypatch.setattr(ops, 'FWD_SPLITK', False)
     assert engine.DEC_RING > 1 and engine.BWD_CHUNKS > 1 and engine.ATTN_HOIST and engine.LEAF.enabled and engine.HOIST2
     out1, g1 = run()
     for name, a, b in zip(('mel', 'mel_post', 'gate', 'align'), out1, out0):
         close(a, b, rtol=1e-4, atol=1e-6, what=f'out.{name}')
     bad = []
     for k in g0:
-        noisy = k.startswith(('encoder.convolutions.', 'embedding.'))
         try:
-            close(g1[k], g0[k], rtol=3e-2 if noisy else 1e-3, atol=2e-6, what=f'g_grad.{k}')
+            close(g1[k], g0[k], rtol=1e-3, atol=2e-6, what=f'g_grad.{k}')
         except AssertionError as e:
             bad.append(str(e))
     assert not bad, '\n'.join(bad)
