@@ -289,9 +289,24 @@ def main():
     frames = sum(out_lens)
     _lib.check(_lib.lib().gt_prof_set_context_rows(sum(in_lens)), 'gt_prof_set_context_rows')
 
+    # GANTRON_GRAPH=1 (hipGraph replay of the decoder loops) cannot capture on the legacy default stream: the step then
+    # runs on a stream of its own
+    side = torch.cuda.Stream() if os.environ.get('GANTRON_GRAPH', '0') != '0' else None
+
+    def on_step_stream(fn):
+        if side is None:
+            return fn()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            out = fn()
+        torch.cuda.current_stream().wait_stream(side)
+        return out
+
     def pair(it):
-        _, generated = generator_step(G, D, g_opt, crit, batch, hp, iteration=it)
-        discriminator_step(G, D, d_opt, batch, generated, hp)
+        def body():
+            _, generated = generator_step(G, D, g_opt, crit, batch, hp, iteration=it)
+            discriminator_step(G, D, d_opt, batch, generated, hp)
+        on_step_stream(body)
 
     def sync():
         if use_dist:
@@ -341,9 +356,9 @@ def main():
     gen_holder = {}
 
     def g_only():
-        gen_holder['fake'] = generator_step(G, D, g_opt, crit, batch, hp, iteration=args.warmup + args.steps)[1]
+        gen_holder['fake'] = on_step_stream(lambda: generator_step(G, D, g_opt, crit, batch, hp, iteration=args.warmup + args.steps)[1])
     g_s = alone(g_only)
-    d_s = alone(lambda: discriminator_step(G, D, d_opt, batch, gen_holder['fake'], hp))
+    d_s = alone(lambda: on_step_stream(lambda: discriminator_step(G, D, d_opt, batch, gen_holder['fake'], hp)))
     if world > 1:
         t = torch.tensor([g_s, d_s], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -144,8 +144,10 @@ static int run_graphed(const void* args, size_t nbytes, hipStream_t stream, cons
     for (auto& g : g_graphs)
         if (g.key == key) {
             GT_HIP(hipGraphLaunch(g.exec, stream));
+            if (graph_mode() > 1) fprintf(stderr, "[graph] replay (%zu cached)\n", g_graphs.size());
             return 0;
         }
+    if (graph_mode() > 1) fprintf(stderr, "[graph] capture (%zu cached)\n", g_graphs.size());
     if (g_graphs.size() >= 16) {               // new shapes / buffers: drop the old graphs (nothing of them may still run)
         GT_HIP(hipStreamSynchronize(stream));
         for (auto& g : g_graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
@@ -173,19 +175,11 @@ static GtOperand op_rc(const float* p, int64_t ld) {
     GtOperand o = op_kc(p, ld); o.mode = GT_OP_RC; return o;
 }
 // C[M,N] (=|+=) A[M,K] . B(n,k) (+ bias) through the tiled MFMA GEMM (bf16 operands when the loop runs in that mode)
-static int polite_lds() {
-    static const int v = getenv("GANTRON_POLITE_LDS") ? atoi(getenv("GANTRON_POLITE_LDS")) : 0;
-    return v;
-}
 static int block_gemm(GtOperand A, GtOperand B, const float* bias, float* C, int64_t ldc, int M, int N, int K, int accumulate,
                       int bf16, void* stream) {
     GtGemm g = {}; g.A = A; g.B = B; g.C = C; g.ldc = ldc; g.c_batch_stride = 0; g.bias = bias;
     g.M = M; g.N = N; g.K = K; g.batch = 1; g.accumulate = accumulate; g.split_k = 1; g.alpha = 1.f; g.bf16 = bf16;
-    // the block GEMMs run underneath the attention chain: leave room for its kernels on every CU (gt_sgemm_set_polite)
-    const int old = gt_sgemm_set_polite(polite_lds());
-    const int rc = gt_sgemm(&g, stream);
-    (void)gt_sgemm_set_polite(old < 0 ? 0 : old);
-    return rc;
+    return gt_sgemm(&g, stream);
 }
 static int block_steps(int blk) {
     static const int env = getenv("GANTRON_DEC_BLK") ? atoi(getenv("GANTRON_DEC_BLK")) : 0;

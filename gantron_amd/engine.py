@@ -46,8 +46,8 @@ DEC_RING = int(_os.environ.get('GANTRON_DEC_RING', '16'))     # ring of hand-off
 HOIST2 = _os.environ.get('GANTRON_HOIST2', '1') != '0'
 # fused product + cell (+ query) launches of the forward loop (gt_rec_cell_fwd): 1 = attention LSTM, 2 = decoder LSTM, 3 = both
 REC_CELL = int(_os.environ.get('GANTRON_REC_CELL', '3'))
-DEC_BLK = int(_os.environ.get('GANTRON_DEC_BLK', '32'))       # steps per block in that mode
-POLITE_LDS = int(_os.environ.get('GANTRON_POLITE_LDS', '0'))  # dynamic-LDS reservation (bytes) of GEMMs that run under the loops
+DEC_BLK = int(_os.environ.get('GANTRON_DEC_BLK', '16'))       # steps per block in that mode (measured: 8: 160.6 ms per pair,
+                                                              # 12: 157.9, 16: 157.9, 32: 160.5, 48: 160.9, 64: 165.7)
 
 
 def _f32(*shape, device, zero=True):
@@ -105,15 +105,8 @@ class LeafStream:
             self.stream = torch.cuda.Stream(priority=torch.cuda.Stream.priority_range()[0])
         self.stream.wait_stream(torch.cuda.current_stream())
         self.keep.extend(tensors)
-        # GEMMs that run UNDER the decoder backward loop leave room for its kernels on every CU (gt_sgemm_set_polite)
-        polite = POLITE_LDS if ops.SPLITK_TARGET == ops.SPLITK_OVERLAPPED else 0
-        old = lib().gt_sgemm_set_polite(polite) if polite else 0
-        try:
-            with torch.cuda.stream(self.stream):
-                fn()
-        finally:
-            if polite:
-                lib().gt_sgemm_set_polite(max(old, 0))
+        with torch.cuda.stream(self.stream):
+            fn()
 
     def join(self):
         if self.stream is not None and self.enabled:

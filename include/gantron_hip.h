@@ -95,11 +95,6 @@ typedef struct GtGemm {
 } GtGemm;
 
 int gt_sgemm(const GtGemm* g, void* stream);
-/* Occupancy cap for the gt_sgemm launches of the calling thread: `lds_bytes` of dynamic LDS are reserved on top of the
- * kernel's own tiles (0 = no cap; ~70 KB = at most one workgroup per CU, ~40 KB = two), which keeps registers and LDS of
- * every CU free for the latency-critical kernels of the decoder loops when a tile GEMM runs underneath them.  Returns
- * the previous value (negative: error). */
-int gt_sgemm_set_polite(int32_t lds_bytes);
 
 /* ------------------------------------------------------------------- recurrent (small-M) GEMM
  * Per-time-step product of the LSTM recurrences (model.py:391-392,406-407 and the BiLSTM of
