@@ -181,11 +181,7 @@ static int block_gemm(GtOperand A, GtOperand B, const float* bias, float* C, int
     g.M = M; g.N = N; g.K = K; g.batch = 1; g.accumulate = accumulate; g.split_k = 1; g.alpha = 1.f; g.bf16 = bf16;
     return gt_sgemm(&g, stream);
 }
-static int block_steps(int blk) {
-    static const int env = getenv("GANTRON_DEC_BLK") ? atoi(getenv("GANTRON_DEC_BLK")) : 0;
-    const int b = env > 0 ? env : (blk > 0 ? blk : 32);
-    return b < 1 ? 1 : b;
-}
+static int block_steps(int blk) { return blk > 0 ? blk : 32; }
 
 // ---- hoisted decoder-LSTM input product (GtDecoderFwd::W2hp) ---------------------------------------------------------
 // The attention chain (stream A) never reads the decoder LSTM, so it simply runs ahead: per block of `blk` steps it

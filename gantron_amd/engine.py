@@ -46,6 +46,11 @@ DEC_RING = int(_os.environ.get('GANTRON_DEC_RING', '16'))     # ring of hand-off
 HOIST2 = _os.environ.get('GANTRON_HOIST2', '1') != '0'
 # fused product + cell (+ query) launches of the forward loop (gt_rec_cell_fwd): 1 = attention LSTM, 2 = decoder LSTM, 3 = both
 REC_CELL = int(_os.environ.get('GANTRON_REC_CELL', '3'))
+DEC_BLK_BWD = int(_os.environ.get('GANTRON_DEC_BLK_BWD', '16'))
+# K-splits of the decoder LSTM's small recurrent products in the hoisted mode (0: cost model).  That chain has slack
+# (it only follows / feeds the attention chain): fewer, longer workgroups leave the CUs to the critical chain.
+S2_FWD = int(_os.environ.get('GANTRON_S2_FWD', '0'))
+S2_BWD = int(_os.environ.get('GANTRON_S2_BWD', '0'))
 DEC_BLK = int(_os.environ.get('GANTRON_DEC_BLK', '16'))       # steps per block in that mode (measured: 8: 160.6 ms per pair,
                                                               # 12: 157.9, 16: 157.9, 32: 160.5, 48: 160.9, 64: 165.7)
 
@@ -303,6 +308,11 @@ class GeneratorEngine:
         self.E = self.enc_dim + self.noise
         if self.vesus:
             self.E += hp.speakers_embedding + self.mem_labels
+        # The decoder memory is stored Ep columns wide (E rounded up to 4, the extra columns zero): with VESUS conditioning
+        # E = 512 + 64 + 5 + 512 = 1093, and every float4 path of the loop kernels (context, cells, fused product + cell)
+        # wants rows that are multiples of 16 bytes.  The padding lives in activations and packed weight images only --
+        # parameters, gradients and the state_dict keep the reference's shapes.
+        self.Ep = roundup(self.E, 4)
         # hparams.fp16_run (the reference's apex path, train.py:246-250): on MI355X the two decoder LSTM products run
         # with bf16 operands and fp32 accumulation (gt_rec_gemm_bf16); weights, state and every other op stay fp32
         self.bf16 = bool(getattr(hp, 'fp16_run', False))
@@ -339,7 +349,7 @@ class GeneratorEngine:
         hp, dev = self.hp, text.device
         B, Ti = text.shape
         Bp = sv['Bp']
-        H, E, A = self.H, self.E, self.A
+        H, E, Ep, A = self.H, self.E, self.Ep, self.A
         # ---- embedding + encoder convolutions (channels-last rows = (b, t))
         D0 = hp.symbols_embedding_dim
         cin0 = roundup(D0 + self.enc_labels + self.enc_noise, 4)     # channels % 4 == 0 for the im2col operand
@@ -390,10 +400,10 @@ class GeneratorEngine:
 
         PHASES.mark('f.bilstm')
         # ---- decoder memory = [encoder outputs | speaker | labels | style noise]
-        memory = _f32(B, Ti, E, device=dev)
-        mem2 = memory.view(B * Ti, E)
-        call('gt_gather_rows', hs[0], H, idx['ifwd'], B * Ti, H, mem2, E, 0)
-        check(lib().gt_gather_rows(ptr(hs[1]), H, ptr(idx['irev']), B * Ti, H, ptr(memory, H), E, 0, ops._stream()),
+        memory = _f32(B, Ti, Ep, device=dev)                 # columns [E, Ep) stay zero
+        mem2 = memory.view(B * Ti, Ep)
+        call('gt_gather_rows', hs[0], H, idx['ifwd'], B * Ti, H, mem2, Ep, 0)
+        check(lib().gt_gather_rows(ptr(hs[1]), H, ptr(idx['irev']), B * Ti, H, ptr(memory, H), Ep, 0, ops._stream()),
               'gt_gather_rows')
         col = 2 * H
         if self.vesus:
@@ -411,10 +421,24 @@ class GeneratorEngine:
             memory[:, :, col:col + self.noise] = noise if noise.dim() == 3 else noise[:, None, :]
         sv['memory'] = memory
         Wmem = P['decoder.attention_layer.memory_layer.linear_layer.weight']
-        pm = ops.linear(mem2, Wmem, B * Ti, E, A)
+        pm = ops.linear(mem2, Wmem, B * Ti, E, A, ldx=Ep)
         sv['pm'] = pm
 
         return memory, mem2, pm
+
+    def _decoder_operands(self, P):
+        """Weights of the two decoder LSTMs as the loops read them, with the ctx columns padded from E to Ep (zeros):
+        W1cat (4Ha, Ep + Ha) for the operand [ctx | h_att] (the Prenet columns of weight_ih are handled outside the loop),
+        W2ihp (4Hd, Ha + Ep) for [h_att | ctx], and the projection [mel rows; gate row] (n_mel + 1, Hd + Ep) for [h_dec | ctx]."""
+        E, Ep, Pd = self.E, self.Ep, self.P
+        W1ih, W1hh = P['decoder.attention_rnn.weight_ih'], P['decoder.attention_rnn.weight_hh']
+        W2ih = P['decoder.decoder_rnn.weight_ih']
+        Wp, Wg = P['decoder.linear_projection.linear_layer.weight'], P['decoder.gate_layer.linear_layer.weight']
+        pad = (lambda rows: [W1ih.new_zeros(rows, Ep - E)]) if Ep > E else (lambda rows: [])
+        W1cat = torch.cat([W1ih[:, Pd:]] + pad(W1ih.shape[0]) + [W1hh], dim=1).contiguous()
+        W2ihp = torch.cat([W2ih] + pad(W2ih.shape[0]), dim=1).contiguous() if Ep > E else W2ih.contiguous()
+        Wpg = torch.cat((torch.cat([Wp] + pad(Wp.shape[0]), dim=1), torch.cat([Wg] + pad(Wg.shape[0]), dim=1)), dim=0).contiguous()
+        return W1cat, W2ihp, Wpg
 
     # ------------------------------------------------------------------------------ forward
     @_gemm_precision
@@ -426,7 +450,7 @@ class GeneratorEngine:
         B, Ti = text.shape
         To = mels.shape[2]
         Bp = roundup(B, 16) if B <= 64 else roundup(B, 64)      # rows per decoder step (pad rows stay zero)
-        n_mel, H, E, A = self.n_mel, self.H, self.E, self.A
+        n_mel, H, E, Ep, A = self.n_mel, self.H, self.E, self.Ep, self.A
         sv = dict(B=B, Bp=Bp, Ti=Ti, To=To, in_lens=list(in_lens), out_lens=list(out_lens), training=training,
                   text=text)
 
@@ -458,13 +482,13 @@ class GeneratorEngine:
         pre1 = ops.linear(p2, W1ih, To * Bp, Pd, 4 * Ha, bias=bias1, ldw=Pd + E)
 
         # ---- decoder loop
-        K1, K2 = E + Ha, Ha + E + Hd
-        W1cat = torch.cat((W1ih[:, Pd:], W1hh), dim=1).contiguous()
-        W2cat = None if (HOIST2 and not FUSED_CELL) else torch.cat((W2ih, W2hh), dim=1).contiguous()
+        K1, K2 = Ep + Ha, Ha + Ep + Hd             # loop operands are Ep wide in their ctx part (zero columns beyond E)
+        W1cat, W2ihp, Wpg = self._decoder_operands(P)
+        W2cat = None if (HOIST2 and not FUSED_CELL) else torch.cat((W2ihp, W2hh), dim=1).contiguous()
         Apad = roundup(A, 16)
         d = GtDecoderFwd()
         d.B, d.Bp, d.Ti, d.To, d.E, d.ldE, d.P, d.Ha, d.Hd, d.A, d.Apad, d.F, d.Kc = \
-            B, Bp, Ti, To, E, E, Pd, Ha, Hd, A, Apad, self.F, self.Kc
+            B, Bp, Ti, To, Ep, Ep, Pd, Ha, Hd, A, Apad, self.F, self.Kc
         d.S1, d.S2, d.Sq = rec_splits(4 * Ha, K1), rec_splits(4 * Hd, K2), ops.pick_splits(Ha, 16)
         d.p_att = hp.p_attention_dropout if training else 0.0
         d.p_dec = hp.p_decoder_dropout if training else 0.0
@@ -476,10 +500,12 @@ class GeneratorEngine:
             split = rec_splits_bf16 if self.bf16 else rec_splits
             d.bf16 = int(self.bf16)
             d.S1, d.S2 = split(4 * Ha, K1), split(4 * Hd, Hd)
+            if S2_FWD and not self.bf16:
+                d.S2 = ops.pick_splits(Hd, S2_FWD)
             # fused product + cell launches (gt_rec_cell_fwd) take their own packing
-            use_c1 = not self.bf16 and bool(REC_CELL & 1) and CELL_QUERY and Ha % 32 == 0 and E % 4 == 0
-            use_c2 = not self.bf16 and bool(REC_CELL & 2) and Hd % 16 == 0 and (Hd + E) % 4 == 0
-            keep_t['W2ih'] = W2ih if W2ih.is_contiguous() else W2ih.contiguous()
+            use_c1 = not self.bf16 and bool(REC_CELL & 1) and CELL_QUERY and Ha % 32 == 0
+            use_c2 = not self.bf16 and bool(REC_CELL & 2) and Hd % 16 == 0 and Hd % 4 == 0
+            keep_t['W2ih'] = W2ihp
             keep_t['W1c' if use_c1 else 'W1p'] = pack_rec_cell(W1cat, Ha, K1) if use_c1 else pack(W1cat, 4 * Ha, 4 * Ha, K1)
             keep_t['W2hc' if use_c2 else 'W2hp'] = pack_rec_cell(W2hh, Hd, Hd) if use_c2 else pack(W2hh, 4 * Hd, 4 * Hd, Hd)
         elif self.bf16:
@@ -494,25 +520,25 @@ class GeneratorEngine:
         ld1, ld2 = (int(lib().gt_fused_k_padded(K1)), int(lib().gt_fused_k_padded(K2))) if fused else \
             (roundup(K1, 16), roundup(K2, 16))
         if hoist2:
-            ld2 = roundup(Ha + E, 16)           # X2 is the (To, Bp, ld2) history of [h_att_t | ctx_t]
+            ld2 = roundup(Ha + Ep, 16)          # X2 is the (To, Bp, ld2) history of [h_att_t | ctx_t]
         ws = dict(X1=_f32(2, Bp, ld1, device=dev), X2=_f32(To if hoist2 else DEC_RING, Bp, ld2, device=dev),
                   part=_f32(max(d.S1 * Bp * 4 * Ha, d.S2 * Bp * 4 * Hd, d.Sq * Bp * Apad), device=dev, zero=False),
                   part2=_f32(d.S2 * Bp * 4 * Hd, device=dev, zero=False),
                   energies=_f32(B, Ti, device=dev, zero=False))
         hist = dict(gates1=_f32(To, Bp, 4 * Ha, device=dev), c1=_f32(To + 1, Bp, Ha, device=dev),
                     gates2=_f32(To, Bp, 4 * Hd, device=dev), c2=_f32(To + 1, Bp, Hd, device=dev),
-                    hatt=_f32(To, Bp, Ha, device=dev), HC=_f32(To, Bp, Hd + E, device=dev),
+                    hatt=_f32(To, Bp, Ha, device=dev), HC=_f32(To, Bp, Hd + Ep, device=dev),
                     w_hist=_f32(To + 1, B, Ti, device=dev), cum_hist=_f32(To + 1, B, Ti, device=dev),
                     q_hist=_f32(To, B, A, device=dev, zero=False))
         al = 'decoder.attention_layer.'
         d.memory, d.pm, d.lengths, d.pre1, d.bias2 = ptr(memory), ptr(pm), ptr(lens32), ptr(pre1), ptr(bias2)
         d.W1p, d.Wqp, d.W2p = ptr(keep_t.get('W1p')), ptr(keep_t['Wqp']), ptr(keep_t.get('W2p'))
         d.W1g, d.W2g = ptr(keep_t.get('W1g')), ptr(keep_t.get('W2g'))
-        n_wpack = int(lib().gt_attn_wpack_elems(ops.attn_dims(B, Ti, E, A, self.F, self.Kc)))
+        n_wpack = int(lib().gt_attn_wpack_elems(ops.attn_dims(B, Ti, Ep, A, self.F, self.Kc)))
         if n_wpack:
             ws['attn_wpack'] = _f32(n_wpack, device=dev, zero=False)
             d.attn_wpack = ptr(ws['attn_wpack'])
-        if CELL_QUERY and Ha % 32 == 0 and E % 4 == 0:
+        if CELL_QUERY and Ha % 32 == 0:
             Wq = P['decoder.attention_layer.query_layer.linear_layer.weight']
             ws['partq'] = _f32(Ha // 16, Bp, Apad, device=dev, zero=False)      # Ha/32 slabs, Ha/16 with gt_rec_cell_fwd
             d.Wq, d.partq = ptr(Wq), ptr(ws['partq'])
@@ -539,7 +565,7 @@ class GeneratorEngine:
             if use_c2:
                 ws['counters2'] = torch.zeros(nzb * (Hd // 16), dtype=torch.int32, device=dev)
                 d.W2hc, d.counters2 = ptr(keep_t['W2hc']), ptr(ws['counters2'])
-        if ATTN_HOIST and training and lib().gt_attn_hoist_supported(ops.attn_dims(B, Ti, E, A, self.F, self.Kc)):
+        if ATTN_HOIST and training and lib().gt_attn_hoist_supported(ops.attn_dims(B, Ti, Ep, A, self.F, self.Kc)):
             hist['u_hist'] = _f32(To, B, Ti, A, device=dev, zero=False)
             d.u_hist = ptr(hist['u_hist'])
         PHASES.mark('f.pre_loop')
@@ -552,9 +578,7 @@ class GeneratorEngine:
                   prenet_keep=pk)
 
         # ---- mel / gate projection of all steps, output layouts
-        hc = Hd + E
-        Wpg = torch.cat((P['decoder.linear_projection.linear_layer.weight'],
-                         P['decoder.gate_layer.linear_layer.weight']), dim=0).contiguous()
+        hc = Hd + Ep
         bpg = torch.cat((P['decoder.linear_projection.linear_layer.bias'], P['decoder.gate_layer.linear_layer.bias']))
         nout = n_mel + 1
         out81 = ops.linear(hist['HC'], Wpg, To * Bp, hc, nout, bias=bpg)
@@ -601,7 +625,7 @@ class GeneratorEngine:
         hp, dev = self.hp, text.device
         B, Ti = text.shape
         Bp = roundup(B, 16) if B <= 64 else roundup(B, 64)
-        n_mel, E, A, Pd, Ha, Hd = self.n_mel, self.E, self.A, self.P, self.Ha, self.Hd
+        n_mel, E, Ep, A, Pd, Ha, Hd = self.n_mel, self.E, self.Ep, self.A, self.P, self.Ha, self.Hd
         To = int(max_decoder_steps)
         sv = dict(B=B, Bp=Bp, Ti=Ti, To=To, in_lens=[Ti] * B, training=False, text=text)
         memory, mem2, pm = self._encode(P, text, [Ti] * B, {'noise': style}, speaker_ids, emotions, False, sv)
@@ -610,14 +634,14 @@ class GeneratorEngine:
         W2ih, W2hh = P['decoder.decoder_rnn.weight_ih'], P['decoder.decoder_rnn.weight_hh']
         bias1 = P['decoder.attention_rnn.bias_ih'] + P['decoder.attention_rnn.bias_hh']
         bias2 = P['decoder.decoder_rnn.bias_ih'] + P['decoder.decoder_rnn.bias_hh']
-        K1, K2 = E + Ha, Ha + E + Hd
-        W1cat = torch.cat((W1ih[:, Pd:], W1hh), dim=1).contiguous()
-        W2cat = torch.cat((W2ih, W2hh), dim=1).contiguous()
+        K1, K2 = Ep + Ha, Ha + Ep + Hd
+        W1cat, W2ihp, Wpg = self._decoder_operands(P)
+        W2cat = torch.cat((W2ihp, W2hh), dim=1).contiguous()
         Apad = roundup(A, 16)
         q = GtDecoderInfer()
         d = q.step
         d.B, d.Bp, d.Ti, d.To, d.E, d.ldE, d.P, d.Ha, d.Hd, d.A, d.Apad, d.F, d.Kc = \
-            B, Bp, Ti, To, E, E, Pd, Ha, Hd, A, Apad, self.F, self.Kc
+            B, Bp, Ti, To, Ep, Ep, Pd, Ha, Hd, A, Apad, self.F, self.Kc
         d.S1, d.S2, d.Sq = rec_splits(4 * Ha, K1), rec_splits(4 * Hd, K2), ops.pick_splits(Ha, 16)
         d.p_att = d.p_dec = 0.0
         packed = dict(Wqp=pack_rec(P['decoder.attention_layer.query_layer.linear_layer.weight'], Apad, A, Ha))
@@ -629,7 +653,7 @@ class GeneratorEngine:
             packed.update(W1p=pack_rec(W1cat, 4 * Ha, 4 * Ha, K1), W2p=pack_rec(W2cat, 4 * Hd, 4 * Hd, K2))
         lens32 = torch.full((B,), Ti, dtype=torch.int32, device=dev)
         ld1, ld2 = roundup(K1, 16), roundup(K2, 16)
-        nout, hc = n_mel + 1, Hd + E
+        nout, hc = n_mel + 1, Hd + Ep
         ws = dict(X1=_f32(Bp, ld1, device=dev), X2=_f32(Bp, ld2, device=dev),
                   part=_f32(max(d.S1 * Bp * 4 * Ha, d.S2 * Bp * 4 * Hd, d.Sq * Bp * Apad), device=dev, zero=False),
                   energies=_f32(B, Ti, device=dev, zero=False), pre1=_f32(Bp, 4 * Ha, device=dev),
@@ -640,8 +664,6 @@ class GeneratorEngine:
                   w_hist=_f32(To + 1, B, Ti, device=dev), cum_hist=_f32(To + 1, B, Ti, device=dev),
                   q_hist=_f32(To, B, A, device=dev, zero=False), frames=_f32(To + 1, Bp, nout, device=dev),
                   stop=torch.full((B,), 2 ** 31 - 1, dtype=torch.int32, device=dev))
-        Wpg = torch.cat((P['decoder.linear_projection.linear_layer.weight'],
-                         P['decoder.gate_layer.linear_layer.weight']), dim=0).contiguous()
         bpg = torch.cat((P['decoder.linear_projection.linear_layer.bias'], P['decoder.gate_layer.linear_layer.bias']))
         W0 = P['decoder.prenet.layers.0.linear_layer.weight'].contiguous()
         W1 = P['decoder.prenet.layers.1.linear_layer.weight'].contiguous()
@@ -704,10 +726,10 @@ class GeneratorEngine:
         the CUs over the leaf stream's weight-gradient GEMMs was measured: no gain on MI355X.)"""
         hp = self.hp
         B, Bp, Ti, To = sv['B'], sv['Bp'], sv['Ti'], sv['To']
-        n_mel, H, E, A, Pd, Ha, Hd = self.n_mel, self.H, self.E, self.A, self.P, self.Ha, self.Hd
+        n_mel, H, E, Ep, A, Pd, Ha, Hd = self.n_mel, self.H, self.E, self.Ep, self.A, self.P, self.Ha, self.Hd
         dev = sv['memory'].device
         hist = sv['hist']
-        hc, nout = Hd + E, n_mel + 1
+        hc, nout = Hd + Ep, n_mel + 1          # [h_dec | ctx] rows are Ep wide in their ctx part (engine.Ep)
 
         PHASES.mark(None)
         # ---- PostNet backward (channels-last)
@@ -745,6 +767,8 @@ class GeneratorEngine:
         def leaf_proj():
             dWpg = _f32(nout, hc, device=dev)
             ops.linear_dw(dout, hist['HC'], To * Bp, nout, hc, dWpg)
+            if Ep > E:                           # drop the (zero-input) pad columns
+                dWpg = dWpg[:, :Hd + E].contiguous()
             acc_add(G['decoder.linear_projection.linear_layer.weight'], dWpg[:n_mel])
             acc_add(G['decoder.gate_layer.linear_layer.weight'], dWpg[n_mel:])
             bsum = ops.col_sums(dout, To * Bp, nout)
@@ -758,12 +782,12 @@ class GeneratorEngine:
         if dalign is not None:
             dalign_tm = _f32(To, B, Ti, device=dev, zero=False)
             call('gt_permute3', dalign.contiguous(), Ti, To * Ti, 1, To, B, Ti, dalign_tm, 0, 0, 0, 1.0)
-        K1, K2 = E + Ha, Ha + E + Hd
+        K1, K2 = Ep + Ha, Ha + Ep + Hd
         N1pad, N2pad, Apad = roundup(K1, 16), roundup(K2, 16), roundup(A, 16)
         W1ih, W1hh = P['decoder.attention_rnn.weight_ih'], P['decoder.attention_rnn.weight_hh']
         W2ih, W2hh = P['decoder.decoder_rnn.weight_ih'], P['decoder.decoder_rnn.weight_hh']
-        W1cat = torch.cat((W1ih[:, Pd:], W1hh), dim=1).contiguous()
-        W2cat = None if (HOIST2 and not FUSED_CELL) else torch.cat((W2ih, W2hh), dim=1).contiguous()
+        W1cat, W2ihp, _ = self._decoder_operands(P)
+        W2cat = None if (HOIST2 and not FUSED_CELL) else torch.cat((W2ihp, W2hh), dim=1).contiguous()
         Wq = P['decoder.attention_layer.query_layer.linear_layer.weight']
         packT = pack_rec_bf16 if self.bf16 else pack_rec
         hoist2 = HOIST2 and not FUSED_CELL
@@ -774,17 +798,19 @@ class GeneratorEngine:
         WqTp = pack_rec(Wq, Ha, Ha, A, transposed=True)
         b = GtDecoderBwd()
         b.B, b.Bp, b.Ti, b.To, b.E, b.ldE, b.P, b.Ha, b.Hd, b.A, b.Apad, b.F, b.Kc = \
-            B, Bp, Ti, To, E, E, Pd, Ha, Hd, A, Apad, self.F, self.Kc
+            B, Bp, Ti, To, Ep, Ep, Pd, Ha, Hd, A, Apad, self.F, self.Kc
         b.S1, b.S2, b.Sq = rec_splits(N1pad, 4 * Ha), rec_splits(N2pad, 4 * Hd), ops.pick_splits(A, 2)
         if self.bf16:
             b.bf16 = 1
             b.S1, b.S2 = rec_splits_bf16(N1pad, 4 * Ha), rec_splits_bf16(N2pad, 4 * Hd)
         if hoist2:
             b.S2 = (rec_splits_bf16 if self.bf16 else rec_splits)(Hdpad, 4 * Hd)
+            if S2_BWD and not self.bf16:
+                b.S2 = ops.pick_splits(4 * Hd, S2_BWD)
         b.N1pad, b.N2pad = N1pad, N2pad
-        if CELL_QUERY and Ha % 16 == 0 and E % 4 == 0:
+        if CELL_QUERY and Ha % 16 == 0:
             b.Wq = ptr(P['decoder.attention_layer.query_layer.linear_layer.weight'])
-        n_wpack = int(lib().gt_attn_wpack_elems(ops.attn_dims(B, Ti, E, A, self.F, self.Kc)))
+        n_wpack = int(lib().gt_attn_wpack_elems(ops.attn_dims(B, Ti, Ep, A, self.F, self.Kc)))
         wpack_b = _f32(n_wpack, device=dev, zero=False) if n_wpack else None
         b.attn_wpack = ptr(wpack_b)
         training = sv['training']
@@ -793,9 +819,9 @@ class GeneratorEngine:
         al = 'decoder.attention_layer.'
         Wc, Wd, v = (P[al + 'location_layer.location_conv.conv.weight'],
                      P[al + 'location_layer.location_dense.linear_layer.weight'], P[al + 'v.linear_layer.weight'])
-        dims = ops.attn_dims(B, Ti, E, A, self.F, self.Kc)
+        dims = ops.attn_dims(B, Ti, Ep, A, self.F, self.Kc)
         buf = dict(dG1=_f32(To, Bp, 4 * Ha, device=dev), dG2=_f32(To, Bp, 4 * Hd, device=dev),
-                   dctx_hist=_f32(To, B, E, device=dev, zero=False), dpm=_f32(B, Ti, A, device=dev),
+                   dctx_hist=_f32(To, B, Ep, device=dev, zero=False), dpm=_f32(B, Ti, A, device=dev),
                    acc=_f32(int(lib().gt_attn_acc_elems(dims)), device=dev),
                    dc1=_f32(Bp, Ha, device=dev), dc2=_f32(Bp, Hd, device=dev), dwcat=_f32(2, 2, B, Ti, device=dev),
                    dcum_acc=_f32(B, Ti, device=dev), dq_hist=_f32(To, Bp, Apad, device=dev),
@@ -804,10 +830,10 @@ class GeneratorEngine:
                    partX2=None if hoist2 else _f32(DEC_RING, b.S2, Bp, N2pad, device=dev),
                    partQ=_f32(b.Sq, Bp, Ha, device=dev))
         if hoist2:
-            ldxa = roundup(Ha + E, 4)
-            W2ih_c = W2ih if W2ih.is_contiguous() else W2ih.contiguous()
+            ldxa = roundup(Ha + Ep, 4)
+            W2ih_c = W2ihp
             buf.update(dXA=_f32(To, Bp, ldxa, device=dev, zero=False), partXh=_f32(b.S2, Bp, Hdpad, device=dev))
-            b.W2hTp, b.W2ih, b.ldw2, b.ldxa, b.blk = ptr(W2hTp), ptr(W2ih_c), W2ih_c.stride(0), ldxa, DEC_BLK
+            b.W2hTp, b.W2ih, b.ldw2, b.ldxa, b.blk = ptr(W2hTp), ptr(W2ih_c), W2ih_c.stride(0), ldxa, DEC_BLK_BWD
         b.memory, b.pm, b.Wc, b.Wd, b.v = ptr(sv['memory']), ptr(sv['pm']), ptr(Wc), ptr(Wd), ptr(v)
         b.lengths = ptr(sv['lens32'])
         b.att_keep, b.dec_keep = ptr(sv['att_keep']), ptr(sv['dec_keep'])
@@ -894,19 +920,20 @@ class GeneratorEngine:
 
         # ---- d(memory) = sum_t w_t^T dctx_t (batched over b) + dpm @ Wmem ;  dWmem = dpm^T memory
         Wmem = P[al + 'memory_layer.linear_layer.weight']
-        dmem = _f32(B, Ti, E, device=dev, zero=False)
+        dmem = _f32(B, Ti, Ep, device=dev, zero=False)
         sgemm(Operand(hist['w_hist'], RC, ld=B * Ti, offset=B * Ti, batch_stride=Ti),
-              Operand(buf['dctx_hist'], RC, ld=B * E, batch_stride=E), dmem, Ti, E, To, batch=B, c_batch_stride=Ti * E)
-        sgemm(Operand(buf['dpm'], KC, ld=A), Operand(Wmem, RC, ld=E), dmem, B * Ti, E, A, accumulate=True,
+              Operand(buf['dctx_hist'], RC, ld=B * Ep, batch_stride=Ep), dmem, Ti, Ep, To, batch=B, c_batch_stride=Ti * Ep)
+        sgemm(Operand(buf['dpm'], KC, ld=A), Operand(Wmem, RC, ld=E), dmem, B * Ti, E, A, ldc=Ep, accumulate=True,
               bf16=ops.BF16_GEMMS)          # input gradient of the memory layer (a layer GEMM)
-        LEAF.run(lambda: ops.linear_dw(buf['dpm'], sv['memory'], B * Ti, A, E, G[al + 'memory_layer.linear_layer.weight']), buf['dpm'])
+        LEAF.run(lambda: ops.linear_dw(buf['dpm'], sv['memory'], B * Ti, A, E, G[al + 'memory_layer.linear_layer.weight'],
+                                       ldx=Ep), buf['dpm'])
 
         col = 2 * H
         if self.vesus:
             se = hp.speakers_embedding
             # d speaker embedding = sum over Ti of dmem[:, :, col:col+se]  (rows = Ti per item)
             tmp = _f32(Ti, B, se, device=dev, zero=False)
-            check(lib().gt_permute3(ptr(dmem, col), E, Ti * E, 1, Ti, B, se, ptr(tmp), 0, 0, 0, 1.0, ops._stream()),
+            check(lib().gt_permute3(ptr(dmem, col), Ep, Ti * Ep, 1, Ti, B, se, ptr(tmp), 0, 0, 0, 1.0, ops._stream()),
                   'gt_permute3')
             dspk = ops.col_sums(tmp, Ti, B * se).contiguous()
             call('gt_embedding_bwd', sv['speaker_ids'], dspk, se, B, se, G['speaker_embedding.weight'])
@@ -916,9 +943,9 @@ class GeneratorEngine:
         idx = sv['idx']
         C = self.enc_dim
         dhs = _f32(2, Ti * Bp, H, device=dev, zero=False)
-        dm2 = dmem.view(B * Ti, E)
-        call('gt_gather_rows', dm2, E, idx['fwd'], Ti * Bp, H, dhs[0], H, 0)
-        check(lib().gt_gather_rows(ptr(dmem, H), E, ptr(idx['rev']), Ti * Bp, H, ptr(dhs[1]), H, 0, ops._stream()),
+        dm2 = dmem.view(B * Ti, Ep)
+        call('gt_gather_rows', dm2, Ep, idx['fwd'], Ti * Bp, H, dhs[0], H, 0)
+        check(lib().gt_gather_rows(ptr(dmem, H), Ep, ptr(idx['rev']), Ti * Bp, H, ptr(dhs[1]), H, 0, ops._stream()),
               'gt_gather_rows')
         Hpad = roundup(H, 16)
         WhT = torch.stack([pack_rec(P['encoder.lstm.weight_hh_l0' + sfx], Hpad, H, 4 * H, transposed=True)
