@@ -245,8 +245,10 @@ class DeviceBatches:
             text_d, audio_d, len_d = dev(text), dev(audio), dev(audio_len)
             spk_d, emo_d = dev(speakers), dev(emotions)
             mel, gate, _ = self.stft.mel_spectrogram_batch(audio_d, len_d)
+            ready = torch.cuda.Event()
+            ready.record(self.stream)       # end of THIS batch's staging (the next batch is staged behind it)
         out_len = audio_len // hop + 1
-        return (text_d, in_len, mel, gate, spk_d, emo_d, out_len)
+        return (text_d, in_len, mel, gate, spk_d, emo_d, out_len), ready
 
     def __iter__(self):
         staged = None
@@ -258,9 +260,12 @@ class DeviceBatches:
         if staged is not None:
             yield self._release(staged)
 
-    def _release(self, batch):
+    def _release(self, staged):
+        batch, ready = staged
         main = torch.cuda.current_stream(self.device)
-        main.wait_stream(self.stream)
+        # wait for this batch's own event, not for the side stream: batch i+1 is already being copied and transformed
+        # there, and a wait_stream() would put its H2D copy + STFT on the critical path of step i
+        main.wait_event(ready)
         for t in batch:
             if t.is_cuda:
                 t.record_stream(main)
