@@ -96,19 +96,23 @@ struct TileLoader {
                             // IM2COL_K, (b,t) for IM2COL_R; advanced by BK per load instead of dividing every time
     float4 reg[NIT];
 
+    // k-contiguous operands (KC / IM2COL_K): thread = (row tid >> 2 (+ 64 i), k-quad tid & 3), so that 4 consecutive
+    // lanes read the 64 contiguous bytes (one 16-wide k-slab) of a row and a wave instruction touches 16 row segments
+    // instead of 64 scattered 16-byte pieces (the earlier row = lane mapping: every lane in a different cache line).  The
+    // k-major LDS store of that mapping has 2-way bank conflicts between k-quads 0/2 and 1/3, which ds_write_b32 hides.
     __device__ __forceinline__ void init(const OpDev& o, int r0, int kbeg, int tid) {
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             p0[i] = 0; p1[i] = 0; q0[i] = 0; q1[i] = 0;
             if (MODE == GT_OP_IM2COL_K) {
-                const int k = kbeg + 4 * (tid >> 6);
+                const int k = kbeg + 4 * (tid & 3);
                 q0[i] = k / o.C; q1[i] = k - q0[i] * o.C;
             } else if (MODE == GT_OP_IM2COL_R) {
                 const int k = kbeg + (tid + 256 * i) / (BR / 4);
                 q0[i] = k / o.T; q1[i] = k - q0[i] * o.T;
             }
             if (MODE == GT_OP_IM2COL_K) {
-                const int r = r0 + (tid & 63) + 64 * i;
+                const int r = r0 + (tid >> 2) + 64 * i;
                 p0[i] = r / o.T; p1[i] = r - p0[i] * o.T;
             } else if (MODE == GT_OP_IM2COL_R) {
                 const int f = tid + 256 * i;
@@ -122,8 +126,8 @@ struct TileLoader {
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             if (is_ktype<MODE>()) {
-                const int r = r0 + (tid & 63) + 64 * i;
-                const int k = k0 + 4 * (tid >> 6);
+                const int r = r0 + (tid >> 2) + 64 * i;
+                const int k = k0 + 4 * (tid & 3);
                 reg[i] = load_kvec<MODE>(o, base, r, R, k, K, p0[i], p1[i], q0[i], q1[i]);
                 if (MODE == GT_OP_IM2COL_K) {
                     q1[i] += BK;
@@ -145,8 +149,8 @@ struct TileLoader {
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             if (is_ktype<MODE>()) {
-                const int rl = (tid & 63) + 64 * i;
-                const int kq = tid >> 6;
+                const int rl = (tid >> 2) + 64 * i;
+                const int kq = tid & 3;
                 S[(4 * kq + 0) * LD + rl] = reg[i].x;
                 S[(4 * kq + 1) * LD + rl] = reg[i].y;
                 S[(4 * kq + 2) * LD + rl] = reg[i].z;
