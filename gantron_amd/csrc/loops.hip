@@ -761,7 +761,19 @@ int gt_bilstm_run(const GtBiLstm* a, void* stream) {
     const int64_t TB = (int64_t)a->T * a->Bp;
     if (!a->backward) {
         const int64_t pz = (int64_t)a->S * a->Bp * N;
-        for (int s = 0; s < a->T; ++s) {
+        const bool fused = a->Whc != nullptr && a->counters != nullptr && a->H % 16 == 0;
+        const int64_t xdir = (int64_t)a->Bp * a->ldx, xslot = 2 * xdir;
+        for (int s = 0; fused && s < a->T; ++s) {
+            const float* Xc = a->X + (s & 1) * xslot;
+            float* Xn = a->X + ((s + 1) & 1) * xslot;
+            const int64_t dz[9] = {xdir, a->w_zstride, pz, TB * N, (int64_t)(a->T + 1) * a->Bp * a->H, TB * N, TB * a->H, xdir, xdir};
+            GT_TRY(gt_rec_cell_fwd_z(Xc, a->ldx, a->Whc, a->part, a->counters, a->Bp, a->Bp, a->H, a->H, a->S,
+                                     a->pre + (int64_t)s * a->Bp * N, N, a->c + (int64_t)s * a->Bp * a->H, nullptr, 0.f,
+                                     a->gates + (int64_t)s * a->Bp * N, a->c + (int64_t)(s + 1) * a->Bp * a->H,
+                                     a->hs + (int64_t)s * a->Bp * a->H, Xn, a->ldx, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0,
+                                     0, 0, a->active + (int64_t)s * a->Bp, Xc, a->ldx, 2, dz, 0, stream));
+        }
+        for (int s = 0; !fused && s < a->T; ++s) {
             for (int rb = 0; rb < nblk; ++rb)
                 GT_TRY(gt_rec_gemm(a->X + (int64_t)rb * 64 * a->ldx, a->ldx, a->Whp, a->part + (int64_t)rb * 64 * N, mt, N,
                                    a->H, a->S, (int64_t)a->Bp * N, 2, (int64_t)a->Bp * a->ldx, a->w_zstride, pz, stream));

@@ -257,6 +257,13 @@ struct RecCellEpi {
     float* qpart; long q_sstride;         // query slab of column group cg at qpart + cg * q_sstride, rows of Apad
     unsigned* counters;                   // (row blocks, N/64) tickets, zero-initialised ONCE by the caller
     int B, H, A, Apad, S;
+    // packed-sequence semantics (encoder BiLSTM): rows with active[m] == 0 pass their state through (c' = c, the emitted
+    // h_raw is 0, the carried h is h_prev)
+    const int* active; const float* h_prev; long ld_hprev;
+    // two independent problems in one launch (the BiLSTM directions): blockIdx.z = dir * nzb + row block; element offsets
+    // of direction 1 relative to direction 0
+    int nzb;
+    long dX, dW, dPart, dPre, dC, dGates, dHraw, dH0, dHprev;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rc_rsrc(const void* p) {
@@ -271,16 +278,26 @@ __global__ __launch_bounds__(REC_THREADS) void rec_cell_kernel(const float* __re
     else if (prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (prio == 1) __builtin_amdgcn_s_setprio(1);
     const int cg = blockIdx.x, s = blockIdx.y, z = blockIdx.z;
+    const int dir = z / e.nzb, rb = z - dir * e.nzb;
     const int kb0 = s * KBS;
-    float* red = rec_gemm_tile<MT, 0>(X + (long)z * xz, ldx, Wp, N, KB, kb0, min(KB, kb0 + KBS), cg);
+    if (dir != 0) {
+        X += e.dX; Wp += e.dW; part += e.dPart;
+        if (e.pre) e.pre += e.dPre;
+        e.c_prev += e.dC; e.c_out += e.dC;
+        if (e.gates) e.gates += e.dGates;
+        if (e.h_raw) e.h_raw += e.dHraw;
+        if (e.h0) e.h0 += e.dH0;
+        if (e.h_prev) e.h_prev += e.dHprev;
+    }
+    float* red = rec_gemm_tile<MT, 0>(X + (long)rb * xz, ldx, Wp, N, KB, kb0, min(KB, kb0 + KBS), cg);
     constexpr int ROWS = MT * 16;
     constexpr int NV = (ROWS * 16 + REC_THREADS - 1) / REC_THREADS;        // float4 of the tile per thread
     float* lds_h = red + ROWS * EP_LD;             // [ROWS][20] h tile for the query product (inside the staging array)
     unsigned* lds_ticket = reinterpret_cast<unsigned*>(red + ROWS * EP_LD + ROWS * 20);
     static_assert(ROWS * EP_LD + ROWS * 20 + 4 <= ROWS * REC_LD, "epilogue scratch fits the staging buffer");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = 64 * z;                       // first batch row of this row block
-    float* slab0 = part + (long)z * pz + (long)cg * 64;                    // slab 0 of this column group
+    const int row0 = 64 * rb;                      // first batch row of this row block
+    float* slab0 = part + (long)rb * pz + (long)cg * 64;                   // slab 0 of this column group
     if (e.S > 1) {
         // ---- publish this K-slice's tile (write-through), then draw a ticket
         const __amdgpu_buffer_rsrc_t wr = rc_rsrc(slab0 + (long)s * ps);
@@ -307,8 +324,9 @@ __global__ __launch_bounds__(REC_THREADS) void rec_cell_kernel(const float* __re
     const int u = 16 * cg + 4 * uq;                // first of this thread's 4 hidden units
     const bool live = cell_thread && m < e.B;
     const long cidx = (long)m * e.H + u;
-    float4 pre4[4], cp = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 pre4[4], cp = make_float4(0.f, 0.f, 0.f, 0.f), hp4 = make_float4(0.f, 0.f, 0.f, 0.f);
     uchar4 kp = make_uchar4(1, 1, 1, 1);
+    bool act = true;
 #pragma unroll
     for (int q = 0; q < 4; ++q) pre4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live) {
@@ -318,6 +336,10 @@ __global__ __launch_bounds__(REC_THREADS) void rec_cell_kernel(const float* __re
         }
         cp = *reinterpret_cast<const float4*>(e.c_prev + cidx);
         if (e.keep != nullptr) kp = *reinterpret_cast<const uchar4*>(e.keep + cidx);
+        if (e.active != nullptr) {
+            act = e.active[m] != 0;
+            if (e.h_prev != nullptr) hp4 = *reinterpret_cast<const float4*>(e.h_prev + (long)m * e.ld_hprev + u);
+        }
     }
     // query weights of this wave's column blocks: B operand of the 16x16x4 MFMA, lane supplies Wq[n = lane & 15][k..k+3]
     float4 wq[2];
@@ -376,9 +398,9 @@ __global__ __launch_bounds__(REC_THREADS) void rec_cell_kernel(const float* __re
         __syncthreads();
     }
     // ---- cell: thread = (row, 4 units); tile column 16*gate + unit
-    float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);      // carried hidden state (what the next step and the query see)
     if (live) {
-        float4 gv[4], cn;
+        float4 gv[4], cn, hraw;
         float* gvf = reinterpret_cast<float*>(&gv[0]);
         const float* cpf = reinterpret_cast<const float*>(&cp);
         float* cnf = reinterpret_cast<float*>(&cn);
@@ -402,12 +424,14 @@ __global__ __launch_bounds__(REC_THREADS) void rec_cell_kernel(const float* __re
             if (e.keep != nullptr) h *= kpf[el] ? e.scale : 0.f;
             hvf[el] = h;
         }
+        hraw = hv;
+        if (!act) { cn = cp; hraw = make_float4(0.f, 0.f, 0.f, 0.f); hv = hp4; }
         if (e.gates != nullptr) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(e.gates + (long)m * 4 * e.H + q * e.H + u) = gv[q];
         }
         *reinterpret_cast<float4*>(e.c_out + cidx) = cn;
-        if (e.h_raw != nullptr) *reinterpret_cast<float4*>(e.h_raw + cidx) = hv;
+        if (e.h_raw != nullptr) *reinterpret_cast<float4*>(e.h_raw + cidx) = hraw;
         if (e.h0 != nullptr) *reinterpret_cast<float4*>(e.h0 + (long)m * e.ld0 + u) = hv;
         if (e.h1 != nullptr) *reinterpret_cast<float4*>(e.h1 + (long)m * e.ld1 + u) = hv;
         if (e.h2 != nullptr) *reinterpret_cast<float4*>(e.h2 + (long)m * e.ld2 + u) = hv;
@@ -759,39 +783,49 @@ extern "C" int gt_pack_rec_cell_weight(const float* W, int64_t ldw, int32_t H, i
     return 0;
 }
 
-extern "C" int gt_rec_cell_fwd(const float* X, int64_t ldx, const float* Wp, float* part, uint32_t* counters, int32_t Bp,
-                               int32_t B, int32_t H, int32_t K, int32_t splits, const float* pre, int64_t ld_pre,
-                               const float* c_prev, const uint8_t* keep, float p_drop, float* gates, float* c_out,
-                               float* h_raw, float* h0, int64_t ld0, float* h1, int64_t ld1, float* h2, int64_t ld2,
-                               const float* Wq, int64_t ldwq, float* qpart, int64_t q_sstride, int32_t A, int32_t Apad,
-                               int32_t prio, void* stream) {
+int gt_rec_cell_fwd_z(const float* X, int64_t ldx, const float* Wp, float* part, uint32_t* counters, int32_t Bp, int32_t B,
+                      int32_t H, int32_t K, int32_t splits, const float* pre, int64_t ld_pre, const float* c_prev,
+                      const uint8_t* keep, float p_drop, float* gates, float* c_out, float* h_raw, float* h0, int64_t ld0,
+                      float* h1, int64_t ld1, float* h2, int64_t ld2, const float* Wq, int64_t ldwq, float* qpart,
+                      int64_t q_sstride, int32_t A, int32_t Apad, const int32_t* active, const float* h_prev, int64_t ld_hprev,
+                      int32_t ndir, const int64_t* dz, int32_t prio, void* stream) {
     GT_REQUIRE(X && Wp && part && counters && c_prev && c_out, GT_E_ARG, "gt_rec_cell_fwd: NULL pointer");
     GT_REQUIRE(B > 0 && Bp >= B && ((Bp <= 64 && Bp % 16 == 0) || Bp % 64 == 0) && H > 0 && H % 16 == 0 && K > 0 && splits >= 1 &&
                    splits <= 16, GT_E_ARG, "gt_rec_cell_fwd: bad sizes B=%d Bp=%d H=%d K=%d splits=%d", B, Bp, H, K, splits);
     GT_REQUIRE(p_drop >= 0.f && p_drop < 1.f, GT_E_ARG, "gt_rec_cell_fwd: p_drop");
+    GT_REQUIRE(ndir == 1 || (ndir == 2 && dz != nullptr && keep == nullptr && h1 == nullptr && h2 == nullptr && Wq == nullptr),
+               GT_E_ARG, "gt_rec_cell_fwd: the paired launch takes offsets, no dropout, one h destination and no query");
     const int N = 4 * H, KB = cdiv(K, 16);
     GT_REQUIRE(ldx >= (int64_t)KB * 16 && ldx % 4 == 0 && aligned16(X) && aligned16(Wp) && aligned16(part), GT_E_ALIGN,
                "gt_rec_cell_fwd: X needs ldx >= 16*ceil(K/16), ldx %% 4 == 0 and 16-byte alignment");
     auto ok4 = [](const void* p, int64_t ld) { return p == nullptr || (aligned16(p) && ld % 4 == 0); };
     GT_REQUIRE(ok4(pre, ld_pre) && aligned16(c_prev) && (keep == nullptr || (((uintptr_t)keep) & 3) == 0) && ok4(gates, 0) &&
-                   aligned16(c_out) && ok4(h_raw, 0) && ok4(h0, ld0) && ok4(h1, ld1) && ok4(h2, ld2) && ok4(Wq, ldwq),
+                   aligned16(c_out) && ok4(h_raw, 0) && ok4(h0, ld0) && ok4(h1, ld1) && ok4(h2, ld2) && ok4(Wq, ldwq) &&
+                   ok4(h_prev, ld_hprev),
                GT_E_ALIGN, "gt_rec_cell_fwd: every pointer must be 16-byte aligned with leading dimensions %% 4 == 0");
     if (Wq != nullptr)
         GT_REQUIRE(qpart && A > 0 && Apad >= A && Apad % 16 == 0 && Apad <= 256 && q_sstride >= (int64_t)Bp * Apad, GT_E_LIMIT,
                    "gt_rec_cell_fwd: attention_dim %d (padded %d) must fit 16 column blocks", A, Apad);
     const int KBS = cdiv(KB, splits);
     GT_REQUIRE(cdiv(KB, KBS) == splits, GT_E_ARG, "gt_rec_cell_fwd: splits=%d leaves empty slabs for K=%d", splits, K);
-    const int mt = Bp <= 64 ? Bp / 16 : 4, nz = Bp <= 64 ? 1 : Bp / 64;
+    const int mt = Bp <= 64 ? Bp / 16 : 4, nzb = Bp <= 64 ? 1 : Bp / 64;
     RecCellEpi e;
     e.pre = pre; e.ld_pre = ld_pre; e.c_prev = c_prev; e.c_out = c_out; e.keep = keep; e.scale = 1.0f / (1.0f - p_drop);
     e.gates = gates; e.h_raw = h_raw; e.h0 = h0; e.ld0 = ld0; e.h1 = h1; e.ld1 = ld1; e.h2 = h2; e.ld2 = ld2;
     e.Wq = Wq; e.ldwq = ldwq; e.qpart = qpart; e.q_sstride = q_sstride; e.counters = counters;
     e.B = B; e.H = H; e.A = A; e.Apad = Apad; e.S = splits;
-    dim3 grid(N / 64, splits, nz);
+    e.active = active; e.h_prev = h_prev; e.ld_hprev = ld_hprev; e.nzb = nzb;
+    e.dX = e.dW = e.dPart = e.dPre = e.dC = e.dGates = e.dHraw = e.dH0 = e.dHprev = 0;
+    if (ndir == 2) {
+        e.dX = dz[0]; e.dW = dz[1]; e.dPart = dz[2]; e.dPre = dz[3]; e.dC = dz[4]; e.dGates = dz[5]; e.dHraw = dz[6];
+        e.dH0 = dz[7]; e.dHprev = dz[8];
+        for (int i = 0; i < 9; ++i) GT_REQUIRE(dz[i] % 4 == 0, GT_E_ALIGN, "gt_rec_cell_fwd: direction offsets must be multiples of 4");
+    }
+    dim3 grid(N / 64, splits, nzb * ndir);
     hipStream_t st = (hipStream_t)stream;
-    GtProfScope prof(GT_FAM_REC_GEMM, 2.0 * Bp * (double)N * K + (Wq ? 2.0 * Bp * (double)H * A : 0.0),
-                     4.0 * ((double)N * K + (double)Bp * K + (double)Bp * N * (splits > 1 ? 2 * splits - 1 : 0) +
-                            (double)B * H * 12), st);
+    GtProfScope prof(GT_FAM_REC_GEMM, ndir * (2.0 * Bp * (double)N * K + (Wq ? 2.0 * Bp * (double)H * A : 0.0)),
+                     ndir * 4.0 * ((double)N * K + (double)Bp * K + (double)Bp * N * (splits > 1 ? 2 * splits - 1 : 0) +
+                                   (double)B * H * 12), st);
     const long ps = (long)Bp * N;
 #define GT_RC(MT)                                                                                                      \
     hipLaunchKernelGGL((rec_cell_kernel<MT>), grid, dim3(REC_THREADS), 0, st, X, (long)ldx, Wp, part, N, KB, KBS,        \
@@ -805,6 +839,17 @@ extern "C" int gt_rec_cell_fwd(const float* X, int64_t ldx, const float* Wp, flo
 #undef GT_RC
     GT_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int gt_rec_cell_fwd(const float* X, int64_t ldx, const float* Wp, float* part, uint32_t* counters, int32_t Bp,
+                               int32_t B, int32_t H, int32_t K, int32_t splits, const float* pre, int64_t ld_pre,
+                               const float* c_prev, const uint8_t* keep, float p_drop, float* gates, float* c_out,
+                               float* h_raw, float* h0, int64_t ld0, float* h1, int64_t ld1, float* h2, int64_t ld2,
+                               const float* Wq, int64_t ldwq, float* qpart, int64_t q_sstride, int32_t A, int32_t Apad,
+                               int32_t prio, void* stream) {
+    return gt_rec_cell_fwd_z(X, ldx, Wp, part, counters, Bp, B, H, K, splits, pre, ld_pre, c_prev, keep, p_drop, gates, c_out,
+                             h_raw, h0, ld0, h1, ld1, h2, ld2, Wq, ldwq, qpart, q_sstride, A, Apad, nullptr, nullptr, 0, 1,
+                             nullptr, prio, stream);
 }
 
 static int rec_problem(RecProblem& p, const float* X, int64_t ldx, const float* Wp, float* part, int N, int K, int splits,

@@ -44,8 +44,9 @@ DEC_RING = int(_os.environ.get('GANTRON_DEC_RING', '16'))     # ring of hand-off
 # hoisted decoder-LSTM input product (GtDecoderFwd.W2hp / GtDecoderBwd.W2hTp): [h_att | ctx] . W2ih of a block of steps
 # is one tiled GEMM, only h_dec . W2hh stays in the per-step loops
 HOIST2 = _os.environ.get('GANTRON_HOIST2', '1') != '0'
-# fused product + cell (+ query) launches of the forward loop (gt_rec_cell_fwd): 1 = attention LSTM, 2 = decoder LSTM, 3 = both
-REC_CELL = int(_os.environ.get('GANTRON_REC_CELL', '3'))
+# fused product + cell (+ query) launches of the forward loops (gt_rec_cell_fwd): bit 0 = attention LSTM, bit 1 = decoder LSTM,
+# bit 2 = encoder BiLSTM
+REC_CELL = int(_os.environ.get('GANTRON_REC_CELL', '7'))
 DEC_BLK_BWD = int(_os.environ.get('GANTRON_DEC_BLK_BWD', '16'))
 # K-splits of the decoder LSTM's small recurrent products in the hoisted mode (0: cost model).  That chain has slack
 # (it only follows / feeds the attention chain): fewer, longer workgroups leave the CUs to the critical chain.
@@ -391,8 +392,14 @@ class GeneratorEngine:
         gates = _f32(2, Ti, Bp, 4 * H, device=dev, zero=False)
         cst = _f32(2, Ti + 1, Bp, H, device=dev)
         hs = _f32(2, Ti, Bp, H, device=dev, zero=False)
-        Xst = _f32(2, Bp, ldx, device=dev)
+        fused_enc = bool(REC_CELL & 4) and H % 16 == 0         # product + cell of a BiLSTM step as one launch
+        Xst = _f32(2, 2, Bp, ldx, device=dev) if fused_enc else _f32(2, Bp, ldx, device=dev)
         part = _f32(2, S, Bp, 4 * H, device=dev, zero=False)
+        if fused_enc:
+            Whc = torch.stack([pack_rec_cell(P['encoder.lstm.weight_hh_l0' + sfx], H, H) for sfx in ('', '_reverse')])
+            assert Whc.stride(0) == Whp.stride(0)
+            enc_counters = torch.zeros(2 * (Bp // 64 if Bp > 64 else 1) * (H // 16), dtype=torch.int32, device=dev)
+            a.Whc, a.counters = ptr(Whc), ptr(enc_counters)
         a.pre, a.Whp, a.w_zstride, a.active = ptr(pre), ptr(Whp), Whp.stride(0), ptr(idx['active'])
         a.X, a.ldx, a.part, a.gates, a.c, a.hs = ptr(Xst), ldx, ptr(part), ptr(gates), ptr(cst), ptr(hs)
         _run('gt_bilstm_run', a)

@@ -408,6 +408,12 @@ typedef struct GtBiLstm {
     float* dG;                 /* (2, T, Bp, 4H) */
     float* dc;                 /* (2, Bp, H) zero-initialised */
     int32_t Hpad;
+    /* forward only, optional (H % 16 == 0): product + cell of a step as ONE launch (gt_rec_cell_fwd, both directions).
+     * Whc = the two gt_pack_rec_cell_weight images (w_zstride apart), counters = 2 x (Bp > 64 ? Bp/64 : 1) x H/16 zeroed
+     * tickets; X then holds TWO slots of (2, Bp, ldx) (the cell writes the next step's operand while other workgroups
+     * still read this step's). */
+    const float* Whc;
+    uint32_t* counters;
 } GtBiLstm;
 
 /* Free-running decoder of Decoder.inference (model.py:456-497): every step feeds the previous mel

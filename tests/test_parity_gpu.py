@@ -248,10 +248,12 @@ def test_midsize_against_oracle(dev, case):
                 # rounding of zero and fall on the other side of the ReLU for another summation order (tools/
                 # convstack_probe.py counts them against float64).  One such element moves one channel's slice of the
                 # weight gradients below it by percents of the tensor's max-abs while every other entry agrees to
-                # 1e-5: these tensors are held to a relative L2 error instead, with a loose max-abs bound
+                # 1e-5 (measured relative L2 per tensor: 1e-3 with one such element, 2.7e-3 with two -- which of the two
+                # happens depends on the order of the split-K atomics in the forward convolutions): these tensors are
+                # held to a relative L2 error of 5e-3 instead, with a loose max-abs bound
                 got = res['g_grad'][k].double()
                 l2 = float((got - v.double()).norm() / (v.double().norm() + 1e-30))
-                assert l2 <= (5e-2 if bf16 else 2e-3), f'g_grad.{k}: relative L2 error {l2:.3e}'
+                assert l2 <= (5e-2 if bf16 else 5e-3), f'g_grad.{k}: relative L2 error {l2:.3e}'
                 close(got, v, rtol=0.3 if bf16 else 6e-2, atol=GA, what=f'g_grad.{k}')
             else:
                 close(res['g_grad'][k], v, rtol=GT, atol=GA, what=f'g_grad.{k}')
