@@ -47,6 +47,7 @@ HOIST2 = _os.environ.get('GANTRON_HOIST2', '1') != '0'
 # fused product + cell (+ query) launches of the forward loops (gt_rec_cell_fwd): bit 0 = attention LSTM, bit 1 = decoder LSTM,
 # bit 2 = encoder BiLSTM
 REC_CELL = int(_os.environ.get('GANTRON_REC_CELL', '7'))
+ENC_SPLITS = int(_os.environ.get('GANTRON_ENC_SPLITS', '0'))   # K-splits of the fused BiLSTM step (0: cost model)
 DEC_BLK_BWD = int(_os.environ.get('GANTRON_DEC_BLK_BWD', '16'))
 # K-splits of the decoder LSTM's small recurrent products in the hoisted mode (0: cost model).  That chain has slack
 # (it only follows / feeds the attention chain): fewer, longer workgroups leave the CUs to the critical chain.
@@ -393,6 +394,8 @@ class GeneratorEngine:
         cst = _f32(2, Ti + 1, Bp, H, device=dev)
         hs = _f32(2, Ti, Bp, H, device=dev, zero=False)
         fused_enc = bool(REC_CELL & 4) and H % 16 == 0         # product + cell of a BiLSTM step as one launch
+        if fused_enc and ENC_SPLITS:
+            S = a.S = ops.pick_splits(H, ENC_SPLITS)
         Xst = _f32(2, 2, Bp, ldx, device=dev) if fused_enc else _f32(2, Bp, ldx, device=dev)
         part = _f32(2, S, Bp, 4 * H, device=dev, zero=False)
         if fused_enc:

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Run ON THE GPU BOX (gpurun): every rocprofv3 pass behind profiles/rNN_* for the default bench workload.
+#   bash tools/collect_profiles.sh gpurun_out/r02prof
+# Counter passes are separate runs with --kernel-trace only (gpurun refuses --pmc together with the API trace domains).
+set -o pipefail
+OUT=${1:-gpurun_out/prof}
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+ARGS1="bench.py --steps 1 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o r02k -- python3 $ARGS > "$OUT/stats.log" 2>&1 && echo "stats pass done" &&
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -o fetch -- python3 $ARGS1 > "$OUT/fetch.log" 2>&1 && echo "fetch pass done" &&
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -o write -- python3 $ARGS1 > "$OUT/write.log" 2>&1 && echo "write pass done" &&
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d "$OUT/mfma" -o mfma -- python3 $ARGS1 > "$OUT/mfma.log" 2>&1 && echo "mfma pass done" &&
+python3 tools/pmc_traffic.py "$OUT/fetch/fetch_counter_collection.csv" "$OUT/write/write_counter_collection.csv" "$OUT/pmc_traffic.json" > "$OUT/pmc_traffic.txt" &&
+python3 tools/pmc_mfma.py "$OUT/mfma/mfma_counter_collection.csv" "$OUT/pmc_mfma.json" > "$OUT/pmc_mfma.txt" &&
+rm -f "$OUT"/fetch/*_counter_collection.csv "$OUT"/write/*_counter_collection.csv "$OUT"/mfma/*_counter_collection.csv "$OUT"/*/*_kernel_trace.csv &&
+ls -la "$OUT" "$OUT/stats"
