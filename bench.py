@@ -41,12 +41,14 @@ FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (the headline figures with 2:1 sparsity are not used)
 HBM_PEAK_GBS = 8000.0
 FAMILIES = ['rec_gemm', 'sgemm', 'attn_energies_fwd', 'attn_context_fwd', 'attn_context_bwd', 'attn_energies_bwd',
-            'lstm_cell_fwd', 'lstm_cell_bwd']
-KERNEL_OF = {'rec_gemm': 'rec_gemm_kernel', 'sgemm': 'sgemm_kernel', 'attn_energies_fwd': 'attn_energies_fwd_kernel',
+            'lstm_cell_fwd', 'lstm_cell_bwd', 'rec_cell']
+NF = len(FAMILIES)                 # GT_PROF_FAMILIES of include/gantron_hip.h
+# kernel symbol of each family as rocprofv3 / profiles/rNN_pmc_traffic.json name it
+KERNEL_OF = {'rec_gemm': 'rec_gemm_kernel', 'sgemm': 'sgemm_kernel', 'attn_energies_fwd': 'attn_energies_fwd',
              'attn_context_fwd': 'attn_context_fwd_kernel', 'attn_context_bwd': 'attn_context_bwd_kernel',
-             'attn_energies_bwd': 'attn_energies_bwd_kernel', 'lstm_cell_fwd': 'lstm_cell_fwd_kernel',
-             'lstm_cell_bwd': 'lstm_cell_bwd_kernel'}
-MFMA_BOUND = {'rec_gemm', 'sgemm'}
+             'attn_energies_bwd': 'attn_energies_bwd', 'lstm_cell_fwd': 'lstm_cell_fwd_kernel',
+             'lstm_cell_bwd': 'lstm_cell_bwd_kernel', 'rec_cell': 'rec_cell_kernel'}
+MFMA_BOUND = {'rec_gemm', 'sgemm', 'rec_cell'}
 PROF_STRIDE = 64
 
 
@@ -332,7 +334,7 @@ def main():
         pair(args.warmup + i)
     sync()
     elapsed = time.perf_counter() - t0
-    prof_out = (ctypes.c_double * 42)()
+    prof_out = (ctypes.c_double * (5 * NF + 2))()
     _lib.check(lib.gt_prof_end(prof_out), 'gt_prof_end')
     log(f'timed region: {elapsed:.3f} s for {args.steps} pairs')
     if world > 1:
@@ -386,11 +388,11 @@ def main():
         # a bracket = kernel duration (dispatch begin to end, what rocprofv3 reports) + the latency of the two event
         # packets; that latency, in situ = bracket of an empty kernel on the same busy streams - the empty kernel's own
         # duration (gt_prof_calibrate: start / stop timestamps of its dispatch)
-        null_bracket_ms = (out[41] / out[40]) if out[40] > 0 else 0.0
+        null_bracket_ms = (out[5 * NF + 1] / out[5 * NF]) if out[5 * NF] > 0 else 0.0
         null_ms = max(null_bracket_ms - null_us.value * 1e-3, 0.0)
         fam = [dict(name=FAMILIES[f], launches=int(out[4 * f]),
                     ms=max(out[4 * f + 1] - null_ms * out[4 * f], 1e-9) if out[4 * f] else 0.0, flops=out[4 * f + 2],
-                    bytes=out[4 * f + 3], seen=int(out[32 + f])) for f in range(8)]
+                    bytes=out[4 * f + 3], seen=int(out[4 * NF + f])) for f in range(NF)]
         for r in fam:                            # estimated time of ALL launches of the family in the timed region
             r['est_total_ms'] = r['ms'] / r['launches'] * r['seen'] if r['launches'] else 0.0
         # the dominant KERNEL: every family but sgemm is one kernel symbol; the sgemm family is several template

@@ -109,7 +109,7 @@ extern "C" int gt_prof_begin_sampled(int32_t stride) {
 
 // Stops recording, waits for the recorded events and fills per-family totals:
 // out[f*4+0] = bracketed launches, +1 = total ms, +2 = total flops, +3 = total bytes  (f < GT_FAM_COUNT);
-// out[32+f] = all launches of the family seen while profiling
+// out[4*GT_FAM_COUNT + f] = all launches of the family seen while profiling; then the empty-kernel brackets (count, ms)
 extern "C" int gt_prof_end(double* out) {
     g_gt_prof_on = false;
     GT_REQUIRE(out != nullptr, GT_E_ARG, "gt_prof_end: NULL");

@@ -823,7 +823,7 @@ int gt_rec_cell_fwd_z(const float* X, int64_t ldx, const float* Wp, float* part,
     }
     dim3 grid(N / 64, splits, nzb * ndir);
     hipStream_t st = (hipStream_t)stream;
-    GtProfScope prof(GT_FAM_REC_GEMM, ndir * (2.0 * Bp * (double)N * K + (Wq ? 2.0 * Bp * (double)H * A : 0.0)),
+    GtProfScope prof(GT_FAM_REC_CELL, ndir * (2.0 * Bp * (double)N * K + (Wq ? 2.0 * Bp * (double)H * A : 0.0)),
                      ndir * 4.0 * ((double)N * K + (double)Bp * K + (double)Bp * N * (splits > 1 ? 2 * splits - 1 : 0) +
                                    (double)B * H * 12), st);
     const long ps = (long)Bp * N;
