@@ -337,6 +337,8 @@ def main():
     prof_out = (ctypes.c_double * (5 * NF + 2))()
     _lib.check(lib.gt_prof_end(prof_out), 'gt_prof_end')
     log(f'timed region: {elapsed:.3f} s for {args.steps} pairs')
+    from gantron_amd import engine as _engine
+    _engine.check_handoffs()          # no in-launch hand-off of the loop kernels gave up during the timed region
     if world > 1:
         t = torch.tensor([elapsed, float(frames)], device=dev, dtype=torch.float64)
         tmax = t.clone()

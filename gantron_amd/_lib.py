@@ -13,7 +13,7 @@ HEADER = os.path.join(os.path.dirname(_PKG), 'include', 'gantron_hip.h')
 LIB_PATH = os.path.join(_PKG, 'libgantron_hip.so')
 
 _SCALARS = {
-    'int32_t': ctypes.c_int32, 'int64_t': ctypes.c_int64, 'uint64_t': ctypes.c_uint64,
+    'int32_t': ctypes.c_int32, 'int64_t': ctypes.c_int64, 'uint64_t': ctypes.c_uint64, 'uint32_t': ctypes.c_uint32,
     'float': ctypes.c_float, 'int': ctypes.c_int,
 }
 

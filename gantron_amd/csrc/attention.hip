@@ -26,6 +26,12 @@ void gt_launch_attn_energies_bwd_mfma(GtAttnDims d, const float* dw, const float
                                       const float* w_prev, const float* w_cum, const float* pm, const float* Wc,
                                       const float* Wd, const float* v, const int* lengths, float* dq, long ld_dq,
                                       float* dpm, float* dwcat_out, float* acc, const float* wpack, hipStream_t st);
+void gt_launch_attn_step_fwd_mfma(GtAttnDims d, GtSlabs qpart, const float* w_prev, const float* w_cum, const float* pm,
+                                  const float* Wc, const float* Wd, const float* v, const int* lengths, float* q_out,
+                                  const float* wpack, float* u_out, float* erow, unsigned* row_cnt, unsigned step1,
+                                  int* timeout_flag, const float* memory, long ld_mem, float* w_out, const float* cum_in,
+                                  float* cum_out, float* c0, long ld0, float* c1, long ld1, float* c2, long ld2,
+                                  hipStream_t st);
 int gt_attn_wpack_elems_mfma();
 int gt_attn_acc_per_mfma();
 void gt_launch_attn_acc_reduce_mfma(const float* acc, int nwg, float* dv, float* dWd, float* dWc, hipStream_t st);
@@ -712,6 +718,35 @@ extern "C" int gt_attn_energies_fwd_u(GtAttnDims d, GtSlabs qpart, const float* 
         }
     }
 #undef GT_EF
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int32_t gt_attn_step_supported(GtAttnDims d) {
+    return (use_mfma(d) && d.Ti <= 256 && d.E % 4 == 0) ? 1 : 0;
+}
+
+extern "C" int gt_attn_step_fwd(GtAttnDims d, GtSlabs qpart, const float* w_prev, const float* w_cum, const float* pm,
+                                const float* Wc, const float* Wd, const float* v, const int32_t* lengths, float* q_out,
+                                const float* wpack, float* u_out, float* erow, uint32_t* row_cnt, uint32_t step1,
+                                int32_t* timeout_flag, const float* memory, int64_t ld_mem, float* w_out, const float* cum_in,
+                                float* cum_out, float* c0, int64_t ld0, float* c1, int64_t ld1, float* c2, int64_t ld2,
+                                void* stream) {
+    int rc = check_dims(d, "gt_attn_step_fwd");
+    if (rc) return rc;
+    GT_REQUIRE(gt_attn_step_supported(d), GT_E_LIMIT, "gt_attn_step_fwd: needs attention dims (128, 32, 31), Ti <= 256 and E %% 4 == 0");
+    GT_REQUIRE(qpart.p && w_prev && w_cum && pm && Wc && Wd && v && erow && row_cnt && memory && w_out && step1 >= 1, GT_E_ARG,
+               "gt_attn_step_fwd: NULL pointer");
+    GT_REQUIRE(cum_out == nullptr || cum_in != nullptr, GT_E_ARG, "gt_attn_step_fwd: cum_in missing");
+    auto ok4 = [](const void* p, int64_t ld) { return p == nullptr || (aligned16(p) && ld % 4 == 0); };
+    GT_REQUIRE(ok4(memory, ld_mem) && ld_mem >= d.E && ok4(c0, ld0) && ok4(c1, ld1) && ok4(c2, ld2), GT_E_ALIGN,
+               "gt_attn_step_fwd: memory and the context destinations must be 16-byte aligned with leading dimensions %% 4 == 0");
+    const double ctx_rows = g_gt_prof_ctx_rows > 0.0 ? g_gt_prof_ctx_rows : (double)d.B * d.Ti;
+    GtProfScope prof(GT_FAM_ATTN_E_FWD, 2.0 * d.B * d.Ti * (double)(d.F * 2 * d.Kc + d.A * d.F + 2 * d.A) + 2.0 * ctx_rows * d.E,
+                     4.0 * (d.B * d.Ti * (d.A + 3.0) + ctx_rows * d.E + d.B * (3.0 * d.E + 4.0 * d.Ti)), (hipStream_t)stream);
+    gt_launch_attn_step_fwd_mfma(d, qpart, w_prev, w_cum, pm, Wc, Wd, v, lengths, q_out, wpack, u_out, erow, row_cnt, step1,
+                                 timeout_flag, memory, (long)ld_mem, w_out, cum_in, cum_out, c0, (long)ld0, c1, (long)ld1, c2,
+                                 (long)ld2, (hipStream_t)stream);
     GT_LAUNCH_CHECK();
     return 0;
 }

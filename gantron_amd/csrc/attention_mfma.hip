@@ -262,6 +262,222 @@ __global__ __launch_bounds__(256) void attn_energies_fwd_mfma(GtAttnDims d, GtSl
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// One launch for a whole forward attention step (model.py:70-91): energies of this workgroup's 32 positions, then --
+// INSIDE the launch -- the workgroups of a batch row exchange their energies, every one of them normalises the row
+// (softmax) and accumulates the context for a slice of the E columns over all valid positions.
+//
+// Hand-off (MI355X_MICROARCH.md, visibility, "sc1 stores + drained + one agent-scope atomic per workgroup; the consumer
+// polls the counter with sc1 loads and reads the payload with sc1 loads"): the 32 energies are written through, the
+// storing wave drains, ONE lane adds to the row's arrival counter; ONE lane polls that counter (relaxed agent loads,
+// s_sleep between polls) until the row's NCv workgroups of this step have arrived, the workgroup's barrier releases the
+// others, every energy is then read with an sc1 load.  Counters are monotonic over the loop (target = NCv * step): zeroed
+// once per loop call, never reset.  Progress: only the <= NCv workgroups of one row wait for each other; workgroup ids are
+// laid out so that the rows of a group of 8 are contiguous (at most one group is ever partially dispatched) and the
+// chunks of a row share an XCD (id % 8 == row % 8); nothing outside this launch ever waits for it, so slots always free
+// up.  The poll is nevertheless bounded: on time-out the workgroup raises `timeout_flag` and carries on with what it has
+// (the step is then wrong, the launch still ends).
+struct AttnStepFwd {
+    GtAttnDims d; GtSlabs qpart;
+    const float* w_prev; const float* w_cum; const float* pm; const float* Wc; const float* Wd; const float* v;
+    const int* lengths; float* q_out; const float* wpack; float* u_out;
+    float* erow; unsigned* row_cnt; unsigned step1; int* timeout_flag;
+    const float* memory; long ld_mem; float* w_out; const float* cum_in; float* cum_out;
+    float* c0; long ld0; float* c1; long ld1; float* c2; long ld2;
+    int NC;
+};
+
+__global__ __launch_bounds__(256) void attn_step_fwd_mfma(AttnStepFwd a) {
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ SharedM S;
+    const GtAttnDims& d = a.d;
+    // workgroup id -> (row, chunk): groups of 8 rows; inside a group id = chunk * 8 + (row % 8)
+    const int L = blockIdx.x;
+    const int grp = L / (8 * a.NC), rem = L - grp * 8 * a.NC;
+    const int chunk = rem >> 3, b = grp * 8 + (rem & 7);
+    if (b >= d.B) return;
+    const int t0 = chunk * CT;
+    const int Tv = a.lengths != nullptr ? min(a.lengths[b], d.Ti) : d.Ti;      // valid positions of this row
+    if (t0 >= Tv) return;                                                    // chunk entirely in the padding: not a member
+    const int NCv = (Tv + CT - 1) / CT;                                      // members of this row's exchange
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    // ---- phase 1: energies of positions [t0, t0 + 32)  (as attn_energies_fwd_mfma)
+    float4 pm4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = threadIdx.x + 256 * i, tl = f >> 5, c4 = f & 31;
+        pm4[i] = *reinterpret_cast<const float4*>(a.pm + ((long)b * d.Ti + min(t0 + tl, d.Ti - 1)) * A + 4 * c4);
+    }
+    const bool qvec = ((a.qpart.ld | a.qpart.slab_stride) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.qpart.p) & 15) == 0;
+    float qv = 0.f;
+    if (qvec) {
+        const int sg = threadIdx.x >> 5, c4 = threadIdx.x & 31;
+        const float* qp = a.qpart.p + (long)b * a.qpart.ld + 4 * c4;
+        float4 qa = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int base = 0; base < a.qpart.n; base += 64) {
+            float4 t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = *reinterpret_cast<const float4*>(qp + (long)min(base + sg + 8 * j, a.qpart.n - 1) * a.qpart.slab_stride);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float w = base + sg + 8 * j < a.qpart.n ? 1.f : 0.f;
+                qa.x += w * t[j].x; qa.y += w * t[j].y; qa.z += w * t[j].z; qa.w += w * t[j].w;
+            }
+        }
+        *reinterpret_cast<float4*>(&S.g[sg * A + 4 * c4]) = qa;
+    } else {
+        const float* qp = a.qpart.p + (long)b * a.qpart.ld + (threadIdx.x & (A - 1));
+#pragma unroll 8
+        for (int s2 = 0; s2 < a.qpart.n; ++s2) qv += qp[(long)s2 * a.qpart.slab_stride];
+    }
+    stage_common(S, d, a.Wc, a.Wd, a.v, a.w_prev, a.w_cum, b, t0, a.wpack);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = threadIdx.x + 256 * i, tl = f >> 5, c4 = f & 31;
+        *reinterpret_cast<float4*>(&S.ds[tl * LDS_ + 4 * c4]) = pm4[i];
+    }
+    if (qvec) {
+        __syncthreads();
+        if (threadIdx.x < A) {
+            qv = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qv += S.g[j * A + threadIdx.x];
+        }
+    }
+    if (threadIdx.x < A) {
+        S.q[threadIdx.x] = qv;
+        if (chunk == 0 && a.q_out != nullptr) a.q_out[(long)b * A + threadIdx.x] = qv;
+    }
+    __syncthreads();
+    conv_tile(S, wave, lane);
+    __syncthreads();
+    f32x4 acc[2][2];
+    dense_tiles(S, wave, lane, acc);
+    float ep[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float sum = 0.f;
+#pragma unroll
+            for (int nl = 0; nl < 2; ++nl) {
+                const int dd = 32 * wave + 16 * nl + r;
+                const float u = tanhf(acc[mt][nl][e] + S.q[dd] + S.ds[(16 * mt + 4 * kq + e) * LDS_ + dd]);
+                sum += S.v[dd] * u;
+                if (a.u_out != nullptr && t0 + 16 * mt + 4 * kq + e < d.Ti)
+                    a.u_out[((long)b * d.Ti + t0 + 16 * mt + 4 * kq + e) * A + dd] = u;
+            }
+            sum += __shfl_xor(sum, 1, 64);
+            sum += __shfl_xor(sum, 2, 64);
+            sum += __shfl_xor(sum, 4, 64);
+            sum += __shfl_xor(sum, 8, 64);
+            ep[mt][e] = sum;
+        }
+    if (r == 0) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) S.epart[wave][16 * mt + 4 * kq + e] = ep[mt][e];
+    }
+    __syncthreads();
+    // ---- publish this chunk's energies (wave 0), then wait for the row
+    float* erow = a.erow + (long)b * d.Ti;
+    if (wave == 0) {
+        if (lane < CT && t0 + lane < d.Ti) {
+            float e = (S.epart[0][lane] + S.epart[1][lane]) + (S.epart[2][lane] + S.epart[3][lane]);
+            if (t0 + lane >= Tv) e = -INFINITY;
+            __hip_atomic_store(erow + t0 + lane, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // write-through (sc1)
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the storing wave drains (its u_out stores included)
+        if (lane == 0) {
+            unsigned* cnt = a.row_cnt + b;
+            __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = (unsigned)NCv * a.step1;
+            unsigned spins = 0;
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 21)) {                    // seconds: something is badly wrong, do not hang the GPU
+                    if (a.timeout_flag != nullptr) *a.timeout_flag = 1;
+                    break;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: softmax over the row (every member computes it; energies read with sc1 loads), S.g holds w
+    float* w = S.g;                                  // Ti <= 256 (host check)
+    float mx = -INFINITY;
+    for (int t = threadIdx.x; t < Tv; t += 256) {
+        const float e = __hip_atomic_load(erow + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w[t] = e;
+        mx = fmaxf(mx, e);
+    }
+    mx = block_max(mx, S.red);
+    float sum = 0.f;
+    for (int t = threadIdx.x; t < Tv; t += 256) {
+        const float ex = __expf(w[t] - mx);
+        w[t] = ex;
+        sum += ex;
+    }
+    sum = block_sum(sum, S.red);
+    const float inv = 1.0f / sum;
+    for (int t = threadIdx.x; t < Tv; t += 256) w[t] *= inv;
+    __syncthreads();
+    if (chunk == 0) {
+        for (int t = threadIdx.x; t < d.Ti; t += 256) {
+            const float wt = t < Tv ? w[t] : 0.f;
+            a.w_out[(long)b * d.Ti + t] = wt;
+            if (a.cum_out != nullptr) a.cum_out[(long)b * d.Ti + t] = a.cum_in[(long)b * d.Ti + t] + wt;
+        }
+    }
+    // ---- phase 3: context for this member's slice of the E columns, over all valid positions
+    const int W = ((d.E + NCv - 1) / NCv + 3) & ~3;          // columns per member (multiple of 4)
+    const int col0 = chunk * W;
+    const int W4 = max(0, min(W, d.E - col0)) >> 2;           // float4 columns of this slice
+    if (W4 <= 0) return;
+    const int W4e = min(W4, 256), PG = 256 / W4e;             // position groups folded through LDS
+    const int cq = threadIdx.x % W4e, pg = threadIdx.x / W4e;
+    float4* fold = reinterpret_cast<float4*>(S.ds);           // [PG][W4e] float4 (S.ds is free after phase 1)
+    for (int cbase = 0; cbase < W4; cbase += W4e) {           // one trip unless a slice is wider than 1024 columns
+        const int c4 = cbase + cq;
+        const bool live = pg < PG && c4 < W4;
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+        if (live) {
+            const float* mp = a.memory + (long)b * d.Ti * a.ld_mem + col0 + 4 * c4;
+            int p = pg;
+            for (; p + 3 * PG < Tv; p += 4 * PG) {            // four rows in flight per thread
+                const float4 m0 = *reinterpret_cast<const float4*>(mp + (long)p * a.ld_mem);
+                const float4 m1 = *reinterpret_cast<const float4*>(mp + (long)(p + PG) * a.ld_mem);
+                const float4 m2 = *reinterpret_cast<const float4*>(mp + (long)(p + 2 * PG) * a.ld_mem);
+                const float4 m3 = *reinterpret_cast<const float4*>(mp + (long)(p + 3 * PG) * a.ld_mem);
+                const float w0 = w[p], w1 = w[p + PG], w2 = w[p + 2 * PG], w3 = w[p + 3 * PG];
+                a0.x += w0 * m0.x + w2 * m2.x; a0.y += w0 * m0.y + w2 * m2.y; a0.z += w0 * m0.z + w2 * m2.z; a0.w += w0 * m0.w + w2 * m2.w;
+                a1.x += w1 * m1.x + w3 * m3.x; a1.y += w1 * m1.y + w3 * m3.y; a1.z += w1 * m1.z + w3 * m3.z; a1.w += w1 * m1.w + w3 * m3.w;
+            }
+            for (; p < Tv; p += PG) {
+                const float4 m0 = *reinterpret_cast<const float4*>(mp + (long)p * a.ld_mem);
+                const float w0 = w[p];
+                a0.x += w0 * m0.x; a0.y += w0 * m0.y; a0.z += w0 * m0.z; a0.w += w0 * m0.w;
+            }
+            fold[pg * W4e + cq] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+        }
+        __syncthreads();
+        if (pg == 0 && c4 < W4) {
+            float4 c = fold[cq];
+            for (int j = 1; j < PG; ++j) {
+                const float4 t = fold[j * W4e + cq];
+                c.x += t.x; c.y += t.y; c.z += t.z; c.w += t.w;
+            }
+            const int col = col0 + 4 * c4;
+            if (a.c0 != nullptr) *reinterpret_cast<float4*>(a.c0 + (long)b * a.ld0 + col) = c;
+            if (a.c1 != nullptr) *reinterpret_cast<float4*>(a.c1 + (long)b * a.ld1 + col) = c;
+            if (a.c2 != nullptr) *reinterpret_cast<float4*>(a.c2 + (long)b * a.ld2 + col) = c;
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void attn_energies_bwd_mfma(GtAttnDims d, const float* dw, const float* w,
                                                               const float* q, const float* w_prev, const float* w_cum,
                                                               const float* pm, const float* Wc, const float* Wd,
@@ -753,6 +969,22 @@ void gt_launch_attn_energies_fwd_mfma(GtAttnDims d, GtSlabs qpart, const float* 
     dim3 grid(d.B, cdiv(d.Ti, CT));
     hipLaunchKernelGGL(attn_energies_fwd_mfma, grid, dim3(256), 0, st, d, qpart, w_prev, w_cum, pm, Wc, Wd, v, lengths,
                        q_out, energies, wpack, u_out);
+}
+
+void gt_launch_attn_step_fwd_mfma(GtAttnDims d, GtSlabs qpart, const float* w_prev, const float* w_cum, const float* pm,
+                                  const float* Wc, const float* Wd, const float* v, const int* lengths, float* q_out,
+                                  const float* wpack, float* u_out, float* erow, unsigned* row_cnt, unsigned step1,
+                                  int* timeout_flag, const float* memory, long ld_mem, float* w_out, const float* cum_in,
+                                  float* cum_out, float* c0, long ld0, float* c1, long ld1, float* c2, long ld2,
+                                  hipStream_t st) {
+    AttnStepFwd a;
+    a.d = d; a.qpart = qpart; a.w_prev = w_prev; a.w_cum = w_cum; a.pm = pm; a.Wc = Wc; a.Wd = Wd; a.v = v; a.lengths = lengths;
+    a.q_out = q_out; a.wpack = wpack; a.u_out = u_out; a.erow = erow; a.row_cnt = row_cnt; a.step1 = step1;
+    a.timeout_flag = timeout_flag; a.memory = memory; a.ld_mem = ld_mem; a.w_out = w_out; a.cum_in = cum_in; a.cum_out = cum_out;
+    a.c0 = c0; a.ld0 = ld0; a.c1 = c1; a.ld1 = ld1; a.c2 = c2; a.ld2 = ld2;
+    a.NC = cdiv(d.Ti, CT);
+    const int groups = cdiv(d.B, 8);
+    hipLaunchKernelGGL(attn_step_fwd_mfma, dim3(groups * 8 * a.NC), dim3(256), 0, st, a);
 }
 
 void gt_launch_attn_energies_bwd_rec_mfma(GtAttnDims d, const float* dw, const float* w, const float* u, const float* Wc,

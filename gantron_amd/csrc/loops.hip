@@ -224,6 +224,8 @@ static int decoder_fwd_hoisted(const GtDecoderFwd* a, void* stream) {
     const bool fusedB = a->W2hc != nullptr && a->counters2 != nullptr && !a->bf16 && a->Hd % 16 == 0 && (a->Hd + a->E) % 4 == 0;
     GT_REQUIRE((a->W1c == nullptr || fusedA) && (a->W2hc == nullptr || fusedB), GT_E_ARG,
                "gt_decoder_fwd: W1c / W2hc need fp32, Wq + partq, Ha %% 32 == 0, Hd %% 16 == 0, E %% 4 == 0 and their counters");
+    const bool attn_step = a->row_cnt != nullptr && gt_attn_step_supported(d) && wpack != nullptr && a->ld1 % 4 == 0 &&
+                           a->ld2 % 4 == 0 && a->ldE % 4 == 0 && (a->Hd % 4 == 0) && a->To < (1 << 24);
     const int64_t x1_slot = fusedA ? (int64_t)a->Bp * a->ld1 : 0;      // operand ping-pong (see GtDecoderFwd::W1c)
     const int64_t xh_slot = fusedB ? (int64_t)a->Bp * a->ldh : 0;
     int nblock = 0;
@@ -261,10 +263,19 @@ static int decoder_fwd_hoisted(const GtDecoderFwd* a, void* stream) {
                     GT_TRY(rec_rows(XAt, a->ld2, a->Wqp, a->part, a->Bp, a->Apad, a->Ha, a->Sq, sA));
                 }
             }
-            GT_TRY(gt_attn_energies_fwd_u(d, cq ? slabs(a->partq, a->Ha / (fusedA ? 16 : 32), (int64_t)a->Bp * a->Apad, a->Apad)
-                                                : slabs(a->part, a->Sq, (int64_t)a->Bp * a->Apad, a->Apad),
-                                          a->w_hist + (int64_t)t * BT, a->cum_hist + (int64_t)t * BT, a->pm, a->Wc, a->Wd, a->v,
-                                          a->lengths, a->q_hist + (int64_t)t * a->B * a->A, a->energies, wpack,
+            const GtSlabs qs = cq ? slabs(a->partq, a->Ha / (fusedA ? 16 : 32), (int64_t)a->Bp * a->Apad, a->Apad)
+                                  : slabs(a->part, a->Sq, (int64_t)a->Bp * a->Apad, a->Apad);
+            if (attn_step) {        // energies + softmax + context: one launch, the row's workgroups meet inside it
+                GT_TRY(gt_attn_step_fwd(d, qs, a->w_hist + (int64_t)t * BT, a->cum_hist + (int64_t)t * BT, a->pm, a->Wc, a->Wd,
+                                        a->v, a->lengths, a->q_hist + (int64_t)t * a->B * a->A, wpack,
+                                        a->u_hist ? a->u_hist + (int64_t)t * BT * a->A : nullptr, a->energies, a->row_cnt,
+                                        (uint32_t)(t + 1), a->attn_timeout, a->memory, a->ldE, a->w_hist + (int64_t)(t + 1) * BT,
+                                        a->cum_hist + (int64_t)t * BT, a->cum_hist + (int64_t)(t + 1) * BT, X1n, a->ld1,
+                                        XAt + a->Ha, a->ld2, hc_t + a->Hd, hc_ld, sA));
+                continue;
+            }
+            GT_TRY(gt_attn_energies_fwd_u(d, qs, a->w_hist + (int64_t)t * BT, a->cum_hist + (int64_t)t * BT, a->pm, a->Wc, a->Wd,
+                                          a->v, a->lengths, a->q_hist + (int64_t)t * a->B * a->A, a->energies, wpack,
                                           a->u_hist ? a->u_hist + (int64_t)t * BT * a->A : nullptr, sA));
             GT_TRY(gt_attn_context_fwd(d, a->energies, a->memory, a->ldE, a->lengths, a->w_hist + (int64_t)(t + 1) * BT,
                                        a->cum_hist + (int64_t)t * BT, a->cum_hist + (int64_t)(t + 1) * BT, X1n, a->ld1,

@@ -57,6 +57,32 @@ DEC_BLK = int(_os.environ.get('GANTRON_DEC_BLK', '16'))       # steps per block 
                                                               # 12: 157.9, 16: 157.9, 32: 160.5, 48: 160.9, 64: 165.7)
 
 
+# energies + softmax + context of a forward step as one launch (gt_attn_step_fwd: the row's workgroups meet inside it).
+# Measured slower than the two launches it replaces (20.8 vs 11.1 + 6.5 us stand-alone, forward loop 49.5 vs 45.7 ms): the
+# in-launch wait costs what the kernel boundary cost and the context phase loses its prefetch.  Off by default.
+ATTN_STEP = _os.environ.get('GANTRON_ATTN_STEP', '0') != '0'
+_HANDOFF_FLAGS = {}
+
+
+def handoff_flag(device):
+    """Per-device int32 word that kernels with an in-launch wait raise when a bounded wait gives up (the step's result is
+    then undefined).  Nothing on the step's path reads it (that would synchronise); check_handoffs() does."""
+    key = torch.device(device).index
+    if key not in _HANDOFF_FLAGS:
+        _HANDOFF_FLAGS[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _HANDOFF_FLAGS[key]
+
+
+def check_handoffs():
+    """Raise if any in-launch hand-off timed out since the last check (synchronises: call it where the loop already
+    does -- logging, validation, the end of a benchmark)."""
+    for key, flag in _HANDOFF_FLAGS.items():
+        if int(flag.item()) != 0:
+            flag.zero_()
+            raise RuntimeError(f'an in-launch hand-off of a decoder-loop kernel timed out on cuda:{key}: results since the '
+                               'last check are invalid (GANTRON_ATTN_STEP=0 selects the two-launch attention step)')
+
+
 def _f32(*shape, device, zero=True):
     return (torch.zeros if zero else torch.empty)(*shape, device=device, dtype=torch.float32)
 
@@ -575,6 +601,9 @@ class GeneratorEngine:
             if use_c2:
                 ws['counters2'] = torch.zeros(nzb * (Hd // 16), dtype=torch.int32, device=dev)
                 d.W2hc, d.counters2 = ptr(keep_t['W2hc']), ptr(ws['counters2'])
+        if hoist2 and ATTN_STEP and lib().gt_attn_step_supported(ops.attn_dims(B, Ti, Ep, A, self.F, self.Kc)):
+            ws['row_cnt'] = torch.zeros(B, dtype=torch.int32, device=dev)
+            d.row_cnt, d.attn_timeout = ptr(ws['row_cnt']), ptr(handoff_flag(dev))
         if ATTN_HOIST and training and lib().gt_attn_hoist_supported(ops.attn_dims(B, Ti, Ep, A, self.F, self.Kc)):
             hist['u_hist'] = _f32(To, B, Ti, A, device=dev, zero=False)
             d.u_hist = ptr(hist['u_hist'])

@@ -150,6 +150,8 @@ def train(output_directory, checkpoint_path, warm_start, n_gpus, rank, group_nam
 
     def checkpoint_and_validate():
         nonlocal best_val_loss, best_path, prev_check, prev_val
+        from .engine import check_handoffs
+        check_handoffs()              # a checkpoint must not be written from steps whose in-launch hand-offs gave up
         val_loss = validate(generator, criterion, valset, iteration, hparams.batch_size, n_gpus, collate_fn,
                             hparams.distributed_run, rank, hparams)
         if rank == 0:

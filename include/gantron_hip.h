@@ -277,6 +277,20 @@ int64_t gt_attn_acc_elems(GtAttnDims d);     /* size of `acc` (dv | dWd | dWc pe
 int gt_attn_acc_reduce(GtAttnDims d, const float* acc, float* dv, float* dWd, float* dWc,
                        void* stream);
 int32_t gt_attn_chunks(int32_t Ti);
+/* One launch for a whole forward attention step = gt_attn_energies_fwd_u + gt_attn_context_fwd (model.py:70-91), for the
+ * dimensions gt_attn_step_supported() accepts ((128, 32, 31), Ti <= 256, E % 4 == 0).  The workgroups of a batch row
+ * exchange their energies INSIDE the launch: `erow` (B, Ti) receives them (write-through), `row_cnt` (B) uint32 arrival
+ * counters -- zero-initialised ONCE per loop, monotonic -- tell a row's workgroups when the row is complete for step
+ * number `step1` = t + 1 (1, 2, 3, ... in launch order); then every workgroup normalises the row and accumulates the
+ * context for its slice of the E columns.  The wait is bounded: on time-out *timeout_flag (int32, may be NULL) is set
+ * to 1 and the step's result is undefined.  Other arguments as in the two calls it replaces. */
+int32_t gt_attn_step_supported(GtAttnDims d);
+int gt_attn_step_fwd(GtAttnDims d, GtSlabs qpart, const float* w_prev, const float* w_cum, const float* pm,
+                     const float* Wc, const float* Wd, const float* v, const int32_t* lengths, float* q_out,
+                     const float* wpack, float* u_out, float* erow, uint32_t* row_cnt, uint32_t step1,
+                     int32_t* timeout_flag, const float* memory, int64_t ld_mem, float* w_out, const float* cum_in,
+                     float* cum_out, float* c0, int64_t ld0, float* c1, int64_t ld1, float* c2, int64_t ld2,
+                     void* stream);
 
 /* ------------------------------------------------------------------------- sequential loops
  * gt_decoder_fwd / gt_decoder_bwd: the teacher-forced decoder loop (Decoder.forward + decode,
@@ -345,6 +359,11 @@ typedef struct GtDecoderFwd {
     const float* W2hc;         /* gt_pack_rec_cell_weight of [4Hd] x [Hd] */
     uint32_t* counters1;       /* (Bp > 64 ? Bp/64 : 1) x Ha/16 tickets, zero-initialised */
     uint32_t* counters2;       /* ... x Hd/16 */
+    /* row_cnt != NULL (and gt_attn_step_supported): energies + softmax + context of a step are ONE launch
+     * (gt_attn_step_fwd); `energies` is the exchange buffer, row_cnt (B) zero-initialised arrival counters,
+     * attn_timeout (int32, may be NULL) is raised if an in-launch wait gives up. */
+    uint32_t* row_cnt;
+    int32_t* attn_timeout;
 } GtDecoderFwd;
 
 typedef struct GtDecoderBwd {

@@ -66,6 +66,8 @@ def run_pair_hip(hp, g_state, d_state, batch, mask_seed, dev, vesus=False):
     d_loss.backward()
     res['d_loss'] = dict(real=real_loss.detach().cpu(), fake=fake_loss.detach().cpu(), total=d_loss.detach().cpu())
     res['d_grad'] = {k: p.grad.detach().cpu() for k, p in D.named_parameters()}
+    from gantron_amd import engine
+    engine.check_handoffs()
     return res
 
 
