@@ -413,9 +413,12 @@ def main():
         # PMC counters cannot be read from inside the process, so the figure is the latest profiled one
         try:
             import glob
-            pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))[-1]))
+            pmc_path = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))[-1]
+            pmc = json.load(open(pmc_path))
             roof['traffic'] = pmc['kernels'][KERNEL_OF[dom['name']]]['hbm_bytes_per_launch']
-            roof['traffic_source'] = 'profiles/ PMC passes (FETCH_SIZE x2 + WRITE_SIZE), bytes per launch'
+            roof['traffic_source'] = ('NOT measured in this run (PMC counters cannot be read in-process): copied from the committed '
+                                      f'{os.path.relpath(pmc_path, ROOT)} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this '
+                                      'same command, tools/collect_profiles.sh), bytes per launch')
             roof['algorithmic_bytes_per_launch'] = dom['bytes'] / max(dom['launches'], 1)
         except (IndexError, KeyError, OSError, ValueError):
             pass

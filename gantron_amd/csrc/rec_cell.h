@@ -1,0 +1,226 @@
+// Epilogue of the fused recurrent product + LSTM cell launches (gt_rec_cell_fwd), shared by the fp32 kernel
+// (recurrent.hip) and the bf16-operand kernel (recurrent_bf16.hip): both end their main loop with the folded
+// [rows][64 columns] fp32 tile in LDS (row stride REC_EP_LD), columns = the four gates of 16 hidden units.
+#pragma once
+#include "common.h"
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct RecCellEpi {
+    const float* pre; long ld_pre;        // (rows, 4H) gate pre-activations [i | f | g | o] (PyTorch gate order), added
+    const float* c_prev; float* c_out;    // (rows, H)
+    const uint8_t* keep; float scale;     // dropout on h (or NULL)
+    float* gates;                         // (rows, 4H) gate values saved for the backward pass (may alias `pre`)
+    float* h_raw; float* h0; long ld0; float* h1; long ld1; float* h2; long ld2;     // h destinations (NULL = skip)
+    const float* Wq; long ldwq;           // query_layer weight (A, H) or NULL
+    float* qpart; long q_sstride;         // query slab of column group cg at qpart + cg * q_sstride, rows of Apad
+    unsigned* counters;                   // (row blocks, N/64) tickets, zero-initialised ONCE by the caller
+    int B, H, A, Apad, S;
+    // packed-sequence semantics (encoder BiLSTM): rows with active[m] == 0 pass their state through (c' = c, the emitted
+    // h_raw is 0, the carried h is h_prev)
+    const int* active; const float* h_prev; long ld_hprev;
+    // two independent problems in one launch (the BiLSTM directions): blockIdx.z = dir * nzb + row block; element offsets
+    // of direction 1 relative to direction 0
+    int nzb;
+    long dX, dW, dPart, dPre, dC, dGates, dHraw, dH0, dHprev;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rc_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+
+
+constexpr int REC_EP_LD = 68;             // epilogue tile row stride (floats)
+constexpr int REC_EP_THREADS = 512;
+
+// direction 1 of a paired launch: offsets of the epilogue's pointers (X / Wp / part are the kernel's business)
+__device__ __forceinline__ void rec_cell_dir1(RecCellEpi& e) {
+    if (e.pre) e.pre += e.dPre;
+    e.c_prev += e.dC; e.c_out += e.dC;
+    if (e.gates) e.gates += e.dGates;
+    if (e.h_raw) e.h_raw += e.dHraw;
+    if (e.h0) e.h0 += e.dH0;
+    if (e.h_prev) e.h_prev += e.dHprev;
+}
+
+// red: the tile (ROWS x 64, stride REC_EP_LD) followed by >= ROWS * 20 + 4 floats of scratch, all in LDS; part: slabs of
+// this (direction, row block); cg / s: column group and K-slice of this workgroup; rb: row block; ticket: this group's
+// counter.  Every thread of the workgroup calls it (it contains barriers); returns when the workgroup is done.
+template <int MT>
+__device__ __forceinline__ void rec_cell_epilogue(float* red, const RecCellEpi& e, float* part, long ps, int N, int cg, int s,
+                                                  int rb, unsigned* ticket) {
+    constexpr int EP_LD = REC_EP_LD;
+    constexpr int REC_THREADS = REC_EP_THREADS;
+    constexpr int ROWS = MT * 16;
+    constexpr int NV = (ROWS * 16 + REC_THREADS - 1) / REC_THREADS;        // float4 of the tile per thread
+    float* lds_h = red + ROWS * EP_LD;             // [ROWS][20] h tile for the query product (inside the staging array)
+    unsigned* lds_ticket = reinterpret_cast<unsigned*>(red + ROWS * EP_LD + ROWS * 20);
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = 64 * rb;                      // first batch row of this row block
+    float* slab0 = part + (long)cg * 64;                                    // slab 0 of this column group
+    if (e.S > 1) {
+        // ---- publish this K-slice's tile (write-through), then draw a ticket
+        const __amdgpu_buffer_rsrc_t wr = rc_rsrc(slab0 + (long)s * ps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int f = tid + REC_THREADS * i;
+            const int row = f >> 4, c4 = f & 15;
+            if (row < ROWS) {
+                const float4 v = *reinterpret_cast<const float4*>(&red[row * EP_LD + 4 * c4]);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), wr, (int)(((long)row * N + 4 * c4) * 4), 0, 16);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // EVERY storing wave drains its stores
+        __syncthreads();
+        if (tid == 0)
+            *lds_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if ((*lds_ticket % (unsigned)e.S) != (unsigned)(e.S - 1)) return;       // not the last K-slice of this group
+    }
+    // ---- last arriver: inputs of the cell are requested together with the other K-slices' slabs
+    const bool cell_thread = tid < ROWS * 4;
+    const int crow = tid >> 2, uq = tid & 3;
+    const int m = row0 + crow;                     // batch row
+    const int u = 16 * cg + 4 * uq;                // first of this thread's 4 hidden units
+    const bool live = cell_thread && m < e.B;
+    const long cidx = (long)m * e.H + u;
+    float4 pre4[4], cp = make_float4(0.f, 0.f, 0.f, 0.f), hp4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    uchar4 kp = make_uchar4(1, 1, 1, 1);
+    bool act = true;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pre4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        if (e.pre != nullptr) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pre4[q] = *reinterpret_cast<const float4*>(e.pre + (long)m * e.ld_pre + q * e.H + u);
+        }
+        cp = *reinterpret_cast<const float4*>(e.c_prev + cidx);
+        if (e.keep != nullptr) kp = *reinterpret_cast<const uchar4*>(e.keep + cidx);
+        if (e.active != nullptr) {
+            act = e.active[m] != 0;
+            if (e.h_prev != nullptr) hp4 = *reinterpret_cast<const float4*>(e.h_prev + (long)m * e.ld_hprev + u);
+        }
+    }
+    // query weights of this wave's column blocks: B operand of the 16x16x4 MFMA, lane supplies Wq[n = lane & 15][k..k+3]
+    float4 wq[2];
+    const int ncb = e.Wq != nullptr ? e.Apad / 16 : 0;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        wq[sl] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int cb = wave + 8 * sl;
+        if (cb < ncb) {
+            const int ch = min(cb * 16 + (lane & 15), e.A - 1);
+            const float4 t = *reinterpret_cast<const float4*>(e.Wq + (long)ch * e.ldwq + 16 * cg + 4 * (lane >> 4));
+            if (cb * 16 + (lane & 15) < e.A) wq[sl] = t;
+        }
+    }
+    if (e.S > 1) {
+        const __amdgpu_buffer_rsrc_t rd = rc_rsrc(slab0);
+        float4 acc[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s0 = 0; s0 < e.S; s0 += 4) {       // four slabs in flight per pass
+            float4 t[4][NV];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // slabs beyond S and this workgroup's own (still in LDS) are replaced by a re-read of slab 0 and masked
+                const int sj = s0 + j;
+                const bool use = sj < e.S && sj != s;
+                const long base = (long)(use ? sj : 0) * ps;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const int f = min(tid + REC_THREADS * i, ROWS * 16 - 1);
+                    const int row = f >> 4, c4 = f & 15;
+                    t[j][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rd, (int)((base + (long)row * N + 4 * c4) * 4), 0, 16));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int sj = s0 + j;
+                const float w = (sj < e.S && sj != s) ? 1.f : 0.f;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    acc[i].x += w * t[j][i].x; acc[i].y += w * t[j][i].y; acc[i].z += w * t[j][i].z; acc[i].w += w * t[j][i].w;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int f = tid + REC_THREADS * i;
+            const int row = f >> 4, c4 = f & 15;
+            if (row < ROWS) {
+                float4* d = reinterpret_cast<float4*>(&red[row * EP_LD + 4 * c4]);
+                float4 v = *d;
+                v.x += acc[i].x; v.y += acc[i].y; v.z += acc[i].z; v.w += acc[i].w;
+                *d = v;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- cell: thread = (row, 4 units); tile column 16*gate + unit
+    float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);      // carried hidden state (what the next step and the query see)
+    if (live) {
+        float4 gv[4], cn, hraw;
+        float* gvf = reinterpret_cast<float*>(&gv[0]);
+        const float* cpf = reinterpret_cast<const float*>(&cp);
+        float* cnf = reinterpret_cast<float*>(&cn);
+        float* hvf = reinterpret_cast<float*>(&hv);
+        const unsigned char* kpf = reinterpret_cast<const unsigned char*>(&kp);
+        float gi[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 t = *reinterpret_cast<const float4*>(&red[crow * EP_LD + 16 * q + 4 * uq]);
+            gi[4 * q + 0] = t.x + pre4[q].x; gi[4 * q + 1] = t.y + pre4[q].y;
+            gi[4 * q + 2] = t.z + pre4[q].z; gi[4 * q + 3] = t.w + pre4[q].w;
+        }
+#pragma unroll
+        for (int el = 0; el < 4; ++el) {
+            const float ig = sigmoidf_(gi[0 * 4 + el]), fg = sigmoidf_(gi[1 * 4 + el]);
+            const float gg = tanhf(gi[2 * 4 + el]), og = sigmoidf_(gi[3 * 4 + el]);
+            gvf[0 * 4 + el] = ig; gvf[1 * 4 + el] = fg; gvf[2 * 4 + el] = gg; gvf[3 * 4 + el] = og;
+            const float c = fg * cpf[el] + ig * gg;
+            cnf[el] = c;
+            float h = og * tanhf(c);
+            if (e.keep != nullptr) h *= kpf[el] ? e.scale : 0.f;
+            hvf[el] = h;
+        }
+        hraw = hv;
+        if (!act) { cn = cp; hraw = make_float4(0.f, 0.f, 0.f, 0.f); hv = hp4; }
+        if (e.gates != nullptr) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(e.gates + (long)m * 4 * e.H + q * e.H + u) = gv[q];
+        }
+        *reinterpret_cast<float4*>(e.c_out + cidx) = cn;
+        if (e.h_raw != nullptr) *reinterpret_cast<float4*>(e.h_raw + cidx) = hraw;
+        if (e.h0 != nullptr) *reinterpret_cast<float4*>(e.h0 + (long)m * e.ld0 + u) = hv;
+        if (e.h1 != nullptr) *reinterpret_cast<float4*>(e.h1 + (long)m * e.ld1 + u) = hv;
+        if (e.h2 != nullptr) *reinterpret_cast<float4*>(e.h2 + (long)m * e.ld2 + u) = hv;
+    }
+    if (ncb == 0) return;
+    // ---- query slab of this column group: [ROWS x 16 units] . [16 x Apad]
+    if (cell_thread) *reinterpret_cast<float4*>(&lds_h[crow * 20 + 4 * uq]) = hv;       // rows beyond the batch: zeros
+    __syncthreads();
+    float* qout = e.qpart + (long)cg * e.q_sstride;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        const int cb = wave + 8 * sl;
+        if (cb >= ncb) break;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const float4 x = *reinterpret_cast<const float4*>(&lds_h[(16 * mt + (lane & 15)) * 20 + 4 * (lane >> 4)]);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, wq[sl].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, wq[sl].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, wq[sl].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, wq[sl].w, acc, 0, 0, 0);
+            // C layout: column n = lane & 15, rows 4*(lane>>4) + r
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                qout[(long)(row0 + 16 * mt + 4 * (lane >> 4) + r) * e.Apad + cb * 16 + (lane & 15)] = acc[r];
+        }
+    }
+}
+
+}  // namespace
