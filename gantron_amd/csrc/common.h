@@ -135,8 +135,9 @@ int gt_cell_bwd_z(GtSlabs dh_a, GtSlabs dh_b, GtSlabs dh_c, const float* dh_dire
 
 // gt_rec_cell_fwd with packed-sequence semantics (active / h_prev, see lstm_cell_fwd_kernel) and, for ndir == 2, two
 // independent problems in one launch (the BiLSTM directions); dz = element offsets of direction 1:
-// {X, Wp, part, pre, c (prev and out), gates, h_raw, h0, h_prev}.  Used by gt_bilstm_run.
-int gt_rec_cell_fwd_z(const float* X, int64_t ldx, const float* Wp, float* part, uint32_t* counters, int32_t Bp, int32_t B,
+// {X, Wp, part, pre, c (prev and out), gates, h_raw, h0, h_prev}.  Used by gt_bilstm_run.  wbf16: Wp is the bf16 image of
+// gt_pack_rec_cell_weight_bf16 (dz[1] then counts 16-bit elements).
+int gt_rec_cell_fwd_z(const float* X, int64_t ldx, const void* Wp, int wbf16, float* part, uint32_t* counters, int32_t Bp, int32_t B,
                       int32_t H, int32_t K, int32_t splits, const float* pre, int64_t ld_pre, const float* c_prev,
                       const uint8_t* keep, float p_drop, float* gates, float* c_out, float* h_raw, float* h0, int64_t ld0,
                       float* h1, int64_t ld1, float* h2, int64_t ld2, const float* Wq, int64_t ldwq, float* qpart,

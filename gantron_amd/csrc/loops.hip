@@ -219,11 +219,11 @@ static int decoder_fwd_hoisted(const GtDecoderFwd* a, void* stream) {
     }
     const int blk = block_steps(a->blk);
     const int64_t xa_step = (int64_t)a->Bp * a->ld2;
-    // fused product + cell (+ query) launches: fp32, float4-friendly sizes
-    const bool fusedA = a->W1c != nullptr && a->counters1 != nullptr && !a->bf16 && cq && a->Ha % 16 == 0;
-    const bool fusedB = a->W2hc != nullptr && a->counters2 != nullptr && !a->bf16 && a->Hd % 16 == 0 && (a->Hd + a->E) % 4 == 0;
+    // fused product + cell (+ query) launches: float4-friendly sizes (bf16 mode: the bf16 images of the same packing)
+    const bool fusedA = a->W1c != nullptr && a->counters1 != nullptr && cq && a->Ha % 16 == 0;
+    const bool fusedB = a->W2hc != nullptr && a->counters2 != nullptr && a->Hd % 16 == 0 && (a->Hd + a->E) % 4 == 0;
     GT_REQUIRE((a->W1c == nullptr || fusedA) && (a->W2hc == nullptr || fusedB), GT_E_ARG,
-               "gt_decoder_fwd: W1c / W2hc need fp32, Wq + partq, Ha %% 32 == 0, Hd %% 16 == 0, E %% 4 == 0 and their counters");
+               "gt_decoder_fwd: W1c / W2hc need Wq + partq, Ha %% 32 == 0, Hd %% 16 == 0, E %% 4 == 0 and their counters");
     const bool attn_step = a->row_cnt != nullptr && gt_attn_step_supported(d) && wpack != nullptr && a->ld1 % 4 == 0 &&
                            a->ld2 % 4 == 0 && a->ldE % 4 == 0 && (a->Hd % 4 == 0) && a->To < (1 << 24);
     const int64_t x1_slot = fusedA ? (int64_t)a->Bp * a->ld1 : 0;      // operand ping-pong (see GtDecoderFwd::W1c)
@@ -241,11 +241,12 @@ static int decoder_fwd_hoisted(const GtDecoderFwd* a, void* stream) {
             float* X1c = a->X1 + (t & 1) * x1_slot;            // [ctx_{t-1} | h_att_{t-1}]
             float* X1n = a->X1 + ((t + 1) & 1) * x1_slot;      // receives h_att_t (cell) and ctx_t (context kernel)
             if (fusedA) {       // product + cell + dropout + query slabs: one launch
-                GT_TRY(gt_rec_cell_fwd(X1c, a->ld1, a->W1c, a->part, a->counters1, a->Bp, a->B, a->Ha, K1, a->S1,
+                GT_TRY(gt_rec_cell_fwd_z(X1c, a->ld1, a->W1c, a->bf16, a->part, a->counters1, a->Bp, a->B, a->Ha, K1, a->S1,
                                        a->pre1 + (int64_t)t * a->Bp * N1, N1, a->c1 + (int64_t)t * a->Bp * a->Ha, k1, a->p_att,
                                        a->gates1 + (int64_t)t * a->Bp * N1, a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha,
                                        a->hatt + (int64_t)t * a->Bp * a->Ha, X1n + a->E, a->ld1, XAt, a->ld2, nullptr, 0, a->Wq,
-                                       a->Ha, a->partq, (int64_t)a->Bp * a->Apad, a->A, a->Apad, two ? kPrioA : 0, sA));
+                                       a->Ha, a->partq, (int64_t)a->Bp * a->Apad, a->A, a->Apad, nullptr, nullptr, 0, 1, nullptr,
+                                       two ? kPrioA : 0, sA));
             } else {
                 GT_TRY(rec_rows(X1c, a->ld1, a->W1p, a->part, a->Bp, N1, K1, a->S1, sA, a->bf16, two ? kPrioA : 0));
                 if (cq)      // cell + query projection in one launch
@@ -295,10 +296,11 @@ static int decoder_fwd_hoisted(const GtDecoderFwd* a, void* stream) {
             float* Xhc = a->Xh + (t & 1) * xh_slot;
             float* Xhn = a->Xh + ((t + 1) & 1) * xh_slot;
             if (fusedB) {
-                GT_TRY(gt_rec_cell_fwd(Xhc, a->ldh, a->W2hc, a->part2, a->counters2, a->Bp, a->B, a->Hd, a->Hd, a->S2,
+                GT_TRY(gt_rec_cell_fwd_z(Xhc, a->ldh, a->W2hc, a->bf16, a->part2, a->counters2, a->Bp, a->B, a->Hd, a->Hd, a->S2,
                                        a->pre2 + (int64_t)t * a->Bp * N2, N2, a->c2 + (int64_t)t * a->Bp * a->Hd, k2, a->p_dec,
                                        a->gates2 + (int64_t)t * a->Bp * N2, a->c2 + (int64_t)(t + 1) * a->Bp * a->Hd, nullptr,
-                                       Xhn, a->ldh, hc_t, hc_ld, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, two ? kPrioB : 0, sB));
+                                       Xhn, a->ldh, hc_t, hc_ld, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, nullptr, nullptr, 0, 1,
+                                       nullptr, two ? kPrioB : 0, sB));
                 continue;
             }
             GT_TRY(rec_rows(Xhc, a->ldh, a->W2hp, a->part2, a->Bp, N2, a->Hd, a->S2, sB, a->bf16, two ? kPrioB : 0));
@@ -778,7 +780,7 @@ int gt_bilstm_run(const GtBiLstm* a, void* stream) {
             const float* Xc = a->X + (s & 1) * xslot;
             float* Xn = a->X + ((s + 1) & 1) * xslot;
             const int64_t dz[9] = {xdir, a->w_zstride, pz, TB * N, (int64_t)(a->T + 1) * a->Bp * a->H, TB * N, TB * a->H, xdir, xdir};
-            GT_TRY(gt_rec_cell_fwd_z(Xc, a->ldx, a->Whc, a->part, a->counters, a->Bp, a->Bp, a->H, a->H, a->S,
+            GT_TRY(gt_rec_cell_fwd_z(Xc, a->ldx, a->Whc, 0, a->part, a->counters, a->Bp, a->Bp, a->H, a->H, a->S,
                                      a->pre + (int64_t)s * a->Bp * N, N, a->c + (int64_t)s * a->Bp * a->H, nullptr, 0.f,
                                      a->gates + (int64_t)s * a->Bp * N, a->c + (int64_t)(s + 1) * a->Bp * a->H,
                                      a->hs + (int64_t)s * a->Bp * a->H, Xn, a->ldx, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0,

@@ -4,10 +4,7 @@
 #pragma once
 #include "common.h"
 
-namespace {
-
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
+// (plain data: crosses translation units by value)
 struct RecCellEpi {
     const float* pre; long ld_pre;        // (rows, 4H) gate pre-activations [i | f | g | o] (PyTorch gate order), added
     const float* c_prev; float* c_out;    // (rows, H)
@@ -26,6 +23,11 @@ struct RecCellEpi {
     int nzb;
     long dX, dW, dPart, dPre, dC, dGates, dHraw, dH0, dHprev;
 };
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rc_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);

@@ -587,12 +587,17 @@ extern "C" int gt_pack_rec_cell_weight(const float* W, int64_t ldw, int32_t H, i
     return 0;
 }
 
-int gt_rec_cell_fwd_z(const float* X, int64_t ldx, const float* Wp, float* part, uint32_t* counters, int32_t Bp, int32_t B,
+struct RecCellEpi;
+int gt_launch_rec_cell_bf16(const float* X, int64_t ldx, const void* Wp, float* part, int32_t Bp, int32_t N, int32_t K,
+                            int32_t splits, int32_t ndir, int prio, const RecCellEpi& e, void* stream);      // recurrent_bf16.hip
+
+int gt_rec_cell_fwd_z(const float* X, int64_t ldx, const void* Wpv, int wbf16, float* part, uint32_t* counters, int32_t Bp, int32_t B,
                       int32_t H, int32_t K, int32_t splits, const float* pre, int64_t ld_pre, const float* c_prev,
                       const uint8_t* keep, float p_drop, float* gates, float* c_out, float* h_raw, float* h0, int64_t ld0,
                       float* h1, int64_t ld1, float* h2, int64_t ld2, const float* Wq, int64_t ldwq, float* qpart,
                       int64_t q_sstride, int32_t A, int32_t Apad, const int32_t* active, const float* h_prev, int64_t ld_hprev,
                       int32_t ndir, const int64_t* dz, int32_t prio, void* stream) {
+    const float* Wp = static_cast<const float*>(Wpv);
     GT_REQUIRE(X && Wp && part && counters && c_prev && c_out, GT_E_ARG, "gt_rec_cell_fwd: NULL pointer");
     GT_REQUIRE(B > 0 && Bp >= B && ((Bp <= 64 && Bp % 16 == 0) || Bp % 64 == 0) && H > 0 && H % 16 == 0 && K > 0 && splits >= 1 &&
                    splits <= 16, GT_E_ARG, "gt_rec_cell_fwd: bad sizes B=%d Bp=%d H=%d K=%d splits=%d", B, Bp, H, K, splits);
@@ -628,8 +633,9 @@ int gt_rec_cell_fwd_z(const float* X, int64_t ldx, const float* Wp, float* part,
     dim3 grid(N / 64, splits, nzb * ndir);
     hipStream_t st = (hipStream_t)stream;
     GtProfScope prof(GT_FAM_REC_CELL, ndir * (2.0 * Bp * (double)N * K + (Wq ? 2.0 * Bp * (double)H * A : 0.0)),
-                     ndir * 4.0 * ((double)N * K + (double)Bp * K + (double)Bp * N * (splits > 1 ? 2 * splits - 1 : 0) +
-                                   (double)B * H * 12), st);
+                     ndir * ((wbf16 ? 2.0 : 4.0) * (double)N * K +
+                             4.0 * ((double)Bp * K + (double)Bp * N * (splits > 1 ? 2 * splits - 1 : 0) + (double)B * H * 12)), st);
+    if (wbf16) return gt_launch_rec_cell_bf16(X, ldx, Wpv, part, Bp, N, K, splits, ndir, prio, e, stream);
     const long ps = (long)Bp * N;
 #define GT_RC(MT)                                                                                                      \
     hipLaunchKernelGGL((rec_cell_kernel<MT>), grid, dim3(REC_THREADS), 0, st, X, (long)ldx, Wp, part, N, KB, KBS,        \
@@ -651,7 +657,18 @@ extern "C" int gt_rec_cell_fwd(const float* X, int64_t ldx, const float* Wp, flo
                                float* h_raw, float* h0, int64_t ld0, float* h1, int64_t ld1, float* h2, int64_t ld2,
                                const float* Wq, int64_t ldwq, float* qpart, int64_t q_sstride, int32_t A, int32_t Apad,
                                int32_t prio, void* stream) {
-    return gt_rec_cell_fwd_z(X, ldx, Wp, part, counters, Bp, B, H, K, splits, pre, ld_pre, c_prev, keep, p_drop, gates, c_out,
+    return gt_rec_cell_fwd_z(X, ldx, Wp, 0, part, counters, Bp, B, H, K, splits, pre, ld_pre, c_prev, keep, p_drop, gates, c_out,
+                             h_raw, h0, ld0, h1, ld1, h2, ld2, Wq, ldwq, qpart, q_sstride, A, Apad, nullptr, nullptr, 0, 1,
+                             nullptr, prio, stream);
+}
+
+extern "C" int gt_rec_cell_fwd_bf16(const float* X, int64_t ldx, const void* Wp, float* part, uint32_t* counters, int32_t Bp,
+                                    int32_t B, int32_t H, int32_t K, int32_t splits, const float* pre, int64_t ld_pre,
+                                    const float* c_prev, const uint8_t* keep, float p_drop, float* gates, float* c_out,
+                                    float* h_raw, float* h0, int64_t ld0, float* h1, int64_t ld1, float* h2, int64_t ld2,
+                                    const float* Wq, int64_t ldwq, float* qpart, int64_t q_sstride, int32_t A, int32_t Apad,
+                                    int32_t prio, void* stream) {
+    return gt_rec_cell_fwd_z(X, ldx, Wp, 1, part, counters, Bp, B, H, K, splits, pre, ld_pre, c_prev, keep, p_drop, gates, c_out,
                              h_raw, h0, ld0, h1, ld1, h2, ld2, Wq, ldwq, qpart, q_sstride, A, Apad, nullptr, nullptr, 0, 1,
                              nullptr, prio, stream);
 }

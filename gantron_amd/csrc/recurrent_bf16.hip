@@ -11,6 +11,7 @@
 // and the k-blocks of half (w>>2) of every chunk, K split over blockIdx.y into slabs.
 #include <stdint.h>
 #include "common.h"
+#include "rec_cell.h"
 
 namespace {
 
@@ -31,14 +32,17 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 
 // W (N x K, row stride ldw; or K x N when transposed) -> Wp[N/16][KB32][64 lanes][8 bf16]: lane l of block (nb, kb)
 // holds B[k = 32 kb + 8 (l >> 4) + j][column 16 nb + (l & 15)], j = 0..7, zero padded.
+// cellH > 0 (gt_pack_rec_cell_weight_bf16): W is a (4 cellH x K) LSTM weight and packed column 64 cg + 16 g + u is its row
+// g * cellH + 16 cg + u, so that a 64-column group holds the four gates of 16 hidden units (gt_rec_cell_fwd_bf16).
 __global__ __launch_bounds__(256) void pack_rec_weight_bf16_kernel(const float* W, long ldw, int transposed, int N,
-                                                                   int n_valid, int K, int KB, uint4* Wp) {
+                                                                   int n_valid, int K, int KB, int cellH, uint4* Wp) {
     const long total = (long)(N / 16) * KB * 64;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int lane = (int)(idx & 63);
         const long blk = idx >> 6;
         const int kb = (int)(blk % KB), nb = (int)(blk / KB);
-        const int n = nb * 16 + (lane & 15);
+        int n = nb * 16 + (lane & 15);
+        if (cellH > 0) n = ((n >> 4) & 3) * cellH + 16 * (n >> 6) + (n & 15);
         const int k = kb * 32 + 8 * (lane >> 4);
         float v[8];
 #pragma unroll
@@ -50,29 +54,28 @@ __global__ __launch_bounds__(256) void pack_rec_weight_bf16_kernel(const float* 
     }
 }
 
-template <int MT, int NCH>
-__global__ __launch_bounds__(RB_THREADS) void rec_gemm_bf16_kernel(const float* __restrict__ X, long ldx, int kvalid,
-                                                                   const uint4* __restrict__ Wp, float* __restrict__ part,
-                                                                   int N, int KB, int KBS, long xz, long wz, long pz,
-                                                                   long ps, int prio) {
+__device__ __forceinline__ void rb_setprio(int prio) {
     // issue priority of the waves: 3 = the loops' critical (attention) chain, 2 = the other chain, 0 = everything else
     if (prio == 3) __builtin_amdgcn_s_setprio(3);
     else if (prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+}
+
+// One workgroup's [MT*16 rows x 64 columns] tile of X . W^T over the k-blocks [kb0, kb1) of packed weights Wz: returns it
+// folded over the two K-halves in LDS (row stride REC_EP_LD floats, at the start of the staging array Xs), after a barrier.
+template <int MT, int NCH>
+__device__ __forceinline__ float* rec_bf16_tile(unsigned short* Xs, const float* __restrict__ Xz, long ldx, int kvalid,
+                                                const uint4* __restrict__ Wz, int N, int KB, int kb0, int kb1, int cg) {
     constexpr int XV = MT * 2;         // float4 per thread per chunk (MT*16 rows x 64 float4 / 512 threads)
     constexpr int XR = NCH < RB_XR ? NCH : RB_XR;
-    constexpr int EP_LD = 68;
-    static_assert(MT * 16 * RB_LD * 2 >= MT * 16 * EP_LD * 4, "epilogue tile fits the staging buffer");
-    __shared__ __attribute__((aligned(16))) unsigned short Xs[MT * 16 * RB_LD];
-    const int s = blockIdx.y, z = blockIdx.z, cg = blockIdx.x;
-    const int kb0 = s * KBS, kb1 = min(KB, kb0 + KBS);
-    const float* Xz = X + (long)z * xz;
+    constexpr int EP_LD = REC_EP_LD;
+    static_assert(MT * 16 * RB_LD * 2 >= (MT * 16 * (EP_LD + 20) + 4) * 4, "epilogue tile + scratch fit the staging buffer");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = wave >> 2;
     int nb = cg * 4 + (wave & 3);
     const bool active = nb * 16 < N;   // inactive waves (N % 64 != 0) still stage and join the barriers
     if (!active) nb = 0;
-    const uint4* wp = Wp + (long)z * wz + ((long)nb * KB) * 64 + lane;
+    const uint4* wp = Wz + ((long)nb * KB) * 64 + lane;
 
     // ---- every load of the slice, issued together.  Out-of-range blocks are clamped to a valid address and
     // zeroed by a select (a predicated load would put s_waitcnt vmcnt(0) in front of everything behind it).
@@ -141,6 +144,21 @@ __global__ __launch_bounds__(RB_THREADS) void rec_gemm_bf16_kernel(const float* 
             for (int r = 0; r < 4; ++r) red[(mt * 16 + erow + r) * EP_LD + ecol] += acc[mt][r];
     }
     __syncthreads();
+    return red;
+}
+
+template <int MT, int NCH>
+__global__ __launch_bounds__(RB_THREADS) void rec_gemm_bf16_kernel(const float* __restrict__ X, long ldx, int kvalid,
+                                                                   const uint4* __restrict__ Wp, float* __restrict__ part,
+                                                                   int N, int KB, int KBS, long xz, long wz, long pz,
+                                                                   long ps, int prio) {
+    rb_setprio(prio);
+    __shared__ __attribute__((aligned(16))) unsigned short Xs[MT * 16 * RB_LD];
+    const int s = blockIdx.y, z = blockIdx.z, cg = blockIdx.x;
+    const int kb0 = s * KBS;
+    const float* red = rec_bf16_tile<MT, NCH>(Xs, X + (long)z * xz, ldx, kvalid, Wp + (long)z * wz, N, KB, kb0, min(KB, kb0 + KBS), cg);
+    constexpr int EP_LD = REC_EP_LD;
+    const int tid = threadIdx.x;
     float* out = part + (long)z * pz + (long)s * ps + (long)cg * 64;
     const int ncols = min(64, N - cg * 64);
 #pragma unroll
@@ -150,6 +168,25 @@ __global__ __launch_bounds__(RB_THREADS) void rec_gemm_bf16_kernel(const float* 
         if (row < MT * 16 && 4 * c4 < ncols)
             *reinterpret_cast<float4*>(out + (long)row * N + 4 * c4) = *reinterpret_cast<const float4*>(&red[row * EP_LD + 4 * c4]);
     }
+}
+
+// gt_rec_cell_fwd_bf16: the product above with the fused cell epilogue of rec_cell.h (gate-grouped packing, last-arriver
+// split-K).  Same launch geometry as the fp32 rec_cell_kernel: blockIdx = (column group, K-slice, direction * nzb + row block).
+template <int MT, int NCH>
+__global__ __launch_bounds__(RB_THREADS) void rec_cell_bf16_kernel(const float* __restrict__ X, long ldx, int kvalid,
+                                                                   const uint4* __restrict__ Wp, float* part, int N, int KB,
+                                                                   int KBS, long xz, long pz, long ps, int prio, RecCellEpi e) {
+    rb_setprio(prio);
+    __shared__ __attribute__((aligned(16))) unsigned short Xs[MT * 16 * RB_LD];
+    const int cg = blockIdx.x, s = blockIdx.y, z = blockIdx.z;
+    const int dir = z / e.nzb, rb = z - dir * e.nzb;
+    const int kb0 = s * KBS;
+    if (dir != 0) {
+        X += e.dX; Wp += e.dW / 8; part += e.dPart;          // dW counts bf16 elements
+        rec_cell_dir1(e);
+    }
+    float* red = rec_bf16_tile<MT, NCH>(Xs, X + (long)rb * xz, ldx, kvalid, Wp, N, KB, kb0, min(KB, kb0 + KBS), cg);
+    rec_cell_epilogue<MT>(red, e, part + (long)rb * pz, ps, N, cg, s, rb, e.counters + (long)z * gridDim.x + cg);
 }
 
 }  // namespace
@@ -169,7 +206,7 @@ extern "C" int gt_pack_rec_weight_bf16(const float* W, int64_t ldw, int32_t tran
     const long total = (long)(N / 16) * KB * 64;
     const int blocks = (int)std::min<long>(cdiv64(total, 256), 4096);
     hipLaunchKernelGGL(pack_rec_weight_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, W, (long)ldw,
-                       transposed, N, n_valid, K, KB, reinterpret_cast<uint4*>(Wp));
+                       transposed, N, n_valid, K, KB, 0, reinterpret_cast<uint4*>(Wp));
     GT_LAUNCH_CHECK();
     return 0;
 }
@@ -221,6 +258,57 @@ int gt_rec_gemm_bf16_prio(const float* X, int64_t ldx, const void* Wp, float* pa
     }
 #undef GT_RECB_M
 #undef GT_RECB
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+// packing for gt_rec_cell_fwd_bf16: W is the (4H x K) LSTM weight in PyTorch gate order
+extern "C" int gt_pack_rec_cell_weight_bf16(const float* W, int64_t ldw, int32_t H, int32_t K, void* Wp, void* stream) {
+    GT_REQUIRE(W && Wp && H > 0 && H % 16 == 0 && K > 0, GT_E_ARG, "gt_pack_rec_cell_weight_bf16: H=%d must be a multiple of 16", H);
+    GT_REQUIRE(aligned16(Wp), GT_E_ALIGN, "gt_pack_rec_cell_weight_bf16: Wp must be 16-byte aligned");
+    const int N = 4 * H, KB = cdiv(K, 32);
+    const long total = (long)(N / 16) * KB * 64;
+    const int blocks = (int)std::min<long>(cdiv64(total, 256), 4096);
+    hipLaunchKernelGGL(pack_rec_weight_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, W, (long)ldw, 0, N, N, K, KB,
+                       H, reinterpret_cast<uint4*>(Wp));
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+// launch of the bf16-operand fused product + cell; arguments already validated by gt_rec_cell_fwd_z (recurrent.hip)
+int gt_launch_rec_cell_bf16(const float* X, int64_t ldx, const void* Wp, float* part, int32_t Bp, int32_t N, int32_t K,
+                            int32_t splits, int32_t ndir, int prio, const RecCellEpi& e, void* stream) {
+    const int KB = cdiv(K, 32);
+    const int kvalid = cdiv(K, 16) * 16;
+    const int KBS = cdiv(KB, splits);
+    GT_REQUIRE(cdiv(KB, KBS) == splits, GT_E_ARG, "gt_rec_cell_fwd_bf16: splits=%d leaves empty slabs for K=%d", splits, K);
+    GT_REQUIRE(KBS <= RB_NCH * RB_CB, GT_E_ARG, "gt_rec_cell_fwd_bf16: K-slice of %d exceeds %d (use >= %d splits)", KBS * 32,
+               RB_NCH * RB_CB * 32, cdiv(KB, RB_NCH * RB_CB));
+    GT_REQUIRE(e.dW % 8 == 0, GT_E_ALIGN, "gt_rec_cell_fwd_bf16: direction offset of the weights must be a multiple of 8");
+    const int mt = Bp <= 64 ? Bp / 16 : 4, nzb = Bp <= 64 ? 1 : Bp / 64;
+    dim3 grid(N / 64, splits, nzb * ndir);
+    hipStream_t st = (hipStream_t)stream;
+    const uint4* wp = reinterpret_cast<const uint4*>(Wp);
+    const long ps = (long)Bp * N;
+    const int nch = cdiv(KBS, RB_CB);
+#define GT_RCB(MT, NCH)                                                                                                  \
+    hipLaunchKernelGGL((rec_cell_bf16_kernel<MT, NCH>), grid, dim3(RB_THREADS), 0, st, X, (long)ldx, kvalid, wp, part, N, KB, \
+                       KBS, (long)(64 * ldx), (long)64 * N, ps, prio, e)
+#define GT_RCB_M(MT)                         \
+    switch (nch) {                           \
+        case 1: GT_RCB(MT, 1); break;        \
+        case 2: GT_RCB(MT, 2); break;        \
+        case 3: GT_RCB(MT, 3); break;        \
+        default: GT_RCB(MT, 4); break;       \
+    }
+    switch (mt) {
+        case 1: GT_RCB_M(1); break;
+        case 2: GT_RCB_M(2); break;
+        case 3: GT_RCB_M(3); break;
+        default: GT_RCB_M(4); break;
+    }
+#undef GT_RCB_M
+#undef GT_RCB
     GT_LAUNCH_CHECK();
     return 0;
 }

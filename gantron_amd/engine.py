@@ -45,8 +45,8 @@ DEC_RING = int(_os.environ.get('GANTRON_DEC_RING', '16'))     # ring of hand-off
 # is one tiled GEMM, only h_dec . W2hh stays in the per-step loops
 HOIST2 = _os.environ.get('GANTRON_HOIST2', '1') != '0'
 # fused product + cell (+ query) launches of the forward loops (gt_rec_cell_fwd): bit 0 = attention LSTM, bit 1 = decoder LSTM,
-# bit 2 = encoder BiLSTM
-REC_CELL = int(_os.environ.get('GANTRON_REC_CELL', '7'))
+# bit 2 = encoder BiLSTM; bits 3 / 4 = attention / decoder LSTM in bf16 mode (gt_rec_cell_fwd_bf16)
+REC_CELL = int(_os.environ.get('GANTRON_REC_CELL', '31'))
 ENC_SPLITS = int(_os.environ.get('GANTRON_ENC_SPLITS', '0'))   # K-splits of the fused BiLSTM step (0: cost model)
 DEC_BLK_BWD = int(_os.environ.get('GANTRON_DEC_BLK_BWD', '16'))
 # K-splits of the decoder LSTM's small recurrent products in the hoisted mode (0: cost model).  That chain has slack
@@ -225,8 +225,13 @@ def pack_rec_bf16(W2d, N, n_valid, K, transposed=False):
     return out
 
 
-def pack_rec_cell(W2d, H, K):
-    """Pack a (4H x K) LSTM weight for gt_rec_cell_fwd (a workgroup's 64 columns = the four gates of 16 hidden units)."""
+def pack_rec_cell(W2d, H, K, bf16=False):
+    """Pack a (4H x K) LSTM weight for gt_rec_cell_fwd / gt_rec_cell_fwd_bf16 (a workgroup's 64 columns = the four gates
+    of 16 hidden units)."""
+    if bf16:
+        out = torch.empty(int(lib().gt_rec_weight_bf16_elems(4 * H, K)), device=W2d.device, dtype=torch.bfloat16)
+        call('gt_pack_rec_cell_weight_bf16', W2d, W2d.stride(0), H, K, out)
+        return out
     out = torch.empty(int(lib().gt_rec_weight_elems(4 * H, K)), device=W2d.device, dtype=torch.float32)
     call('gt_pack_rec_cell_weight', W2d, W2d.stride(0), H, K, out)
     return out
@@ -539,11 +544,13 @@ class GeneratorEngine:
             if S2_FWD and not self.bf16:
                 d.S2 = ops.pick_splits(Hd, S2_FWD)
             # fused product + cell launches (gt_rec_cell_fwd) take their own packing
-            use_c1 = not self.bf16 and bool(REC_CELL & 1) and CELL_QUERY and Ha % 32 == 0
-            use_c2 = not self.bf16 and bool(REC_CELL & 2) and Hd % 16 == 0 and Hd % 4 == 0
+            use_c1 = bool(REC_CELL & (8 if self.bf16 else 1)) and CELL_QUERY and Ha % 32 == 0
+            use_c2 = bool(REC_CELL & (16 if self.bf16 else 2)) and Hd % 16 == 0 and Hd % 4 == 0
             keep_t['W2ih'] = W2ihp
-            keep_t['W1c' if use_c1 else 'W1p'] = pack_rec_cell(W1cat, Ha, K1) if use_c1 else pack(W1cat, 4 * Ha, 4 * Ha, K1)
-            keep_t['W2hc' if use_c2 else 'W2hp'] = pack_rec_cell(W2hh, Hd, Hd) if use_c2 else pack(W2hh, 4 * Hd, 4 * Hd, Hd)
+            keep_t['W1c' if use_c1 else 'W1p'] = pack_rec_cell(W1cat, Ha, K1, self.bf16) if use_c1 else \
+                pack(W1cat, 4 * Ha, 4 * Ha, K1)
+            keep_t['W2hc' if use_c2 else 'W2hp'] = pack_rec_cell(W2hh, Hd, Hd, self.bf16) if use_c2 else \
+                pack(W2hh, 4 * Hd, 4 * Hd, Hd)
         elif self.bf16:
             d.bf16 = 1
             d.S1, d.S2 = rec_splits_bf16(4 * Ha, K1), rec_splits_bf16(4 * Hd, K2)

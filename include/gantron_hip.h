@@ -148,6 +148,16 @@ int gt_pack_rec_weight_bf16(const float* W, int64_t ldw, int32_t transposed, int
 int gt_rec_gemm_bf16(const float* X, int64_t ldx, const void* Wp, float* part, int32_t mtiles, int32_t N,
                      int32_t K, int32_t splits, int64_t part_sstride, int32_t nz, int64_t x_zstride,
                      int64_t w_zstride, int64_t part_zstride, void* stream);
+/* gt_rec_cell_fwd with bf16-packed weights (gt_pack_rec_cell_weight_bf16: gt_rec_weight_bf16_elems(4H, K) 16-bit
+ * elements, gate-grouped columns): bf16 MFMA product with fp32 accumulation, the cell, dropout and the query slabs in
+ * fp32 exactly as in gt_rec_cell_fwd.  splits >= gt_rec_bf16_min_splits(K), <= 16. */
+int gt_pack_rec_cell_weight_bf16(const float* W, int64_t ldw, int32_t H, int32_t K, void* Wp, void* stream);
+int gt_rec_cell_fwd_bf16(const float* X, int64_t ldx, const void* Wp, float* part, uint32_t* counters, int32_t Bp,
+                         int32_t B, int32_t H, int32_t K, int32_t splits, const float* pre, int64_t ld_pre,
+                         const float* c_prev, const uint8_t* keep, float p_drop, float* gates, float* c_out,
+                         float* h_raw, float* h0, int64_t ld0, float* h1, int64_t ld1, float* h2, int64_t ld2,
+                         const float* Wq, int64_t ldwq, float* qpart, int64_t q_sstride, int32_t A, int32_t Apad,
+                         int32_t prio, void* stream);
 
 /* Two products with their own shapes (both with 16*mtiles rows) in ONE launch: the decoder loops issue the
  * attention-LSTM and decoder-LSTM products of a step together so that they share the device as co-resident
@@ -351,11 +361,11 @@ typedef struct GtDecoderFwd {
                                   writes the gate values of the same elements) */
     float* Xh; int64_t ldh;    /* (Bp, ldh >= 16*ceil(Hd/16)) zero-initialised: h_dec operand of the per-step product */
     int32_t blk;               /* steps per block (hand-off granularity between the two chains); <= 0: 32 */
-    /* Fused product + cell launches (gt_rec_cell_fwd) inside the hoisted mode, fp32 only.  W1c != NULL: the attention
+    /* Fused product + cell launches (gt_rec_cell_fwd / gt_rec_cell_fwd_bf16 when bf16 = 1) inside the hoisted mode.  W1c != NULL: the attention
      * LSTM step is ONE launch (product, cell, dropout, h scatter, query slabs): X1 must hold two (Bp, ld1) slots (the
      * cell writes the next step's operand while other workgroups still read this step's), partq Ha/16 slabs.
      * W2hc != NULL: the same for the decoder LSTM's h_dec product; Xh then holds two (Bp, ldh) slots. */
-    const float* W1c;          /* gt_pack_rec_cell_weight of [4Ha] x [ctx(E) | h_att(Ha)] */
+    const float* W1c;          /* gt_pack_rec_cell_weight (bf16 = 1: ..._bf16 image) of [4Ha] x [ctx(E) | h_att(Ha)] */
     const float* W2hc;         /* gt_pack_rec_cell_weight of [4Hd] x [Hd] */
     uint32_t* counters1;       /* (Bp > 64 ? Bp/64 : 1) x Ha/16 tickets, zero-initialised */
     uint32_t* counters2;       /* ... x Hd/16 */

@@ -231,20 +231,28 @@ def test_cell_query_fused(dev, Bsz, H, A, S):
 
 @pytest.mark.parametrize('Bsz,H,K,S,A', [(64, 1024, 2048, 4, 128), (5, 32, 100, 2, 8), (70, 64, 333, 3, 40), (64, 1024, 1024, 4, 0),
                                          (33, 48, 50, 1, 24), (64, 1024, 3072, 6, 0)])
-def test_rec_cell_fused(dev, Bsz, H, K, S, A):
+@pytest.mark.parametrize('bf16', [False, True])
+def test_rec_cell_fused(dev, Bsz, H, K, S, A, bf16):
     """gt_rec_cell_fwd = gt_rec_gemm + gt_lstm_cell_fwd (+ the query projection) in ONE launch: the K-splits of a
     column group meet through write-through slabs and a ticket, the last one runs the cell.  Three launches in a
-    row on the same workspace (the tickets carry over from launch to launch), each with fresh inputs."""
+    row on the same workspace (the tickets carry over from launch to launch), each with fresh inputs.
+    bf16: gt_rec_cell_fwd_bf16 -- X and W rounded to bf16 (nearest even) for the product, everything else fp32."""
     from gantron_amd import ops
     from gantron_amd._lib import lib
+    from gantron_amd.engine import pack_rec_cell
     p = 0.1
     Bp = ops.roundup(Bsz, 16) if Bsz <= 64 else ops.roundup(Bsz, 64)
     Apad = ops.roundup(max(A, 1), 16)
     ld = ops.roundup(K, 16) + 16
-    S = ops.pick_splits(K, S)
     W = g(4 * H, K, scale=0.1)
-    Wp = torch.empty(int(lib().gt_rec_weight_elems(4 * H, K)), device=dev)
-    ops.call('gt_pack_rec_cell_weight', W.to(dev), K, H, K, Wp)
+    if bf16:
+        kb = -(-K // 32)
+        S = next(s for s in range(max(S, int(lib().gt_rec_bf16_min_splits(K))), 17) if -(-kb // -(-kb // s)) == s)
+        W = W.bfloat16().float()
+    else:
+        S = ops.pick_splits(K, S)
+    Wp = pack_rec_cell(W.to(dev), H, K, bf16)
+    fn = 'gt_rec_cell_fwd_bf16' if bf16 else 'gt_rec_cell_fwd'
     Wq = g(max(A, 1), H, seed=4, scale=0.1)
     part = torch.full((S, Bp, 4 * H), float('nan'), device=dev)
     counters = torch.zeros((Bp // 64 if Bp > 64 else 1) * (H // 16), dtype=torch.int32, device=dev)
@@ -254,7 +262,8 @@ def test_rec_cell_fused(dev, Bsz, H, K, S, A):
         pre = g(Bp, 4 * H, seed=20 + rep, scale=0.5)
         c_prev = g(Bp, H, seed=30 + rep)
         keep = (torch.rand(Bp, H, generator=torch.Generator().manual_seed(40 + rep)) >= p)
-        gates_in = (X[:Bsz, :K].double() @ W.double().t() + pre[:Bsz].double())
+        Xr = X.bfloat16().float() if bf16 else X
+        gates_in = (Xr[:Bsz, :K].double() @ W.double().t() + pre[:Bsz].double())
         i, f, gg, o = gates_in.chunk(4, dim=1)
         c = torch.sigmoid(f) * c_prev[:Bsz].double() + torch.sigmoid(i) * torch.tanh(gg)
         h = torch.sigmoid(o) * torch.tanh(c) * keep[:Bsz].double() / (1 - p)
@@ -262,7 +271,7 @@ def test_rec_cell_fused(dev, Bsz, H, K, S, A):
         c_out = torch.zeros(Bp, H, device=dev); h_raw = torch.zeros(Bp, H, device=dev)
         h0 = torch.zeros(Bp, H + 8, device=dev); h1 = torch.zeros(Bp, H, device=dev)
         qpart = torch.full((H // 16, Bp, Apad), float('nan'), device=dev)
-        ops.call('gt_rec_cell_fwd', X.to(dev), ld, Wp, part, counters, Bp, Bsz, H, K, S, gates, 4 * H, c_prev.to(dev),
+        ops.call(fn, X.to(dev), ld, Wp, part, counters, Bp, Bsz, H, K, S, gates, 4 * H, c_prev.to(dev),
                  keep.to(torch.uint8).to(dev), p, gates, c_out, h_raw, ops.ptr(h0, 4), H + 8, h1, H, None, 0,
                  Wq.to(dev) if A else None, H, qpart if A else None, Bp * Apad, A, Apad, 3)
         close(c_out[:Bsz], c, rtol=1e-5, atol=2e-5, what=f'c (launch {rep})')
