@@ -27,7 +27,8 @@ struct GemmDev {
     float* C;
     const float* bias;
     long ldc, a_bs, b_bs, c_bs;
-    int M, N, K, accumulate, split_k, k_per_split, bf16;
+    int M, N, K, accumulate, split_k, k_per_split;
+    int bf16;               // 0: fp32 MFMA, 1: operands rounded to bf16, 2 / 3: fp32 product from 2 / 3 bf16 planes (xgemm_kernel)
     float alpha;
 };
 
@@ -429,13 +430,308 @@ __global__ __launch_bounds__(256) void hgemm_kernel(GemmDev g) {
         }
 }
 
+
+// =====================================================================================================================
+// fp32 product on the bf16 matrix pipe ("split" mode, gt_sgemm_set_fp32_split).  gfx950 multiplies bf16 sixteen times
+// faster than fp32 (v_mfma_f32_32x32x16_bf16: 32768 flop in 32 cycles, v_mfma_f32_32x32x2_f32: 4096 flop in 64), so an
+// fp32 operand is staged as NP bf16 PLANES, x = x0 + x1 (+ x2) with x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)
+// (each residual is exact in fp32; three planes hold all 24 significand bits), and a . b is accumulated in fp32 from the
+// plane products of order < NP:  NP = 3: a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0)  -- six MFMAs, every product
+// exact, dropped terms <= 2^-24 |a||b| (the rounding unit of the fp32 MFMA itself);  NP = 2: a0 b0 + a0 b1 + a1 b0 --
+// three MFMAs, dropped terms <= 2^-16 |a||b|.  Same contract, operand modes and epilogue as sgemm_kernel; 32-wide k-tiles;
+// operands are split in registers on their way into LDS.  Inf / NaN inputs give NaN (inf - inf in the residual).
+//
+// LDS images (per plane): a k-contiguous operand (KC / IM2COL_K) is stored row-major [row][32 k + 8] (80-byte rows: the
+// 16-byte fragments of 16 consecutive rows tile all 64 banks) and its MFMA fragment is one ds_read_b128; a
+// reduction-major operand (RC / IM2COL_R) is stored AS IT ARRIVES, k-major [k][rows + 32] (row stride == 64 bytes mod
+// 256), every lane writing the 4 consecutive rows of its float4 as one 8-byte store, and its fragment is gathered by two
+// ds_read_b64_tr_b16 (the hardware transposes 4 k x 16 rows per 16 lanes): no register transpose, no bank conflicts on
+// either side.
+constexpr int BKX = 32;
+constexpr int LDX = BKX + 8;
+typedef short v4i16_t __attribute__((ext_vector_type(4)));
+typedef short v8i16_t __attribute__((ext_vector_type(8)));
+
+// NV float4 -> their NP bf16 planes, packed in pairs (x, y) -> lo, (z, w) -> hi with the first element in the low half.
+// Per plane and pair: v_cvt_pk_bf16_f32, unpack both halves (shift, mask), two subtractions; the pairs advance plane by
+// plane, side by side, so that no instruction waits for the one in front of it.  (The empty asm statements keep a pair
+// packed -- otherwise every element is converted a second time for u << 16 -- and keep the subtractions apart:
+// v_pk_add_f32 is slow to issue beside MFMAs.)
+template <int NP, int NV>
+__device__ __forceinline__ void split_all(const float4 (&reg)[NV], unsigned (&lo)[NV][NP], unsigned (&hi)[NV][NP]) {
+    float v[NV][4];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { v[i][0] = reg[i].x; v[i][1] = reg[i].y; v[i][2] = reg[i].z; v[i][3] = reg[i].w; }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        unsigned u[NV][2];
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const bf16x2_t b = {(__bf16)v[i][2 * h], (__bf16)v[i][2 * h + 1]};
+                u[i][h] = __builtin_bit_cast(unsigned, b);
+                asm("" : "+v"(u[i][h]));
+            }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { lo[i][p] = u[i][0]; hi[i][p] = u[i][1]; }
+        if (p + 1 < NP) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    v[i][2 * h] -= __uint_as_float(u[i][h] << 16);
+                    asm("" : "+v"(v[i][2 * h]));
+                    v[i][2 * h + 1] -= __uint_as_float(u[i][h] & 0xffff0000u);
+                    asm("" : "+v"(v[i][2 * h + 1]));
+                }
+        }
+    }
+}
+
+// FAST loads: the tile lies inside the matrix, the k-tile inside the reduction range and the operand is 16-byte
+// addressable, so nothing is checked per element; conv taps outside [0, T) read a clamped address and select zero
+template <int MODE>
+__device__ __forceinline__ float4 fast_kvec(const OpDev& o, const float* base, int r, int k, int b, int t, int tap, int c) {
+    if (MODE == GT_OP_KC) return *reinterpret_cast<const float4*>(base + (long)r * o.ld + k);
+    const int tt = t + tap * o.dil - o.pad;
+    const bool ok = tt >= 0 && tt < o.T;
+    const float4 v = *reinterpret_cast<const float4*>(base + ((long)b * o.T + (ok ? tt : t)) * o.C + c);
+    return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+template <int MODE>
+__device__ __forceinline__ float4 fast_rvec(const OpDev& o, const float* base, int r, int k, int tap, int c, int b, int t) {
+    if (MODE == GT_OP_RC) return *reinterpret_cast<const float4*>(base + (long)k * o.ld + r);
+    const int tt = t + tap * o.dil - o.pad;
+    const bool ok = tt >= 0 && tt < o.T;
+    const float4 v = *reinterpret_cast<const float4*>(base + ((long)b * o.T + (ok ? tt : t)) * o.C + c);
+    return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+template <int MODE, int BR, int NP>
+struct TileLoaderX {
+    static constexpr bool KT = is_ktype<MODE>();
+    static constexpr int NK = BR / 32;            // k-type: float4 per thread (row f / 8, k-quad f % 8)
+    static constexpr int RQ = BR / 4;             // r-type: row quads per tile
+    static constexpr int KPT = BKX / (256 / RQ);  // r-type: consecutive k per thread (4 for 128 rows, 2 for 64)
+    static constexpr int NV = KT ? NK : KPT;
+    static constexpr int SR = BR + 32;            // r-type: bf16 elements per k-row of the LDS image
+    static constexpr int PLANE = KT ? BR * LDX : BKX * SR;        // bf16 elements per plane
+    float4 reg[NV];
+    int p0[KT ? NK : 1], p1[KT ? NK : 1];         // fixed decomposition of the row index
+    int q0, q1;                                   // running decomposition of the first k
+    long foff;                                    // KC / RC: element offset of this thread's first load of the next k-tile
+
+    __device__ __forceinline__ void init(const OpDev& o, int r0, int kbeg, int tid) {
+        q0 = q1 = 0;
+        foff = MODE == GT_OP_KC ? (long)(r0 + tid / 8) * o.ld + kbeg + 4 * (tid & 7)
+                                : (long)(kbeg + KPT * (tid / RQ)) * o.ld + r0 + 4 * (tid % RQ);
+#pragma unroll
+        for (int i = 0; i < (KT ? NK : 1); ++i) { p0[i] = 0; p1[i] = 0; }
+        if (MODE == GT_OP_IM2COL_K) {
+            const int k = kbeg + 4 * (tid & 7);
+            q0 = k / o.C; q1 = k - q0 * o.C;                      // (tap, c) of this thread's k-quad
+#pragma unroll
+            for (int i = 0; i < NK; ++i) {
+                const int r = r0 + (tid + 256 * i) / 8;
+                p0[i] = r / o.T; p1[i] = r - p0[i] * o.T;         // (b, t) of the row
+            }
+        } else if (MODE == GT_OP_IM2COL_R) {
+            const int r = r0 + 4 * (tid % RQ);
+            p0[0] = r / o.C; p1[0] = r - p0[0] * o.C;             // (tap, c) of the row quad
+            const int k = kbeg + KPT * (tid / RQ);
+            q0 = k / o.T; q1 = k - q0 * o.T;                      // (b, t) of the first k
+        }
+    }
+    template <bool FAST>
+    __device__ __forceinline__ void load(const OpDev& o, const float* base, int r0, int R, int k0, int K, int tid) {
+        load_into<FAST>(o, base, r0, R, k0, K, tid, reg);
+    }
+    __device__ __forceinline__ void store(unsigned short* S, int tid) const { store_from(S, tid, reg); }
+
+    // the same with the registers named by the caller
+    template <bool FAST>
+    __device__ __forceinline__ void load_into(const OpDev& o, const float* base, int r0, int R, int k0, int K, int tid,
+                                              float4 (&reg)[NV]) {
+        if (KT) {
+            const int k = k0 + 4 * (tid & 7);
+#pragma unroll
+            for (int i = 0; i < NK; ++i) {
+                const int r = r0 + (tid + 256 * i) / 8;
+                if (FAST && MODE == GT_OP_KC) reg[i] = *reinterpret_cast<const float4*>(base + foff + 32 * i * o.ld);
+                else reg[i] = FAST ? fast_kvec<MODE>(o, base, r, k, p0[i], p1[i], q0, q1)
+                                   : load_kvec<MODE>(o, base, r, R, k, K, p0[i], p1[i], q0, q1);
+            }
+            foff += BKX;
+            if (MODE == GT_OP_IM2COL_K) {
+                q1 += BKX;
+                while (q1 >= o.C) { q1 -= o.C; ++q0; }
+            }
+        } else {
+            const int r = r0 + 4 * (tid % RQ);
+            const int k = k0 + KPT * (tid / RQ);
+            int b = q0, t = q1;
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                if (FAST && MODE == GT_OP_RC) reg[j] = *reinterpret_cast<const float4*>(base + foff + j * o.ld);
+                else reg[j] = FAST ? fast_rvec<MODE>(o, base, r, k + j, p0[0], p1[0], b, t)
+                                   : load_rvec<MODE>(o, base, r, R, k + j, K, p0[0], p1[0], b, t);
+                if (MODE == GT_OP_IM2COL_R) { if (++t >= o.T) { t = 0; ++b; } }
+            }
+            foff += BKX * o.ld;
+            if (MODE == GT_OP_IM2COL_R) {
+                q1 += BKX;
+                while (q1 >= o.T) { q1 -= o.T; ++q0; }
+            }
+        }
+    }
+    __device__ __forceinline__ void store_from(unsigned short* S, int tid, const float4 (&reg)[NV]) const {
+        unsigned lo[NV][NP], hi[NV][NP];
+        split_all<NP, NV>(reg, lo, hi);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            unsigned short* d;
+            if (KT) {
+                const int f = tid + 256 * i;
+                d = &S[(f / 8) * LDX + 4 * (f & 7)];                       // [row][k .. k+3]
+            } else {
+                d = &S[(KPT * (tid / RQ) + i) * SR + 4 * (tid % RQ)];      // [k][row .. row+3]
+            }
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(d + p * PLANE) = make_uint2(lo[i][p], hi[i][p]);
+        }
+    }
+    // MFMA operand of the 32x32x16 product for rows [w0 + 32 i, +32) of the tile, k-step s, plane p: lane l holds
+    // [row l & 31][k = 16 s + 8 (l >> 5) .. + 7]
+    static __device__ __forceinline__ int frag_base(int w0, int lane) {
+        if (KT) return (w0 + (lane & 31)) * LDX + 8 * (lane >> 5);
+        // transposed read: lane 4q + r of a 16-lane group addresses k-row q, columns 4r .. 4r+3 of the group's 16 rows
+        return (8 * (lane >> 5) + ((lane & 15) >> 2)) * SR + w0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    }
+    static __device__ __forceinline__ bf16x8_t frag(const unsigned short* S, int base, int p, int i, int s) {
+        if (KT) return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(S + base + p * PLANE + 32 * i * LDX + 16 * s));
+        typedef __attribute__((address_space(3))) v4i16_t* lds_v4;
+        const unsigned short* q = S + base + p * PLANE + 32 * i + 16 * s * SR;
+        const v4i16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(q));
+        const v4i16_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(q + 4 * SR));
+        return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+};
+
+template <int BM, int BN, int AMODE, int BMODE, int NP>
+__global__ __launch_bounds__(256) void xgemm_kernel(GemmDev g) {
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    typedef TileLoaderX<AMODE, BM, NP> LA;
+    typedef TileLoaderX<BMODE, BN, NP> LB;
+    __shared__ __attribute__((aligned(16))) unsigned short smem[NP * (LA::PLANE + LB::PLANE)];
+    unsigned short* Ax = smem;
+    unsigned short* Bx = smem + NP * LA::PLANE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int batch = blockIdx.z / g.split_k, kz = blockIdx.z - batch * g.split_k;
+    const int kbeg = kz * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    const float* Ab = g.A.p + (long)batch * g.a_bs;
+    const float* Bb = g.B.p + (long)batch * g.b_bs;
+    float* Cb = g.C + (long)batch * g.c_bs;
+    // every lane of the workgroup takes the same branch: unchecked vector loads while the tile is interior
+    const bool inside = m0 + BM <= g.M && n0 + BN <= g.N && g.A.vec && g.B.vec;
+
+    LA la;
+    LB lb;
+    la.init(g.A, m0, kbeg, tid);
+    lb.init(g.B, n0, kbeg, tid);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+    if (kbeg < kend) {
+        if (inside && kbeg + BKX <= kend) {
+            la.template load<true>(g.A, Ab, m0, g.M, kbeg, kend, tid);
+            lb.template load<true>(g.B, Bb, n0, g.N, kbeg, kend, tid);
+        } else {
+            la.template load<false>(g.A, Ab, m0, g.M, kbeg, kend, tid);
+            lb.template load<false>(g.B, Bb, n0, g.N, kbeg, kend, tid);
+        }
+    }
+    const int abase = LA::frag_base(wm0, lane), bbase = LB::frag_base(wn0, lane);
+    for (int k0 = kbeg; k0 < kend; k0 += BKX) {
+        la.store(Ax, tid);
+        lb.store(Bx, tid);
+        __syncthreads();
+        if (k0 + BKX < kend) {
+            if (inside && k0 + 2 * BKX <= kend) {
+                la.template load<true>(g.A, Ab, m0, g.M, k0 + BKX, kend, tid);
+                lb.template load<true>(g.B, Bb, n0, g.N, k0 + BKX, kend, tid);
+            } else {
+                la.template load<false>(g.A, Ab, m0, g.M, k0 + BKX, kend, tid);
+                lb.template load<false>(g.B, Bb, n0, g.N, k0 + BKX, kend, tid);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < BKX / 16; ++s) {
+            bf16x8_t a[NP][TM], b[NP][TN];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[p][i] = LA::frag(Ax, abase, p, i, s);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[p][j] = LB::frag(Bx, bbase, p, j, s);
+            }
+            // smallest terms first; between two MFMAs on the same accumulator lie the other TM * TN - 1 tiles
+#pragma unroll
+            for (int ord = NP - 1; ord >= 0; --ord)
+#pragma unroll
+                for (int pa = 0; pa <= ord; ++pa)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa][i], b[ord - pa][j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // epilogue: as sgemm_kernel
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn0 + 32 * j + (lane & 31);
+            if (n >= g.N) continue;
+            const float bias = (g.bias != nullptr && kz == 0) ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= g.M) continue;
+                float* c = Cb + (long)m * g.ldc + n;
+                const float v = g.alpha * acc[i][j][r] + bias;
+                if (g.split_k > 1) atomicAdd(c, v);
+                else if (g.accumulate) *c += v;
+                else *c = v;
+            }
+        }
+}
+
+// (Measured and not adopted: a producer / consumer form with 512 threads -- waves 4..7 load, split and store the next
+// k-tile into a second LDS buffer while waves 0..3 only issue MFMAs, two k-tiles of loads in flight.  182-186 TFLOP/s
+// against 191-193 for xgemm_kernel on the decoder weight gradients: SQ_VALU_MFMA_COEXEC_CYCLES stays at 1 %, the
+// vector work of one wave does not run beside the MFMAs of its SIMD partner, so the two kinds of wave take turns.)
 template <int BM, int BN>
 int launch_tile(const GemmDev& d, dim3 grid, hipStream_t st, int lds_pad) {
     const int am = d.A.mode, bm = d.B.mode;
 #define GT_CASE(AM, BMD)                                                                                    \
     if (am == AM && bm == BMD) {                                                                            \
-        if (d.bf16) hipLaunchKernelGGL((hgemm_kernel<BM, BN, AM, BMD>), grid, dim3(256), lds_pad, st, d);    \
-        else hipLaunchKernelGGL((sgemm_kernel<BM, BN, AM, BMD>), grid, dim3(256), lds_pad, st, d);          \
+        if (d.bf16 == 1) hipLaunchKernelGGL((hgemm_kernel<BM, BN, AM, BMD>), grid, dim3(256), lds_pad, st, d);           \
+        else if (d.bf16 == 2) hipLaunchKernelGGL((xgemm_kernel<BM, BN, AM, BMD, 2>), grid, dim3(256), lds_pad, st, d);   \
+        else if (d.bf16 == 3) hipLaunchKernelGGL((xgemm_kernel<BM, BN, AM, BMD, 3>), grid, dim3(256), lds_pad, st, d);   \
+        else hipLaunchKernelGGL((sgemm_kernel<BM, BN, AM, BMD>), grid, dim3(256), lds_pad, st, d);                      \
         return 0;                                                                                           \
     }
     GT_CASE(GT_OP_KC, GT_OP_KC)
@@ -478,7 +774,17 @@ int prep_operand(const GtOperand& s, OpDev& o, int rows, int K, const char* name
     return 0;
 }
 
+int g_fp32_planes = 0;       // gt_sgemm_set_fp32_split: how GtGemm.bf16 == 0 products are computed
+
 }  // namespace
+
+extern "C" int gt_sgemm_set_fp32_split(int32_t planes) {
+    GT_REQUIRE(planes == 0 || planes == 2 || planes == 3, GT_E_ARG, "gt_sgemm_set_fp32_split: planes must be 0, 2 or 3");
+    g_fp32_planes = planes;
+    return 0;
+}
+
+extern "C" int32_t gt_sgemm_get_fp32_split(void) { return g_fp32_planes; }
 
 extern "C" int gt_sgemm(const GtGemm* g, void* stream) {
     GT_REQUIRE(g != nullptr && g->C != nullptr, GT_E_ARG, "gt_sgemm: NULL argument");
@@ -493,8 +799,9 @@ extern "C" int gt_sgemm(const GtGemm* g, void* stream) {
     d.a_bs = g->A.batch_stride; d.b_bs = g->B.batch_stride; d.c_bs = g->c_batch_stride;
     d.M = g->M; d.N = g->N; d.K = g->K; d.accumulate = g->accumulate; d.alpha = g->alpha;
     d.split_k = g->split_k;
-    d.bf16 = g->bf16 != 0;
-    const int kstep = d.bf16 ? BKH : BK;        // k-tile of the kernel: splits are whole k-tiles
+    GT_REQUIRE(g->bf16 >= 0 && g->bf16 <= 3, GT_E_ARG, "gt_sgemm: bf16 = %d (0 fp32, 1 bf16 operands, 2 / 3 split planes)", g->bf16);
+    d.bf16 = g->bf16 != 0 ? g->bf16 : g_fp32_planes;
+    const int kstep = d.bf16 == 1 ? BKH : d.bf16 >= 2 ? BKX : BK;        // k-tile of the kernel: splits are whole k-tiles
     const int kblocks = cdiv(g->K, kstep);
     d.k_per_split = cdiv(kblocks, g->split_k) * kstep;
     d.split_k = cdiv(g->K, d.k_per_split);   // drop empty splits

@@ -60,6 +60,40 @@ class bf16_gemms:
         BF16_GEMMS = self.old
 
 
+# How fp32 GEMMs are computed (gt_sgemm_set_fp32_split): 0 = fp32 matrix pipe, 3 = three bf16 planes per operand and
+# six bf16 MFMAs (fp32-accurate, 16/6 of the fp32 pipe's rate), 2 = two planes / three MFMAs (2^-16 accuracy class).
+# GANTRON_FP32_SPLIT picks the process default, applied when the first GEMM is issued.
+FP32_SPLIT = int(_os.environ.get('GANTRON_FP32_SPLIT', '3'))
+_split_applied = None
+
+
+def set_fp32_split(planes):
+    global FP32_SPLIT, _split_applied
+    check(lib().gt_sgemm_set_fp32_split(int(planes)), 'gt_sgemm_set_fp32_split')
+    FP32_SPLIT = _split_applied = int(planes)
+
+
+def apply_fp32_split():
+    """Push FP32_SPLIT into the library if it is not there yet (cheap; called on the GEMM entry points and by the engines
+    before they enter the C loops, which issue their own fp32 GEMMs)."""
+    if _split_applied != FP32_SPLIT:
+        set_fp32_split(FP32_SPLIT)
+
+
+class fp32_split:
+    """with ops.fp32_split(planes): ... -- fp32 GEMMs inside the block are computed with that many bf16 planes."""
+
+    def __init__(self, planes):
+        self.planes = int(planes)
+
+    def __enter__(self):
+        self.old = FP32_SPLIT
+        set_fp32_split(self.planes)
+
+    def __exit__(self, *exc):
+        set_fp32_split(self.old)
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -72,6 +106,7 @@ def ptr(t, offset=0):
 
 
 def call(name, *args):
+    apply_fp32_split()
     conv = [a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args]
     check(getattr(lib(), name)(*conv, _stream()), name)
 
@@ -131,7 +166,8 @@ def sgemm(A, B, C, M, N, K, ldc=None, bias=None, accumulate=False, split_k=1, ba
     g.bias = ptr(bias)
     g.M, g.N, g.K, g.batch = M, N, K, batch
     g.accumulate, g.split_k, g.alpha = int(accumulate), split_k, alpha
-    g.bf16 = int(bool(bf16))
+    g.bf16 = int(bf16)              # False / True, or 2 / 3: that many bf16 planes whatever the process setting
+    apply_fp32_split()
     if split_k > 1 and not accumulate:
         raise ValueError('split_k > 1 accumulates: zero C and pass accumulate=True')
     check(lib().gt_sgemm(ctypes.byref(g), _stream()), 'gt_sgemm')

@@ -93,11 +93,24 @@ typedef struct GtGemm {
     int32_t accumulate;         /* 0: C = ..., 1: C += ... */
     int32_t split_k;            /* >= 1; > 1 uses fp32 atomics and therefore always accumulates */
     float alpha;
-    int32_t bf16;               /* 1: operands rounded to bf16 (nearest even) in the tile loader, bf16 MFMA, fp32
-                                   accumulation and output (hparams.fp16_run) */
+    int32_t bf16;               /* 0: fp32 product (computed as gt_sgemm_set_fp32_split selects);
+                                   1: operands rounded to bf16 (nearest even) in the tile loader, bf16 MFMA, fp32
+                                   accumulation and output (hparams.fp16_run);
+                                   2 / 3: fp32 product from 2 / 3 bf16 planes per operand, regardless of the setting */
 } GtGemm;
 
 int gt_sgemm(const GtGemm* g, void* stream);
+
+/* How products with GtGemm.bf16 == 0 are computed (process-wide; default 0):
+ *   0  v_mfma_f32_32x32x2_f32, the fp32 matrix pipe (157 TFLOP/s peak on MI355X);
+ *   3  every fp32 operand x is staged as three bf16 planes x0 + x1 + x2 = x (exact: 3 x 8 significand bits) and
+ *      a . b = a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0) runs as six bf16 MFMAs with fp32 accumulation: each
+ *      product is exact, the dropped terms are <= 2^-24 |a||b| -- the rounding unit of the fp32 pipe itself -- and the
+ *      bf16 pipe is 16x faster, so the product costs 6/16 of the fp32 MFMA time;
+ *   2  two planes, three MFMAs: dropped terms <= 2^-16 |a||b| (the accuracy class of 3xTF32).
+ * Inf / NaN operands produce NaN in modes 2 / 3. */
+int gt_sgemm_set_fp32_split(int32_t planes);
+int32_t gt_sgemm_get_fp32_split(void);
 
 /* ------------------------------------------------------------------- recurrent (small-M) GEMM
  * Per-time-step product of the LSTM recurrences (model.py:391-392,406-407 and the BiLSTM of

@@ -27,23 +27,67 @@ def g(*shape, seed=0, scale=1.0):
 # ------------------------------------------------------------------------------------- sgemm
 def rb(t, bf16):
     """operand as the bf16 variant of gt_sgemm sees it (rounded to nearest even), in fp64"""
-    return t.to(torch.bfloat16).double() if bf16 else t.double()
+    return t.to(torch.bfloat16).double() if bf16 is True else t.double()
 
 
-@pytest.mark.parametrize('bf16', [False, True])
+# GtGemm.bf16: False = fp32 MFMA, True = operands rounded to bf16, 3 / 2 = fp32 product from three / two bf16 planes per
+# operand (xgemm_kernel).  Three planes hold to the fp32 tolerances; two planes drop terms of 2^-16 |a||b|.
+PRECISIONS = [False, True, 3, 2]
+
+
+def native_if_false(bf16):
+    """`False` means the fp32 matrix pipe in these tests, whatever the process default (GANTRON_FP32_SPLIT) is."""
+    import contextlib
+    from gantron_amd import ops
+    return ops.fp32_split(0) if bf16 is False else contextlib.nullcontext()
+
+
+def tol(bf16, atol):
+    return dict(rtol=1e-5, atol=atol) if bf16 != 2 else dict(rtol=1e-4, atol=100 * atol)
+
+
+@pytest.mark.parametrize('bf16', PRECISIONS)
 @pytest.mark.parametrize('M,N,K', [(200, 150, 70), (64, 64, 16), (129, 257, 333), (1, 80, 2048), (515, 1, 33), (300, 260, 1000),
                                    (2000, 1536, 200)])     # the last one runs on 128x128 tiles (>= 192 of them)
 def test_sgemm_kc_kc(dev, M, N, K, bf16):
     from gantron_amd import ops
     A, B, bias = g(M, K), g(N, K, seed=1), g(N, seed=2)
     C = torch.empty(M, N, device=dev)
-    ops.sgemm(ops.Operand(A.to(dev), ops.KC, ld=K), ops.Operand(B.to(dev), ops.KC, ld=K), C, M, N, K, bias=bias.to(dev),
-              bf16=bf16)
-    close(C, rb(A, bf16) @ rb(B, bf16).t() + bias.double(), rtol=1e-5, atol=1e-5, what='sgemm kc/kc')
+    with native_if_false(bf16):
+        ops.sgemm(ops.Operand(A.to(dev), ops.KC, ld=K), ops.Operand(B.to(dev), ops.KC, ld=K), C, M, N, K, bias=bias.to(dev),
+                  bf16=bf16)
+    close(C, rb(A, bf16) @ rb(B, bf16).t() + bias.double(), what='sgemm kc/kc', **tol(bf16, 1e-5))
 
 
-@pytest.mark.parametrize('bf16', [False, True])
+def test_sgemm_split_planes_accuracy(dev):
+    """The three-plane product is as accurate as the fp32 matrix pipe (errors against fp64 within a factor of two of each
+    other, over five decades of operand magnitude inside one reduction); two planes sit at the 2^-16 level."""
+    from gantron_amd import ops
+    M, N, K = 384, 512, 4096
+    gen = torch.Generator().manual_seed(5)
+    A = torch.randn(M, K, generator=gen) * torch.exp(torch.randn(M, K, generator=gen) * 2.5)
+    B = torch.randn(N, K, generator=gen) * torch.exp(torch.randn(N, K, generator=gen) * 2.5)
+    ref = A.double() @ B.double().t()
+    scale = (A.double().abs() @ B.double().abs().t())           # sum |a||b|: what a rounding error is relative to
+    err = {}
+    for prec in (False, 3, 2):
+        C = torch.empty(M, N, device=dev)
+        with native_if_false(prec):
+            ops.sgemm(ops.Operand(A.to(dev), ops.KC, ld=K), ops.Operand(B.to(dev), ops.KC, ld=K), C, M, N, K, bf16=prec)
+        err[prec] = float(((C.cpu().double() - ref).abs() / scale).max())
+    # fp32 accumulation over K = 4096 terms leaves a few 1e-6 of sum |a||b| on either pipe
+    assert err[False] < 1e-5 and err[3] < 1e-5, err
+    assert err[3] < 1.5 * err[False], err
+    assert err[2] < 4e-5, err                                   # 2^-16 per product
+
+
+@pytest.mark.parametrize('bf16', PRECISIONS)
 def test_sgemm_modes_accumulate_splitk_batch(dev, bf16):
+    with native_if_false(bf16):
+        _sgemm_modes(dev, bf16)
+
+
+def _sgemm_modes(dev, bf16):
     from gantron_amd import ops
     import functools
     M, N, K = 96, 130, 700
@@ -54,14 +98,14 @@ def test_sgemm_modes_accumulate_splitk_batch(dev, bf16):
     C = torch.zeros(M, N, device=dev)
     ops.sgemm(ops.Operand(A.t().contiguous().to(dev), ops.RC, ld=M), ops.Operand(B.t().contiguous().to(dev), ops.RC, ld=N),
               C, M, N, K)
-    close(C, ref, rtol=1e-5, atol=1e-4, what='rc/rc')
+    close(C, ref, **tol(bf16, 1e-4), what='rc/rc')
     # KC/RC and RC/KC
     C.zero_()
     ops.sgemm(ops.Operand(A.to(dev), ops.KC, ld=K), ops.Operand(B.t().contiguous().to(dev), ops.RC, ld=N), C, M, N, K)
-    close(C, ref, rtol=1e-5, atol=1e-4, what='kc/rc')
+    close(C, ref, **tol(bf16, 1e-4), what='kc/rc')
     C.zero_()
     ops.sgemm(ops.Operand(A.t().contiguous().to(dev), ops.RC, ld=M), ops.Operand(B.to(dev), ops.KC, ld=K), C, M, N, K)
-    close(C, ref, rtol=1e-5, atol=1e-4, what='rc/kc')
+    close(C, ref, **tol(bf16, 1e-4), what='rc/kc')
     # accumulate + split-K on top of existing content, unaligned leading dimension (scalar path)
     C0 = g(M, N + 3, seed=5)
     Cd = C0.clone().to(dev)
@@ -69,7 +113,7 @@ def test_sgemm_modes_accumulate_splitk_batch(dev, bf16):
               accumulate=True, split_k=5, alpha=0.5)
     want = C0.double()
     want[:, :N] += 0.5 * ref
-    close(Cd, want, rtol=1e-5, atol=1e-4, what='accumulate split-k')
+    close(Cd, want, **tol(bf16, 1e-4), what='accumulate split-k')
     # batched, operands at an element offset
     nb = 3
     Ab, Bb = g(nb, M, K, seed=7), g(nb, N, K, seed=8)
@@ -77,16 +121,16 @@ def test_sgemm_modes_accumulate_splitk_batch(dev, bf16):
     Apad = torch.cat((torch.zeros(5), Ab.reshape(-1))).to(dev)
     ops.sgemm(ops.Operand(Apad, ops.KC, ld=K, offset=5, batch_stride=M * K),
               ops.Operand(Bb.to(dev), ops.KC, ld=K, batch_stride=N * K), Cb, M, N, K, batch=nb, c_batch_stride=M * N)
-    close(Cb, torch.bmm(rb(Ab, bf16), rb(Bb, bf16).transpose(1, 2)), rtol=1e-5, atol=1e-4, what='batched')
+    close(Cb, torch.bmm(rb(Ab, bf16), rb(Bb, bf16).transpose(1, 2)), **tol(bf16, 1e-4), what='batched')
     # 128x128 tiles (>= 192 of them), reduction-major operands: the shape class of the weight-gradient GEMMs
     M2, N2, K2 = 1536, 2000, 150
     A2, B2 = g(K2, M2, seed=11), g(K2, N2, seed=12)
     C2 = torch.zeros(M2, N2, device=dev)
     ops.sgemm(ops.Operand(A2.to(dev), ops.RC, ld=M2), ops.Operand(B2.to(dev), ops.RC, ld=N2), C2, M2, N2, K2)
-    close(C2, rb(A2, bf16).t() @ rb(B2, bf16), rtol=1e-5, atol=1e-4, what='rc/rc 128x128 tiles')
+    close(C2, rb(A2, bf16).t() @ rb(B2, bf16), **tol(bf16, 1e-4), what='rc/rc 128x128 tiles')
 
 
-@pytest.mark.parametrize('bf16', [False, True])
+@pytest.mark.parametrize('bf16', PRECISIONS)
 @pytest.mark.parametrize('B,T,Cin,Cout,K,dil', [(3, 37, 16, 24, 5, 1), (2, 9, 32, 48, 5, 2), (4, 150, 80, 512, 5, 1)])
 def test_conv1d_fwd_dx_dw(dev, B, T, Cin, Cout, K, dil, bf16):
     """bf16: ops.bf16_gemms (hparams.fp16_run) -- every product takes its two operands rounded to bf16, so the
@@ -100,15 +144,15 @@ def test_conv1d_fwd_dx_dw(dev, B, T, Cin, Cout, K, dil, bf16):
     gx, gw = torch.autograd.grad(y, (xr, Wr), rb(dy, bf16))
     xcl = x.permute(0, 2, 1).contiguous().view(B * T, Cin).to(dev)
     Wd = W.to(dev)
-    with ops.bf16_gemms(bf16):
+    with ops.bf16_gemms(bf16 is True), ops.fp32_split(0 if isinstance(bf16, bool) else bf16):
         ycl = ops.conv1d_fwd(xcl, ops.conv_weight_fwd(Wd), bias.to(dev), B, T, Cin, Cout, K, dil)
-        close(ycl.view(B, T, Cout).permute(0, 2, 1), y, rtol=1e-5, atol=1e-4, what='conv fwd')
+        close(ycl.view(B, T, Cout).permute(0, 2, 1), y, **tol(bf16, 1e-4), what='conv fwd')
         dycl = dy.permute(0, 2, 1).contiguous().view(B * T, Cout).to(dev)
         dx = ops.conv1d_dx(dycl, ops.conv_weight_bwd(Wd), B, T, Cin, Cout, K, dil)
-        close(dx.view(B, T, Cin).permute(0, 2, 1), gx, rtol=1e-5, atol=1e-4, what='conv dx')
+        close(dx.view(B, T, Cin).permute(0, 2, 1), gx, **tol(bf16, 1e-4), what='conv dx')
         dW = torch.zeros(Cout, Cin, K, device=dev)
         ops.conv1d_dw(dycl, xcl, B, T, Cin, Cout, K, dil, dW)
-        close(dW, gw, rtol=1e-5, atol=1e-4, what='conv dw')
+        close(dW, gw, **tol(bf16, 1e-4), what='conv dw')
 
 
 # ---------------------------------------------------------------------------- recurrent kernels

@@ -7,6 +7,8 @@ from gantron_amd import ops
 dev = torch.device('cuda:0')
 ops.BF16_GEMMS = bool(os.environ.get('BF16'))      # BF16=1: layer GEMMs with bf16 operands (hparams.fp16_run)
 REPS = int(os.environ.get('REPS', 10))
+if os.environ.get('SPLIT'):                         # SPLIT=3 / 2: fp32 products from that many bf16 planes (xgemm_kernel)
+    ops.set_fp32_split(int(os.environ['SPLIT']))
 
 
 def timeit(name, fn, flops):

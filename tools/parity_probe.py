@@ -39,3 +39,9 @@ rows = sorted(((float((res['g_grad'][k] - grads[k]).abs().max() / (grads[k].abs(
                for k in grads if float(grads[k].abs().max()) > 1e-5), reverse=True)
 for e, k, s in rows[:8]:
     print(f'{e:.2e}  {k}  (scale {s:.2e})')
+# discriminator step of the same pair (fake = the oracle's own mel_post)
+kr, kf = common.draw_disc_keep(stream, hp, B, To), common.draw_disc_keep(stream, hp, B, To)
+dl, dgrads = R.discriminator_step_grads(Dp, mel, ol, out[1], ol, kr, kf, hp)
+for k in dgrads:
+    d = (res['d_grad'][k].double() - dgrads[k].double())
+    print(f'd_grad {k}: max err {float(d.abs().max()):.2e} rel L2 {float(d.norm() / (dgrads[k].double().norm() + 1e-30)):.2e} (scale {float(dgrads[k].abs().max()):.2e})')
