@@ -227,6 +227,10 @@ def main():
     ap.add_argument('--bf16', action='store_true',
                     help='BASELINE config 3 (hparams.fp16_run): bf16 operands in the decoder LSTM products and the layer '
                          'GEMMs, fp32 accumulation and master weights; NOT the headline metric, the default line is fp32')
+    ap.add_argument('--fp32-split', type=int, choices=(0, 2, 3), default=None,
+                    help='how the tiled fp32 GEMMs are computed (gt_sgemm_set_fp32_split): 3 = three bf16 planes per operand, six '
+                         'exact products, fp32 accumulation (default, GANTRON_FP32_SPLIT); 0 = the fp32 matrix pipe; 2 = two '
+                         'planes, 2^-16 accuracy class')
     ap.add_argument('--vesus', action='store_true',
                     help='BASELINE config 4: VESUS labels + speaker embedding + noise (E = 1093), 50/50 LJ / VESUS-shaped mix')
     ap.add_argument('--merged', action='store_true',
@@ -260,6 +264,15 @@ def main():
     from gantron_amd.train_steps import discriminator_step, generator_step
 
     hp = HParams((VESUS_HPARAMS if args.vesus else HPARAMS) + f',batch_size={args.batch}' + (',fp16_run=True' if args.bf16 else ''))
+    from gantron_amd import ops as _ops
+    if args.fp32_split is not None:
+        _ops.FP32_SPLIT = args.fp32_split
+    GEMM_ARITH = {0: 'fp32 MFMA (v_mfma_f32_32x32x2_f32)',
+                  3: 'fp32 operands split exactly into three bf16 planes in the tile loader, six bf16 MFMA products (each exact), '
+                     'fp32 accumulation: dropped terms <= 2^-24 |a||b|, measured error vs fp64 <= the fp32 MFMA\'s in every operand '
+                     'mode (tests/test_kernels_gpu.py::test_sgemm_split_planes_accuracy, tools/split_accuracy.py)',
+                  2: 'fp32 operands split into two bf16 planes, three bf16 MFMA products, fp32 accumulation: dropped terms '
+                     '<= 2^-16 |a||b|'}[_ops.FP32_SPLIT]
     # GANTRON_FORCE_DIST=1 exercises the RCCL gradient-averaging path on a single rank (1-GPU boxes)
     use_dist = world > 1 or os.environ.get('GANTRON_FORCE_DIST') == '1'
     if use_dist:
@@ -449,6 +462,8 @@ def main():
                                 per_gpu_batch=args.batch, global_batch=args.batch * world, Ti_max=Ti, To_max=To,
                                 valid_frames_per_rank=frames, padded_frames_per_rank=args.batch * To,
                                 parallelism='dp%d' % world, pair_tflop=fl / 1e12,
+                                tiled_gemm_arithmetic='bf16 operands, fp32 accumulation' if args.bf16 else GEMM_ARITH,
+                                recurrent_product_arithmetic='bf16 operands, fp32 accumulation' if args.bf16 else 'fp32 MFMA (v_mfma_f32_16x16x4_f32)',
                                 padded_frames_per_s=args.batch * To * world * args.steps / elapsed,
                                 g_step_ms=g_s * 1e3, d_step_ms=d_s * 1e3,
                                 schedule_2g1d_frames_per_s=2 * total_frames / (2 * g_s + d_s),

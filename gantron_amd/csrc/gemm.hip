@@ -491,21 +491,26 @@ __device__ __forceinline__ void split_all(const float4 (&reg)[NV], unsigned (&lo
 
 // FAST loads: the tile lies inside the matrix, the k-tile inside the reduction range and the operand is 16-byte
 // addressable, so nothing is checked per element; conv taps outside [0, T) read a clamped address and select zero
+// (the zeroing is a bitwise AND: with a select the compiler moves the load under a branch, and a branch around a load
+// hides the number of loads in flight from its s_waitcnt insertion, which then waits for all of them)
+__device__ __forceinline__ float4 mask4(const float4& v, bool ok) {
+    const unsigned m = ok ? 0xffffffffu : 0u;
+    return make_float4(__uint_as_float(__float_as_uint(v.x) & m), __uint_as_float(__float_as_uint(v.y) & m),
+                       __uint_as_float(__float_as_uint(v.z) & m), __uint_as_float(__float_as_uint(v.w) & m));
+}
 template <int MODE>
 __device__ __forceinline__ float4 fast_kvec(const OpDev& o, const float* base, int r, int k, int b, int t, int tap, int c) {
     if (MODE == GT_OP_KC) return *reinterpret_cast<const float4*>(base + (long)r * o.ld + k);
     const int tt = t + tap * o.dil - o.pad;
     const bool ok = tt >= 0 && tt < o.T;
-    const float4 v = *reinterpret_cast<const float4*>(base + ((long)b * o.T + (ok ? tt : t)) * o.C + c);
-    return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    return mask4(*reinterpret_cast<const float4*>(base + ((long)b * o.T + (ok ? tt : t)) * o.C + c), ok);
 }
 template <int MODE>
 __device__ __forceinline__ float4 fast_rvec(const OpDev& o, const float* base, int r, int k, int tap, int c, int b, int t) {
     if (MODE == GT_OP_RC) return *reinterpret_cast<const float4*>(base + (long)k * o.ld + r);
     const int tt = t + tap * o.dil - o.pad;
     const bool ok = tt >= 0 && tt < o.T;
-    const float4 v = *reinterpret_cast<const float4*>(base + ((long)b * o.T + (ok ? tt : t)) * o.C + c);
-    return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    return mask4(*reinterpret_cast<const float4*>(base + ((long)b * o.T + (ok ? tt : t)) * o.C + c), ok);
 }
 
 template <int MODE, int BR, int NP>
@@ -576,7 +581,7 @@ struct TileLoaderX {
                 if (FAST && MODE == GT_OP_RC) reg[j] = *reinterpret_cast<const float4*>(base + foff + j * o.ld);
                 else reg[j] = FAST ? fast_rvec<MODE>(o, base, r, k + j, p0[0], p1[0], b, t)
                                    : load_rvec<MODE>(o, base, r, R, k + j, K, p0[0], p1[0], b, t);
-                if (MODE == GT_OP_IM2COL_R) { if (++t >= o.T) { t = 0; ++b; } }
+                if (MODE == GT_OP_IM2COL_R) { ++t; const int w = t >= o.T; t = w ? 0 : t; b += w; }
             }
             foff += BKX * o.ld;
             if (MODE == GT_OP_IM2COL_R) {
@@ -588,6 +593,10 @@ struct TileLoaderX {
     __device__ __forceinline__ void store_from(unsigned short* S, int tid, const float4 (&reg)[NV]) const {
         unsigned lo[NV][NP], hi[NV][NP];
         split_all<NP, NV>(reg, lo, hi);
+        store_planes(S, tid, lo, hi);
+    }
+    static __device__ __forceinline__ void store_planes(unsigned short* S, int tid, const unsigned (&lo)[NV][NP],
+                                                        const unsigned (&hi)[NV][NP]) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             unsigned short* d;
@@ -722,7 +731,12 @@ __global__ __launch_bounds__(256) void xgemm_kernel(GemmDev g) {
 // (Measured and not adopted: a producer / consumer form with 512 threads -- waves 4..7 load, split and store the next
 // k-tile into a second LDS buffer while waves 0..3 only issue MFMAs, two k-tiles of loads in flight.  182-186 TFLOP/s
 // against 191-193 for xgemm_kernel on the decoder weight gradients: SQ_VALU_MFMA_COEXEC_CYCLES stays at 1 %, the
-// vector work of one wave does not run beside the MFMAs of its SIMD partner, so the two kinds of wave take turns.)
+// vector work of one wave does not run beside the MFMAs of its SIMD partner, so the two kinds of wave take turns.
+// Also not adopted: a software-pipelined form, one 4-wave workgroup per CU with the whole register file, two LDS buffers,
+// loads two k-tiles ahead with counted vmcnt waits, and -- pinned by sched_barrier -- one split stage (<= 5 vector
+// instructions), one fragment read and one plane store in every MFMA gap of the same wave: 186 TFLOP/s.  Its parts:
+// MFMAs + fragment reads alone 300, + plane stores 258; the split does not hide in the gaps (dependent cvt / shift / sub
+// chains).  xgemm_kernel with two workgroups per CU stays the fastest form measured.)
 template <int BM, int BN>
 int launch_tile(const GemmDev& d, dim3 grid, hipStream_t st, int lds_pad) {
     const int am = d.A.mode, bm = d.B.mode;

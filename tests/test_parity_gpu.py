@@ -151,11 +151,22 @@ def test_full_size_matches_reference_summaries(dev, golden_dir, name):
 
 @pytest.mark.parametrize('case', ['ragged5', 'batch70', 'full_dims_b64', 'full_dims_b20', 'full_dims_long', 'ragged5_bf16',
                                   'full_dims_b20_bf16', 'full_dims_b64_t200', 'vesus_b64', 'vesus_b128_bf16',
-                                  'full_dims_b64_bf16'])
+                                  'full_dims_b64_bf16', 'ragged5_f32pipe', 'full_dims_b64_f32pipe'])
 def test_midsize_against_oracle(dev, case):
     """B=5 (padded to 16 rows) with ragged lengths and To not a multiple of the discriminator window, and
     B=70 (> 64 rows: two 64-row blocks per recurrent launch): HIP path vs the CPU oracle on identical
-    seeded inputs and masks."""
+    seeded inputs and masks.  *_f32pipe: the same case with the tiled GEMMs on the fp32 matrix pipe
+    (gt_sgemm_set_fp32_split(0)) instead of the default three-plane bf16 split."""
+    import contextlib
+    from gantron_amd import ops
+    if case.endswith('_f32pipe'):
+        with ops.fp32_split(0):
+            return _midsize_against_oracle(dev, case[:-len('_f32pipe')])
+    with (ops.fp32_split(3) if ops.FP32_SPLIT == 0 else contextlib.nullcontext()):
+        return _midsize_against_oracle(dev, case)
+
+
+def _midsize_against_oracle(dev, case):
     from gantron_amd.hparams import HParams
     from oracle import gantron_ref as R
     hp = HParams('use_labels=False,use_noise=True,n_mel_channels=16,encoder_embedding_dim=32,symbols_embedding_dim=32,'
@@ -545,7 +556,16 @@ def test_full_size_training_step_is_schedule_invariant(dev, monkeypatch):
     bad = []
     for k in g0:
         try:
-            close(g1[k], g0[k], rtol=1e-3, atol=2e-6, what=f'g_grad.{k}')
+            if k.startswith(('encoder.convolutions.', 'embedding.')):
+                # the encoder's gradients pass through the whole decoder backward first and are the worst-conditioned of
+                # the step (test_midsize_against_oracle holds them to a relative L2 error for the same reason): between
+                # the two schedules the decoder LSTM's input product is a per-step fp32 product in one and a block GEMM
+                # in the other, i.e. two roundings of the same sums.  Relative L2 2e-3, max-abs 1e-2.
+                l2 = float((g1[k].double() - g0[k].double()).norm() / (g0[k].double().norm() + 1e-30))
+                assert l2 <= 2e-3, f'g_grad.{k}: relative L2 difference {l2:.3e}'
+                close(g1[k], g0[k], rtol=1e-2, atol=2e-6, what=f'g_grad.{k}')
+            else:
+                close(g1[k], g0[k], rtol=1e-3, atol=2e-6, what=f'g_grad.{k}')
         except AssertionError as e:
             bad.append(str(e))
     assert not bad, '\n'.join(bad)
