@@ -556,7 +556,7 @@ def test_full_size_training_step_is_schedule_invariant(dev, monkeypatch):
     bad = []
     for k in g0:
         try:
-            if k.startswith(('encoder.convolutions.', 'embedding.')):
+            if k.startswith(('encoder.convolutions.', 'embedding.')) and not k.endswith('.0.conv.bias'):     # (zero gradient there)
                 # the encoder's gradients pass through the whole decoder backward first and are the worst-conditioned of
                 # the step (test_midsize_against_oracle holds them to a relative L2 error for the same reason): between
                 # the two schedules the decoder LSTM's input product is a per-step fp32 product in one and a block GEMM
