@@ -49,7 +49,7 @@ KERNEL_OF = {'rec_gemm': 'rec_gemm_kernel', 'sgemm': 'sgemm_kernel', 'attn_energ
              'attn_energies_bwd': 'attn_energies_bwd', 'lstm_cell_fwd': 'lstm_cell_fwd_kernel',
              'lstm_cell_bwd': 'lstm_cell_bwd_kernel', 'rec_cell': 'rec_cell_kernel'}
 MFMA_BOUND = {'rec_gemm', 'sgemm', 'rec_cell'}
-PROF_STRIDE = 64
+PROF_STRIDE = 61              # prime: the families alternate between two or three shapes per decoder step, an even stride samples one of them
 
 
 def _lj_lengths(rs, n):
@@ -347,7 +347,7 @@ def main():
         pair(args.warmup + i)
     sync()
     elapsed = time.perf_counter() - t0
-    prof_out = (ctypes.c_double * (5 * NF + 2))()
+    prof_out = (ctypes.c_double * (6 * NF + 2))()          # GT_PROF_DOUBLES
     _lib.check(lib.gt_prof_end(prof_out), 'gt_prof_end')
     log(f'timed region: {elapsed:.3f} s for {args.steps} pairs')
     from gantron_amd import engine as _engine
@@ -405,9 +405,11 @@ def main():
         # duration (gt_prof_calibrate: start / stop timestamps of its dispatch)
         null_bracket_ms = (out[5 * NF + 1] / out[5 * NF]) if out[5 * NF] > 0 else 0.0
         null_ms = max(null_bracket_ms - null_us.value * 1e-3, 0.0)
-        fam = [dict(name=FAMILIES[f], launches=int(out[4 * f]),
-                    ms=max(out[4 * f + 1] - null_ms * out[4 * f], 1e-9) if out[4 * f] else 0.0, flops=out[4 * f + 2],
-                    bytes=out[4 * f + 3], seen=int(out[4 * NF + f])) for f in range(NF)]
+        # (the recurrent-product families are timed by their launches' own start / stop stamps -- out[5 NF + 2 + f] of
+        # them -- which carry no event latency: hipExtLaunchKernelGGL, the duration rocprofv3 reports for the kernel)
+        fam = [dict(name=FAMILIES[f], launches=int(out[4 * f]), exact=int(out[5 * NF + 2 + f]),
+                    ms=max(out[4 * f + 1] - null_ms * (out[4 * f] - out[5 * NF + 2 + f]), 1e-9) if out[4 * f] else 0.0,
+                    flops=out[4 * f + 2], bytes=out[4 * f + 3], seen=int(out[4 * NF + f])) for f in range(NF)]
         for r in fam:                            # estimated time of ALL launches of the family in the timed region
             r['est_total_ms'] = r['ms'] / r['launches'] * r['seen'] if r['launches'] else 0.0
         # the dominant KERNEL: every family but sgemm is one kernel symbol; the sgemm family is several template
@@ -435,8 +437,10 @@ def main():
             roof['algorithmic_bytes_per_launch'] = dom['bytes'] / max(dom['launches'], 1)
         except (IndexError, KeyError, OSError, ValueError):
             pass
-        roof.update(kernel=KERNEL_OF[dom['name']], sampled_launches=dom['launches'], sample_stride=PROF_STRIDE,
+        roof.update(kernel=KERNEL_OF[dom['name']] + ('' if not args.bf16 else ' (bf16-operand instantiation)'), sampled_launches=dom['launches'], sample_stride=PROF_STRIDE,
                     avg_launch_us=avg_ms * 1e3,
+                    timing=('start / stop events of the sampled launches themselves (hipExtLaunchKernelGGL: dispatch begin to end)'
+                            if dom['exact'] == dom['launches'] else 'event brackets on the launch stream minus the in-situ event latency'),
                     event_latency_us=null_ms * 1e3, empty_kernel_bracket_us=null_bracket_ms * 1e3, empty_kernel_us=null_us.value,
                     families={r['name']: dict(launches=r['launches'], ms=round(r['ms'], 3), all_launches=r['seen'],
                                               est_ms_per_pair=round(r['est_total_ms'] / args.steps, 2),

@@ -35,7 +35,7 @@ extern "C" int64_t gt_abi_sizeof(int32_t which) {
 bool g_gt_prof_on = false;
 double g_gt_prof_ctx_rows = 0.0;      // valid memory rows of the batch (gt_prof_set_context_rows), 0 = charge B*Ti
 namespace {
-struct ProfRec { int fam; double flops, bytes; hipEvent_t e0, e1; };
+struct ProfRec { int fam; double flops, bytes; hipEvent_t e0, e1; bool exact; };
 std::vector<ProfRec> g_recs;
 std::vector<hipEvent_t> g_pool;
 size_t g_pool_next = 0;
@@ -56,7 +56,7 @@ static long g_prof_null_ctr = 0;
 void gt_prof_mark(int family, double flops, double bytes, hipStream_t st, bool begin) {
     if (begin) {
         ProfRec r;
-        r.fam = family; r.flops = flops; r.bytes = bytes;
+        r.fam = family; r.flops = flops; r.bytes = bytes; r.exact = false;
         r.e0 = next_event(); r.e1 = next_event();
         hipEventRecord(r.e0, st);
         g_recs.push_back(r);
@@ -66,7 +66,7 @@ void gt_prof_mark(int family, double flops, double bytes, hipStream_t st, bool b
             // the same bracket around an EMPTY kernel, in the same place of the same busy stream: what the bracket
             // itself costs in situ
             ProfRec r;
-            r.fam = GT_FAM_COUNT; r.flops = 0; r.bytes = 0;
+            r.fam = GT_FAM_COUNT; r.flops = 0; r.bytes = 0; r.exact = false;
             r.e0 = next_event(); r.e1 = next_event();
             hipEventRecord(r.e0, st);
             hipLaunchKernelGGL(gt_null_kernel, dim3(256), dim3(256), 0, st);
@@ -74,6 +74,14 @@ void gt_prof_mark(int family, double flops, double bytes, hipStream_t st, bool b
             g_recs.push_back(r);
         }
     }
+}
+
+void gt_prof_exact(int family, double flops, double bytes, hipEvent_t* e0, hipEvent_t* e1) {
+    ProfRec r;
+    r.fam = family; r.flops = flops; r.bytes = bytes; r.exact = true;
+    r.e0 = next_event(); r.e1 = next_event();
+    g_recs.push_back(r);
+    *e0 = r.e0; *e1 = r.e1;
 }
 
 static int g_prof_stride = 1;
@@ -109,13 +117,15 @@ extern "C" int gt_prof_begin_sampled(int32_t stride) {
 
 // Stops recording, waits for the recorded events and fills per-family totals:
 // out[f*4+0] = bracketed launches, +1 = total ms, +2 = total flops, +3 = total bytes  (f < GT_FAM_COUNT);
-// out[4*GT_FAM_COUNT + f] = all launches of the family seen while profiling; then the empty-kernel brackets (count, ms)
+// out[4*GT_FAM_COUNT + f] = all launches of the family seen while profiling; then the empty-kernel brackets (count, ms);
+// out[5*GT_FAM_COUNT + 2 + f] = how many of the family's timed launches carry their own dispatch stamps (no event latency)
 extern "C" int gt_prof_end(double* out) {
     g_gt_prof_on = false;
     GT_REQUIRE(out != nullptr, GT_E_ARG, "gt_prof_end: NULL");
     for (int i = 0; i < GT_FAM_COUNT * 4; ++i) out[i] = 0.0;
     for (int i = 0; i < GT_FAM_COUNT; ++i) out[GT_FAM_COUNT * 4 + i] = (double)g_prof_count[i];
     out[GT_FAM_COUNT * 5] = out[GT_FAM_COUNT * 5 + 1] = 0.0;       // in-situ empty-kernel brackets: count, total ms
+    for (int i = 0; i < GT_FAM_COUNT; ++i) out[GT_FAM_COUNT * 5 + 2 + i] = 0.0;     // launches timed by their own dispatch stamps
     for (auto& r : g_recs) {
         hipError_t e = hipEventSynchronize(r.e1);
         GT_REQUIRE(e == hipSuccess, (int)e, "gt_prof_end: event sync failed");
@@ -129,6 +139,7 @@ extern "C" int gt_prof_end(double* out) {
         }
         out[r.fam * 4 + 0] += 1.0;
         out[r.fam * 4 + 1] += ms;
+        if (r.exact) out[GT_FAM_COUNT * 5 + 2 + r.fam] += 1.0;
         out[r.fam * 4 + 2] += r.flops;
         out[r.fam * 4 + 3] += r.bytes;
     }

@@ -1,6 +1,7 @@
 // Internal helpers shared by the HIP translation units of libgantron_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -39,6 +40,7 @@ extern bool g_gt_capturing;          // loops.hip: stream capture in progress (G
 extern double g_gt_prof_ctx_rows;   // valid attention-memory rows of the current batch (0: unknown, charge B*Ti)
 bool gt_prof_sample(int family);      // true for every `stride`-th launch of the family while profiling
 void gt_prof_mark(int family, double flops, double bytes, hipStream_t st, bool begin);
+void gt_prof_exact(int family, double flops, double bytes, hipEvent_t* e0, hipEvent_t* e1);
 // internal (not part of the C ABI): recurrent products with raised wave priority for the loops' critical chain
 int gt_rec_gemm_prio(const float* X, int64_t ldx, const float* Wp, float* part, int32_t mtiles, int32_t N, int32_t K,
                      int32_t splits, int64_t part_sstride, int32_t nz, int64_t x_zstride, int64_t w_zstride,
@@ -47,13 +49,20 @@ int gt_rec_gemm_bf16_prio(const float* X, int64_t ldx, const void* Wp, float* pa
                           int32_t splits, int64_t part_sstride, int32_t nz, int64_t x_zstride, int64_t w_zstride,
                           int64_t part_zstride, int prio, void* stream);
 
+// Timing of a sampled launch.  Default: two events recorded on the stream around the launch (a bracket = kernel duration +
+// event latency + whatever the dispatch waits for).  exact = true: nothing is recorded here; the launch itself carries the
+// events (hipExtLaunchKernelGGL(..., prof.e0, prof.e1, 0, ...)) and they are stamped with the dispatch's own begin / end --
+// the duration a profiler reports.  e0 / e1 are NULL when this launch is not sampled (a plain launch then).
 struct GtProfScope {
-    int fam; hipStream_t st; bool on;
-    GtProfScope(int family, double flops, double bytes, hipStream_t s)
-        : fam(family), st(s), on(g_gt_prof_on && gt_prof_sample(family)) {
-        if (on) gt_prof_mark(fam, flops, bytes, st, true);
+    int fam; hipStream_t st; bool on; bool exact;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    GtProfScope(int family, double flops, double bytes, hipStream_t s, bool exact_ = false)
+        : fam(family), st(s), on(g_gt_prof_on && gt_prof_sample(family)), exact(exact_) {
+        if (!on) return;
+        if (exact) gt_prof_exact(fam, flops, bytes, &e0, &e1);
+        else gt_prof_mark(fam, flops, bytes, st, true);
     }
-    ~GtProfScope() { if (on) gt_prof_mark(fam, 0, 0, st, false); }
+    ~GtProfScope() { if (on && !exact) gt_prof_mark(fam, 0, 0, st, false); }
 };
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }

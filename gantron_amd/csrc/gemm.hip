@@ -828,8 +828,10 @@ extern "C" int gt_sgemm(const GtGemm* g, void* stream) {
     const long gz = (long)g->batch * d.split_k;
     GT_REQUIRE(gz <= 65535, GT_E_LIMIT, "gt_sgemm: batch*split_k too large");
     // (Measured and not adopted: capping these launches at one or two workgroups per CU with a dynamic-LDS reservation, so
-    // that the loops' latency-critical kernels always find free registers next to a GEMM running under them: no effect on
-    // the pair, 160.5 vs 161.9-162.4 ms -- the loop kernels are not waiting for residency.)
+    // that the loops' latency-critical kernels always find free registers next to a GEMM running under them.  sgemm_kernel:
+    // no effect on the pair, 160.5 vs 161.9-162.4 ms.  xgemm_kernel (61 KB LDS, 190 registers: two of its workgroups fill a
+    // CU's register file) capped at one workgroup per CU while the loops run: 146.9 vs 134.0 ms -- the GEMMs slow down by
+    // more than the loop kernels gain.)
     const int lds_pad = 0;
     if (big) {
         dim3 grid(cdiv(g->N, 128), cdiv(g->M, 128), (unsigned)gz);

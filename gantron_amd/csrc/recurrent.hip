@@ -538,18 +538,18 @@ int gt_rec_gemm_prio(const float* X, int64_t ldx, const float* Wp, float* part, 
     dim3 grid(cdiv(N, 64), splits, nz);
     hipStream_t st = (hipStream_t)stream;
     GtProfScope prof(GT_FAM_REC_GEMM, 2.0 * 16 * mtiles * (double)N * K * nz,
-                     4.0 * nz * ((double)N * K + 16.0 * mtiles * K + 16.0 * mtiles * N * splits), st);
+                     4.0 * nz * ((double)N * K + 16.0 * mtiles * K + 16.0 * mtiles * N * splits), st, true);
     // reserve enough LDS that at most ONE workgroup fits a CU: the grid is sized to the CU count and
     // two co-resident workgroups would serialise on one CU's matrix pipes while another CU idles
     static const int lds_pad = getenv("GANTRON_REC_LDS_PAD") ? atoi(getenv("GANTRON_REC_LDS_PAD")) : 0;
 #define GT_REC(MT)                                                                                    \
-    hipLaunchKernelGGL((rec_gemm_kernel<MT>), grid, dim3(REC_THREADS), lds_pad, st, X, (long)ldx, Wp, part, N, KB, \
-                       KBS, (long)x_zstride, (long)w_zstride, (long)part_zstride, (long)part_sstride, prio)
+    hipExtLaunchKernelGGL((rec_gemm_kernel<MT>), grid, dim3(REC_THREADS), lds_pad, st, prof.e0, prof.e1, 0, X, (long)ldx, \
+                          Wp, part, N, KB, KBS, (long)x_zstride, (long)w_zstride, (long)part_zstride, (long)part_sstride, prio)
     static const int dbg = getenv("GANTRON_REC_DEBUG") ? atoi(getenv("GANTRON_REC_DEBUG")) : 0;
     if (dbg && mtiles == 4) {   // diagnostic variants (wrong results by construction)
 #define GT_RECD(D)                                                                                       \
-    hipLaunchKernelGGL((rec_gemm_kernel<4, D>), grid, dim3(REC_THREADS), lds_pad, st, X, (long)ldx, Wp, part, N, KB,  \
-                       KBS, (long)x_zstride, (long)w_zstride, (long)part_zstride, (long)part_sstride, prio)
+    hipExtLaunchKernelGGL((rec_gemm_kernel<4, D>), grid, dim3(REC_THREADS), lds_pad, st, prof.e0, prof.e1, 0, X, (long)ldx, \
+                          Wp, part, N, KB, KBS, (long)x_zstride, (long)w_zstride, (long)part_zstride, (long)part_sstride, prio)
         switch (dbg) {
             case 1: GT_RECD(1); break;
             case 2: GT_RECD(2); break;
@@ -589,7 +589,8 @@ extern "C" int gt_pack_rec_cell_weight(const float* W, int64_t ldw, int32_t H, i
 
 struct RecCellEpi;
 int gt_launch_rec_cell_bf16(const float* X, int64_t ldx, const void* Wp, float* part, int32_t Bp, int32_t N, int32_t K,
-                            int32_t splits, int32_t ndir, int prio, const RecCellEpi& e, void* stream);      // recurrent_bf16.hip
+                            int32_t splits, int32_t ndir, int prio, const RecCellEpi& e, hipEvent_t e0, hipEvent_t e1,
+                            void* stream);      // recurrent_bf16.hip
 
 int gt_rec_cell_fwd_z(const float* X, int64_t ldx, const void* Wpv, int wbf16, float* part, uint32_t* counters, int32_t Bp, int32_t B,
                       int32_t H, int32_t K, int32_t splits, const float* pre, int64_t ld_pre, const float* c_prev,
@@ -634,12 +635,12 @@ int gt_rec_cell_fwd_z(const float* X, int64_t ldx, const void* Wpv, int wbf16, f
     hipStream_t st = (hipStream_t)stream;
     GtProfScope prof(GT_FAM_REC_CELL, ndir * (2.0 * Bp * (double)N * K + (Wq ? 2.0 * Bp * (double)H * A : 0.0)),
                      ndir * ((wbf16 ? 2.0 : 4.0) * (double)N * K +
-                             4.0 * ((double)Bp * K + (double)Bp * N * (splits > 1 ? 2 * splits - 1 : 0) + (double)B * H * 12)), st);
-    if (wbf16) return gt_launch_rec_cell_bf16(X, ldx, Wpv, part, Bp, N, K, splits, ndir, prio, e, stream);
+                             4.0 * ((double)Bp * K + (double)Bp * N * (splits > 1 ? 2 * splits - 1 : 0) + (double)B * H * 12)), st, true);
+    if (wbf16) return gt_launch_rec_cell_bf16(X, ldx, Wpv, part, Bp, N, K, splits, ndir, prio, e, prof.e0, prof.e1, stream);
     const long ps = (long)Bp * N;
 #define GT_RC(MT)                                                                                                      \
-    hipLaunchKernelGGL((rec_cell_kernel<MT>), grid, dim3(REC_THREADS), 0, st, X, (long)ldx, Wp, part, N, KB, KBS,        \
-                       (long)(64 * ldx), (long)64 * N, ps, prio, e)
+    hipExtLaunchKernelGGL((rec_cell_kernel<MT>), grid, dim3(REC_THREADS), 0, st, prof.e0, prof.e1, 0, X, (long)ldx, Wp, part,  \
+                          N, KB, KBS, (long)(64 * ldx), (long)64 * N, ps, prio, e)
     switch (mt) {
         case 1: GT_RC(1); break;
         case 2: GT_RC(2); break;

@@ -237,12 +237,13 @@ int gt_rec_gemm_bf16_prio(const float* X, int64_t ldx, const void* Wp, float* pa
     dim3 grid(cdiv(N, 64), splits, nz);
     hipStream_t st = (hipStream_t)stream;
     GtProfScope prof(GT_FAM_REC_GEMM, 2.0 * 16 * mtiles * (double)N * K * nz,
-                     (double)nz * (2.0 * N * K + 4.0 * (16.0 * mtiles * K + 16.0 * mtiles * N * splits)), st);
+                     (double)nz * (2.0 * N * K + 4.0 * (16.0 * mtiles * K + 16.0 * mtiles * N * splits)), st, true);
     const uint4* wp = reinterpret_cast<const uint4*>(Wp);
     const int nch = cdiv(KBS, RB_CB);           // chunks of a slice: one instantiation each (all loads issued up front)
 #define GT_RECB(MT, NCH)                                                                                              \
-    hipLaunchKernelGGL((rec_gemm_bf16_kernel<MT, NCH>), grid, dim3(RB_THREADS), 0, st, X, (long)ldx, kvalid, wp, part, N, \
-                       KB, KBS, (long)x_zstride, (long)(w_zstride / 8), (long)part_zstride, (long)part_sstride, prio)
+    hipExtLaunchKernelGGL((rec_gemm_bf16_kernel<MT, NCH>), grid, dim3(RB_THREADS), 0, st, prof.e0, prof.e1, 0, X, (long)ldx, \
+                          kvalid, wp, part, N, KB, KBS, (long)x_zstride, (long)(w_zstride / 8), (long)part_zstride,        \
+                          (long)part_sstride, prio)
 #define GT_RECB_M(MT)                        \
     switch (nch) {                           \
         case 1: GT_RECB(MT, 1); break;       \
@@ -277,7 +278,8 @@ extern "C" int gt_pack_rec_cell_weight_bf16(const float* W, int64_t ldw, int32_t
 
 // launch of the bf16-operand fused product + cell; arguments already validated by gt_rec_cell_fwd_z (recurrent.hip)
 int gt_launch_rec_cell_bf16(const float* X, int64_t ldx, const void* Wp, float* part, int32_t Bp, int32_t N, int32_t K,
-                            int32_t splits, int32_t ndir, int prio, const RecCellEpi& e, void* stream) {
+                            int32_t splits, int32_t ndir, int prio, const RecCellEpi& e, hipEvent_t e0, hipEvent_t e1,
+                            void* stream) {
     const int KB = cdiv(K, 32);
     const int kvalid = cdiv(K, 16) * 16;
     const int KBS = cdiv(KB, splits);
@@ -292,8 +294,8 @@ int gt_launch_rec_cell_bf16(const float* X, int64_t ldx, const void* Wp, float* 
     const long ps = (long)Bp * N;
     const int nch = cdiv(KBS, RB_CB);
 #define GT_RCB(MT, NCH)                                                                                                  \
-    hipLaunchKernelGGL((rec_cell_bf16_kernel<MT, NCH>), grid, dim3(RB_THREADS), 0, st, X, (long)ldx, kvalid, wp, part, N, KB, \
-                       KBS, (long)(64 * ldx), (long)64 * N, ps, prio, e)
+    hipExtLaunchKernelGGL((rec_cell_bf16_kernel<MT, NCH>), grid, dim3(RB_THREADS), 0, st, e0, e1, 0, X, (long)ldx, kvalid, wp, \
+                          part, N, KB, KBS, (long)(64 * ldx), (long)64 * N, ps, prio, e)
 #define GT_RCB_M(MT)                         \
     switch (nch) {                           \
         case 1: GT_RCB(MT, 1); break;        \

@@ -129,10 +129,23 @@ class LeafStream:
         self.stream = None
         self.keep = []
         self.enabled = _os.environ.get('GANTRON_LEAF_STREAM', '1') != '0'
+        # GANTRON_LEAF_DEFER=1: queue the leaves and run them on the main stream at flush() / join(), after the loop they
+        # would otherwise share the chip with
+        self.defer = _os.environ.get('GANTRON_LEAF_DEFER', '0') == '1'
+        self.queue = []
+
+    def flush(self):
+        q, self.queue = self.queue, []
+        for fn in q:
+            fn()
 
     def run(self, fn, *tensors):
         if not self.enabled:
             fn()
+            return
+        if self.defer:
+            self.keep.extend(tensors)
+            self.queue.append(fn)
             return
         if self.stream is None:
             self.stream = torch.cuda.Stream(priority=torch.cuda.Stream.priority_range()[0])
@@ -142,6 +155,7 @@ class LeafStream:
             fn()
 
     def join(self):
+        self.flush()
         if self.stream is not None and self.enabled:
             torch.cuda.current_stream().wait_stream(self.stream)
         self.keep.clear()
@@ -795,6 +809,7 @@ class GeneratorEngine:
             # the PostNet's gradients are complete long before the decoder loop ends: weight gradients come off the leaf
             # stream, BatchNorm gradients off this one
             ev = torch.cuda.Event()
+            LEAF.flush()
             if LEAF.enabled and LEAF.stream is not None:
                 LEAF.stream.wait_stream(torch.cuda.current_stream())
                 ev.record(LEAF.stream)
@@ -944,8 +959,10 @@ class GeneratorEngine:
                     ptr(buf['acc']), ptr(wpack_p), ops._stream()), 'gt_attn_param_grads'), de_hist, wpack_p)
                 if ci == 0:                       # dpm is complete: the main stream reads it after the loop
                     dpm_ready = torch.cuda.Event()
-                    dpm_ready.record(LEAF.stream if LEAF.enabled else torch.cuda.current_stream())
+                    dpm_ready.record(LEAF.stream if (LEAF.enabled and LEAF.stream is not None) else torch.cuda.current_stream())
             LEAF.run(lambda lo=lo, hi=hi: leaf_decoder(lo, hi), dHC)
+        if LEAF.defer:
+            LEAF.flush()                          # (dpm below comes out of the queued leaves)
         if hoist:
             torch.cuda.current_stream().wait_event(dpm_ready)
         LEAF.run(lambda: call('gt_attn_acc_reduce', dims, buf['acc'], G[al + 'v.linear_layer.weight'],
