@@ -736,7 +736,8 @@ __global__ __launch_bounds__(256) void xgemm_kernel(GemmDev g) {
 // loads two k-tiles ahead with counted vmcnt waits, and -- pinned by sched_barrier -- one split stage (<= 5 vector
 // instructions), one fragment read and one plane store in every MFMA gap of the same wave: 186 TFLOP/s.  Its parts:
 // MFMAs + fragment reads alone 300, + plane stores 258; the split does not hide in the gaps (dependent cvt / shift / sub
-// chains).  xgemm_kernel with two workgroups per CU stays the fastest form measured.)
+// chains).  And 256 x 128 tiles with wave tiles of 128 x 64 (the split amortised over twice the MFMAs, one workgroup per
+// CU): 178 against 196 on the same GEMMs.  xgemm_kernel with two workgroups per CU stays the fastest form measured.)
 template <int BM, int BN>
 int launch_tile(const GemmDev& d, dim3 grid, hipStream_t st, int lds_pad) {
     const int am = d.A.mode, bm = d.B.mode;
