@@ -219,8 +219,8 @@ def cpu_baseline(seconds_budget=45.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--fixed-shape', action='store_true', help='nominal Ti=150, To=800 for every item')
     ap.add_argument('--no-cpu-baseline', action='store_true')

@@ -450,7 +450,6 @@ __global__ __launch_bounds__(256) void hgemm_kernel(GemmDev g) {
 constexpr int BKX = 32;
 constexpr int LDX = BKX + 8;
 typedef short v4i16_t __attribute__((ext_vector_type(4)));
-typedef short v8i16_t __attribute__((ext_vector_type(8)));
 
 // NV float4 -> their NP bf16 planes, packed in pairs (x, y) -> lo, (z, w) -> hi with the first element in the low half.
 // Per plane and pair: v_cvt_pk_bf16_f32, unpack both halves (shift, mask), two subtractions; the pairs advance plane by
@@ -550,14 +549,6 @@ struct TileLoaderX {
     }
     template <bool FAST>
     __device__ __forceinline__ void load(const OpDev& o, const float* base, int r0, int R, int k0, int K, int tid) {
-        load_into<FAST>(o, base, r0, R, k0, K, tid, reg);
-    }
-    __device__ __forceinline__ void store(unsigned short* S, int tid) const { store_from(S, tid, reg); }
-
-    // the same with the registers named by the caller
-    template <bool FAST>
-    __device__ __forceinline__ void load_into(const OpDev& o, const float* base, int r0, int R, int k0, int K, int tid,
-                                              float4 (&reg)[NV]) {
         if (KT) {
             const int k = k0 + 4 * (tid & 7);
 #pragma unroll
@@ -590,13 +581,9 @@ struct TileLoaderX {
             }
         }
     }
-    __device__ __forceinline__ void store_from(unsigned short* S, int tid, const float4 (&reg)[NV]) const {
+    __device__ __forceinline__ void store(unsigned short* S, int tid) const {
         unsigned lo[NV][NP], hi[NV][NP];
         split_all<NP, NV>(reg, lo, hi);
-        store_planes(S, tid, lo, hi);
-    }
-    static __device__ __forceinline__ void store_planes(unsigned short* S, int tid, const unsigned (&lo)[NV][NP],
-                                                        const unsigned (&hi)[NV][NP]) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             unsigned short* d;

@@ -35,7 +35,7 @@ REC_SPLITS_OVERRIDE = int(_os.environ.get("GANTRON_REC_SPLITS", "0"))     # diag
 FUSED_CELL = _os.environ.get('GANTRON_FUSED_CELL', '0') != '0'
 HOST_TIMING = _os.environ.get('GANTRON_HOST_TIMING') == '1'      # diagnostics: host time spent issuing each loop
 CELL_QUERY = _os.environ.get('GANTRON_CELL_QUERY', '1') != '0'    # attention cell + query product in one launch
-BWD_CHUNKS = int(_os.environ.get("GANTRON_BWD_CHUNKS", "6"))
+BWD_CHUNKS = int(_os.environ.get("GANTRON_BWD_CHUNKS", "12"))
 # hoisted attention backward (gt_attn_param_grads): keep tanh(.) of every step (B*Ti*A floats each) so that the loop
 # only computes the recurrent terms of the energies backward
 ATTN_HOIST = _os.environ.get('GANTRON_ATTN_HOIST', '1') != '0'

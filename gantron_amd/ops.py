@@ -15,10 +15,11 @@ from ._lib import GtAttnDims, GtGemm, GtOperand, GtSlabs, check, lib
 
 KC, RC, IM2COL_K, IM2COL_R = 0, 1, 2, 3
 # Workgroups a weight-gradient GEMM should reach (default_split_k).  Two regimes, both measured on the benchmark
-# batch: a GEMM nothing else overlaps wants ~1024 workgroups of 128x128 tiles (postnet conv dW 41 -> 103 TFLOP/s);
+# batch: a GEMM nothing else overlaps wants ~512 workgroups of 128x128 tiles (two per CU for the three-plane kernel; the
+# fp32-pipe kernel liked ~1024: postnet conv dW 41 -> 103 TFLOP/s; pair 133.3 -> 131.9 ms with 512 and 12 backward chunks);
 # the same setting for the GEMMs that run on the leaf stream UNDER the decoder backward loop makes the pair 2 ms
 # slower (they crowd out the latency-bound loop kernels), so the engine lowers the target there.
-SPLITK_EXPOSED = int(_os.environ.get('GANTRON_SPLITK_TARGET', '1024'))
+SPLITK_EXPOSED = int(_os.environ.get('GANTRON_SPLITK_TARGET', '512'))
 SPLITK_OVERLAPPED = int(_os.environ.get('GANTRON_SPLITK_OVERLAPPED', '128'))
 SPLITK_TARGET = SPLITK_EXPOSED
 FWD_SPLITK = _os.environ.get('GANTRON_FWD_SPLITK', '1') != '0'
