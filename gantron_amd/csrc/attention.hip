@@ -9,6 +9,7 @@
 // gradients in per-workgroup slabs (no atomics) that gt_attn_acc_reduce folds after the loop.
 #include <stdlib.h>
 #include "common.h"
+#include "attn_ctx_bwd.h"
 
 // matrix-core versions for the reference's default dimensions (attention_mfma.hip)
 void gt_launch_attn_energies_bwd_rec_mfma(GtAttnDims d, const float* dw, const float* w, const float* u, const float* Wc,
@@ -32,6 +33,17 @@ void gt_launch_attn_step_fwd_mfma(GtAttnDims d, GtSlabs qpart, const float* w_pr
                                   int* timeout_flag, const float* memory, long ld_mem, float* w_out, const float* cum_in,
                                   float* cum_out, float* c0, long ld0, float* c1, long ld1, float* c2, long ld2,
                                   hipStream_t st);
+void gt_launch_attn_bwd_wterms_mfma(GtAttnDims d, int nsteps, const float* w, long w_step, const float* u, const float* Wc,
+                                     const float* Wd, const float* v, const int* lengths, float* dq2, long dq2_step,
+                                     long ld_dq2, float* dwcat2, const float* wpack, hipStream_t st);
+void gt_launch_attn_bwd_step_mfma(GtAttnDims d, GtSlabs da, GtSlabs db, const float* dctx_direct, long ld_direct,
+                                  const float* memory, long ld_mem, const int* lengths, float* dwcat_in, float* dcum_acc,
+                                  const float* dw_extern, float* dctx_out, long ld_dctx_out, const float* w, const float* u,
+                                  const float* Wc, const float* Wd, const float* v, const float* wpack, const float* sum_prev,
+                                  const float* dwcat2_prev, float* sum_out, float* dq, long ld_dq, float* dwcat_out,
+                                  float* e1_out, bool vec, bool vec_slabs, hipStream_t st);
+void gt_launch_attn_bwd_fixup(GtAttnDims d, int nsteps, int nch, const float* sum, const float* w, long w_step, float* de,
+                              float* dq, long dq_step, long ld_dq, const float* dq2, hipStream_t st);
 int gt_attn_wpack_elems_mfma();
 int gt_attn_acc_per_mfma();
 void gt_launch_attn_acc_reduce_mfma(const float* acc, int nwg, float* dv, float* dWd, float* dWc, hipStream_t st);
@@ -301,10 +313,7 @@ __global__ __launch_bounds__(256) void attn_context_fwd_kernel(GtAttnDims d, con
     }
 }
 
-// grid (chunks of CT positions, B).  dw[t'] = memory[b][t'] . dctx + carried alignment gradients.
-// NE4 > 0 (E == 256 * NE4, VEC): the workgroup's 32 memory rows and the carried per-position values are requested
-// at the very top and arrive while the upstream context gradient is being summed from its K-split slabs, so the
-// kernel is two memory round trips deep instead of five.
+// grid (B, chunks of CT positions).  dw[t'] = memory[b][t'] . dctx + carried alignment gradients (attn_ctx_bwd.h).
 template <bool VEC, int NE4 = 0>
 __global__ __launch_bounds__(256) void attn_context_bwd_kernel(GtAttnDims d, GtSlabs da, GtSlabs db,
                                                                const float* dctx_direct, long ld_direct,
@@ -331,121 +340,11 @@ __global__ __launch_bounds__(256) void attn_context_bwd_kernel(GtAttnDims d, GtS
         }
         return;
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* mb = memory + (long)b * d.Ti * ld_mem;
-    constexpr int NR = NE4 > 0 ? NE4 : 1;
-    float4 mr[8][NR];
-    float pf_cum = 0.f, pf_w0 = 0.f, pf_w1 = 0.f, pf_ext = 0.f;
-    const long pi = (long)b * d.Ti + min(t0 + (int)threadIdx.x, d.Ti - 1);
-    const long plane = (long)d.B * d.Ti;
-    if (NE4 > 0) {
-        // wave w owns rows t0 + w + 4*r (r < 8); row indices are clamped so that no load is predicated
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const float* row = mb + (long)min(t0 + wave + 4 * r, Tv - 1) * ld_mem + 4 * lane;
-#pragma unroll
-            for (int i = 0; i < NR; ++i) mr[r][i] = *reinterpret_cast<const float4*>(row + 256 * i);
-        }
-        if (threadIdx.x < CT) {
-            if (dwcat_in != nullptr) { pf_cum = dcum_acc[pi]; pf_w0 = dwcat_in[pi]; pf_w1 = dwcat_in[plane + pi]; }
-            if (dw_extern != nullptr) pf_ext = dw_extern[pi];
-        }
-    }
-    if (NE4 == 1 * 4 && blockDim.x == 256) {
-        // E == 1024: one float4 of the context gradient per thread, all slab loads of a thread issued together
-        const int e = 4 * threadIdx.x;
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        auto add_slabs = [&](const GtSlabs& sl) __attribute__((always_inline)) {
-            if (sl.p == nullptr) return;
-            const float* p = sl.p + (long)b * sl.ld + e;
-#pragma unroll 4
-            for (int s2 = 0; s2 < sl.n; ++s2) {
-                const float4 t = *reinterpret_cast<const float4*>(p + (long)s2 * sl.slab_stride);
-                g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
-            }
-        };
-        add_slabs(da);
-        add_slabs(db);
-        if (dctx_direct != nullptr) {
-            const float4 t = *reinterpret_cast<const float4*>(dctx_direct + (long)b * ld_direct + e);
-            g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
-        }
-        *reinterpret_cast<float4*>(&dctx[e]) = g;
-        if (chunk == 0 && dctx_out != nullptr) *reinterpret_cast<float4*>(dctx_out + (long)b * ld_dctx_out + e) = g;
-    } else
-    for (int e = threadIdx.x; e < d.E; e += blockDim.x) {
-        float g = 0.f;
-        if (da.p != nullptr) g += slab_sum(da.p, da.n, da.slab_stride, (long)b * da.ld + e);
-        if (db.p != nullptr) g += slab_sum(db.p, db.n, db.slab_stride, (long)b * db.ld + e);
-        if (dctx_direct != nullptr) g += dctx_direct[(long)b * ld_direct + e];
-        dctx[e] = g;
-        if (chunk == 0 && dctx_out != nullptr) dctx_out[(long)b * ld_dctx_out + e] = g;
-    }
     if (chunk == 0 && dq_zero != nullptr)
         for (int i = threadIdx.x; i < d.A; i += blockDim.x) dq_zero[(long)b * ld_dq + i] = 0.f;
-    __syncthreads();
-    if (NE4 > 0) {
-        const float4* dc4 = reinterpret_cast<const float4*>(dctx);
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            const float4 dc = dc4[lane + 64 * i];
-#pragma unroll
-            for (int r = 0; r < 8; ++r)
-                acc[r] += mr[r][i].x * dc.x + mr[r][i].y * dc.y + mr[r][i].z * dc.z + mr[r][i].w * dc.w;
-        }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const float v = wave_sum(acc[r]);
-            if (lane == 0) dots[wave + 4 * r] = v;
-        }
-    } else if (VEC) {
-        // wave w owns rows t0 + w + 4*i (i < 8); 4 rows in flight per pass
-        const int e4n = d.E / 4;
-        const float4* dc4 = reinterpret_cast<const float4*>(dctx);
-        for (int pass = 0; pass < 2; ++pass) {
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
-            int trow[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) trow[r] = min(t0 + wave + 4 * (4 * pass + r), Tv - 1);
-            for (int e4 = lane; e4 < e4n; e4 += 64) {
-                const float4 dc = dc4[e4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float4 m = *reinterpret_cast<const float4*>(mb + (long)trow[r] * ld_mem + 4 * e4);
-                    acc[r] += m.x * dc.x + m.y * dc.y + m.z * dc.z + m.w * dc.w;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v = wave_sum(acc[r]);
-                if (lane == 0) dots[wave + 4 * (4 * pass + r)] = v;
-            }
-        }
-    } else {
-        for (int tl = wave; tl < CT; tl += 4) {
-            const int t = min(t0 + tl, Tv - 1);
-            const float* m = mb + (long)t * ld_mem;
-            float acc = 0.f;
-            for (int e = lane; e < d.E; e += 64) acc += m[e] * dctx[e];
-            acc = wave_sum(acc);
-            if (lane == 0) dots[tl] = acc;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < CT && t0 + threadIdx.x < d.Ti) {
-        const long i = (long)b * d.Ti + t0 + threadIdx.x;
-        float carried = 0.f;
-        if (dwcat_in != nullptr) {
-            const float cum = (NE4 > 0 ? pf_cum + pf_w1 : dcum_acc[i] + dwcat_in[plane + i]);
-            dcum_acc[i] = cum;
-            carried = (NE4 > 0 ? pf_w0 : dwcat_in[i]) + cum;
-            dwcat_in[i] = 0.f;
-            dwcat_in[plane + i] = 0.f;
-        }
-        if (dw_extern != nullptr) carried += (NE4 > 0 ? pf_ext : dw_extern[i]);
-        dw_out[i] = (t0 + (int)threadIdx.x < Tv) ? dots[threadIdx.x] + carried : 0.f;
-    }
+    const float dw = attn_ctx_bwd_dw<VEC, NE4>(d, da, db, dctx_direct, ld_direct, memory, ld_mem, Tv, dwcat_in, dcum_acc,
+                                               dw_extern, dctx_out, ld_dctx_out, nullptr, 0.f, dctx, dots, b, chunk);
+    if (threadIdx.x < CT && t0 + threadIdx.x < d.Ti) dw_out[(long)b * d.Ti + t0 + threadIdx.x] = dw;
 }
 
 // grid (chunks, B).  Energies backward for CT positions; see file header.
@@ -857,6 +756,59 @@ extern "C" int gt_attn_energies_bwd_rec(GtAttnDims d, const float* dw, const flo
                      4.0 * d.B * d.Ti * (d.A + 6.0), (hipStream_t)stream);
     gt_launch_attn_energies_bwd_rec_mfma(d, dw, w, u, Wc, Wd, v, lengths, dq, (long)ld_dq, dwcat_out, de_out, wpack,
                                          (hipStream_t)stream);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gt_attn_bwd_wterms(GtAttnDims d, int32_t nsteps, const float* w, int64_t w_step_stride, const float* u,
+                                  const float* Wc, const float* Wd, const float* v, const int32_t* lengths, float* dq2,
+                                  int64_t dq2_step_stride, int64_t ld_dq2, float* dwcat2, const float* wpack, void* stream) {
+    int rc = check_dims(d, "gt_attn_bwd_wterms");
+    if (rc) return rc;
+    GT_REQUIRE(use_mfma(d), GT_E_ARG, "gt_attn_bwd_wterms: needs the (128, 32, 31) dimensions");
+    GT_REQUIRE(nsteps > 0 && nsteps <= 65535 && w && u && Wc && Wd && v && dq2 && dwcat2 && ld_dq2 >= d.A, GT_E_ARG,
+               "gt_attn_bwd_wterms: bad argument");
+    gt_launch_attn_bwd_wterms_mfma(d, nsteps, w, (long)w_step_stride, u, Wc, Wd, v, lengths, dq2, (long)dq2_step_stride,
+                                   (long)ld_dq2, dwcat2, wpack, (hipStream_t)stream);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gt_attn_bwd_step(GtAttnDims d, GtSlabs dctx_a, GtSlabs dctx_b, const float* dctx_direct, int64_t ld_direct,
+                                const float* memory, int64_t ld_mem, const int32_t* lengths, float* dwcat_in, float* dcum_acc,
+                                const float* dw_extern, float* dctx_out, int64_t ld_dctx_out, const float* w, const float* u,
+                                const float* Wc, const float* Wd, const float* v, const float* wpack, const float* sum_prev,
+                                const float* dwcat2_prev, float* sum_out, float* dq, int64_t ld_dq, float* dwcat_out,
+                                float* e1_out, void* stream) {
+    int rc = check_dims(d, "gt_attn_bwd_step");
+    if (rc) return rc;
+    GT_REQUIRE(use_mfma(d), GT_E_ARG, "gt_attn_bwd_step: needs the (128, 32, 31) dimensions");
+    GT_REQUIRE(memory && ld_mem >= d.E && w && u && Wc && Wd && v && sum_out && dq && dwcat_out && e1_out && ld_dq >= d.A,
+               GT_E_ARG, "gt_attn_bwd_step: bad argument");
+    GT_REQUIRE((sum_prev == nullptr) == (dwcat2_prev == nullptr), GT_E_ARG, "gt_attn_bwd_step: sum_prev and dwcat2_prev go together");
+    GT_REQUIRE((size_t)d.E * 4 <= 32 * 1024, GT_E_LIMIT, "gt_attn_bwd_step: E too large for LDS");
+    const double ctx_rows = g_gt_prof_ctx_rows > 0.0 ? g_gt_prof_ctx_rows : (double)d.B * d.Ti;
+    GtProfScope prof(GT_FAM_ATTN_C_BWD, 2.0 * ctx_rows * (double)d.E + 2.0 * d.B * d.Ti * (double)(d.F * 2 * d.Kc + d.A * d.F + 4 * d.A),
+                     4.0 * (ctx_rows * d.E + d.B * ((1.0 + dctx_a.n + dctx_b.n) * d.E + 6.0 * d.Ti) + d.B * d.Ti * (d.A + 6.0)),
+                     (hipStream_t)stream);
+    const bool vec = (d.E % 4 == 0) && (ld_mem % 4 == 0) && aligned16(memory);
+    auto sl4 = [](const GtSlabs& sl) { return sl.p == nullptr || (aligned16(sl.p) && sl.ld % 4 == 0 && sl.slab_stride % 4 == 0); };
+    const bool vec_slabs = sl4(dctx_a) && sl4(dctx_b) && (dctx_direct == nullptr || (aligned16(dctx_direct) && ld_direct % 4 == 0)) &&
+                           (dctx_out == nullptr || (aligned16(dctx_out) && ld_dctx_out % 4 == 0));
+    gt_launch_attn_bwd_step_mfma(d, dctx_a, dctx_b, dctx_direct, (long)ld_direct, memory, (long)ld_mem, lengths, dwcat_in,
+                                 dcum_acc, dw_extern, dctx_out, (long)ld_dctx_out, w, u, Wc, Wd, v, wpack, sum_prev, dwcat2_prev,
+                                 sum_out, dq, (long)ld_dq, dwcat_out, e1_out, vec, vec_slabs, (hipStream_t)stream);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gt_attn_bwd_fixup(GtAttnDims d, int32_t nsteps, const float* sum, const float* w, int64_t w_step_stride,
+                                 float* de, float* dq, int64_t dq_step_stride, int64_t ld_dq, const float* dq2, void* stream) {
+    int rc = check_dims(d, "gt_attn_bwd_fixup");
+    if (rc) return rc;
+    GT_REQUIRE(nsteps > 0 && nsteps <= 65535 && sum && w && de && dq && dq2 && d.A == 128, GT_E_ARG, "gt_attn_bwd_fixup: bad argument");
+    gt_launch_attn_bwd_fixup(d, nsteps, cdiv(d.Ti, CT), sum, w, (long)w_step_stride, de, dq, (long)dq_step_stride, (long)ld_dq,
+                             dq2, (hipStream_t)stream);
     GT_LAUNCH_CHECK();
     return 0;
 }

@@ -16,6 +16,7 @@
 // bank-conflict free (see the LD* constants).
 #include <stddef.h>
 #include "common.h"
+#include "attn_ctx_bwd.h"
 
 namespace {
 
@@ -690,46 +691,13 @@ __global__ __launch_bounds__(256) void attn_energies_bwd_mfma(GtAttnDims d, cons
 // backward loop only needs the RECURRENT terms of the energies backward -- dq and d[w_prev; w_cum] -- and the
 // softmax-backward vector de; the parameter gradients (dv, dWd, dWc) and d(processed memory) are sums over all steps
 // with no consumer inside the loop and are produced by attn_param_grads_mfma in one batched pass per loop chunk.
-__global__ __launch_bounds__(256) void attn_energies_bwd_rec_mfma(GtAttnDims d, const float* dw, const float* w,
-                                                                  const float* u, const float* Wc, const float* Wd,
-                                                                  const float* v, const int* lengths, float* dq, long ld_dq,
-                                                                  float* dwcat_out, float* de_out, const float* wpack) {
-    __builtin_amdgcn_s_setprio(3);      // the attention chain is the serial critical path of the decoder loops: its waves
-                                        // issue ahead of the co-resident waves of the other chain and of the leaf GEMMs
-    __shared__ SharedM S;
-    const int b = blockIdx.x, t0 = blockIdx.y * CT;       // grid (B, chunks), as the forward kernel
-    if (lengths != nullptr && t0 >= lengths[b]) {
-        if (threadIdx.x < CT && t0 + threadIdx.x < d.Ti) de_out[(long)b * d.Ti + t0 + threadIdx.x] = 0.f;
-        return;
-    }
+// Recurrent terms of the energies backward for one (b, 32-position) tile from the softmax-backward vector: S.de holds de
+// of the tile's positions, S.ds the tanh outputs u (both in LDS, weights staged): dq[b] += sum_t de v (1 - u^2) and
+// d[w_prev; w_cum] += conv^T(dense^T(.)) by atomics.  Every thread of the workgroup calls it (barriers inside).
+__device__ __forceinline__ void energies_rec_tail(SharedM& S, const GtAttnDims& d, int b, int t0, float* dq, long ld_dq,
+                                                  float* dwcat_out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, kq = lane >> 4;
-    float4 u4[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int f = threadIdx.x + 256 * i, tl = f >> 5, c4 = f & 31;
-        u4[i] = *reinterpret_cast<const float4*>(u + ((long)b * d.Ti + min(t0 + tl, d.Ti - 1)) * A + 4 * c4);
-    }
-    const long ti = (long)b * d.Ti + min((int)threadIdx.x, d.Ti - 1);
-    const float w_t = w[ti], dw_t = dw[ti];
-    const long tci = (long)b * d.Ti + min(t0 + (int)(threadIdx.x & (CT - 1)), d.Ti - 1);
-    const float w_c = w[tci], dw_c = dw[tci];
-    stage_common(S, d, Wc, Wd, v, nullptr, nullptr, b, t0, wpack, false);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int f = threadIdx.x + 256 * i, tl = f >> 5, c4 = f & 31;
-        *reinterpret_cast<float4*>(&S.ds[tl * LDS_ + 4 * c4]) = u4[i];
-    }
-    float part = (int)threadIdx.x < d.Ti ? w_t * dw_t : 0.f;
-    for (int t = threadIdx.x + 256; t < d.Ti; t += 256) part += w[(long)b * d.Ti + t] * dw[(long)b * d.Ti + t];
-    const float dot = block_sum(part, S.red);
-    if (threadIdx.x < CT) {
-        const int t = t0 + threadIdx.x;
-        const float de = (t < d.Ti) ? w_c * (dw_c - dot) : 0.f;
-        S.de[threadIdx.x] = de;
-        if (t < d.Ti) de_out[(long)b * d.Ti + t] = de;
-    }
-    __syncthreads();
     float dqs[2] = {0.f, 0.f};
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -798,6 +766,180 @@ __global__ __launch_bounds__(256) void attn_energies_bwd_rec_mfma(GtAttnDims d, 
             for (int k = klo; k <= khi; ++k) a += S.g[(p - k) * LDG + c * KC + k];
             atomicAdd(&dwcat_out[(long)c * d.B * d.Ti + (long)b * d.Ti + t], a);
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_energies_bwd_rec_mfma(GtAttnDims d, const float* dw, const float* w,
+                                                                  const float* u, const float* Wc, const float* Wd,
+                                                                  const float* v, const int* lengths, float* dq, long ld_dq,
+                                                                  float* dwcat_out, float* de_out, const float* wpack) {
+    __builtin_amdgcn_s_setprio(3);      // the attention chain is the serial critical path of the decoder loops: its waves
+                                        // issue ahead of the co-resident waves of the other chain and of the leaf GEMMs
+    __shared__ SharedM S;
+    const int b = blockIdx.x, t0 = blockIdx.y * CT;       // grid (B, chunks), as the forward kernel
+    if (lengths != nullptr && t0 >= lengths[b]) {
+        if (threadIdx.x < CT && t0 + threadIdx.x < d.Ti) de_out[(long)b * d.Ti + t0 + threadIdx.x] = 0.f;
+        return;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    float4 u4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = threadIdx.x + 256 * i, tl = f >> 5, c4 = f & 31;
+        u4[i] = *reinterpret_cast<const float4*>(u + ((long)b * d.Ti + min(t0 + tl, d.Ti - 1)) * A + 4 * c4);
+    }
+    const long ti = (long)b * d.Ti + min((int)threadIdx.x, d.Ti - 1);
+    const float w_t = w[ti], dw_t = dw[ti];
+    const long tci = (long)b * d.Ti + min(t0 + (int)(threadIdx.x & (CT - 1)), d.Ti - 1);
+    const float w_c = w[tci], dw_c = dw[tci];
+    stage_common(S, d, Wc, Wd, v, nullptr, nullptr, b, t0, wpack, false);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = threadIdx.x + 256 * i, tl = f >> 5, c4 = f & 31;
+        *reinterpret_cast<float4*>(&S.ds[tl * LDS_ + 4 * c4]) = u4[i];
+    }
+    float part = (int)threadIdx.x < d.Ti ? w_t * dw_t : 0.f;
+    for (int t = threadIdx.x + 256; t < d.Ti; t += 256) part += w[(long)b * d.Ti + t] * dw[(long)b * d.Ti + t];
+    const float dot = block_sum(part, S.red);
+    if (threadIdx.x < CT) {
+        const int t = t0 + threadIdx.x;
+        const float de = (t < d.Ti) ? w_c * (dw_c - dot) : 0.f;
+        S.de[threadIdx.x] = de;
+        if (t < d.Ti) de_out[(long)b * d.Ti + t] = de;
+    }
+    __syncthreads();
+    energies_rec_tail(S, d, b, t0, dq, ld_dq, dwcat_out);
+}
+
+// ---- fused backward step ---------------------------------------------------------------------------------------------
+// The backward attention chain was context_bwd (dw for all positions of a row) -> energies_bwd_rec (softmax backward needs
+// the ROW sum s = sum_t w dw, then everything is per position) -- two dependent launches because of one scalar per row.
+// Everything downstream of the softmax backward is LINEAR in de = w (dw - s) = w dw - s w:
+//     dq = Lq(w dw) - s Lq(w),    d[w_prev; w_cum] = Lw(w dw) - s Lw(w),
+// and Lq(w), Lw(w) depend on forward quantities only (the step's weights w, its tanh outputs u, the location layer).  So
+//  * gt_attn_bwd_wterms computes dq2 = Lq(w_t), dwcat2 = Lw(w_t) for ALL steps in one batched launch before the loop,
+//  * attn_bwd_step_kernel (one launch per step) computes dw for its 32 positions, e1 = w dw, the tile's share of s, and
+//    Lq(e1), Lw(e1) -- no cross-workgroup dependency --
+//  * and the consumers subtract s times the precomputed term: the next step's carried alignment gradient (in this kernel),
+//    the attention cell backward's dq (gt_cell_bwd_query_c), and -- off the critical path -- the stored dq / de histories
+//    (gt_attn_bwd_fixup before the weight-gradient passes that read them).
+// One dependent launch less per backward step.
+__global__ __launch_bounds__(256) void attn_bwd_wterms_mfma(GtAttnDims d, const float* w, long w_step, const float* u,
+                                                            const float* Wc, const float* Wd, const float* v,
+                                                            const int* lengths, float* dq2, long dq2_step, long ld_dq2,
+                                                            float* dwcat2, const float* wpack) {
+    __shared__ SharedM S;
+    const int b = blockIdx.x, t0 = blockIdx.y * CT, step = blockIdx.z;       // grid (B, chunks, steps)
+    if (lengths != nullptr && t0 >= lengths[b]) return;                      // outputs are zero-initialised
+    const long BTi = (long)d.B * d.Ti;
+    u += (long)step * BTi * A;
+    w += (long)step * w_step;
+    dq2 += (long)step * dq2_step;
+    dwcat2 += (long)step * 2 * BTi;
+    float4 u4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = threadIdx.x + 256 * i, tl = f >> 5, c4 = f & 31;
+        u4[i] = *reinterpret_cast<const float4*>(u + ((long)b * d.Ti + min(t0 + tl, d.Ti - 1)) * A + 4 * c4);
+    }
+    const float w_c = w[(long)b * d.Ti + min(t0 + (int)(threadIdx.x & (CT - 1)), d.Ti - 1)];
+    stage_common(S, d, Wc, Wd, v, nullptr, nullptr, b, t0, wpack, false);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = threadIdx.x + 256 * i, tl = f >> 5, c4 = f & 31;
+        *reinterpret_cast<float4*>(&S.ds[tl * LDS_ + 4 * c4]) = u4[i];
+    }
+    if (threadIdx.x < CT) S.de[threadIdx.x] = (t0 + (int)threadIdx.x < d.Ti) ? w_c : 0.f;
+    __syncthreads();
+    energies_rec_tail(S, d, b, t0, dq2, ld_dq2, dwcat2);
+}
+
+struct AttnBwdStep {
+    GtAttnDims d;
+    GtSlabs da, db;
+    const float* dctx_direct; long ld_direct;
+    const float* memory; long ld_mem;
+    const int* lengths;
+    float* dwcat_in; float* dcum_acc; const float* dw_extern;
+    float* dctx_out; long ld_dctx_out;
+    const float* w; const float* u;
+    const float* Wc; const float* Wd; const float* v; const float* wpack;
+    const float* sum_prev; const float* dwcat2_prev;      // NULL on the last step (nothing carried yet)
+    float* sum_out;                                       // (B, chunks) this step's partial row sums
+    float* dq; long ld_dq; float* dwcat_out; float* e1_out;
+};
+
+template <bool VEC, int NE4>
+__global__ __launch_bounds__(256) void attn_bwd_step_kernel(AttnBwdStep a) {
+    __builtin_amdgcn_s_setprio(3);      // the attention chain is the serial critical path of the decoder loops
+    extern __shared__ __attribute__((aligned(16))) float dctx[];   // E floats
+    __shared__ SharedM S;
+    __shared__ float dots[CT];
+    const GtAttnDims& d = a.d;
+    const int b = blockIdx.x, chunk = blockIdx.y, t0 = chunk * CT, nch = gridDim.y;      // grid (B, chunks)
+    const int Tv = a.lengths != nullptr ? min(a.lengths[b], d.Ti) : d.Ti;
+    if (t0 >= Tv) {
+        if (threadIdx.x < CT && t0 + threadIdx.x < d.Ti) {
+            const long i = (long)b * d.Ti + t0 + threadIdx.x;
+            if (a.dwcat_in != nullptr) { a.dwcat_in[i] = 0.f; a.dwcat_in[(long)d.B * d.Ti + i] = 0.f; }
+            a.e1_out[i] = 0.f;
+        }
+        if (threadIdx.x == 0) a.sum_out[(long)b * nch + chunk] = 0.f;
+        return;
+    }
+    // requests that do not depend on the context gradient go out first: the tile's tanh outputs, its weights, the
+    // previous step's row sum
+    float4 u4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = threadIdx.x + 256 * i, tl = f >> 5, c4 = f & 31;
+        u4[i] = *reinterpret_cast<const float4*>(a.u + ((long)b * d.Ti + min(t0 + tl, d.Ti - 1)) * A + 4 * c4);
+    }
+    const float w_c = a.w[(long)b * d.Ti + min(t0 + (int)(threadIdx.x & (CT - 1)), d.Ti - 1)];
+    float s_prev = 0.f;
+    if (a.sum_prev != nullptr)
+        for (int c = 0; c < nch; ++c) s_prev += a.sum_prev[(long)b * nch + c];
+    stage_common(S, d, a.Wc, a.Wd, a.v, nullptr, nullptr, b, t0, a.wpack, false);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = threadIdx.x + 256 * i, tl = f >> 5, c4 = f & 31;
+        *reinterpret_cast<float4*>(&S.ds[tl * LDS_ + 4 * c4]) = u4[i];
+    }
+    const float dw = attn_ctx_bwd_dw<VEC, NE4>(d, a.da, a.db, a.dctx_direct, a.ld_direct, a.memory, a.ld_mem, Tv, a.dwcat_in,
+                                               a.dcum_acc, a.dw_extern, a.dctx_out, a.ld_dctx_out, a.dwcat2_prev, s_prev,
+                                               dctx, dots, b, chunk);
+    if (threadIdx.x < 64) {         // wave 0: e1 of the tile's positions and their sum
+        const bool pos = threadIdx.x < CT && t0 + (int)threadIdx.x < d.Ti;
+        const float e1 = pos ? w_c * dw : 0.f;
+        if (threadIdx.x < CT) S.de[threadIdx.x] = e1;
+        if (pos) a.e1_out[(long)b * d.Ti + t0 + threadIdx.x] = e1;
+        const float tot = wave_sum(threadIdx.x < CT ? e1 : 0.f);
+        if (threadIdx.x == 0) a.sum_out[(long)b * nch + chunk] = tot;
+    }
+    __syncthreads();
+    energies_rec_tail(S, d, b, t0, a.dq, a.ld_dq, a.dwcat_out);
+}
+
+// de[t] = e1[t] - s_t w_t and dq[t] -= s_t dq2[t] for `nsteps` steps (the histories the weight-gradient passes read):
+// one thread per element of max(B*Ti, B*A) per step, grid (blocks, steps)
+__global__ __launch_bounds__(256) void attn_bwd_fixup_kernel(GtAttnDims d, int nch, const float* sum, const float* w, long w_step,
+                                                             float* de, float* dq, long dq_step, long ld_dq, const float* dq2) {
+    const int step = blockIdx.y;
+    const long BTi = (long)d.B * d.Ti;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const float* sm = sum + (long)step * d.B * nch;
+    if (i < BTi) {
+        const int b = (int)(i / d.Ti);
+        float s = 0.f;
+        for (int c = 0; c < nch; ++c) s += sm[(long)b * nch + c];
+        de[(long)step * BTi + i] -= s * w[(long)step * w_step + i];
+    }
+    if (i < (long)d.B * A) {
+        const int b = (int)(i / A), c0 = (int)(i - (long)b * A);
+        float s = 0.f;
+        for (int c = 0; c < nch; ++c) s += sm[(long)b * nch + c];
+        dq[(long)step * dq_step + (long)b * ld_dq + c0] -= s * dq2[(long)step * dq_step + (long)b * ld_dq + c0];
     }
 }
 
@@ -993,6 +1135,39 @@ void gt_launch_attn_energies_bwd_rec_mfma(GtAttnDims d, const float* dw, const f
     dim3 grid(d.B, cdiv(d.Ti, CT));
     hipLaunchKernelGGL(attn_energies_bwd_rec_mfma, grid, dim3(256), 0, st, d, dw, w, u, Wc, Wd, v, lengths, dq, ld_dq,
                        dwcat_out, de_out, wpack);
+}
+
+void gt_launch_attn_bwd_wterms_mfma(GtAttnDims d, int nsteps, const float* w, long w_step, const float* u, const float* Wc,
+                                     const float* Wd, const float* v, const int* lengths, float* dq2, long dq2_step,
+                                     long ld_dq2, float* dwcat2, const float* wpack, hipStream_t st) {
+    dim3 grid(d.B, cdiv(d.Ti, CT), nsteps);
+    hipLaunchKernelGGL(attn_bwd_wterms_mfma, grid, dim3(256), 0, st, d, w, w_step, u, Wc, Wd, v, lengths, dq2, dq2_step,
+                       ld_dq2, dwcat2, wpack);
+}
+
+void gt_launch_attn_bwd_step_mfma(GtAttnDims d, GtSlabs da, GtSlabs db, const float* dctx_direct, long ld_direct,
+                                  const float* memory, long ld_mem, const int* lengths, float* dwcat_in, float* dcum_acc,
+                                  const float* dw_extern, float* dctx_out, long ld_dctx_out, const float* w, const float* u,
+                                  const float* Wc, const float* Wd, const float* v, const float* wpack, const float* sum_prev,
+                                  const float* dwcat2_prev, float* sum_out, float* dq, long ld_dq, float* dwcat_out,
+                                  float* e1_out, bool vec, bool vec_slabs, hipStream_t st) {
+    AttnBwdStep a;
+    a.d = d; a.da = da; a.db = db; a.dctx_direct = dctx_direct; a.ld_direct = ld_direct; a.memory = memory; a.ld_mem = ld_mem;
+    a.lengths = lengths; a.dwcat_in = dwcat_in; a.dcum_acc = dcum_acc; a.dw_extern = dw_extern; a.dctx_out = dctx_out;
+    a.ld_dctx_out = ld_dctx_out; a.w = w; a.u = u; a.Wc = Wc; a.Wd = Wd; a.v = v; a.wpack = wpack; a.sum_prev = sum_prev;
+    a.dwcat2_prev = dwcat2_prev; a.sum_out = sum_out; a.dq = dq; a.ld_dq = ld_dq; a.dwcat_out = dwcat_out; a.e1_out = e1_out;
+    dim3 grid(d.B, cdiv(d.Ti, CT));
+    const size_t dyn = (size_t)d.E * 4;
+    if (vec && d.E == 1024 && vec_slabs) hipLaunchKernelGGL((attn_bwd_step_kernel<true, 4>), grid, dim3(256), dyn, st, a);
+    else if (vec) hipLaunchKernelGGL((attn_bwd_step_kernel<true, 0>), grid, dim3(256), dyn, st, a);
+    else hipLaunchKernelGGL((attn_bwd_step_kernel<false, 0>), grid, dim3(256), dyn, st, a);
+}
+
+void gt_launch_attn_bwd_fixup(GtAttnDims d, int nsteps, int nch, const float* sum, const float* w, long w_step, float* de,
+                              float* dq, long dq_step, long ld_dq, const float* dq2, hipStream_t st) {
+    const long n = (long)d.B * (d.Ti > A ? d.Ti : A);
+    dim3 grid((unsigned)((n + 255) / 256), nsteps);
+    hipLaunchKernelGGL(attn_bwd_fixup_kernel, grid, dim3(256), 0, st, d, nch, sum, w, w_step, de, dq, dq_step, ld_dq, dq2);
 }
 
 void gt_launch_attn_param_grads_mfma(GtAttnDims d, int nsteps, const float* u, const float* de, const float* w_prev,

@@ -171,6 +171,8 @@ constexpr int CB_LD = CB_U + 4;
 struct CellBwdQuery {
     GtSlabs da, dc;                   // d h_att from the decoder-LSTM product and from the next step's product
     const float* dq; long ld_dq;      // (Bp, ld_dq) gradient of the query, columns [0, A)
+    const float* dq_sum; int n_sum;   // optional (gt_cell_bwd_query_c): the query gradient is dq - s dq2 with s[m] the sum of
+    const float* dq2;                 // row m's n_sum entries of dq_sum; dq2 laid out like dq
     const float* Wq; long ldwq;       // (A, Ha)
     const float* dc_next;
     const float* gates; const float* c_new; const float* c_prev;
@@ -191,12 +193,20 @@ __global__ __launch_bounds__(64) void cell_bwd_query_kernel(CellBwdQuery a) {
     {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const float* xq = a.dq + (long)(row0 + (lane & 15)) * a.ld_dq + 4 * (lane >> 4);
+        const float* xq2 = a.dq2 != nullptr ? a.dq2 + (long)(row0 + (lane & 15)) * a.ld_dq + 4 * (lane >> 4) : xq;
+        float sm = 0.f;
+        if (a.dq2 != nullptr && row0 + (lane & 15) < a.B)
+            for (int c = 0; c < a.n_sum; ++c) sm += a.dq_sum[(long)(row0 + (lane & 15)) * a.n_sum + c];
         const float* wc = a.Wq + u0 + (lane & 15);
         const int nkb = (a.A + 15) / 16;
 #pragma unroll 4
         for (int kb = 0; kb < nkb; ++kb) {
             // A operand: dq[m = lane & 15][k = 16 kb + 4 (lane >> 4) + j]; columns >= A of dq are zero (padded buffer)
-            const float4 x = *reinterpret_cast<const float4*>(xq + 16 * kb);
+            float4 x = *reinterpret_cast<const float4*>(xq + 16 * kb);
+            if (a.dq2 != nullptr) {
+                const float4 x2 = *reinterpret_cast<const float4*>(xq2 + 16 * kb);
+                x.x -= sm * x2.x; x.y -= sm * x2.y; x.z -= sm * x2.z; x.w -= sm * x2.w;
+            }
             const int k0 = 16 * kb + 4 * (lane >> 4);
             // B operand: Wq[k][n = lane & 15], rows clamped (the matching dq columns are zero)
             const float b0 = wc[(long)min(k0 + 0, a.A - 1) * a.ldwq];
@@ -275,6 +285,17 @@ extern "C" int gt_cell_bwd_query(GtSlabs dh_a, GtSlabs dh_c, const float* dq, in
                                  const float* dc_next, const float* gates, const float* c_new, const float* c_prev,
                                  const uint8_t* keep, float p_drop, float* dgates, float* dc_prev, int32_t B, int32_t Bp,
                                  int32_t H, int32_t A, void* stream) {
+    return gt_cell_bwd_query_c(dh_a, dh_c, dq, ld_dq, nullptr, 0, nullptr, Wq, ldwq, dc_next, gates, c_new, c_prev, keep, p_drop,
+                               dgates, dc_prev, B, Bp, H, A, stream);
+}
+
+extern "C" int gt_cell_bwd_query_c(GtSlabs dh_a, GtSlabs dh_c, const float* dq, int64_t ld_dq, const float* dq_sum,
+                                   int32_t n_sum, const float* dq2, const float* Wq, int64_t ldwq, const float* dc_next,
+                                   const float* gates, const float* c_new, const float* c_prev, const uint8_t* keep,
+                                   float p_drop, float* dgates, float* dc_prev, int32_t B, int32_t Bp, int32_t H, int32_t A,
+                                   void* stream) {
+    GT_REQUIRE((dq2 == nullptr) == (dq_sum == nullptr) && (dq2 == nullptr || (n_sum > 0 && aligned16(dq2))), GT_E_ARG,
+               "gt_cell_bwd_query_c: dq_sum (B x n_sum) and dq2 go together");
     GT_REQUIRE(dq && Wq && gates && c_new && c_prev && dgates && dc_prev, GT_E_ARG, "gt_cell_bwd_query: NULL pointer");
     GT_REQUIRE(B > 0 && Bp >= B && ((Bp <= 64 && Bp % 16 == 0) || Bp % 64 == 0) && H > 0 && H % CB_U == 0 && A > 0, GT_E_ARG,
                "gt_cell_bwd_query: bad sizes B=%d Bp=%d H=%d A=%d (H must be a multiple of %d)", B, Bp, H, A, CB_U);
@@ -285,6 +306,7 @@ extern "C" int gt_cell_bwd_query(GtSlabs dh_a, GtSlabs dh_c, const float* dq, in
                    aligned16(dgates) && aligned16(dc_prev) && H % 4 == 0,
                GT_E_ALIGN, "gt_cell_bwd_query: every pointer must be 16-byte aligned with leading dimensions %% 4 == 0");
     CellBwdQuery a;
+    a.dq_sum = dq_sum; a.n_sum = n_sum; a.dq2 = dq2;
     a.da = dh_a; a.dc = dh_c; a.dq = dq; a.ld_dq = ld_dq; a.Wq = Wq; a.ldwq = ldwq; a.dc_next = dc_next; a.gates = gates;
     a.c_new = c_new; a.c_prev = c_prev; a.keep = keep; a.scale = 1.0f / (1.0f - p_drop); a.dgates = dgates; a.dc_prev = dc_prev;
     a.B = B; a.H = H; a.A = A; a.mtiles = 1;

@@ -599,6 +599,33 @@ static int decoder_bwd_hoisted(const GtDecoderBwd* a, void* stream) {
             float* dq_t = a->dq_hist + (int64_t)t * a->Bp * a->Apad;
             float* dwcat_in = a->dwcat + (int64_t)((t + 1) & 1) * 2 * BT;
             float* dwcat_out = a->dwcat + (int64_t)(t & 1) * 2 * BT;
+            const bool fused_attn = a->sum_hist != nullptr && a->dq2_hist != nullptr && a->dwcat2_hist != nullptr &&
+                                    a->u_hist != nullptr && a->de_hist != nullptr;
+            const int nch = gt_attn_chunks(a->Ti);
+            if (fused_attn) {
+                // context + energies backward of the step in ONE launch (gt_attn_bwd_step); the row sums of the softmax
+                // backward are applied by the consumers: the next call here (carried planes), the cell backward below
+                GT_TRY(gt_attn_bwd_step(d, slabs(dXA_t + a->Ha, 1, 0, a->ldxa),
+                                        last ? kNoSlabs : slabs(a->partX1, a->S1, sX1, a->N1pad), dhc_t + a->Hd, hc_ld,
+                                        a->memory, a->ldE, a->lengths, dwcat_in, a->dcum_acc,
+                                        a->dalign ? a->dalign + (int64_t)t * BT : nullptr,
+                                        a->dctx_hist + (int64_t)t * a->B * a->E, a->E, a->w_hist + (int64_t)(t + 1) * BT,
+                                        a->u_hist + (int64_t)t * BT * a->A, a->Wc, a->Wd, a->v, wpack,
+                                        last ? nullptr : a->sum_hist + (int64_t)(t + 1) * a->B * nch,
+                                        last ? nullptr : a->dwcat2_hist + (int64_t)(t + 1) * 2 * BT,
+                                        a->sum_hist + (int64_t)t * a->B * nch, dq_t, a->Apad, dwcat_out,
+                                        a->de_hist + (int64_t)t * BT, sA));
+                GT_REQUIRE(bq, GT_E_ARG, "gt_decoder_bwd: the fused attention step needs the query gradient inside the cell backward (Wq)");
+                GT_TRY(gt_cell_bwd_query_c(slabs(dXA_t, 1, 0, a->ldxa),
+                                           last ? kNoSlabs : slabs(a->partX1 + a->E, a->S1, sX1, a->N1pad), dq_t, a->Apad,
+                                           a->sum_hist + (int64_t)t * a->B * nch, nch,
+                                           a->dq2_hist + (int64_t)t * a->Bp * a->Apad, a->Wq, a->Ha, a->dc1,
+                                           a->gates1 + (int64_t)t * a->Bp * N1, a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha,
+                                           a->c1 + (int64_t)t * a->Bp * a->Ha, k1, a->p_att, dG1_t, a->dc1, a->B, a->Bp, a->Ha,
+                                           a->A, sA));
+                if (t > 0) GT_TRY(rec_rows(dG1_t, N1, a->W1Tp, a->partX1, a->Bp, a->N1pad, N1, a->S1, sA, a->bf16, two ? kPrioA : 0));
+                continue;
+            }
             GT_TRY(gt_attn_context_bwd(d, slabs(dXA_t + a->Ha, 1, 0, a->ldxa),
                                        last ? kNoSlabs : slabs(a->partX1, a->S1, sX1, a->N1pad), dhc_t + a->Hd, hc_ld,
                                        a->memory, a->ldE, a->lengths, dwcat_in, a->dcum_acc,

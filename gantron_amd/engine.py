@@ -44,6 +44,8 @@ DEC_RING = int(_os.environ.get('GANTRON_DEC_RING', '16'))     # ring of hand-off
 # hoisted decoder-LSTM input product (GtDecoderFwd.W2hp / GtDecoderBwd.W2hTp): [h_att | ctx] . W2ih of a block of steps
 # is one tiled GEMM, only h_dec . W2hh stays in the per-step loops
 HOIST2 = _os.environ.get('GANTRON_HOIST2', '1') != '0'
+# one launch per backward attention step (gt_attn_bwd_step) instead of context + energies backward; needs ATTN_HOIST, HOIST2
+ATTN_BWD_FUSED = _os.environ.get('GANTRON_ATTN_BWD_FUSED', '0') == '1'     # measured slower: off
 # fused product + cell (+ query) launches of the forward loops (gt_rec_cell_fwd): bit 0 = attention LSTM, bit 1 = decoder LSTM,
 # bit 2 = encoder BiLSTM; bits 3 / 4 = attention / decoder LSTM in bf16 mode (gt_rec_cell_fwd_bf16)
 REC_CELL = int(_os.environ.get('GANTRON_REC_CELL', '31'))
@@ -913,6 +915,17 @@ class GeneratorEngine:
             wpack_p = _f32(n_wpack, device=dev, zero=False)
             call('gt_attn_pack_weights', dims, Wc, Wd, wpack_p)
             BT = B * Ti
+        fused_attn = hoist and hoist2 and ATTN_BWD_FUSED
+        if fused_attn:
+            # the terms of the energies backward that are linear in the step's own weights, for every step at once
+            # (gt_attn_bwd_wterms): what the per-step launch subtracts s times from, see attention_mfma.hip
+            nch = int(lib().gt_attn_chunks(Ti))
+            fz = dict(sum_hist=_f32(To, B, nch, device=dev, zero=False), dq2_hist=_f32(To, Bp, Apad, device=dev),
+                      dwcat2_hist=_f32(To, 2, B, Ti, device=dev))
+            check(lib().gt_attn_bwd_wterms(dims, To, ptr(hist['w_hist'], BT), BT, ptr(hist['u_hist']), ptr(Wc), ptr(Wd), ptr(v),
+                                           ptr(sv['lens32']), ptr(fz['dq2_hist']), Bp * Apad, Apad, ptr(fz['dwcat2_hist']),
+                                           ptr(wpack_p), ops._stream()), 'gt_attn_bwd_wterms')
+            b.sum_hist, b.dq2_hist, b.dwcat2_hist = ptr(fz['sum_hist']), ptr(fz['dq2_hist']), ptr(fz['dwcat2_hist'])
         dG1, dG2 = buf['dG1'], buf['dG2']
         g1ih, g1hh = G['decoder.attention_rnn.weight_ih'], G['decoder.attention_rnn.weight_hh']
         g2ih, g2hh = G['decoder.decoder_rnn.weight_ih'], G['decoder.decoder_rnn.weight_hh']
@@ -952,6 +965,11 @@ class GeneratorEngine:
             _run('gt_decoder_bwd', b)
             if HOST_TIMING:
                 print(f'[host] gt_decoder_bwd steps {hi}..{lo} issued in {1e3 * (_time.perf_counter() - _t0):.1f} ms', flush=True)
+            if fused_attn:      # de / dq of the chunk's steps still lack their row-sum terms
+                LEAF.run(lambda lo=lo, hi=hi: check(lib().gt_attn_bwd_fixup(
+                    dims, hi - lo + 1, ptr(fz['sum_hist'], lo * B * nch), ptr(hist['w_hist'], (lo + 1) * BT), BT,
+                    ptr(de_hist, lo * BT), ptr(buf['dq_hist'], lo * Bp * Apad), Bp * Apad, Apad,
+                    ptr(fz['dq2_hist'], lo * Bp * Apad), ops._stream()), 'gt_attn_bwd_fixup'), de_hist, fz['sum_hist'], fz['dq2_hist'])
             if hoist:
                 LEAF.run(lambda lo=lo, hi=hi: check(lib().gt_attn_param_grads(
                     dims, hi - lo + 1, ptr(hist['u_hist'], lo * BT * A), ptr(de_hist, lo * BT), ptr(hist['w_hist'], lo * BT),

@@ -622,6 +622,63 @@ def test_attention_hoisted_backward_equals_in_loop(dev, B, Ti):
         close(a, b, rtol=1e-5, atol=1e-6, what=name)
 
 
+@pytest.mark.parametrize('B,Ti,E', [(3, 150, 1024), (5, 77, 64), (2, 33, 1096), (64, 187, 1024)])
+def test_attention_bwd_step_fused(dev, B, Ti, E):
+    """gt_attn_bwd_wterms (once) + gt_attn_bwd_step per step (+ gt_attn_bwd_fixup) == gt_attn_context_bwd +
+    gt_attn_energies_bwd_rec per step, over a CHAIN of 4 backward steps (the carried alignment gradients of a step come out
+    of the step after it): the softmax backward's row sum is applied by the consumers instead of inside the step."""
+    from gantron_amd import ops
+    from gantron_amd._lib import lib
+    A, Fn, Kc, S = 128, 32, 31, 4
+    d = ops.attn_dims(B, Ti, E, A, Fn, Kc)
+    nch = int(lib().gt_attn_chunks(Ti))
+    lens = torch.tensor(([Ti, Ti - 7, max(Ti - 20, 3), Ti - 1, 5] * 13)[:B])
+    lens32 = lens.to(torch.int32).to(dev)
+    Wc, Wd, v = g(Fn, 2, Kc, seed=1, scale=0.3).to(dev), g(A, Fn, seed=2, scale=0.3).to(dev), g(1, A, seed=3, scale=0.5).to(dev)
+    wpack = torch.empty(int(lib().gt_attn_wpack_elems(d)), device=dev)
+    ops.call('gt_attn_pack_weights', d, Wc, Wd, wpack)
+    memory = g(B, Ti, E, seed=4, scale=0.5).to(dev)
+    mask = (torch.arange(Ti)[None, :] < lens[:, None])
+    w = torch.stack([torch.softmax(g(B, Ti, seed=20 + s).masked_fill(~mask, float('-inf')), 1) for s in range(S)]).to(dev)
+    u = torch.stack([torch.tanh(g(B, Ti, A, seed=30 + s)) for s in range(S)]).to(dev)
+    dctx_dir = torch.stack([g(B, E, seed=40 + s, scale=0.2) for s in range(S)]).to(dev)
+    dslab = torch.stack([g(3, B, E + 8, seed=50 + s, scale=0.2) for s in range(S)]).to(dev)      # 3 K-split slabs, offset columns
+    dalign = torch.stack([g(B, Ti, seed=60 + s, scale=0.1) for s in range(S)]).to(dev)
+    Apad = 144
+
+    def run(fused):
+        dwcat = torch.zeros(2, 2, B, Ti, device=dev); dcum = torch.zeros(B, Ti, device=dev)
+        dq = torch.zeros(S, B, Apad, device=dev); de = torch.full((S, B, Ti), float('nan'), device=dev)
+        dctx_out = torch.full((S, B, E), float('nan'), device=dev)
+        dw = torch.empty(B, Ti, device=dev)
+        if fused:
+            sums = torch.full((S, B, nch), float('nan'), device=dev)
+            dq2 = torch.zeros(S, B, Apad, device=dev); dwc2 = torch.zeros(S, 2, B, Ti, device=dev)
+            ops.call('gt_attn_bwd_wterms', d, S, w, B * Ti, u, Wc, Wd, v, lens32, dq2, B * Apad, Apad, dwc2, wpack)
+        for s in reversed(range(S)):             # backward order
+            din, dout = dwcat[(s + 1) & 1], dwcat[s & 1]
+            sl = ops.slabs(dslab[s], 3, B * (E + 8), E + 8, offset=4)
+            if fused:
+                prev = s + 1 < S
+                ops.call('gt_attn_bwd_step', d, sl, ops.NO_SLABS, dctx_dir[s], E, memory, E, lens32, din, dcum,
+                         dalign[s], dctx_out[s], E, w[s], u[s], Wc, Wd, v, wpack, sums[s + 1] if prev else None,
+                         dwc2[s + 1] if prev else None, sums[s], dq[s], Apad, dout, de[s])
+            else:
+                ops.call('gt_attn_context_bwd', d, sl, ops.NO_SLABS, dctx_dir[s], E, memory, E, lens32, din, dcum,
+                         dalign[s], dctx_out[s], E, dq[s], Apad, dw)
+                ops.call('gt_attn_energies_bwd_rec', d, dw, w[s], u[s], Wc, Wd, v, lens32, dq[s], Apad, dout, de[s], wpack)
+        if fused:
+            ops.call('gt_attn_bwd_fixup', d, S, sums, w, B * Ti, de, dq, B * Apad, Apad, dq2)
+            last = dwcat[0] - sums[0].sum(1)[None, :, None] * dwc2[0]     # what a step -1 would read as its carried planes
+        else:
+            last = dwcat[0].clone()
+        return dq, de, dctx_out, dcum, last
+
+    ref, got = run(False), run(True)
+    for name, a, bb in zip(('dq', 'de', 'dctx', 'dcum_acc', 'carried d[w_prev; w_cum]'), got, ref):
+        close(a, bb, rtol=2e-5, atol=2e-6, what=name)
+
+
 # ------------------------------------------------------------------------- BN / elementwise
 @pytest.mark.parametrize('rows,C,act', [(300, 24, 1), (1000, 80, 2), (77, 8, 0)])
 def test_bn_act_drop(dev, rows, C, act):
