@@ -35,13 +35,13 @@ void gt_launch_attn_step_fwd_mfma(GtAttnDims d, GtSlabs qpart, const float* w_pr
                                   hipStream_t st);
 void gt_launch_attn_bwd_wterms_mfma(GtAttnDims d, int nsteps, const float* w, long w_step, const float* u, const float* Wc,
                                      const float* Wd, const float* v, const int* lengths, float* dq2, long dq2_step,
-                                     long ld_dq2, float* dwcat2, const float* wpack, hipStream_t st);
+                                     long ld_dq2, float* dwcat2, float* p_hist, const float* wpack, hipStream_t st);
 void gt_launch_attn_bwd_step_mfma(GtAttnDims d, GtSlabs da, GtSlabs db, const float* dctx_direct, long ld_direct,
                                   const float* memory, long ld_mem, const int* lengths, float* dwcat_in, float* dcum_acc,
                                   const float* dw_extern, float* dctx_out, long ld_dctx_out, const float* w, const float* u,
-                                  const float* Wc, const float* Wd, const float* v, const float* wpack, const float* sum_prev,
-                                  const float* dwcat2_prev, float* sum_out, float* dq, long ld_dq, float* dwcat_out,
-                                  float* e1_out, bool vec, bool vec_slabs, hipStream_t st);
+                                  const float* v, const float* p, const float* sum_prev, const float* dwcat2_prev,
+                                  float* sum_out, float* dq, long ld_dq, float* dwcat_out, float* e1_out, bool vec,
+                                  bool vec_slabs, hipStream_t st);
 void gt_launch_attn_bwd_fixup(GtAttnDims d, int nsteps, int nch, const float* sum, const float* w, long w_step, float* de,
                               float* dq, long dq_step, long ld_dq, const float* dq2, hipStream_t st);
 int gt_attn_wpack_elems_mfma();
@@ -762,14 +762,15 @@ extern "C" int gt_attn_energies_bwd_rec(GtAttnDims d, const float* dw, const flo
 
 extern "C" int gt_attn_bwd_wterms(GtAttnDims d, int32_t nsteps, const float* w, int64_t w_step_stride, const float* u,
                                   const float* Wc, const float* Wd, const float* v, const int32_t* lengths, float* dq2,
-                                  int64_t dq2_step_stride, int64_t ld_dq2, float* dwcat2, const float* wpack, void* stream) {
+                                  int64_t dq2_step_stride, int64_t ld_dq2, float* dwcat2, float* p_hist, const float* wpack,
+                                  void* stream) {
     int rc = check_dims(d, "gt_attn_bwd_wterms");
     if (rc) return rc;
     GT_REQUIRE(use_mfma(d), GT_E_ARG, "gt_attn_bwd_wterms: needs the (128, 32, 31) dimensions");
-    GT_REQUIRE(nsteps > 0 && nsteps <= 65535 && w && u && Wc && Wd && v && dq2 && dwcat2 && ld_dq2 >= d.A, GT_E_ARG,
-               "gt_attn_bwd_wterms: bad argument");
+    GT_REQUIRE(nsteps > 0 && nsteps <= 65535 && w && u && Wc && Wd && v && dq2 && dwcat2 && p_hist && ld_dq2 >= d.A && aligned16(p_hist),
+               GT_E_ARG, "gt_attn_bwd_wterms: bad argument");
     gt_launch_attn_bwd_wterms_mfma(d, nsteps, w, (long)w_step_stride, u, Wc, Wd, v, lengths, dq2, (long)dq2_step_stride,
-                                   (long)ld_dq2, dwcat2, wpack, (hipStream_t)stream);
+                                   (long)ld_dq2, dwcat2, p_hist, wpack, (hipStream_t)stream);
     GT_LAUNCH_CHECK();
     return 0;
 }
@@ -777,26 +778,26 @@ extern "C" int gt_attn_bwd_wterms(GtAttnDims d, int32_t nsteps, const float* w, 
 extern "C" int gt_attn_bwd_step(GtAttnDims d, GtSlabs dctx_a, GtSlabs dctx_b, const float* dctx_direct, int64_t ld_direct,
                                 const float* memory, int64_t ld_mem, const int32_t* lengths, float* dwcat_in, float* dcum_acc,
                                 const float* dw_extern, float* dctx_out, int64_t ld_dctx_out, const float* w, const float* u,
-                                const float* Wc, const float* Wd, const float* v, const float* wpack, const float* sum_prev,
-                                const float* dwcat2_prev, float* sum_out, float* dq, int64_t ld_dq, float* dwcat_out,
-                                float* e1_out, void* stream) {
+                                const float* v, const float* p, const float* sum_prev, const float* dwcat2_prev,
+                                float* sum_out, float* dq, int64_t ld_dq, float* dwcat_out, float* e1_out, void* stream) {
     int rc = check_dims(d, "gt_attn_bwd_step");
     if (rc) return rc;
     GT_REQUIRE(use_mfma(d), GT_E_ARG, "gt_attn_bwd_step: needs the (128, 32, 31) dimensions");
-    GT_REQUIRE(memory && ld_mem >= d.E && w && u && Wc && Wd && v && sum_out && dq && dwcat_out && e1_out && ld_dq >= d.A,
-               GT_E_ARG, "gt_attn_bwd_step: bad argument");
+    GT_REQUIRE(memory && ld_mem >= d.E && w && u && v && p && aligned16(p) && aligned16(u) && aligned16(v) && sum_out && dq &&
+                   dwcat_out && e1_out && ld_dq >= d.A && cdiv(d.Ti, CT) <= 16,
+               GT_E_ARG, "gt_attn_bwd_step: bad argument (Ti <= 512)");
     GT_REQUIRE((sum_prev == nullptr) == (dwcat2_prev == nullptr), GT_E_ARG, "gt_attn_bwd_step: sum_prev and dwcat2_prev go together");
     GT_REQUIRE((size_t)d.E * 4 <= 32 * 1024, GT_E_LIMIT, "gt_attn_bwd_step: E too large for LDS");
     const double ctx_rows = g_gt_prof_ctx_rows > 0.0 ? g_gt_prof_ctx_rows : (double)d.B * d.Ti;
-    GtProfScope prof(GT_FAM_ATTN_C_BWD, 2.0 * ctx_rows * (double)d.E + 2.0 * d.B * d.Ti * (double)(d.F * 2 * d.Kc + d.A * d.F + 4 * d.A),
-                     4.0 * (ctx_rows * d.E + d.B * ((1.0 + dctx_a.n + dctx_b.n) * d.E + 6.0 * d.Ti) + d.B * d.Ti * (d.A + 6.0)),
+    GtProfScope prof(GT_FAM_ATTN_C_BWD, 2.0 * ctx_rows * (double)d.E + 2.0 * d.B * d.Ti * (double)(d.A + 2 * d.Kc),
+                     4.0 * (ctx_rows * d.E + d.B * ((1.0 + dctx_a.n + dctx_b.n) * d.E + 6.0 * d.Ti) + d.B * d.Ti * (d.A + 64 + 6.0)),
                      (hipStream_t)stream);
     const bool vec = (d.E % 4 == 0) && (ld_mem % 4 == 0) && aligned16(memory);
     auto sl4 = [](const GtSlabs& sl) { return sl.p == nullptr || (aligned16(sl.p) && sl.ld % 4 == 0 && sl.slab_stride % 4 == 0); };
     const bool vec_slabs = sl4(dctx_a) && sl4(dctx_b) && (dctx_direct == nullptr || (aligned16(dctx_direct) && ld_direct % 4 == 0)) &&
                            (dctx_out == nullptr || (aligned16(dctx_out) && ld_dctx_out % 4 == 0));
     gt_launch_attn_bwd_step_mfma(d, dctx_a, dctx_b, dctx_direct, (long)ld_direct, memory, (long)ld_mem, lengths, dwcat_in,
-                                 dcum_acc, dw_extern, dctx_out, (long)ld_dctx_out, w, u, Wc, Wd, v, wpack, sum_prev, dwcat2_prev,
+                                 dcum_acc, dw_extern, dctx_out, (long)ld_dctx_out, w, u, v, p, sum_prev, dwcat2_prev,
                                  sum_out, dq, (long)ld_dq, dwcat_out, e1_out, vec, vec_slabs, (hipStream_t)stream);
     GT_LAUNCH_CHECK();
     return 0;

@@ -815,28 +815,59 @@ __global__ __launch_bounds__(256) void attn_energies_bwd_rec_mfma(GtAttnDims d, 
 // ---- fused backward step ---------------------------------------------------------------------------------------------
 // The backward attention chain was context_bwd (dw for all positions of a row) -> energies_bwd_rec (softmax backward needs
 // the ROW sum s = sum_t w dw, then everything is per position) -- two dependent launches because of one scalar per row.
-// Everything downstream of the softmax backward is LINEAR in de = w (dw - s) = w dw - s w:
-//     dq = Lq(w dw) - s Lq(w),    d[w_prev; w_cum] = Lw(w dw) - s Lw(w),
-// and Lq(w), Lw(w) depend on forward quantities only (the step's weights w, its tanh outputs u, the location layer).  So
-//  * gt_attn_bwd_wterms computes dq2 = Lq(w_t), dwcat2 = Lw(w_t) for ALL steps in one batched launch before the loop,
+// Everything downstream of the softmax backward is LINEAR in de = w (dw - s) = w dw - s w.  With
+//     M[t][d] = v[d] (1 - u[t][d]^2)   and   P = (M . Wd) . Wc   ([t][(c,k)], 62 columns per position),
+// both functions of forward quantities only,
+//     dq[d] = sum_t de[t] M[t][d],      d[w_prev; w_cum][c][t0 + p - 15] = sum_k de[p-k] P[p-k][(c,k)].
+// So
+//  * gt_attn_bwd_wterms (ONE batched launch over all steps, before the loop, off the critical path) computes P for every
+//    step (the two small GEMMs of the energies backward, on M instead of on de M) and the s-terms dq2 = Lq(w_t),
+//    dwcat2 = Lw(w_t);
 //  * attn_bwd_step_kernel (one launch per step) computes dw for its 32 positions, e1 = w dw, the tile's share of s, and
-//    Lq(e1), Lw(e1) -- no cross-workgroup dependency --
-//  * and the consumers subtract s times the precomputed term: the next step's carried alignment gradient (in this kernel),
+//    applies e1 to M and P with a few dozen multiply-adds per thread -- no GEMM, no weights, no cross-workgroup dependency;
+//  * the consumers subtract s times the precomputed term: the next step's carried alignment gradient (in this kernel),
 //    the attention cell backward's dq (gt_cell_bwd_query_c), and -- off the critical path -- the stored dq / de histories
 //    (gt_attn_bwd_fixup before the weight-gradient passes that read them).
-// One dependent launch less per backward step.
+constexpr int PW = 64;      // columns of a P row in memory (62 used)
+
+// dq[b][d] += sum_t e[t] M[t][d],  dwcat[c][b][t0 + p - 15] += sum_k e[p-k] P[p-k][c KC + k]  (e, M, P in LDS: e[CT],
+// M rows LDS_ apart, P rows LDG apart)
+__device__ __forceinline__ void apply_e(const float* e, const float* M, const float* P, const GtAttnDims& d, int b, int t0,
+                                        float* dq, long ld_dq, float* dwcat_out) {
+    {
+        const int dd = threadIdx.x & (A - 1), half = threadIdx.x >> 7;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < CT / 2; ++i) acc += e[16 * half + i] * M[(16 * half + i) * LDS_ + dd];
+        atomicAdd(&dq[(long)b * ld_dq + dd], acc);
+    }
+    if (threadIdx.x < 2 * (CT + KC - 1)) {
+        const int c = threadIdx.x / (CT + KC - 1), p = threadIdx.x - c * (CT + KC - 1);
+        const int t = t0 + p - (KC - 1) / 2;
+        if (t >= 0 && t < d.Ti) {
+            float acc = 0.f;
+            const int klo = max(0, p - (CT - 1)), khi = min(KC - 1, p);
+            for (int k = klo; k <= khi; ++k) acc += e[p - k] * P[(p - k) * LDG + c * KC + k];
+            atomicAdd(&dwcat_out[(long)c * d.B * d.Ti + (long)b * d.Ti + t], acc);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void attn_bwd_wterms_mfma(GtAttnDims d, const float* w, long w_step, const float* u,
                                                             const float* Wc, const float* Wd, const float* v,
                                                             const int* lengths, float* dq2, long dq2_step, long ld_dq2,
-                                                            float* dwcat2, const float* wpack) {
+                                                            float* dwcat2, float* p_hist, const float* wpack) {
     __shared__ SharedM S;
     const int b = blockIdx.x, t0 = blockIdx.y * CT, step = blockIdx.z;       // grid (B, chunks, steps)
-    if (lengths != nullptr && t0 >= lengths[b]) return;                      // outputs are zero-initialised
+    if (lengths != nullptr && t0 >= lengths[b]) return;                      // dq2 / dwcat2 are zero-initialised; P unread
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kq = lane >> 4;
     const long BTi = (long)d.B * d.Ti;
     u += (long)step * BTi * A;
     w += (long)step * w_step;
     dq2 += (long)step * dq2_step;
     dwcat2 += (long)step * 2 * BTi;
+    p_hist += (long)step * BTi * PW;
     float4 u4[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -845,14 +876,56 @@ __global__ __launch_bounds__(256) void attn_bwd_wterms_mfma(GtAttnDims d, const 
     }
     const float w_c = w[(long)b * d.Ti + min(t0 + (int)(threadIdx.x & (CT - 1)), d.Ti - 1)];
     stage_common(S, d, Wc, Wd, v, nullptr, nullptr, b, t0, wpack, false);
+    __syncthreads();                                   // S.v
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4; ++i) {                      // M = v (1 - u^2), zero beyond Ti
         const int f = threadIdx.x + 256 * i, tl = f >> 5, c4 = f & 31;
-        *reinterpret_cast<float4*>(&S.ds[tl * LDS_ + 4 * c4]) = u4[i];
+        const float4 vv = *reinterpret_cast<const float4*>(&S.v[4 * c4]);
+        const float m = (t0 + tl < d.Ti) ? 1.f : 0.f;
+        *reinterpret_cast<float4*>(&S.ds[tl * LDS_ + 4 * c4]) =
+            make_float4(m * vv.x * (1.f - u4[i].x * u4[i].x), m * vv.y * (1.f - u4[i].y * u4[i].y),
+                        m * vv.z * (1.f - u4[i].z * u4[i].z), m * vv.w * (1.f - u4[i].w * u4[i].w));
     }
     if (threadIdx.x < CT) S.de[threadIdx.x] = (t0 + (int)threadIdx.x < d.Ti) ? w_c : 0.f;
     __syncthreads();
-    energies_rec_tail(S, d, b, t0, dq2, ld_dq2, dwcat2);
+    {   // M . Wd
+        const int mt = wave >> 1, nt = wave & 1;
+        f32x4 c3 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s4 = 0; s4 < 8; ++s4) {
+            const int k0 = 16 * s4 + 4 * kq;
+            c3 = mfma4(ld4(&S.ds[(16 * mt + r) * LDS_ + k0]), ld4s(&S.wd[k0 * LDD + 16 * nt + r], LDD), c3);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) S.dlocf[(16 * mt + 4 * kq + e) * LDL + 16 * nt + r] = c3[e];
+    }
+    __syncthreads();
+    {   // P = (M . Wd) . Wc
+        const int mt = wave >> 1;
+        f32x4 c6[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s4 = 0; s4 < 2; ++s4) {
+            const int k0 = 16 * s4 + 4 * kq;
+            const float4 a6 = ld4(&S.dlocf[(16 * mt + r) * LDL + k0]);
+#pragma unroll
+            for (int nl = 0; nl < 2; ++nl) {
+                const int kk = 16 * (2 * (wave & 1) + nl) + r;
+                c6[nl] = mfma4(a6, ld4s(&S.wc[k0 * LDC + kk], LDC), c6[nl]);
+            }
+        }
+#pragma unroll
+        for (int nl = 0; nl < 2; ++nl) {
+            const int kk = 16 * (2 * (wave & 1) + nl) + r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) S.g[(16 * mt + 4 * kq + e) * LDG + kk] = c6[nl][e];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < CT * PW; i += 256) {               // P rows of the tile's valid positions
+        const int tl = i / PW, kk = i - tl * PW;
+        if (t0 + tl < d.Ti) p_hist[((long)b * d.Ti + t0 + tl) * PW + kk] = S.g[tl * LDG + kk];
+    }
+    apply_e(S.de, S.ds, S.g, d, b, t0, dq2, ld_dq2, dwcat2);
 }
 
 struct AttnBwdStep {
@@ -863,19 +936,24 @@ struct AttnBwdStep {
     const int* lengths;
     float* dwcat_in; float* dcum_acc; const float* dw_extern;
     float* dctx_out; long ld_dctx_out;
-    const float* w; const float* u;
-    const float* Wc; const float* Wd; const float* v; const float* wpack;
+    const float* w; const float* u; const float* v; const float* p;       // p: this step's (B, Ti, PW) rows of P
     const float* sum_prev; const float* dwcat2_prev;      // NULL on the last step (nothing carried yet)
     float* sum_out;                                       // (B, chunks) this step's partial row sums
     float* dq; long ld_dq; float* dwcat_out; float* e1_out;
+};
+
+struct SharedStep {
+    alignas(16) float M[CT * LDS_];
+    alignas(16) float P[CT * LDG];
+    float e[CT];
+    float dots[CT];
 };
 
 template <bool VEC, int NE4>
 __global__ __launch_bounds__(256) void attn_bwd_step_kernel(AttnBwdStep a) {
     __builtin_amdgcn_s_setprio(3);      // the attention chain is the serial critical path of the decoder loops
     extern __shared__ __attribute__((aligned(16))) float dctx[];   // E floats
-    __shared__ SharedM S;
-    __shared__ float dots[CT];
+    __shared__ SharedStep S;
     const GtAttnDims& d = a.d;
     const int b = blockIdx.x, chunk = blockIdx.y, t0 = chunk * CT, nch = gridDim.y;      // grid (B, chunks)
     const int Tv = a.lengths != nullptr ? min(a.lengths[b], d.Ti) : d.Ti;
@@ -888,37 +966,56 @@ __global__ __launch_bounds__(256) void attn_bwd_step_kernel(AttnBwdStep a) {
         if (threadIdx.x == 0) a.sum_out[(long)b * nch + chunk] = 0.f;
         return;
     }
-    // requests that do not depend on the context gradient go out first: the tile's tanh outputs, its weights, the
+    // requests that do not depend on the context gradient go out first: the tile's tanh outputs (-> M), its P rows, the
     // previous step's row sum
-    float4 u4[4];
+    float4 u4[4], p4[2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int f = threadIdx.x + 256 * i, tl = f >> 5, c4 = f & 31;
         u4[i] = *reinterpret_cast<const float4*>(a.u + ((long)b * d.Ti + min(t0 + tl, d.Ti - 1)) * A + 4 * c4);
     }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int f = threadIdx.x + 256 * i, tl = f >> 4, c4 = f & 15;
+        p4[i] = *reinterpret_cast<const float4*>(a.p + ((long)b * d.Ti + min(t0 + tl, Tv - 1)) * PW + 4 * c4);
+    }
     const float w_c = a.w[(long)b * d.Ti + min(t0 + (int)(threadIdx.x & (CT - 1)), d.Ti - 1)];
     float s_prev = 0.f;
-    if (a.sum_prev != nullptr)
-        for (int c = 0; c < nch; ++c) s_prev += a.sum_prev[(long)b * nch + c];
-    stage_common(S, d, a.Wc, a.Wd, a.v, nullptr, nullptr, b, t0, a.wpack, false);
+    if (a.sum_prev != nullptr) {
+        float sp[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) sp[c] = a.sum_prev[(long)b * nch + min(c, nch - 1)];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) s_prev += c < nch ? sp[c] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int f = threadIdx.x + 256 * i, tl = f >> 5, c4 = f & 31;
-        *reinterpret_cast<float4*>(&S.ds[tl * LDS_ + 4 * c4]) = u4[i];
+        const float4 vv = *reinterpret_cast<const float4*>(a.v + 4 * c4);
+        const float m = (t0 + tl < d.Ti) ? 1.f : 0.f;
+        *reinterpret_cast<float4*>(&S.M[tl * LDS_ + 4 * c4]) =
+            make_float4(m * vv.x * (1.f - u4[i].x * u4[i].x), m * vv.y * (1.f - u4[i].y * u4[i].y),
+                        m * vv.z * (1.f - u4[i].z * u4[i].z), m * vv.w * (1.f - u4[i].w * u4[i].w));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int f = threadIdx.x + 256 * i, tl = f >> 4, c4 = f & 15;
+        float* dst = &S.P[tl * LDG + 4 * c4];         // LDG = 66: rows are 8-byte aligned only
+        dst[0] = p4[i].x; dst[1] = p4[i].y; dst[2] = p4[i].z; dst[3] = p4[i].w;
     }
     const float dw = attn_ctx_bwd_dw<VEC, NE4>(d, a.da, a.db, a.dctx_direct, a.ld_direct, a.memory, a.ld_mem, Tv, a.dwcat_in,
                                                a.dcum_acc, a.dw_extern, a.dctx_out, a.ld_dctx_out, a.dwcat2_prev, s_prev,
-                                               dctx, dots, b, chunk);
+                                               dctx, S.dots, b, chunk);
     if (threadIdx.x < 64) {         // wave 0: e1 of the tile's positions and their sum
         const bool pos = threadIdx.x < CT && t0 + (int)threadIdx.x < d.Ti;
         const float e1 = pos ? w_c * dw : 0.f;
-        if (threadIdx.x < CT) S.de[threadIdx.x] = e1;
+        if (threadIdx.x < CT) S.e[threadIdx.x] = e1;
         if (pos) a.e1_out[(long)b * d.Ti + t0 + threadIdx.x] = e1;
         const float tot = wave_sum(threadIdx.x < CT ? e1 : 0.f);
         if (threadIdx.x == 0) a.sum_out[(long)b * nch + chunk] = tot;
     }
     __syncthreads();
-    energies_rec_tail(S, d, b, t0, a.dq, a.ld_dq, a.dwcat_out);
+    apply_e(S.e, S.M, S.P, d, b, t0, a.dq, a.ld_dq, a.dwcat_out);
 }
 
 // de[t] = e1[t] - s_t w_t and dq[t] -= s_t dq2[t] for `nsteps` steps (the histories the weight-gradient passes read):
@@ -1139,22 +1236,22 @@ void gt_launch_attn_energies_bwd_rec_mfma(GtAttnDims d, const float* dw, const f
 
 void gt_launch_attn_bwd_wterms_mfma(GtAttnDims d, int nsteps, const float* w, long w_step, const float* u, const float* Wc,
                                      const float* Wd, const float* v, const int* lengths, float* dq2, long dq2_step,
-                                     long ld_dq2, float* dwcat2, const float* wpack, hipStream_t st) {
+                                     long ld_dq2, float* dwcat2, float* p_hist, const float* wpack, hipStream_t st) {
     dim3 grid(d.B, cdiv(d.Ti, CT), nsteps);
     hipLaunchKernelGGL(attn_bwd_wterms_mfma, grid, dim3(256), 0, st, d, w, w_step, u, Wc, Wd, v, lengths, dq2, dq2_step,
-                       ld_dq2, dwcat2, wpack);
+                       ld_dq2, dwcat2, p_hist, wpack);
 }
 
 void gt_launch_attn_bwd_step_mfma(GtAttnDims d, GtSlabs da, GtSlabs db, const float* dctx_direct, long ld_direct,
                                   const float* memory, long ld_mem, const int* lengths, float* dwcat_in, float* dcum_acc,
                                   const float* dw_extern, float* dctx_out, long ld_dctx_out, const float* w, const float* u,
-                                  const float* Wc, const float* Wd, const float* v, const float* wpack, const float* sum_prev,
-                                  const float* dwcat2_prev, float* sum_out, float* dq, long ld_dq, float* dwcat_out,
-                                  float* e1_out, bool vec, bool vec_slabs, hipStream_t st) {
+                                  const float* v, const float* p, const float* sum_prev, const float* dwcat2_prev,
+                                  float* sum_out, float* dq, long ld_dq, float* dwcat_out, float* e1_out, bool vec,
+                                  bool vec_slabs, hipStream_t st) {
     AttnBwdStep a;
     a.d = d; a.da = da; a.db = db; a.dctx_direct = dctx_direct; a.ld_direct = ld_direct; a.memory = memory; a.ld_mem = ld_mem;
     a.lengths = lengths; a.dwcat_in = dwcat_in; a.dcum_acc = dcum_acc; a.dw_extern = dw_extern; a.dctx_out = dctx_out;
-    a.ld_dctx_out = ld_dctx_out; a.w = w; a.u = u; a.Wc = Wc; a.Wd = Wd; a.v = v; a.wpack = wpack; a.sum_prev = sum_prev;
+    a.ld_dctx_out = ld_dctx_out; a.w = w; a.u = u; a.v = v; a.p = p; a.sum_prev = sum_prev;
     a.dwcat2_prev = dwcat2_prev; a.sum_out = sum_out; a.dq = dq; a.ld_dq = ld_dq; a.dwcat_out = dwcat_out; a.e1_out = e1_out;
     dim3 grid(d.B, cdiv(d.Ti, CT));
     const size_t dyn = (size_t)d.E * 4;

@@ -195,8 +195,16 @@ __global__ __launch_bounds__(64) void cell_bwd_query_kernel(CellBwdQuery a) {
         const float* xq = a.dq + (long)(row0 + (lane & 15)) * a.ld_dq + 4 * (lane >> 4);
         const float* xq2 = a.dq2 != nullptr ? a.dq2 + (long)(row0 + (lane & 15)) * a.ld_dq + 4 * (lane >> 4) : xq;
         float sm = 0.f;
-        if (a.dq2 != nullptr && row0 + (lane & 15) < a.B)
-            for (int c = 0; c < a.n_sum; ++c) sm += a.dq_sum[(long)(row0 + (lane & 15)) * a.n_sum + c];
+        if (a.dq2 != nullptr) {
+            // the row's <= 16 tile sums, all requested at once (clamped indices, masked afterwards)
+            const int rowc = min(row0 + (lane & 15), a.B - 1);
+            float sp[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) sp[c] = a.dq_sum[(long)rowc * a.n_sum + min(c, a.n_sum - 1)];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) sm += c < a.n_sum ? sp[c] : 0.f;
+            if (row0 + (lane & 15) >= a.B) sm = 0.f;
+        }
         const float* wc = a.Wq + u0 + (lane & 15);
         const int nkb = (a.A + 15) / 16;
 #pragma unroll 4
@@ -294,7 +302,7 @@ extern "C" int gt_cell_bwd_query_c(GtSlabs dh_a, GtSlabs dh_c, const float* dq, 
                                    const float* gates, const float* c_new, const float* c_prev, const uint8_t* keep,
                                    float p_drop, float* dgates, float* dc_prev, int32_t B, int32_t Bp, int32_t H, int32_t A,
                                    void* stream) {
-    GT_REQUIRE((dq2 == nullptr) == (dq_sum == nullptr) && (dq2 == nullptr || (n_sum > 0 && aligned16(dq2))), GT_E_ARG,
+    GT_REQUIRE((dq2 == nullptr) == (dq_sum == nullptr) && (dq2 == nullptr || (n_sum > 0 && n_sum <= 16 && aligned16(dq2))), GT_E_ARG,
                "gt_cell_bwd_query_c: dq_sum (B x n_sum) and dq2 go together");
     GT_REQUIRE(dq && Wq && gates && c_new && c_prev && dgates && dc_prev, GT_E_ARG, "gt_cell_bwd_query: NULL pointer");
     GT_REQUIRE(B > 0 && Bp >= B && ((Bp <= 64 && Bp % 16 == 0) || Bp % 64 == 0) && H > 0 && H % CB_U == 0 && A > 0, GT_E_ARG,

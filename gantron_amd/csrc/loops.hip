@@ -600,7 +600,7 @@ static int decoder_bwd_hoisted(const GtDecoderBwd* a, void* stream) {
             float* dwcat_in = a->dwcat + (int64_t)((t + 1) & 1) * 2 * BT;
             float* dwcat_out = a->dwcat + (int64_t)(t & 1) * 2 * BT;
             const bool fused_attn = a->sum_hist != nullptr && a->dq2_hist != nullptr && a->dwcat2_hist != nullptr &&
-                                    a->u_hist != nullptr && a->de_hist != nullptr;
+                                    a->p_hist != nullptr && a->u_hist != nullptr && a->de_hist != nullptr;
             const int nch = gt_attn_chunks(a->Ti);
             if (fused_attn) {
                 // context + energies backward of the step in ONE launch (gt_attn_bwd_step); the row sums of the softmax
@@ -610,7 +610,7 @@ static int decoder_bwd_hoisted(const GtDecoderBwd* a, void* stream) {
                                         a->memory, a->ldE, a->lengths, dwcat_in, a->dcum_acc,
                                         a->dalign ? a->dalign + (int64_t)t * BT : nullptr,
                                         a->dctx_hist + (int64_t)t * a->B * a->E, a->E, a->w_hist + (int64_t)(t + 1) * BT,
-                                        a->u_hist + (int64_t)t * BT * a->A, a->Wc, a->Wd, a->v, wpack,
+                                        a->u_hist + (int64_t)t * BT * a->A, a->v, a->p_hist + (int64_t)t * BT * 64,
                                         last ? nullptr : a->sum_hist + (int64_t)(t + 1) * a->B * nch,
                                         last ? nullptr : a->dwcat2_hist + (int64_t)(t + 1) * 2 * BT,
                                         a->sum_hist + (int64_t)t * a->B * nch, dq_t, a->Apad, dwcat_out,

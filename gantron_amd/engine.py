@@ -921,11 +921,18 @@ class GeneratorEngine:
             # (gt_attn_bwd_wterms): what the per-step launch subtracts s times from, see attention_mfma.hip
             nch = int(lib().gt_attn_chunks(Ti))
             fz = dict(sum_hist=_f32(To, B, nch, device=dev, zero=False), dq2_hist=_f32(To, Bp, Apad, device=dev),
-                      dwcat2_hist=_f32(To, 2, B, Ti, device=dev))
-            check(lib().gt_attn_bwd_wterms(dims, To, ptr(hist['w_hist'], BT), BT, ptr(hist['u_hist']), ptr(Wc), ptr(Wd), ptr(v),
-                                           ptr(sv['lens32']), ptr(fz['dq2_hist']), Bp * Apad, Apad, ptr(fz['dwcat2_hist']),
-                                           ptr(wpack_p), ops._stream()), 'gt_attn_bwd_wterms')
-            b.sum_hist, b.dq2_hist, b.dwcat2_hist = ptr(fz['sum_hist']), ptr(fz['dq2_hist']), ptr(fz['dwcat2_hist'])
+                      dwcat2_hist=_f32(To, 2, B, Ti, device=dev), p_hist=_f32(To, B, Ti, 64, device=dev, zero=False))
+            # on the leaf stream: it needs forward quantities only and overlaps the PostNet / projection backward
+            LEAF.run(lambda: check(lib().gt_attn_bwd_wterms(
+                dims, To, ptr(hist['w_hist'], BT), BT, ptr(hist['u_hist']), ptr(Wc), ptr(Wd), ptr(v), ptr(sv['lens32']),
+                ptr(fz['dq2_hist']), Bp * Apad, Apad, ptr(fz['dwcat2_hist']), ptr(fz['p_hist']), ptr(wpack_p), ops._stream()),
+                'gt_attn_bwd_wterms'), wpack_p)
+            if LEAF.defer:
+                LEAF.flush()
+            if LEAF.enabled and LEAF.stream is not None and not LEAF.defer:
+                torch.cuda.current_stream().wait_stream(LEAF.stream)
+            b.sum_hist, b.dq2_hist, b.dwcat2_hist, b.p_hist = (ptr(fz['sum_hist']), ptr(fz['dq2_hist']), ptr(fz['dwcat2_hist']),
+                                                               ptr(fz['p_hist']))
         dG1, dG2 = buf['dG1'], buf['dG2']
         g1ih, g1hh = G['decoder.attention_rnn.weight_ih'], G['decoder.attention_rnn.weight_hh']
         g2ih, g2hh = G['decoder.decoder_rnn.weight_ih'], G['decoder.decoder_rnn.weight_hh']

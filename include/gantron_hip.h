@@ -307,28 +307,29 @@ int gt_attn_param_grads(GtAttnDims d, int32_t nsteps, const float* u, const floa
                         const float* w_cum, int64_t step_stride, const float* Wc, const float* Wd,
                         const float* v, const int32_t* lengths, float* dpm, float* acc, const float* wpack,
                         void* stream);
-/* Fused backward attention step ((128, 32, 31) dimensions).  The softmax backward needs one scalar per batch row,
- * s = sum_t w dw, but everything after it is linear in de = w dw - s w:  dq = Lq(w dw) - s Lq(w),
- * d[w_prev; w_cum] = Lw(w dw) - s Lw(w), and Lq(w), Lw(w) depend on forward quantities only.
- *  gt_attn_bwd_wterms : dq2[t] = Lq(w_t) (step stride dq2_step_stride, rows ld_dq2 apart) and dwcat2[t] = Lw(w_t)
- *                       ((2, B, Ti) per step) for `nsteps` steps in one launch; outputs zero-initialised by the caller;
- *                       w advances by w_step_stride per step, u by B*Ti*A.
+/* Fused backward attention step ((128, 32, 31) dimensions, Ti <= 512).  The softmax backward needs one scalar per batch
+ * row, s = sum_t w dw, but everything after it is linear in de = w dw - s w.  With M[t][d] = v[d] (1 - u[t][d]^2) and
+ * P = (M . Wd) . Wc (62 columns per position, stored 64 wide), functions of forward quantities only:
+ *     dq[d] = sum_t de[t] M[t][d],   d[w_prev; w_cum][c][t0 + p - 15] = sum_k de[p - k] P[p - k][(c, k)].
+ *  gt_attn_bwd_wterms : for `nsteps` steps in ONE launch: p_hist[t] = P ((B, Ti, 64) per step), dq2[t] = Lq(w_t) (step
+ *                       stride dq2_step_stride, rows ld_dq2 apart) and dwcat2[t] = Lw(w_t) ((2, B, Ti) per step); dq2 /
+ *                       dwcat2 zero-initialised by the caller; w advances by w_step_stride per step, u by B*Ti*A.
  *  gt_attn_bwd_step   : gt_attn_context_bwd's inputs (dctx sources, memory, carried planes dwcat_in / dcum_acc, dw_extern,
- *                       dctx_out) + the step's w and u.  Writes e1 = w dw to e1_out (B, Ti), the tile sums of e1 to sum_out
- *                       (B, gt_attn_chunks(Ti)), and ADDS Lq(e1) to dq (zeroed by the caller) and Lw(e1) to dwcat_out.
- *                       sum_prev / dwcat2_prev (both or neither): the previous call's sum_out and that step's dwcat2 -- the
- *                       carried planes are read as dwcat_in - s_prev dwcat2_prev.
+ *                       dctx_out) + the step's w, u and P rows.  Writes e1 = w dw to e1_out (B, Ti), the tile sums of e1 to
+ *                       sum_out (B, gt_attn_chunks(Ti)), and ADDS Lq(e1) to dq (zeroed by the caller) and Lw(e1) to
+ *                       dwcat_out.  sum_prev / dwcat2_prev (both or neither): the previous call's sum_out and that step's
+ *                       dwcat2 -- the carried planes are read as dwcat_in - s_prev dwcat2_prev.
  *  gt_attn_bwd_fixup  : de[t] = e1[t] - s_t w_t and dq[t] -= s_t dq2[t] for `nsteps` steps (sum: (nsteps, B, chunks)).
  * The attention cell backward takes the correction on the fly (gt_cell_bwd_query_c). */
 int gt_attn_bwd_wterms(GtAttnDims d, int32_t nsteps, const float* w, int64_t w_step_stride, const float* u,
                        const float* Wc, const float* Wd, const float* v, const int32_t* lengths, float* dq2,
-                       int64_t dq2_step_stride, int64_t ld_dq2, float* dwcat2, const float* wpack, void* stream);
+                       int64_t dq2_step_stride, int64_t ld_dq2, float* dwcat2, float* p_hist, const float* wpack,
+                       void* stream);
 int gt_attn_bwd_step(GtAttnDims d, GtSlabs dctx_a, GtSlabs dctx_b, const float* dctx_direct, int64_t ld_direct,
                      const float* memory, int64_t ld_mem, const int32_t* lengths, float* dwcat_in, float* dcum_acc,
                      const float* dw_extern, float* dctx_out, int64_t ld_dctx_out, const float* w, const float* u,
-                     const float* Wc, const float* Wd, const float* v, const float* wpack, const float* sum_prev,
-                     const float* dwcat2_prev, float* sum_out, float* dq, int64_t ld_dq, float* dwcat_out,
-                     float* e1_out, void* stream);
+                     const float* v, const float* p, const float* sum_prev, const float* dwcat2_prev, float* sum_out,
+                     float* dq, int64_t ld_dq, float* dwcat_out, float* e1_out, void* stream);
 int gt_attn_bwd_fixup(GtAttnDims d, int32_t nsteps, const float* sum, const float* w, int64_t w_step_stride,
                       float* de, float* dq, int64_t dq_step_stride, int64_t ld_dq, const float* dq2, void* stream);
 int64_t gt_attn_acc_elems(GtAttnDims d);     /* size of `acc` (dv | dWd | dWc per workgroup) */
@@ -471,13 +472,14 @@ typedef struct GtDecoderBwd {
     float* partXh;             /* (S2, Bp, Hdpad) zero-initialised */
     int32_t blk;               /* steps per block; <= 0: 32 */
     /* Fused backward attention step (all three non-NULL, together with u_hist / de_hist and the hoisted mode above): ONE
-     * launch per step (gt_attn_bwd_step) instead of gt_attn_context_bwd + gt_attn_energies_bwd_rec.  dq2_hist / dwcat2_hist
-     * come from gt_attn_bwd_wterms over all steps BEFORE the loop; sum_hist receives the per-tile row sums.  After the
+     * launch per step (gt_attn_bwd_step) instead of gt_attn_context_bwd + gt_attn_energies_bwd_rec.  dq2_hist / dwcat2_hist /
+     * p_hist come from gt_attn_bwd_wterms over all steps BEFORE the loop; sum_hist receives the per-tile row sums.  After the
      * loop de_hist holds w dw (not yet minus s w) and dq_hist the uncorrected dq: gt_attn_bwd_fixup finishes both before
      * anything outside the loop reads them.  dq_hist must be zero-initialised (nothing in the loop zeroes it). */
     float* sum_hist;           /* (To, B, gt_attn_chunks(Ti)) */
     const float* dq2_hist;     /* (To, Bp, Apad), the layout of dq_hist */
     const float* dwcat2_hist;  /* (To, 2, B, Ti) */
+    const float* p_hist;       /* (To, B, Ti, 64) */
 } GtDecoderBwd;
 
 typedef struct GtBiLstm {

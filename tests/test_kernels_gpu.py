@@ -654,14 +654,15 @@ def test_attention_bwd_step_fused(dev, B, Ti, E):
         if fused:
             sums = torch.full((S, B, nch), float('nan'), device=dev)
             dq2 = torch.zeros(S, B, Apad, device=dev); dwc2 = torch.zeros(S, 2, B, Ti, device=dev)
-            ops.call('gt_attn_bwd_wterms', d, S, w, B * Ti, u, Wc, Wd, v, lens32, dq2, B * Apad, Apad, dwc2, wpack)
+            ph = torch.full((S, B, Ti, 64), float('nan'), device=dev)
+            ops.call('gt_attn_bwd_wterms', d, S, w, B * Ti, u, Wc, Wd, v, lens32, dq2, B * Apad, Apad, dwc2, ph, wpack)
         for s in reversed(range(S)):             # backward order
             din, dout = dwcat[(s + 1) & 1], dwcat[s & 1]
             sl = ops.slabs(dslab[s], 3, B * (E + 8), E + 8, offset=4)
             if fused:
                 prev = s + 1 < S
                 ops.call('gt_attn_bwd_step', d, sl, ops.NO_SLABS, dctx_dir[s], E, memory, E, lens32, din, dcum,
-                         dalign[s], dctx_out[s], E, w[s], u[s], Wc, Wd, v, wpack, sums[s + 1] if prev else None,
+                         dalign[s], dctx_out[s], E, w[s], u[s], v, ph[s], sums[s + 1] if prev else None,
                          dwc2[s + 1] if prev else None, sums[s], dq[s], Apad, dout, de[s])
             else:
                 ops.call('gt_attn_context_bwd', d, sl, ops.NO_SLABS, dctx_dir[s], E, memory, E, lens32, din, dcum,
