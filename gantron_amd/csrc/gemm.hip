@@ -724,7 +724,9 @@ __global__ __launch_bounds__(256) void xgemm_kernel(GemmDev g) {
 // instructions), one fragment read and one plane store in every MFMA gap of the same wave: 186 TFLOP/s.  Its parts:
 // MFMAs + fragment reads alone 300, + plane stores 258; the split does not hide in the gaps (dependent cvt / shift / sub
 // chains).  And 256 x 128 tiles with wave tiles of 128 x 64 (the split amortised over twice the MFMAs, one workgroup per
-// CU): 178 against 196 on the same GEMMs.  xgemm_kernel with two workgroups per CU stays the fastest form measured.)
+// CU): 178 against 196 on the same GEMMs.  XCD-contiguous tile order (each XCD's L2 sees 4 m-rows x 16 n-tiles instead of
+// every m-row): 201.5 -> 205.7 on one GEMM, nothing on the others, pair 133.5 vs 133.2 ms.  xgemm_kernel with two workgroups
+// per CU and the plain tile order stays.)
 template <int BM, int BN>
 int launch_tile(const GemmDev& d, dim3 grid, hipStream_t st, int lds_pad) {
     const int am = d.A.mode, bm = d.B.mode;
