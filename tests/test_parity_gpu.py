@@ -166,6 +166,16 @@ def test_midsize_against_oracle(dev, case):
         return _midsize_against_oracle(dev, case)
 
 
+def test_fused_attention_backward_step_against_oracle(dev, monkeypatch):
+    """The opt-in one-launch backward attention step (GANTRON_ATTN_BWD_FUSED: gt_attn_bwd_wterms + gt_attn_bwd_step +
+    gt_cell_bwd_query_c + gt_attn_bwd_fixup) through a whole generator + discriminator pair at the reference's attention
+    dimensions, against the oracle."""
+    from gantron_amd import engine
+    monkeypatch.setattr(engine, 'ATTN_BWD_FUSED', True)
+    assert engine.ATTN_HOIST and engine.HOIST2
+    _midsize_against_oracle(dev, 'full_dims_b20')
+
+
 def _midsize_against_oracle(dev, case):
     from gantron_amd.hparams import HParams
     from oracle import gantron_ref as R
