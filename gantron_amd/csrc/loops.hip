@@ -566,10 +566,18 @@ static int decoder_bwd_hoisted(const GtDecoderBwd* a, void* stream) {
     }
     const int blk = block_steps(a->blk);
     int nblock = 0;
+    // GANTRON_BLOCK_TIMING=1 (diagnostic): events around the B-chain block, its block GEMM and the A-chain block; printed
+    // at the end of the call (synchronises)
+    static const bool block_timing = getenv("GANTRON_BLOCK_TIMING") != nullptr;
+    struct BT_ { hipEvent_t b0, b1, g1, a0, a1; int steps; };
+    std::vector<BT_> bts;
+    auto mark = [&](hipEvent_t* e, hipStream_t st) { if (block_timing) { (void)hipEventCreate(e); (void)hipEventRecord(*e, st); } };
     for (int b1 = t_hi; b1 >= t_lo;) {
         // the very first blocks of a backward pass are short: stream A idles until stream B has finished one
         const int len = (t_hi == a->To - 1 && nblock < 2) ? max(blk / 4, 1) : blk;
         const int b0 = max(t_lo, b1 - len + 1);
+        BT_ bt; bt.steps = b1 - b0 + 1;
+        mark(&bt.b0, sB);
         // ---- decoder LSTM chain (stream B, leads), steps b1 .. b0
         for (int t = b1; t >= b0; --t) {
             const bool last = (t == a->To - 1);
@@ -582,13 +590,16 @@ static int decoder_bwd_hoisted(const GtDecoderBwd* a, void* stream) {
                                     a->Hd, sB));
             if (t > 0) GT_TRY(rec_rows(dG2_t, N2, a->W2hTp, a->partXh, a->Bp, Hdpad, N2, a->S2, sB, a->bf16, two ? kPrioB : 0));
         }
+        mark(&bt.b1, sB);
         GT_TRY(block_gemm(op_kc(a->dG2 + (int64_t)b0 * a->Bp * N2, N2), op_rc(a->W2ih, a->ldw2), nullptr,
                           a->dXA + (int64_t)b0 * a->Bp * a->ldxa, a->ldxa, (b1 - b0 + 1) * a->Bp, a->Ha + a->E, N2, 0, a->bf16, sB));
+        mark(&bt.g1, sB);
         if (two) {
             GT_TRY(loop_event(ctx, 1 + (size_t)(nblock % 32), &ev));
             GT_HIP(hipEventRecord(ev, sB));
             GT_HIP(hipStreamWaitEvent(sA, ev, 0));
         }
+        mark(&bt.a0, sA);
         // ---- attention chain (stream A), steps b1 .. b0
         for (int t = b1; t >= b0; --t) {
             const bool last = (t == a->To - 1);
@@ -656,9 +667,29 @@ static int decoder_bwd_hoisted(const GtDecoderBwd* a, void* stream) {
             }
             if (t > 0) GT_TRY(rec_rows(dG1_t, N1, a->W1Tp, a->partX1, a->Bp, a->N1pad, N1, a->S1, sA, a->bf16, two ? kPrioA : 0));
         }
+        mark(&bt.a1, sA);
+        if (block_timing) bts.push_back(bt);
         b1 = b0 - 1;
         ++nblock;
     }
+    if (block_timing && !bts.empty()) {
+        (void)hipStreamSynchronize(sA); (void)hipStreamSynchronize(sB);
+        for (size_t i = 0; i < bts.size(); ++i) {
+            float bms = 0, gms = 0, ams = 0, lag = 0, await = 0;
+            (void)hipEventElapsedTime(&bms, bts[i].b0, bts[i].b1);
+            (void)hipEventElapsedTime(&gms, bts[i].b1, bts[i].g1);
+            (void)hipEventElapsedTime(&ams, bts[i].a0, bts[i].a1);
+            (void)hipEventElapsedTime(&lag, bts[i].g1, bts[i].a0);           // > 0: A reached the block after B's GEMM was done
+            if (i > 0) (void)hipEventElapsedTime(&await, bts[i - 1].a1, bts[i].a0);
+            fprintf(stderr, "[block] steps %2d  B chain %7.1f us (%.1f/step)  dXA GEMM %6.1f us  A chain %7.1f us (%.1f/step)  "
+                            "B-done -> A-start %8.1f us  A idle before block %6.1f us\n", bts[i].steps, bms * 1e3,
+                    bms * 1e3 / bts[i].steps, gms * 1e3, ams * 1e3, ams * 1e3 / bts[i].steps, lag * 1e3, await * 1e3);
+        }
+    }
+    // (Measured and not adopted: letting the decoder-LSTM chain keep its lead across the calls of a chunked backward instead
+    // of joining it at the end of every call -- each call then starts without the attention chain waiting ~0.7 ms for the other
+    // chain's first block -- 132.7 / 133.6 against 132.8 / 132.9 ms: that wait coincided with the previous chunk's
+    // weight-gradient GEMMs, which simply ran faster while it lasted.)
     return 0;
 }
 
