@@ -579,16 +579,25 @@ static int decoder_bwd_hoisted(const GtDecoderBwd* a, void* stream) {
         BT_ bt; bt.steps = b1 - b0 + 1;
         mark(&bt.b0, sB);
         // ---- decoder LSTM chain (stream B, leads), steps b1 .. b0
+        // countersB != NULL: the product of step t + 1 and the cell backward of step t are ONE launch (gt_rec_cellbwd)
+        const bool fusedB = a->countersB != nullptr && !a->bf16 && a->Hd % 64 == 0 && a->S2 <= 16;
         for (int t = b1; t >= b0; --t) {
             const bool last = (t == a->To - 1);
             const uint8_t* k2 = a->dec_keep ? a->dec_keep + (int64_t)t * a->Bp * a->Hd : nullptr;
             const float* dhc_t = a->dHC + (int64_t)t * a->Bp * hc_ld;
             float* dG2_t = a->dG2 + (int64_t)t * a->Bp * N2;
+            if (fusedB && !last) {
+                GT_TRY(gt_rec_cellbwd(a->dG2 + (int64_t)(t + 1) * a->Bp * N2, N2, a->W2hTp, a->partXh, a->countersB, a->Bp, a->B,
+                                      a->Hd, N2, a->S2, dhc_t, hc_ld, a->dc2, a->gates2 + (int64_t)t * a->Bp * N2,
+                                      a->c2 + (int64_t)(t + 1) * a->Bp * a->Hd, a->c2 + (int64_t)t * a->Bp * a->Hd, k2, a->p_dec,
+                                      dG2_t, two ? kPrioB : 0, sB));
+                continue;
+            }
             GT_TRY(gt_lstm_cell_bwd(last ? kNoSlabs : slabs(a->partXh, a->S2, sXh, Hdpad), kNoSlabs, kNoSlabs, dhc_t, hc_ld,
                                     a->dc2, a->gates2 + (int64_t)t * a->Bp * N2, a->c2 + (int64_t)(t + 1) * a->Bp * a->Hd,
                                     a->c2 + (int64_t)t * a->Bp * a->Hd, k2, a->p_dec, nullptr, dG2_t, a->dc2, nullptr, a->B,
                                     a->Hd, sB));
-            if (t > 0) GT_TRY(rec_rows(dG2_t, N2, a->W2hTp, a->partXh, a->Bp, Hdpad, N2, a->S2, sB, a->bf16, two ? kPrioB : 0));
+            if (t > 0 && !fusedB) GT_TRY(rec_rows(dG2_t, N2, a->W2hTp, a->partXh, a->Bp, Hdpad, N2, a->S2, sB, a->bf16, two ? kPrioB : 0));
         }
         mark(&bt.b1, sB);
         GT_TRY(block_gemm(op_kc(a->dG2 + (int64_t)b0 * a->Bp * N2, N2), op_rc(a->W2ih, a->ldw2), nullptr,

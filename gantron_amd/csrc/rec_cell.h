@@ -226,3 +226,138 @@ __device__ __forceinline__ void rec_cell_epilogue(float* red, const RecCellEpi& 
 }
 
 }  // namespace
+
+// ---- backward counterpart: recurrent input-gradient product + cell backward of the PREVIOUS step ---------------------
+// The product of step t, d h_{t-1} = dG_t . W_hh (64 hidden units per workgroup, K-splits meeting as above), is what the
+// cell backward of step t - 1 waits for: the last arriver of a column group adds the emitted-state gradient, runs the cell
+// backward for its 64 units x all rows and writes dG_{t-1} -- the next launch's operand.  (gt_rec_cellbwd)
+struct RecCellBwdEpi {
+    const float* dh_direct; long ld_direct;     // (rows, >= H) gradient of the h EMITTED by step t - 1, or NULL
+    const float* gates;                         // (rows, 4H) gate values of step t - 1
+    const float* c_new; const float* c_prev;    // (rows, H) cell state after / before step t - 1
+    const uint8_t* keep; float scale;           // dropout mask of step t - 1's h (or NULL)
+    float* dc;                                  // (rows, H) carried cell-state gradient, read and replaced
+    float* dgates;                              // (rows, 4H) pre-activation gate gradients of step t - 1
+    unsigned* counters;
+    int B, H, S;
+};
+
+namespace {
+
+template <int MT>
+__device__ __forceinline__ void rec_cellbwd_epilogue(float* red, const RecCellBwdEpi& e, float* part, long ps, int N, int cg,
+                                                     int s, int rb, unsigned* ticket) {
+    constexpr int EP_LD = REC_EP_LD;
+    constexpr int REC_THREADS = REC_EP_THREADS;
+    constexpr int ROWS = MT * 16;
+    constexpr int NV = (ROWS * 16 + REC_THREADS - 1) / REC_THREADS;        // float4 of the tile per thread
+    unsigned* lds_ticket = reinterpret_cast<unsigned*>(red + ROWS * EP_LD);
+    const int tid = threadIdx.x;
+    const int row0 = 64 * rb;
+    float* slab0 = part + (long)cg * 64;
+    if (e.S > 1) {
+        const __amdgpu_buffer_rsrc_t wr = rc_rsrc(slab0 + (long)s * ps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int f = tid + REC_THREADS * i;
+            const int row = f >> 4, c4 = f & 15;
+            if (row < ROWS) {
+                const float4 v = *reinterpret_cast<const float4*>(&red[row * EP_LD + 4 * c4]);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), wr, (int)(((long)row * N + 4 * c4) * 4), 0, 16);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // EVERY storing wave drains its stores
+        __syncthreads();
+        if (tid == 0) *lds_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if ((*lds_ticket % (unsigned)e.S) != (unsigned)(e.S - 1)) return;       // not the last K-slice of this group
+    }
+    // ---- last arriver: thread = (row, 4 units) x NV; the cell's inputs are requested together with the other slabs
+    float4 gi[NV], gf[NV], gg[NV], go[NV], cn[NV], cp[NV], dcn[NV], dd[NV];
+    uchar4 kp[NV];
+    bool live[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int f = min(tid + REC_THREADS * i, ROWS * 16 - 1);
+        const int row = f >> 4, c4 = f & 15;
+        const int m = row0 + row, u = 64 * cg + 4 * c4;
+        live[i] = (tid + REC_THREADS * i < ROWS * 16) && m < e.B && u < e.H;
+        const int mc = min(m, e.B - 1), uc = min(u, e.H - 4);
+        const long idx = (long)mc * e.H + uc;
+        const float* gt = e.gates + (long)mc * 4 * e.H + uc;
+        gi[i] = *reinterpret_cast<const float4*>(gt); gf[i] = *reinterpret_cast<const float4*>(gt + e.H);
+        gg[i] = *reinterpret_cast<const float4*>(gt + 2 * e.H); go[i] = *reinterpret_cast<const float4*>(gt + 3 * e.H);
+        cn[i] = *reinterpret_cast<const float4*>(e.c_new + idx);
+        cp[i] = *reinterpret_cast<const float4*>(e.c_prev + idx);
+        dcn[i] = *reinterpret_cast<const float4*>(e.dc + idx);
+        dd[i] = e.dh_direct != nullptr ? *reinterpret_cast<const float4*>(e.dh_direct + (long)mc * e.ld_direct + uc)
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        kp[i] = e.keep != nullptr ? *reinterpret_cast<const uchar4*>(e.keep + idx) : make_uchar4(1, 1, 1, 1);
+    }
+    float4 acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e.S > 1) {
+        const __amdgpu_buffer_rsrc_t rd = rc_rsrc(slab0);
+        for (int s0 = 0; s0 < e.S; s0 += 4) {       // four slabs in flight per pass
+            float4 t[4][NV];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int sj = s0 + j;
+                const bool use = sj < e.S && sj != s;
+                const long base = (long)(use ? sj : 0) * ps;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const int f = min(tid + REC_THREADS * i, ROWS * 16 - 1);
+                    const int row = f >> 4, c4 = f & 15;
+                    t[j][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rd, (int)((base + (long)row * N + 4 * c4) * 4), 0, 16));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int sj = s0 + j;
+                const float w = (sj < e.S && sj != s) ? 1.f : 0.f;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    acc[i].x += w * t[j][i].x; acc[i].y += w * t[j][i].y; acc[i].z += w * t[j][i].z; acc[i].w += w * t[j][i].w;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (!live[i]) continue;
+        const int f = tid + REC_THREADS * i;
+        const int row = f >> 4, c4 = f & 15;
+        const int m = row0 + row, u = 64 * cg + 4 * c4;
+        const float4 own = *reinterpret_cast<const float4*>(&red[row * EP_LD + 4 * c4]);
+        const float dhv[4] = {acc[i].x + own.x + dd[i].x, acc[i].y + own.y + dd[i].y, acc[i].z + own.z + dd[i].z,
+                              acc[i].w + own.w + dd[i].w};
+        const float giv[4] = {gi[i].x, gi[i].y, gi[i].z, gi[i].w}, gfv[4] = {gf[i].x, gf[i].y, gf[i].z, gf[i].w};
+        const float ggv[4] = {gg[i].x, gg[i].y, gg[i].z, gg[i].w}, gov[4] = {go[i].x, go[i].y, go[i].z, go[i].w};
+        const float cnv[4] = {cn[i].x, cn[i].y, cn[i].z, cn[i].w}, cpv[4] = {cp[i].x, cp[i].y, cp[i].z, cp[i].w};
+        const float dcv[4] = {dcn[i].x, dcn[i].y, dcn[i].z, dcn[i].w};
+        const unsigned char kpv[4] = {kp[i].x, kp[i].y, kp[i].z, kp[i].w};
+        float dgi[4], dgf[4], dgg[4], dgo[4], dcp[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float dh = dhv[q];
+            if (e.keep != nullptr) dh *= (kpv[q] ? e.scale : 0.f);
+            const float tc = tanhf(cnv[q]);
+            const float dcell = dcv[q] + dh * gov[q] * (1.f - tc * tc);
+            dgi[q] = dcell * ggv[q] * giv[q] * (1.f - giv[q]);
+            dgf[q] = dcell * cpv[q] * gfv[q] * (1.f - gfv[q]);
+            dgg[q] = dcell * giv[q] * (1.f - ggv[q] * ggv[q]);
+            dgo[q] = dh * tc * gov[q] * (1.f - gov[q]);
+            dcp[q] = dcell * gfv[q];
+        }
+        float* dg = e.dgates + (long)m * 4 * e.H + u;
+        *reinterpret_cast<float4*>(dg) = make_float4(dgi[0], dgi[1], dgi[2], dgi[3]);
+        *reinterpret_cast<float4*>(dg + e.H) = make_float4(dgf[0], dgf[1], dgf[2], dgf[3]);
+        *reinterpret_cast<float4*>(dg + 2 * e.H) = make_float4(dgg[0], dgg[1], dgg[2], dgg[3]);
+        *reinterpret_cast<float4*>(dg + 3 * e.H) = make_float4(dgo[0], dgo[1], dgo[2], dgo[3]);
+        *reinterpret_cast<float4*>(e.dc + (long)m * e.H + u) = make_float4(dcp[0], dcp[1], dcp[2], dcp[3]);
+    }
+}
+
+}  // namespace

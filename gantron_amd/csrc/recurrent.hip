@@ -265,6 +265,22 @@ __global__ __launch_bounds__(REC_THREADS) void rec_cell_kernel(const float* __re
     rec_cell_epilogue<MT>(red, e, part + (long)rb * pz, ps, N, cg, s, rb, e.counters + (long)z * gridDim.x + cg);
 }
 
+// gt_rec_cellbwd: see rec_cell.h.  Same launch geometry as rec_cell_kernel: blockIdx = (64-unit column group, K-slice,
+// 64-row block).
+template <int MT>
+__global__ __launch_bounds__(REC_THREADS) void rec_cellbwd_kernel(const float* __restrict__ X, long ldx,
+                                                                  const float* __restrict__ Wp, float* part, int N, int KB,
+                                                                  int KBS, long xz, long pz, long ps, int prio, RecCellBwdEpi e) {
+    if (prio == 3) __builtin_amdgcn_s_setprio(3);
+    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+    const int cg = blockIdx.x, s = blockIdx.y, rb = blockIdx.z;
+    const int kb0 = s * KBS;
+    float* red = rec_gemm_tile<MT, 0>(X + (long)rb * xz, ldx, Wp, N, KB, kb0, min(KB, kb0 + KBS), cg);
+    static_assert(MT * 16 * REC_EP_LD + 4 <= MT * 16 * REC_LD, "epilogue scratch fits the staging buffer");
+    rec_cellbwd_epilogue<MT>(red, e, part + (long)rb * pz, ps, N, cg, s, rb, e.counters + (long)rb * gridDim.x + cg);
+}
+
 struct CellFwd {
     GtSlabs part;
     const float* pre; long ld_pre;
@@ -672,6 +688,47 @@ extern "C" int gt_rec_cell_fwd_bf16(const float* X, int64_t ldx, const void* Wp,
     return gt_rec_cell_fwd_z(X, ldx, Wp, 1, part, counters, Bp, B, H, K, splits, pre, ld_pre, c_prev, keep, p_drop, gates, c_out,
                              h_raw, h0, ld0, h1, ld1, h2, ld2, Wq, ldwq, qpart, q_sstride, A, Apad, nullptr, nullptr, 0, 1,
                              nullptr, prio, stream);
+}
+
+extern "C" int gt_rec_cellbwd(const float* X, int64_t ldx, const float* Wp, float* part, uint32_t* counters, int32_t Bp,
+                              int32_t B, int32_t H, int32_t K, int32_t splits, const float* dh_direct, int64_t ld_direct,
+                              float* dc, const float* gates, const float* c_new, const float* c_prev, const uint8_t* keep,
+                              float p_drop, float* dgates, int32_t prio, void* stream) {
+    GT_REQUIRE(X && Wp && part && counters && dc && gates && c_new && c_prev && dgates, GT_E_ARG, "gt_rec_cellbwd: NULL pointer");
+    GT_REQUIRE(B > 0 && Bp >= B && ((Bp <= 64 && Bp % 16 == 0) || Bp % 64 == 0) && H > 0 && H % 64 == 0 && K > 0 && splits >= 1 &&
+                   splits <= 16, GT_E_ARG, "gt_rec_cellbwd: bad sizes B=%d Bp=%d H=%d (%% 64) K=%d splits=%d", B, Bp, H, K, splits);
+    GT_REQUIRE(p_drop >= 0.f && p_drop < 1.f, GT_E_ARG, "gt_rec_cellbwd: p_drop");
+    const int N = H, KB = cdiv(K, 16);
+    GT_REQUIRE(ldx >= (int64_t)KB * 16 && ldx % 4 == 0 && aligned16(X) && aligned16(Wp) && aligned16(part), GT_E_ALIGN,
+               "gt_rec_cellbwd: X needs ldx >= 16*ceil(K/16), ldx %% 4 == 0 and 16-byte alignment");
+    GT_REQUIRE(aligned16(dc) && aligned16(gates) && aligned16(c_new) && aligned16(c_prev) && aligned16(dgates) &&
+                   (dh_direct == nullptr || (aligned16(dh_direct) && ld_direct % 4 == 0)) &&
+                   (keep == nullptr || (((uintptr_t)keep) & 3) == 0),
+               GT_E_ALIGN, "gt_rec_cellbwd: every pointer must be 16-byte aligned with leading dimensions %% 4 == 0");
+    const int KBS = cdiv(KB, splits);
+    GT_REQUIRE(cdiv(KB, KBS) == splits, GT_E_ARG, "gt_rec_cellbwd: splits=%d leaves empty slabs for K=%d", splits, K);
+    const int mt = Bp <= 64 ? Bp / 16 : 4, nzb = Bp <= 64 ? 1 : Bp / 64;
+    RecCellBwdEpi e;
+    e.dh_direct = dh_direct; e.ld_direct = ld_direct; e.gates = gates; e.c_new = c_new; e.c_prev = c_prev; e.keep = keep;
+    e.scale = 1.0f / (1.0f - p_drop); e.dc = dc; e.dgates = dgates; e.counters = counters; e.B = B; e.H = H; e.S = splits;
+    dim3 grid(N / 64, splits, nzb);
+    hipStream_t st = (hipStream_t)stream;
+    GtProfScope prof(GT_FAM_REC_GEMM, 2.0 * Bp * (double)N * K,
+                     4.0 * ((double)N * K + (double)Bp * K + (double)Bp * N * (splits > 1 ? 2 * splits - 1 : 0) + (double)B * H * 14), st,
+                     true);
+    const long ps = (long)Bp * N;
+#define GT_RCB(MT)                                                                                                     \
+    hipExtLaunchKernelGGL((rec_cellbwd_kernel<MT>), grid, dim3(REC_THREADS), 0, st, prof.e0, prof.e1, 0, X, (long)ldx, Wp, part,  \
+                          N, KB, KBS, (long)(64 * ldx), (long)64 * N, ps, prio, e)
+    switch (mt) {
+        case 1: GT_RCB(1); break;
+        case 2: GT_RCB(2); break;
+        case 3: GT_RCB(3); break;
+        default: GT_RCB(4); break;
+    }
+#undef GT_RCB
+    GT_LAUNCH_CHECK();
+    return 0;
 }
 
 static int rec_problem(RecProblem& p, const float* X, int64_t ldx, const float* Wp, float* part, int N, int K, int splits,

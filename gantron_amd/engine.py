@@ -47,7 +47,8 @@ HOIST2 = _os.environ.get('GANTRON_HOIST2', '1') != '0'
 # one launch per backward attention step (gt_attn_bwd_step) instead of context + energies backward; needs ATTN_HOIST, HOIST2
 ATTN_BWD_FUSED = _os.environ.get('GANTRON_ATTN_BWD_FUSED', '0') == '1'     # measured slower: off
 # fused product + cell (+ query) launches of the forward loops (gt_rec_cell_fwd): bit 0 = attention LSTM, bit 1 = decoder LSTM,
-# bit 2 = encoder BiLSTM; bits 3 / 4 = attention / decoder LSTM in bf16 mode (gt_rec_cell_fwd_bf16)
+# bit 2 = encoder BiLSTM; bits 3 / 4 = attention / decoder LSTM in bf16 mode (gt_rec_cell_fwd_bf16); bit 5 = the decoder
+# LSTM's backward product + cell backward (gt_rec_cellbwd; measured 0.3 ms slower per pair than two launches: off)
 REC_CELL = int(_os.environ.get('GANTRON_REC_CELL', '31'))
 ENC_SPLITS = int(_os.environ.get('GANTRON_ENC_SPLITS', '0'))   # K-splits of the fused BiLSTM step (0: cost model)
 DEC_BLK_BWD = int(_os.environ.get('GANTRON_DEC_BLK_BWD', '16'))
@@ -897,6 +898,8 @@ class GeneratorEngine:
             W2ih_c = W2ihp
             buf.update(dXA=_f32(To, Bp, ldxa, device=dev, zero=False), partXh=_f32(b.S2, Bp, Hdpad, device=dev))
             b.W2hTp, b.W2ih, b.ldw2, b.ldxa, b.blk = ptr(W2hTp), ptr(W2ih_c), W2ih_c.stride(0), ldxa, DEC_BLK_BWD
+            if (REC_CELL & 32) and not self.bf16 and Hd % 64 == 0 and b.S2 <= 16:
+                buf['countersB'] = torch.zeros((Bp // 64 if Bp > 64 else 1) * (Hd // 64), dtype=torch.int32, device=dev)
         b.memory, b.pm, b.Wc, b.Wd, b.v = ptr(sv['memory']), ptr(sv['pm']), ptr(Wc), ptr(Wd), ptr(v)
         b.lengths = ptr(sv['lens32'])
         b.att_keep, b.dec_keep = ptr(sv['att_keep']), ptr(sv['dec_keep'])

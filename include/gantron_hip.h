@@ -152,6 +152,17 @@ int gt_rec_cell_fwd(const float* X, int64_t ldx, const float* Wp, float* part, u
                     const float* Wq, int64_t ldwq, float* qpart, int64_t q_sstride, int32_t A, int32_t Apad,
                     int32_t prio, void* stream);
 
+/* Backward counterpart for a recurrence whose only per-step product is d h_{t-1} = dG_t . W_hh (the decoder LSTM in the
+ * hoisted mode, model.py:406-409): ONE launch per step = that product (Wp: gt_pack_rec_weight of W_hh^T, i.e. [H] x [4H],
+ * K = 4H; X = dG_t (Bp, ldx)) + the cell backward of step t - 1 in the last-arriving workgroup of every 64-unit column
+ * group: d h = product + dh_direct (gradient of the emitted h_{t-1}), dropout, gate derivatives -> dgates = dG_{t-1}
+ * (Bp, 4H), dc (Bp, H) replaced by the gradient carried on.  gates / c_new / c_prev / keep are step t - 1's.  H % 64 == 0,
+ * splits <= 16; `part` (splits x Bp x H) and `counters` ((Bp > 64 ? Bp/64 : 1) x H/64, zeroed once) as in gt_rec_cell_fwd. */
+int gt_rec_cellbwd(const float* X, int64_t ldx, const float* Wp, float* part, uint32_t* counters, int32_t Bp,
+                   int32_t B, int32_t H, int32_t K, int32_t splits, const float* dh_direct, int64_t ld_direct, float* dc,
+                   const float* gates, const float* c_new, const float* c_prev, const uint8_t* keep, float p_drop,
+                   float* dgates, int32_t prio, void* stream);
+
 /* bf16-operand variant (hparams.fp16_run, the reference's apex path train.py:246-250 -> bf16 MFMA with fp32
  * accumulation on MI355X): the weights are packed as bf16 fragments of v_mfma_f32_16x16x32_bf16
  * ([N/16][ceil(K/32)][64 lanes][8 bf16], gt_rec_weight_bf16_elems 16-bit elements), the fp32 activations X are
@@ -480,6 +491,9 @@ typedef struct GtDecoderBwd {
     const float* dq2_hist;     /* (To, Bp, Apad), the layout of dq_hist */
     const float* dwcat2_hist;  /* (To, 2, B, Ti) */
     const float* p_hist;       /* (To, B, Ti, 64) */
+    /* hoisted mode, fp32, Hd % 64 == 0: the decoder LSTM's per-step product and the cell backward of the step before it as
+     * ONE launch (gt_rec_cellbwd); (Bp > 64 ? Bp/64 : 1) x Hd/64 tickets, zero-initialised; NULL: two launches */
+    uint32_t* countersB;
 } GtDecoderBwd;
 
 typedef struct GtBiLstm {

@@ -332,6 +332,50 @@ def test_rec_cell_fused(dev, Bsz, H, K, S, A, bf16):
     assert int(counters.min()) == int(counters.max()) == (3 * S if S > 1 else 0)      # one ticket per workgroup and launch
 
 
+@pytest.mark.parametrize('Bsz,H,S', [(64, 1024, 16), (5, 64, 2), (70, 128, 4), (33, 64, 1)])
+def test_rec_cellbwd_fused(dev, Bsz, H, S):
+    """gt_rec_cellbwd = the recurrent input-gradient product dG_t . W_hh + gt_lstm_cell_bwd of step t - 1 in ONE launch, run
+    as a chain of 3 steps on the same workspace (tickets carry over) against the two-launch sequence."""
+    from gantron_amd import ops
+    from gantron_amd._lib import lib
+    from gantron_amd.engine import pack_rec
+    p = 0.1
+    Bp = ops.roundup(Bsz, 16) if Bsz <= 64 else ops.roundup(Bsz, 64)
+    K = 4 * H
+    S = ops.pick_splits(K, S)
+    T = 4
+    Whh = g(4 * H, H, scale=0.1).to(dev)                              # (4H, H): d h = dG . Whh
+    WT = pack_rec(Whh, H, H, K, transposed=True)                      # packed [H] x [4H]
+    gates = torch.sigmoid(g(T, Bp, 4 * H, seed=1)).to(dev)
+    c = g(T + 1, Bp, H, seed=2).to(dev)
+    keep = (torch.rand(T, Bp, H, generator=torch.Generator().manual_seed(3)) >= p).to(torch.uint8).to(dev)
+    dhdir = g(T, Bp, H + 8, seed=4, scale=0.3).to(dev)                # emitted-state gradients, offset columns
+
+    def run(fused):
+        dG = torch.zeros(T, Bp, 4 * H, device=dev); dc = torch.zeros(Bp, H, device=dev)
+        part = torch.full((S, Bp, H), float('nan'), device=dev)
+        counters = torch.zeros((Bp // 64 if Bp > 64 else 1) * (H // 64), dtype=torch.int32, device=dev)
+        # last step: nothing recurrent yet
+        ops.call('gt_lstm_cell_bwd', ops.NO_SLABS, ops.NO_SLABS, ops.NO_SLABS, ops.ptr(dhdir[T - 1], 4), H + 8, dc, gates[T - 1],
+                 c[T], c[T - 1], keep[T - 1], p, None, dG[T - 1], dc, None, Bsz, H)
+        for t in range(T - 1, 0, -1):            # product of step t, cell backward of step t - 1
+            if fused:
+                ops.call('gt_rec_cellbwd', dG[t], 4 * H, WT, part, counters, Bp, Bsz, H, K, S, ops.ptr(dhdir[t - 1], 4), H + 8,
+                         dc, gates[t - 1], c[t], c[t - 1], keep[t - 1], p, dG[t - 1], 2)
+            else:
+                ops.call('gt_rec_gemm', dG[t], 4 * H, WT, part, Bp // 16 if Bp <= 64 else 4, H, K, S, Bp * H,
+                         1 if Bp <= 64 else Bp // 64, 64 * 4 * H, 0, 64 * H)
+                ops.call('gt_lstm_cell_bwd', ops.slabs(part, S, Bp * H, H), ops.NO_SLABS, ops.NO_SLABS, ops.ptr(dhdir[t - 1], 4),
+                         H + 8, dc, gates[t - 1], c[t], c[t - 1], keep[t - 1], p, None, dG[t - 1], dc, None, Bsz, H)
+        return dG, dc, counters
+
+    ref, got = run(False), run(True)
+    close(got[0][:, :Bsz], ref[0][:, :Bsz], rtol=1e-5, atol=1e-6, what='dG')
+    close(got[1][:Bsz], ref[1][:Bsz], rtol=1e-5, atol=1e-6, what='dc')
+    assert float(got[0][:, Bsz:].abs().max()) == 0.0 if Bsz < Bp else True       # pad rows untouched
+    assert int(got[2].min()) == int(got[2].max()) == ((T - 1) * S if S > 1 else 0)
+
+
 @pytest.mark.parametrize('Bsz,H,A,S', [(64, 1024, 128, 6), (5, 32, 8, 2), (70, 64, 40, 3)])
 def test_cell_bwd_query_fused(dev, Bsz, H, A, S):
     """gt_cell_bwd_query = gt_lstm_cell_bwd whose dh also receives dq . Wq computed inside the kernel."""
