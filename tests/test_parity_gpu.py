@@ -176,6 +176,15 @@ def test_fused_attention_backward_step_against_oracle(dev, monkeypatch):
     _midsize_against_oracle(dev, 'full_dims_b20')
 
 
+def test_fused_decoder_lstm_backward_against_oracle(dev, monkeypatch):
+    """The opt-in one-launch decoder-LSTM backward step (GANTRON_REC_CELL bit 5: gt_rec_cellbwd) through a whole generator +
+    discriminator pair at the reference's dimensions, against the oracle."""
+    from gantron_amd import engine
+    monkeypatch.setattr(engine, 'REC_CELL', engine.REC_CELL | 32)
+    assert engine.HOIST2
+    _midsize_against_oracle(dev, 'full_dims_b20')
+
+
 def _midsize_against_oracle(dev, case):
     from gantron_amd.hparams import HParams
     from oracle import gantron_ref as R
