@@ -86,8 +86,24 @@ def check_handoffs():
                                'last check are invalid (GANTRON_ATTN_STEP=0 selects the two-launch attention step)')
 
 
+# GANTRON_POISON=1 (tests): buffers that are NOT zero-initialised start as NaN, so that a read of anything the kernels have
+# not written shows up in the results
+POISON = _os.environ.get('GANTRON_POISON', '0') == '1'
+
+
 def _f32(*shape, device, zero=True):
+    if not zero and POISON:
+        return torch.full(shape, float('nan'), device=device, dtype=torch.float32)
     return (torch.zeros if zero else torch.empty)(*shape, device=device, dtype=torch.float32)
+
+
+def _state(T1, Bp, H, device, zero):
+    """(T1, Bp, H) cell-state history whose slice 0 is the zero initial state; the rest is written step by step (zero = False:
+    only slice 0 is cleared)."""
+    t = _f32(T1, Bp, H, device=device, zero=zero)
+    if not zero:
+        t[0].zero_()
+    return t
 
 
 def _run(name, struct):
@@ -581,13 +597,18 @@ class GeneratorEngine:
             (roundup(K1, 16), roundup(K2, 16))
         if hoist2:
             ld2 = roundup(Ha + Ep, 16)          # X2 is the (To, Bp, ld2) history of [h_att_t | ctx_t]
-        ws = dict(X1=_f32(2, Bp, ld1, device=dev), X2=_f32(To if hoist2 else DEC_RING, Bp, ld2, device=dev),
+        # The per-step histories (5.2 GB at the benchmark batch, forward + backward) are written element for element by the
+        # loop kernels for every row < B; they only have to start as zeros where the loops leave something unwritten that a
+        # later GEMM reads: padded rows (Bp > B), padded context columns (Ep > E), padded leading dimensions.
+        zh = not (Bp == B and Ep == E)
+        ws = dict(X1=_f32(2, Bp, ld1, device=dev),
+                  X2=_f32(To if hoist2 else DEC_RING, Bp, ld2, device=dev, zero=zh or not hoist2 or ld2 != Ha + Ep),
                   part=_f32(max(d.S1 * Bp * 4 * Ha, d.S2 * Bp * 4 * Hd, d.Sq * Bp * Apad), device=dev, zero=False),
                   part2=_f32(d.S2 * Bp * 4 * Hd, device=dev, zero=False),
                   energies=_f32(B, Ti, device=dev, zero=False))
-        hist = dict(gates1=_f32(To, Bp, 4 * Ha, device=dev), c1=_f32(To + 1, Bp, Ha, device=dev),
-                    gates2=_f32(To, Bp, 4 * Hd, device=dev), c2=_f32(To + 1, Bp, Hd, device=dev),
-                    hatt=_f32(To, Bp, Ha, device=dev), HC=_f32(To, Bp, Hd + Ep, device=dev),
+        hist = dict(gates1=_f32(To, Bp, 4 * Ha, device=dev, zero=zh), c1=_state(To + 1, Bp, Ha, dev, zh),
+                    gates2=_f32(To, Bp, 4 * Hd, device=dev, zero=zh), c2=_state(To + 1, Bp, Hd, dev, zh),
+                    hatt=_f32(To, Bp, Ha, device=dev, zero=zh), HC=_f32(To, Bp, Hd + Ep, device=dev, zero=zh),
                     w_hist=_f32(To + 1, B, Ti, device=dev), cum_hist=_f32(To + 1, B, Ti, device=dev),
                     q_hist=_f32(To, B, A, device=dev, zero=False))
         al = 'decoder.attention_layer.'
@@ -884,7 +905,8 @@ class GeneratorEngine:
         Wc, Wd, v = (P[al + 'location_layer.location_conv.conv.weight'],
                      P[al + 'location_layer.location_dense.linear_layer.weight'], P[al + 'v.linear_layer.weight'])
         dims = ops.attn_dims(B, Ti, Ep, A, self.F, self.Kc)
-        buf = dict(dG1=_f32(To, Bp, 4 * Ha, device=dev), dG2=_f32(To, Bp, 4 * Hd, device=dev),
+        zh = not (Bp == B)          # as in forward(): the gate-gradient histories are written for every row < B
+        buf = dict(dG1=_f32(To, Bp, 4 * Ha, device=dev, zero=zh), dG2=_f32(To, Bp, 4 * Hd, device=dev, zero=zh),
                    dctx_hist=_f32(To, B, Ep, device=dev, zero=False), dpm=_f32(B, Ti, A, device=dev),
                    acc=_f32(int(lib().gt_attn_acc_elems(dims)), device=dev),
                    dc1=_f32(Bp, Ha, device=dev), dc2=_f32(Bp, Hd, device=dev), dwcat=_f32(2, 2, B, Ti, device=dev),
