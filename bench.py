@@ -216,6 +216,28 @@ def cpu_baseline(seconds_budget=45.0):
                        f'median {t:.2f} s per pair')
 
 
+def self_launch(world):
+    """`python bench.py --gpus N` without a launcher: one child process per GPU with the torchrun environment
+    (gantron_amd.multiproc.worker_env: RANK / LOCAL_RANK / WORLD_SIZE, MASTER_ADDR=127.0.0.1, a free port, dmabuf IPC),
+    the same command line, supervised (a failing rank stops the others instead of leaving them in a collective).  Rank 0
+    inherits stdout, so its one JSON line is this command's; every rank shares stderr.  The counterpart of the
+    reference's multiproc.py:13-23, which starts `train.py --rank=i` once per GPU."""
+    import subprocess
+    from gantron_amd.multiproc import _free_port, supervise, worker_env
+    port = _free_port()
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for rank in range(world):
+        procs.append(subprocess.Popen(cmd, env=worker_env(rank, world, port),
+                                      stdout=None if rank == 0 else subprocess.DEVNULL))
+    try:
+        return supervise(procs, poll_s=0.2)
+    except KeyboardInterrupt:
+        for p in procs:
+            p.terminate()
+        return 130
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -243,10 +265,16 @@ def main():
             args.batch = 128
         args.bf16 = True
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # the plain command (`python bench.py --gpus N`, no launcher): start the N ranks from here.  Nothing in this
+        # process has touched the GPU yet (importing torch does not), and it never will: it only supervises.
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if world != args.gpus:
+        sys.exit(f'bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}; start it as `python bench.py --gpus N` '
+                 f'(it launches its own ranks) or under torch.distributed.run with --nproc-per-node equal to --gpus')
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP extension has no CPU fallback)'
     # rehearsal on a 1-GPU box (tests/test_training_gpu.py): every rank on device 0 and gloo carrying the CUDA
     # tensors, so that the N > 1 control flow of this script runs before the driver's multi-GPU launch does
@@ -357,9 +385,14 @@ def main():
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        per_rank = [torch.zeros_like(t) for _ in range(world)]          # every rank's own clock: a straggler shows here
+        dist.all_gather(per_rank, torch.tensor([elapsed, float(frames)], device=dev, dtype=torch.float64))
+        rank_ms = [float(x[0]) / args.steps * 1e3 for x in per_rank]
+        rank_frames = [int(x[1]) for x in per_rank]
         elapsed, total_frames = float(tmax[0]), float(t[1])
     else:
         total_frames = float(frames)
+        rank_ms, rank_frames = [elapsed / args.steps * 1e3], [frames]
 
     # ---- SURVEY 8(d) side figures (outside the timed region): G step and D step alone, for the
     # schedule-faithful mix of g_freq=2 generator steps per d_freq=1 discriminator step (hparams.py:95-96)
@@ -391,6 +424,8 @@ def main():
         dist.all_gather(allc, mine)
         allc = torch.stack(allc).cpu()
         dist_info = dict(backend=dist.get_backend(), world_size=dist.get_world_size(),
+                         ms_per_step_min=min(rank_ms), ms_per_step_max=max(rank_ms), ms_per_step_by_rank=[round(x, 3) for x in rank_ms],
+                         valid_frames_by_rank=rank_frames,
                          flat_grad_mb=G._flat_grad.numel() * 4 / 1e6,
                          grad_checksum=[float(allc[0, 0]), float(allc[0, 1])],
                          grad_checksum_equal_on_all_ranks=bool((allc == allc[0:1]).all()))

@@ -2,6 +2,7 @@
 
     python -m gantron_amd.csrc.build        # or: python gantron_amd/csrc/build.py
 """
+import glob
 import os
 import subprocess
 import sys
@@ -31,7 +32,9 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     hipcc = _hipcc()
-    headers = [os.path.join(HERE, 'common.h'), os.path.join(PKG, '..', 'include', 'gantron_hip.h')]
+    # every header next to the sources holds device code of some kernel (rec_cell.h, attn_ctx_bwd.h, ...): any of them
+    # newer than an object rebuilds it
+    headers = sorted(glob.glob(os.path.join(HERE, '*.h'))) + [os.path.join(PKG, '..', 'include', 'gantron_hip.h')]
     objdir = os.path.join(HERE, 'build')
     os.makedirs(objdir, exist_ok=True)
     jobs = []

@@ -127,7 +127,16 @@ def apply_gradient_allreduce(module):
         module.__dict__.setdefault('_early_buckets', []).append((rng[0], rng[1], work))
     module._bucket_ready = bucket_ready
 
+    def drain_stale():
+        """A backward pass that raised after the hook queued its callback, or after a bucket went on the wire, must not
+        leave the NEXT step without its all-reduce: every forward starts from a clean state."""
+        state['queued'] = False
+        for _, _, work in getattr(module, '_early_buckets', None) or []:
+            work.wait()
+        module._early_buckets = []
+
     def set_needs_reduction(mod, inputs, output):
+        drain_stale()
         mod.needs_reduction = True
 
     module.register_forward_hook(set_needs_reduction)
@@ -137,6 +146,7 @@ def apply_gradient_allreduce(module):
         inner = module.adversarial_loss
 
         def adversarial_loss(*a, **k):
+            drain_stale()
             module.needs_reduction = True
             return inner(*a, **k)
         module.adversarial_loss = adversarial_loss

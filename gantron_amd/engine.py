@@ -91,6 +91,16 @@ def check_handoffs():
 POISON = _os.environ.get('GANTRON_POISON', '0') == '1'
 
 
+# Tests and tools/enc_grad_probe.py: when a dict, named intermediates of the next forward / backward are cloned into it
+# (encoder activations whose signs are the ReLU decisions, d(memory), the gradient entering the encoder convolutions).
+TAPS = None
+
+
+def _tap(name, value):
+    if TAPS is not None:
+        TAPS[name] = [v.detach().clone() for v in value] if isinstance(value, (list, tuple)) else value.detach().clone()
+
+
 def _f32(*shape, device, zero=True):
     if not zero and POISON:
         return torch.full(shape, float('nan'), device=device, dtype=torch.float32)
@@ -432,6 +442,7 @@ class GeneratorEngine:
         sv['enc_conv'] = []
         x = self.enc_stack.forward(P, x, B, Ti, rng.get('enc_keep'), training, sv['enc_conv'])
         sv['enc_x3'] = x
+        _tap('enc_act', [s_['x'] for s_ in sv['enc_conv'][1:]] + [x])     # block outputs: (B*Ti, C) after BN, ReLU, dropout
 
         PHASES.mark('f.enc_conv')
         # ---- packed BiLSTM, step-major
@@ -1041,6 +1052,7 @@ class GeneratorEngine:
         LEAF.run(lambda: ops.linear_dw(buf['dpm'], sv['memory'], B * Ti, A, E, G[al + 'memory_layer.linear_layer.weight'],
                                        ldx=Ep), buf['dpm'])
 
+        _tap('dmem', dmem)
         col = 2 * H
         if self.vesus:
             se = hp.speakers_embedding
@@ -1087,6 +1099,7 @@ class GeneratorEngine:
         call('gt_gather_rows', dXs[0], C, idx['ifwd'], B * Ti, C, dx3, C, 0)
         call('gt_gather_rows', dXs[1], C, idx['irev'], B * Ti, C, dx3, C, 1)
 
+        _tap('dx3', dx3)
         PHASES.mark('b.bilstm')
         # ---- encoder convolutions + embedding
         demb = self.enc_stack.backward(P, G, dx3, B, Ti, sv['enc_conv'])

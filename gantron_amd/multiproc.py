@@ -71,14 +71,35 @@ def supervise(procs, poll_s=0.5, grace_s=10.0):
     return status
 
 
+_OWN_FLAGS = {'--gpus': 1, '--log-dir': 1, '--no-rank-flags': 0, '-h': 0, '--help': 0}
+
+
+def split_command_line(argv):
+    """The launcher's own options end at the first token that is not one of them (`-m`, a script path, `--`): everything
+    from there on is the target's command line, passed through untouched.  (argparse.REMAINDER cannot do this: it
+    refuses an option-like first token such as `-m`.)"""
+    i = 0
+    while i < len(argv):
+        key = argv[i].split('=', 1)[0]
+        if key not in _OWN_FLAGS:
+            break
+        i += 1 + (_OWN_FLAGS[key] if '=' not in argv[i] else 0)
+    own, target = argv[:i], argv[i:]
+    if target[:1] == ['--']:
+        target = target[1:]
+    return own, target
+
+
 def main(argv=None):
-    ap = argparse.ArgumentParser(prog='gantron_amd.multiproc', description=__doc__.split('\n')[0])
+    ap = argparse.ArgumentParser(prog='gantron_amd.multiproc', description=__doc__.split('\n')[0],
+                                 usage='%(prog)s [--gpus N] [--log-dir DIR] [--no-rank-flags] (-m module | script.py) [arguments ...]')
     ap.add_argument('--gpus', type=int, default=0, help='processes to start (default: every visible GPU)')
     ap.add_argument('--log-dir', default='logs')
     ap.add_argument('--no-rank-flags', action='store_true',
                     help='do not append --n_gpus/--rank/--group_name (the target reads the environment only)')
-    ap.add_argument('target', nargs=argparse.REMAINDER, help='[-m module | script.py] followed by its arguments')
-    args = ap.parse_args(argv)
+    own, target = split_command_line(list(sys.argv[1:] if argv is None else argv))
+    args = ap.parse_args(own)
+    args.target = target
     if not args.target:
         ap.error('nothing to launch')
     world = args.gpus or _visible_gpus()

@@ -62,7 +62,12 @@ def flat_range(module, prefix):
     """[begin, end) of the flat buffers covered by the parameters whose names start with `prefix` (contiguous when the
     prefix names a sub-module)."""
     hits = [(o, o + -(-n // 4) * 4) for k, o, n in module._flat_layout if k.startswith(prefix)]
-    return (min(h[0] for h in hits), max(h[1] for h in hits)) if hits else None
+    if not hits:
+        return None
+    lo, hi = min(h[0] for h in hits), max(h[1] for h in hits)
+    if sum(e - b for b, e in hits) != hi - lo:
+        raise ValueError(f'parameters named {prefix}* are not contiguous in the flat buffer: [{lo}, {hi}) also holds others')
+    return lo, hi
 
 
 class FlatAdam:

@@ -174,17 +174,36 @@ def lstm_cell(x: Tensor, h: Tensor, c: Tensor, w_ih: Tensor, w_hh: Tensor,
 
 # ----------------------------------------------------------------------------- encoder
 def encoder_forward(P, embedded: Tensor, lengths: Tensor, enc_keep: Optional[List[Tensor]],
-                    training: bool = True, new_stats=None) -> Tensor:
+                    training: bool = True, new_stats=None, relu_pos: Optional[List[Tensor]] = None,
+                    relu_report: Optional[list] = None) -> Tensor:
     """Encoder.forward, model.py:193-212.  embedded: (B, 512, Ti).
     3x[conv5 -> BN -> ReLU -> dropout .5] then a length-packed BiLSTM whose outputs
-    are zero beyond each length."""
+    are zero beyond each length.
+
+    relu_pos (parity tests at >= 1024 encoder rows): per block a bool (B, C, Ti) tensor saying which KEPT elements the
+    implementation under test let through its ReLU.  Of B*Ti*512 pre-activations a few lie within fp32 rounding of zero,
+    and on which side such an element falls depends on the summation order of the convolution before it; one flipped
+    element moves a whole channel's slice of the weight gradients below it.  With relu_pos the restatement takes the
+    other side's DECISION (x * pos instead of relu(x)) wherever its own pre-activation is that close to zero, so that both
+    differentiate the same piecewise-linear function; every disagreement is appended to relu_report as (block, count,
+    largest |pre-activation| among the disagreeing elements, scale) for the caller to bound -- a decision that differs
+    anywhere else is a real error and shows there (and in the outputs)."""
     x = embedded
     n_conv = len([k for k in P if k.startswith('encoder.convolutions.') and k.endswith('.0.conv.weight')])
     for i in range(n_conv):
         w = P[f'encoder.convolutions.{i}.0.conv.weight']
         x = conv1d(x, w, P[f'encoder.convolutions.{i}.0.conv.bias'], padding=(w.size(2) - 1) // 2)
         x = batch_norm_train(x, P, f'encoder.convolutions.{i}.1', training, new_stats)
-        x = keep_scale(F.relu(x), enc_keep[i] if (enc_keep is not None and training) else None, 0.5)
+        keep = enc_keep[i] if (enc_keep is not None and training) else None
+        if relu_pos is not None:
+            kept = torch.ones_like(x, dtype=torch.bool) if keep is None else keep.to(torch.bool)
+            differs = ((x.detach() > 0) != relu_pos[i]) & kept
+            if relu_report is not None:
+                n = int(differs.sum())
+                relu_report.append((i, n, float(x.detach().abs()[differs].max()) if n else 0.0, float(x.detach().abs().max())))
+            x = keep_scale(x * (relu_pos[i] & kept).to(x.dtype), keep, 0.5)
+            continue
+        x = keep_scale(F.relu(x), keep, 0.5)
     x = x.transpose(1, 2)  # (B, Ti, C)
     return bilstm_packed(P, x, lengths)
 
@@ -335,7 +354,8 @@ def generator_forward(P, text: Tensor, text_lengths: Tensor, mels: Tensor, outpu
         if dec_noise is not None:
             emb = torch.cat((emb, dec_noise[:, :, None].repeat(1, 1, emb.size(-1))), dim=1)
         dec_noise = None
-    enc = encoder_forward(P, emb, text_lengths, rng.get('enc_keep'), training, new_stats)
+    enc = encoder_forward(P, emb, text_lengths, rng.get('enc_keep'), training, new_stats,
+                          relu_pos=rng.get('enc_relu_pos'), relu_report=rng.get('enc_relu_report'))
     if 'speaker_embedding.weight' in P:                                      # model.py:655-663
         spk = F.embedding(speaker_ids, P['speaker_embedding.weight'])[:, None].repeat(1, enc.size(1), 1)
         if use_labels and not encoder_inputs:

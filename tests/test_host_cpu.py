@@ -209,6 +209,45 @@ def test_multiproc_launcher_env_and_supervision(tmp_path):
     t0 = time.time()
     r = subprocess.run(base + ['--fail'], env=env, capture_output=True, text=True, timeout=60)
     assert r.returncode == 7 and time.time() - t0 < 30, (r.returncode, r.stderr)
+    # the module form the docstring and the README document: `multiproc [options] -m package.module <arguments>`
+    pkg = tmp_path / 'wpkg'
+    pkg.mkdir()
+    (pkg / '__init__.py').write_text('')
+    (pkg / 'job.py').write_text('from . import __name__ as pkg_name\n' + script.read_text() + 'assert "--extra=1" in sys.argv\n')
+    for sep in ([], ['--']):
+        cmd = [sys.executable, '-m', 'gantron_amd.multiproc', '--gpus=2', '--log-dir', str(tmp_path / 'logs_m')] + sep + \
+              ['-m', 'wpkg.job', '--extra=1']
+        r = subprocess.run(cmd, env=dict(env, PYTHONPATH=ROOT + os.pathsep + str(tmp_path)), capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and 'worker 0 of 2' in r.stdout, (r.returncode, r.stderr)
+
+
+def test_bench_plain_command_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher in front (no WORLD_SIZE): bench.py starts the two ranks itself and
+    supervises them.  Without a GPU each rank stops at its "needs a GPU" check, so what is visible here is the launch
+    itself: two children with RANK 0 / 1, a failing rank reported by the supervisor, its status propagated, no hang and
+    no JSON line.  (The GPU box runs the same command to completion: tests/test_training_gpu.py.)"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       env=env, capture_output=True, text=True, timeout=300)
+    if torch.cuda.is_available():
+        pytest.skip('GPU present: covered by test_bench_two_ranks_rehearsal')
+    assert r.returncode != 0 and '[multiproc] rank' in r.stderr and 'needs a GPU' in r.stderr, (r.returncode, r.stderr[-2000:])
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    # under a launcher whose world size contradicts --gpus the command refuses instead of asserting somewhere inside
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=dict(env, WORLD_SIZE='4', RANK='0'),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'WORLD_SIZE=4' in r.stderr
+
+
+def test_multiproc_splits_its_own_options_from_the_target():
+    from gantron_amd.multiproc import split_command_line
+    assert split_command_line(['--gpus', '4', '-m', 'gantron_amd.train', '-o', 'out', '--gpus', '9']) == \
+        (['--gpus', '4'], ['-m', 'gantron_amd.train', '-o', 'out', '--gpus', '9'])
+    assert split_command_line(['--no-rank-flags', '--log-dir=x', 'bench.py', '--gpus', '2']) == \
+        (['--no-rank-flags', '--log-dir=x'], ['bench.py', '--gpus', '2'])
+    assert split_command_line(['--gpus', '2', '--', '-m', 'mod']) == (['--gpus', '2'], ['-m', 'mod'])
+    assert split_command_line([]) == ([], [])
 
 
 @pytest.mark.parametrize('tag', ['lj', 'vesus', 'vesus_multi'])

@@ -43,7 +43,12 @@ def run_pair_hip(hp, g_state, d_state, batch, mask_seed, dev, vesus=False):
         p.requires_grad = False
     G.zero_grad()
     x, y = G.parse_batch(batch)
-    y_pred = G(x)
+    from gantron_amd import engine
+    engine.TAPS = taps = {}
+    try:
+        y_pred = G(x)
+    finally:
+        engine.TAPS = None
     mel_loss, gate_loss, attn_loss = crit(y_pred, y, x[1], x[-1])
     adv = D.adversarial_loss(y_pred[1], x[-1])
     total = mel_loss + gate_loss + adv + 10 * attn_loss
@@ -54,6 +59,8 @@ def run_pair_hip(hp, g_state, d_state, batch, mask_seed, dev, vesus=False):
                buffers={k: v.detach().cpu() for k, v in G.state_dict().items()
                         if k.endswith(('running_mean', 'running_var'))})
     res['g_loss'] = {k: v.detach().cpu() for k, v in res['g_loss'].items()}
+    # which kept elements each encoder block let through its ReLU, in the oracle's (B, C, Ti) layout
+    res['enc_relu_pos'] = [(a.view(B, Ti, -1) > 0).transpose(1, 2).cpu() for a in taps['enc_act']]
     fake = y_pred[1].detach()
     for p in D.parameters():
         p.requires_grad = True
@@ -66,7 +73,6 @@ def run_pair_hip(hp, g_state, d_state, batch, mask_seed, dev, vesus=False):
     d_loss.backward()
     res['d_loss'] = dict(real=real_loss.detach().cpu(), fake=fake_loss.detach().cpu(), total=d_loss.detach().cpu())
     res['d_grad'] = {k: p.grad.detach().cpu() for k, p in D.named_parameters()}
-    from gantron_amd import engine
     engine.check_handoffs()
     return res
 
@@ -151,14 +157,21 @@ def test_full_size_matches_reference_summaries(dev, golden_dir, name):
 
 @pytest.mark.parametrize('case', ['ragged5', 'batch70', 'full_dims_b64', 'full_dims_b20', 'full_dims_long', 'ragged5_bf16',
                                   'full_dims_b20_bf16', 'full_dims_b64_t200', 'vesus_b64', 'vesus_b128_bf16',
-                                  'full_dims_b64_bf16', 'ragged5_f32pipe', 'full_dims_b64_f32pipe'])
-def test_midsize_against_oracle(dev, case):
+                                  'full_dims_b64_bf16', 'ragged5_f32pipe', 'full_dims_b64_f32pipe',
+                                  'full_dims_b64_poison', 'batch70_poison', 'full_dims_b64_bf16_poison', 'vesus_b64_poison'])
+def test_midsize_against_oracle(dev, case, monkeypatch):
     """B=5 (padded to 16 rows) with ragged lengths and To not a multiple of the discriminator window, and
     B=70 (> 64 rows: two 64-row blocks per recurrent launch): HIP path vs the CPU oracle on identical
     seeded inputs and masks.  *_f32pipe: the same case with the tiled GEMMs on the fp32 matrix pipe
     (gt_sgemm_set_fp32_split(0)) instead of the default three-plane bf16 split."""
     import contextlib
-    from gantron_amd import ops
+    from gantron_amd import engine, ops
+    if case.endswith('_poison'):
+        # *_poison: every buffer the engine does not zero-fill starts as NaN (engine.POISON, GANTRON_POISON=1) -- with
+        # no padded rows (B = 64) the per-step histories are torch.empty: a read of anything the loop kernels have
+        # not written shows up in the outputs / gradients instead of passing on stale-but-finite allocator memory
+        monkeypatch.setattr(engine, 'POISON', True)
+        case = case[:-len('_poison')]
     if case.endswith('_f32pipe'):
         with ops.fp32_split(0):
             return _midsize_against_oracle(dev, case[:-len('_f32pipe')])
@@ -257,7 +270,23 @@ def _midsize_against_oracle(dev, case):
     rng['disc_keep'] = common.draw_disc_keep(stream, hp, B, To)
     Gp = {k: v for k, v in Gp.items() if not k.endswith('num_batches_tracked')}
     obatch = (text, il, mel, gate, ol, spk.long(), emo) if vesus else (text, il, mel, gate, ol)
+    big_encoder = B * Ti >= 1024
+    if big_encoder:
+        # ReLU decisions of the encoder blocks: with B*Ti*512 pre-activations per block a few lie within fp32 rounding of
+        # zero and land on either side depending on the convolution's summation order; ONE flipped element moves a
+        # channel's slice of the weight gradients below it by percents of the tensor's max-abs.  The oracle therefore
+        # takes the HIP path's decisions (oracle/gantron_ref.py: encoder_forward(relu_pos=...)) and reports every
+        # element where its own differed: those must be few and all within rounding of zero -- then both sides
+        # differentiate the same function and every encoder tensor is held to the uniform tolerance again.
+        rng['enc_relu_pos'], rng['enc_relu_report'] = res['enc_relu_pos'], []
     out, losses, grads, new_stats = R.generator_step_grads(Gp, Dp, obatch, rng, hp)
+    if big_encoder:
+        assert len(rng['enc_relu_report']) == hp.encoder_n_convolutions
+        for blk, n, zmax, scale in rng['enc_relu_report']:
+            # fp32: only summation-order noise separates the two pre-activations; bf16 mode: an input on a bf16 rounding
+            # boundary moves one product term by 2^-8 relative
+            assert n <= 64 and zmax <= (5e-3 if bf16 else 2e-5) * scale, \
+                f'encoder block {blk}: {n} ReLU decisions differ from the oracle, largest |pre-activation| {zmax:.3e} of {scale:.3e}'
     for name, t in zip(('mel', 'mel_post', 'gate', 'align'), out):
         close(res['out'][name], t, rtol=OT, atol=1e-5, what=f'out.{name}')
     if bf16 and case == 'ragged5':
@@ -275,20 +304,7 @@ def _midsize_against_oracle(dev, case):
     bad = []
     for k, v in grads.items():
         try:
-            if k.startswith(('encoder.convolutions.', 'embedding.')) and float(v.abs().max()) > 100 * GA and B * Ti >= 1024:
-                # ReLU-threshold sensitivity: with B*Ti*512 pre-activations per encoder block, a few lie within fp32
-                # rounding of zero and fall on the other side of the ReLU for another summation order (tools/
-                # convstack_probe.py counts them against float64).  One such element moves one channel's slice of the
-                # weight gradients below it by percents of the tensor's max-abs while every other entry agrees to
-                # 1e-5 (measured relative L2 per tensor: 1e-3 with one such element, 2.7e-3 with two -- which of the two
-                # happens depends on the order of the split-K atomics in the forward convolutions): these tensors are
-                # held to a relative L2 error of 5e-3 instead, with a loose max-abs bound
-                got = res['g_grad'][k].double()
-                l2 = float((got - v.double()).norm() / (v.double().norm() + 1e-30))
-                assert l2 <= (5e-2 if bf16 else 5e-3), f'g_grad.{k}: relative L2 error {l2:.3e}'
-                close(got, v, rtol=0.3 if bf16 else 6e-2, atol=GA, what=f'g_grad.{k}')
-            else:
-                close(res['g_grad'][k], v, rtol=GT, atol=GA, what=f'g_grad.{k}')
+            close(res['g_grad'][k], v, rtol=GT, atol=GA, what=f'g_grad.{k}')
         except AssertionError as e:
             bad.append(str(e))
     keep_real = common.draw_disc_keep(stream, hp, B, To)
@@ -588,3 +604,39 @@ def test_full_size_training_step_is_schedule_invariant(dev, monkeypatch):
         except AssertionError as e:
             bad.append(str(e))
     assert not bad, '\n'.join(bad)
+
+
+_GRAPH_WORKER = r'''
+import os, sys
+root = sys.argv[1]
+for p in (root, os.path.join(root, 'tests'), os.path.join(root, 'tests', 'golden')):
+    sys.path.insert(0, p)
+import torch
+import test_parity_gpu as T
+dev = torch.device('cuda:0')
+side = torch.cuda.Stream()            # stream capture cannot run on the legacy default stream
+with torch.cuda.stream(side):
+    for _ in range(2):                # the second pass finds its loop calls in the graph cache when the allocator hands
+        T._midsize_against_oracle(dev, sys.argv[2])        # back the same blocks; either way every result is checked
+torch.cuda.synchronize()
+print('graph worker OK')
+'''
+
+
+@pytest.mark.parametrize('case', ['full_dims_b20', 'full_dims_b64_t200'])
+def test_graph_replayed_decoder_loops_against_oracle(dev, tmp_path, case):
+    """BASELINE config 5 names a "hipGraph-captured decoder inner loop": GANTRON_GRAPH makes gt_decoder_fwd / gt_decoder_bwd
+    capture a loop call (both streams and their hand-off events) into a hipGraph and replay it (loops.hip: run_graphed).
+    The switch is read once per process, so the case runs in a child process: a whole generator + discriminator pair at the
+    reference's dimensions against the oracle, twice, with every loop call going through capture + launch.  (Measured
+    slower than eager issue -- DESIGN.md section 3 -- hence off by default; this keeps the path correct.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'graph_worker.py'
+    script.write_text(_GRAPH_WORKER)
+    env = dict(os.environ, GANTRON_GRAPH='2')          # 2: also report capture / replay on stderr
+    out = subprocess.run([sys.executable, str(script), root, case], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    assert 'graph worker OK' in out.stdout
+    assert out.stderr.count('[graph] capture') >= 2, out.stderr[-2000:]       # forward loop + at least one backward chunk

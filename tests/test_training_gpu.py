@@ -387,7 +387,8 @@ _, gen = generator_step(G, D, g_opt, crit, batch, hp, iteration=0)
 g_grad = G._flat_grad.detach().cpu().numpy().copy()
 discriminator_step(G, D, d_opt, batch, gen, hp)
 d_grad = D._flat_grad.detach().cpu().numpy().copy()
-np.savez(os.path.join(out, f'w{world}_rank{rank}.npz'), g_grad=g_grad, d_grad=d_grad,
+from gantron_amd.optim import flat_range
+np.savez(os.path.join(out, f'w{world}_rank{rank}.npz'), g_grad=g_grad, d_grad=d_grad, postnet_range=np.array(flat_range(G, 'postnet.')),
          g_param=G._flat_param.detach().cpu().numpy(), d_param=D._flat_param.detach().cpu().numpy())
 if world > 1:
     dist.destroy_process_group()
@@ -413,6 +414,18 @@ def test_data_parallel_step_two_processes_on_one_gpu(dev, tmp_path):
     for k in ('g_grad', 'd_grad', 'g_param', 'd_param'):
         close(torch.from_numpy(r0[k]), torch.from_numpy(r1[k]), rtol=1e-6, atol=1e-7, what=f'rank0 vs rank1 {k}')
     assert float(np.abs(r0['g_grad']).max()) > 0 and float(np.abs(r0['d_grad']).max()) > 0
+    # ... and that common value IS the mean of the two single-process gradients (each rank's batch run alone from rank
+    # 0's initial weights): a bucket reduced twice, or left out of the all-reduce, or a flat range that covers the wrong
+    # parameters would keep the ranks equal to each other but not to the mean.  The early (side-stream) bucket of
+    # `postnet.` is part of what this drives.
+    for r in range(2):
+        p = subprocess.Popen([sys.executable, str(script), str(r), '0', root, str(tmp_path), '1', MID], env=env)
+        assert p.wait(timeout=600) == 0
+    s0, s1 = np.load(tmp_path / 'w1_rank0.npz'), np.load(tmp_path / 'w1_rank1.npz')
+    close(torch.from_numpy(r0['g_grad']), torch.from_numpy((s0['g_grad'] + s1['g_grad']) / 2), rtol=1e-4, atol=1e-7,
+          what='averaged generator gradient vs mean of the single-process gradients')
+    layout = np.load(tmp_path / 'w2_rank0.npz')['postnet_range']
+    assert layout[1] > layout[0] and float(np.abs(r0['g_grad'][layout[0]:layout[1]]).max()) > 0
 
 
 def test_data_parallel_step_rccl_two_gpus(tmp_path):
@@ -488,7 +501,8 @@ def test_discriminator_step_with_gradient_penalty(dev):
     assert float((grads[10] - grads[0]).abs().max()) > 0
 
 
-def test_bench_two_ranks_rehearsal(dev, tmp_path):
+@pytest.mark.parametrize('launcher', ['self', 'torchrun'])
+def test_bench_two_ranks_rehearsal(dev, tmp_path, launcher):
     """bench.py's N > 1 control flow (per-rank batches, barriers, MAX / SUM reductions of the timings, rank 0 printing
     the one JSON line) on the 1-GPU test box: two ranks share device 0 and gloo carries the CUDA tensors
     (GANTRON_BENCH_DEVICE / GANTRON_BENCH_BACKEND exist for this rehearsal only; the driver's launch uses RCCL)."""
@@ -497,8 +511,13 @@ def test_bench_two_ranks_rehearsal(dev, tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, GANTRON_BENCH_DEVICE='0', GANTRON_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29611', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1', '--batch', '8']
+    # 'self': the plain command, `python bench.py --gpus 2` with no launcher and no WORLD_SIZE -- bench.py starts its own
+    # two ranks (before anything in the parent touches the GPU); 'torchrun': the driver's documented N > 1 launch
+    env.pop('WORLD_SIZE', None), env.pop('RANK', None), env.pop('LOCAL_RANK', None)
+    tail = [os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1', '--batch', '8']
+    cmd = [sys.executable] + tail if launcher == 'self' else \
+        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+         '--master-port', '29611'] + tail
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
@@ -506,6 +525,8 @@ def test_bench_two_ranks_rehearsal(dev, tmp_path):
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['steps'] == 1 and d['scaling'] == 'weak' and d['cpu_baseline'] is None
     assert d['dist']['backend'] == 'gloo' and d['dist']['world_size'] == 2 and d['dist']['grad_checksum_equal_on_all_ranks']
+    assert len(d['dist']['ms_per_step_by_rank']) == 2 and d['dist']['ms_per_step_max'] <= d['ms_per_step'] * 1.0001
+    assert d['dist']['ms_per_step_min'] > 0 and len(set(d['dist']['valid_frames_by_rank'])) == 2       # per-rank batches differ
     assert d['config']['global_batch'] == 16 and d['value'] > 0 and d['roofline'] is not None
 
 

@@ -1,0 +1,134 @@
+"""Where do the encoder-side gradient differences between two schedules of the SAME step come from?
+
+VERDICT r2 weak #2: with the deterministic forward (no split-K atomics in the forward convolutions) the benchmark schedule
+and the plain schedule still differ by up to 4e-3 of max-abs in the encoder convolution gradients while every other tensor
+agrees to 1e-5.  This probe separates the candidates on the benchmark batch (B=64 LJSpeech-shaped, To=870, training mode):
+
+  1. the benchmark schedule twice (B1, B2): run-to-run noise of one schedule (split-K atomics of the weight-gradient GEMMs);
+  2. plain schedule A against B1, with the gradients ENTERING the encoder tapped (d memory, dx3 = gradient of the
+     convolution stack's output): how far apart are the inputs of the encoder backward;
+  3. the same with every weight-gradient GEMM unsplit (deterministic: SPLITK targets = 1);
+  4. float64 backward of the encoder convolution stack (torch, on the device, the HIP path's own ReLU decisions) fed with
+     dx3 of A and of B1: what an EXACT backward makes of the difference that enters it -- if the float64 results differ as
+     much as the fp32 ones, the difference is the conditioning of the function (amplification), not the schedule.
+
+    python tools/enc_grad_probe.py          # ~1 minute on one MI355X
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'tests', 'golden')):
+    sys.path.insert(0, p)
+import torch
+
+import bench
+from gantron_amd import engine, ops
+from gantron_amd.hparams import HParams
+from gantron_amd.loss_function import Tacotron2Loss
+from gantron_amd.model import Tacotron2
+
+ENC = ('encoder.convolutions.', 'embedding.')
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30)), float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def main():
+    dev = torch.device('cuda:0')
+    hp = HParams('use_labels=False,use_noise=True')
+    torch.manual_seed(0)
+    G = Tacotron2(hp).to(dev).train()
+    batch = bench.ljspeech_shaped_batch(hp, 64, seed=3)
+    x, y = G.parse_batch(batch)
+    G.rng_override = G.draw_rng(64, x[0].size(1), x[2].size(2), dev)
+    crit = Tacotron2Loss()
+    bn0 = {k: v.clone() for k, v in G.state_dict().items() if 'running' in k or 'num_batches' in k}
+    ops.FWD_SPLITK = False
+
+    def run():
+        G.load_state_dict(bn0, strict=False)
+        G.zero_grad()
+        engine.TAPS = taps = {}
+        out = G(x)
+        m, gl, al = crit(out, y, x[1], x[-1])
+        (m + gl + 10 * al).backward()
+        torch.cuda.synchronize()
+        engine.TAPS = None
+        return {k: p.grad.detach().clone() for k, p in G.named_parameters()}, taps
+
+    saved = dict(DEC_RING=engine.DEC_RING, BWD_CHUNKS=engine.BWD_CHUNKS, ATTN_HOIST=engine.ATTN_HOIST,
+                 CELL_QUERY=engine.CELL_QUERY, HOIST2=engine.HOIST2, leaf=engine.LEAF.enabled)
+
+    def plain(on):
+        if on:
+            engine.DEC_RING, engine.BWD_CHUNKS, engine.ATTN_HOIST, engine.CELL_QUERY, engine.HOIST2 = 1, 1, False, False, False
+            engine.LEAF.enabled = False
+        else:
+            engine.DEC_RING, engine.BWD_CHUNKS, engine.ATTN_HOIST, engine.CELL_QUERY, engine.HOIST2 = \
+                saved['DEC_RING'], saved['BWD_CHUNKS'], saved['ATTN_HOIST'], saved['CELL_QUERY'], saved['HOIST2']
+            engine.LEAF.enabled = saved['leaf']
+
+    def report(title, ga, gb, ta=None, tb=None):
+        print(f'\n== {title}')
+        if ta is not None:
+            for k in ('dmem', 'dx3'):
+                print(f'   {k:55s} max-abs {rel(ta[k], tb[k])[0]:.2e}  rel-L2 {rel(ta[k], tb[k])[1]:.2e}')
+        worst = 0.0
+        for k in ga:
+            r = rel(ga[k], gb[k])
+            if k.startswith(ENC) and not k.endswith('conv.bias'):
+                print(f'   {k:55s} max-abs {r[0]:.2e}  rel-L2 {r[1]:.2e}')
+            elif not k.endswith('conv.bias'):
+                worst = max(worst, r[0])
+        print(f'   every other tensor: worst max-abs {worst:.2e}')
+
+    gB1, tB1 = run()
+    gB2, tB2 = run()
+    report('benchmark schedule, two runs (B1 vs B2)', gB2, gB1, tB2, tB1)
+    plain(True)
+    gA, tA = run()
+    plain(False)
+    report('plain schedule vs benchmark schedule (A vs B1)', gA, gB1, tA, tB1)
+
+    ex, ov = ops.SPLITK_EXPOSED, ops.SPLITK_OVERLAPPED
+    ops.SPLITK_EXPOSED = ops.SPLITK_OVERLAPPED = ops.SPLITK_TARGET = 1
+    gB3, tB3 = run()
+    gB4, tB4 = run()
+    report('benchmark schedule, weight-gradient GEMMs unsplit, two runs', gB4, gB3, tB4, tB3)
+    plain(True)
+    gA2, tA2 = run()
+    plain(False)
+    report('plain vs benchmark, weight-gradient GEMMs unsplit', gA2, gB3, tA2, tB3)
+    ops.SPLITK_EXPOSED, ops.SPLITK_OVERLAPPED, ops.SPLITK_TARGET = ex, ov, ex
+
+    # ---- float64 backward of the convolution stack from the two tapped dx3
+    P = {k: v.detach().double() for k, v in G.state_dict().items()}
+    text = x[0]
+    B, Ti = text.shape
+    pos = [(a.view(B, Ti, -1) > 0).transpose(1, 2) for a in tB1['enc_act']]
+    keeps = G.rng_override['enc_keep']
+
+    def conv_stack_grads(dx3):
+        W = [P[f'encoder.convolutions.{i}.0.conv.weight'].clone().requires_grad_(True) for i in range(3)]
+        emb = P['embedding.weight'].clone().requires_grad_(True)
+        h = torch.nn.functional.embedding(text, emb).transpose(1, 2)
+        for i in range(3):
+            h = torch.nn.functional.conv1d(h, W[i], P[f'encoder.convolutions.{i}.0.conv.bias'], padding=2)
+            h = torch.nn.functional.batch_norm(h, None, None, P[f'encoder.convolutions.{i}.1.weight'],
+                                               P[f'encoder.convolutions.{i}.1.bias'], True, 0.1, 1e-5)
+            h = h * pos[i].double() * keeps[i].view(B, Ti, -1).transpose(1, 2).double() * 2.0
+        g = torch.autograd.grad(h, W + [emb], dx3.view(B, Ti, -1).transpose(1, 2).double())
+        return dict(zip([f'encoder.convolutions.{i}.0.conv.weight' for i in range(3)] + ['embedding.weight'], g))
+
+    gA64, gB64 = conv_stack_grads(tA['dx3']), conv_stack_grads(tB1['dx3'])
+    print('\n== float64 backward of the convolution stack: dx3 of A vs dx3 of B1 (the inputs differ by the dx3 line above)')
+    for k in gA64:
+        print(f'   {k:55s} max-abs {rel(gA64[k], gB64[k])[0]:.2e}  rel-L2 {rel(gA64[k], gB64[k])[1]:.2e}'
+              f'   | HIP fp32 B1 vs float64(B1 dx3): max-abs {rel(gB1[k], gB64[k])[0]:.2e}')
+
+
+if __name__ == '__main__':
+    main()
