@@ -16,24 +16,59 @@ __device__ __forceinline__ float act_fwd(float z, int act) {
     return act == 1 ? fmaxf(z, 0.f) : (act == 2 ? tanhf(z) : z);
 }
 
-// fold two per-thread partials over the CR_TY row lanes and add them to out[c], out[C+c]
-__device__ __forceinline__ void col_fold(float s0, float s1, int c, int C, float* out) {
+// fold two per-thread partials over the CR_TY row lanes.  ws == NULL: add them to out[c], out[C+c] with one fp32 atomic per
+// (block, channel) -- the order of the row blocks, and with it the last bits of the sums, then depends on dispatch timing.
+// ws != NULL (deterministic form): the block's partials go to ws[blockIdx.y][2][Cp] and the LAST row block of a channel
+// group to arrive (ticket at ws + gridDim.y * 2 * Cp, zeroed by the launcher) adds all of them in row-block order -- the
+// same bits whatever else runs on the device.  BatchNorm statistics are computed this way: activations within rounding of a
+// ReLU threshold otherwise land on either side from one run (or one schedule) to the next, and one such element moves a
+// channel's slice of every gradient below it (tools/enc_grad_probe.py).
+// Hand-off form (MI355X_MICROARCH.md, Valid forms): only wave 0 stores; it drains its stores, one lane releases at agent
+// scope and draws the ticket; the last arriver acquires at agent scope before its plain loads.
+__device__ __forceinline__ void col_fold(float s0, float s1, int c, int C, float* out, float* ws) {
     __shared__ float red[2][CR_TY][CR_TX];
+    __shared__ unsigned last;
     red[0][threadIdx.y][threadIdx.x] = s0;
     red[1][threadIdx.y][threadIdx.x] = s1;
     __syncthreads();
-    if (threadIdx.y == 0 && c < C) {
-        float a = 0.f, b = 0.f;
+    if (threadIdx.y != 0) return;               // wave 0 finishes the job
+    float a = 0.f, b = 0.f;
 #pragma unroll
-        for (int i = 0; i < CR_TY; ++i) { a += red[0][i][threadIdx.x]; b += red[1][i][threadIdx.x]; }
-        atomicAdd(&out[c], a);
-        atomicAdd(&out[C + c], b);
+    for (int i = 0; i < CR_TY; ++i) { a += red[0][i][threadIdx.x]; b += red[1][i][threadIdx.x]; }
+    if (ws == nullptr) {
+        if (c < C) { atomicAdd(&out[c], a); atomicAdd(&out[C + c], b); }
+        return;
     }
+    const long Cp = (long)gridDim.x * CR_TX;
+    float* mine = ws + (long)blockIdx.y * 2 * Cp;
+    mine[c] = a;
+    mine[Cp + c] = b;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned* ticket = reinterpret_cast<unsigned*>(ws + (long)gridDim.y * 2 * Cp) + blockIdx.x;
+        last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.y - 1 ? 1u : 0u;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __builtin_amdgcn_wave_barrier();            // one wave: lane 0's LDS store is visible to the others after this
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (!last || c >= C) return;
+    a = b = 0.f;
+    for (unsigned y = 0; y < gridDim.y; ++y) {
+        a += __builtin_nontemporal_load(ws + (long)y * 2 * Cp + c);
+        b += __builtin_nontemporal_load(ws + (long)y * 2 * Cp + Cp + c);
+    }
+    out[c] = a;
+    out[C + c] = b;
 }
 
 // shift_first: sums of (x-K) and (x-K)^2 with K = x[0][c] (shifted-data variance); else sum x, sum x*y
 __global__ __launch_bounds__(256) void col_stats_kernel(const float* x, const float* y, long rows, int C,
-                                                        int shift_first, float* out) {
+                                                        int shift_first, float* out, float* ws) {
     const int c = blockIdx.x * CR_TX + threadIdx.x;
     const long r0 = (long)blockIdx.y * CR_ROWS;
     const long r1 = min(rows, r0 + CR_ROWS);
@@ -47,7 +82,7 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* x, const fl
             s1 += xv * yv;
         }
     }
-    col_fold(s0, s1, c, C, out);
+    col_fold(s0, s1, c, C, out, ws);
 }
 
 __global__ __launch_bounds__(256) void bn_fwd_kernel(const float* x, const float* stats, long rows, int C,
@@ -86,7 +121,7 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(const float* x, const float
 // dz = dy * keep*scale * act'(z); column sums of dz and dz*xhat
 __global__ __launch_bounds__(256) void bn_bwd1_kernel(const float* dy, const float* x, const float* mean_invstd,
                                                       const float* gamma, const float* beta, long rows, int C, int act,
-                                                      const uint8_t* keep, float scale, float* dz, float* sums) {
+                                                      const uint8_t* keep, float scale, float* dz, float* sums, float* ws) {
     const int c = blockIdx.x * CR_TX + threadIdx.x;
     const long r0 = (long)blockIdx.y * CR_ROWS;
     const long r1 = min(rows, r0 + CR_ROWS);
@@ -106,7 +141,7 @@ __global__ __launch_bounds__(256) void bn_bwd1_kernel(const float* dy, const flo
             s1 += d * xhat;
         }
     }
-    col_fold(s0, s1, c, C, sums);
+    col_fold(s0, s1, c, C, sums, ws);
 }
 
 __global__ __launch_bounds__(256) void bn_bwd2_kernel(const float* dz, const float* x, const float* mean_invstd,
@@ -429,15 +464,29 @@ inline unsigned flat_blocks(long n) { return (unsigned)std::min<long>(std::max<l
 
 #define ST ((hipStream_t)stream)
 
-extern "C" int gt_col_stats(const float* x, const float* y, int64_t rows, int32_t C, float* out2C, void* stream) {
+// floats of workspace the deterministic forms of gt_col_stats / gt_bn_act_drop_bwd1 need (partials + tickets)
+extern "C" int64_t gt_col_ws_elems(int64_t rows, int32_t C) {
+    const int64_t gx = cdiv(C, CR_TX), gy = cdiv64(rows, CR_ROWS);
+    return gy * 2 * gx * CR_TX + gx;
+}
+// zero either the output (atomic form) or the tickets (deterministic form)
+static int col_prepare(float* out2C, float* ws, int64_t rows, int32_t C, hipStream_t st, const char* who) {
+    const int64_t gx = cdiv(C, CR_TX), gy = cdiv64(rows, CR_ROWS);
+    hipError_t e = ws != nullptr ? hipMemsetAsync(ws + gy * 2 * gx * CR_TX, 0, sizeof(unsigned) * gx, st)
+                                 : hipMemsetAsync(out2C, 0, sizeof(float) * 2 * C, st);
+    GT_REQUIRE(e == hipSuccess, (int)e, "%s: memset failed", who);
+    return 0;
+}
+
+extern "C" int gt_col_stats(const float* x, const float* y, int64_t rows, int32_t C, float* out2C, float* ws, void* stream) {
     GT_REQUIRE(x && out2C && rows > 0 && C > 0, GT_E_ARG, "gt_col_stats: bad argument");
-    hipError_t e = hipMemsetAsync(out2C, 0, sizeof(float) * 2 * C, ST);
-    GT_REQUIRE(e == hipSuccess, (int)e, "gt_col_stats: memset failed");
+    int rc = col_prepare(out2C, ws, rows, C, ST, "gt_col_stats");
+    if (rc != 0) return rc;
     dim3 grid(cdiv(C, CR_TX), (unsigned)cdiv64(rows, CR_ROWS));
     // y == x selects the shifted-variance form used by BatchNorm forward
     const int shift_first = (y == x) ? 1 : 0;
     hipLaunchKernelGGL(col_stats_kernel, grid, dim3(CR_TX, CR_TY), 0, ST, x, shift_first ? nullptr : y, (long)rows, C,
-                       shift_first, out2C);
+                       shift_first, out2C, ws);
     GT_LAUNCH_CHECK();
     return 0;
 }
@@ -458,13 +507,13 @@ extern "C" int gt_bn_act_drop_fwd(const float* x, const float* stats, int64_t ro
 
 extern "C" int gt_bn_act_drop_bwd1(const float* dy, const float* x, const float* mean_invstd, const float* gamma,
                                    const float* beta, int64_t rows, int32_t C, int32_t act, const uint8_t* keep,
-                                   float p_drop, float* dz, float* sums2C, void* stream) {
+                                   float p_drop, float* dz, float* sums2C, float* ws, void* stream) {
     GT_REQUIRE(dy && x && mean_invstd && gamma && beta && dz && sums2C && rows > 0 && C > 0, GT_E_ARG, "gt_bn_act_drop_bwd1: bad argument");
-    hipError_t e = hipMemsetAsync(sums2C, 0, sizeof(float) * 2 * C, ST);
-    GT_REQUIRE(e == hipSuccess, (int)e, "gt_bn_act_drop_bwd1: memset failed");
+    int rc = col_prepare(sums2C, ws, rows, C, ST, "gt_bn_act_drop_bwd1");
+    if (rc != 0) return rc;
     dim3 grid(cdiv(C, CR_TX), (unsigned)cdiv64(rows, CR_ROWS));
     hipLaunchKernelGGL(bn_bwd1_kernel, grid, dim3(CR_TX, CR_TY), 0, ST, dy, x, mean_invstd, gamma, beta, (long)rows, C,
-                       act, keep, 1.0f / (1.0f - p_drop), dz, sums2C);
+                       act, keep, 1.0f / (1.0f - p_drop), dz, sums2C, ws);
     GT_LAUNCH_CHECK();
     return 0;
 }

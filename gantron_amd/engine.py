@@ -319,7 +319,7 @@ class ConvBNStack:
             stats = mi = None
             if training:
                 stats = _f32(2 * cout, device=x.device, zero=False)
-                call('gt_col_stats', y, y, rows, cout, stats)
+                call('gt_col_stats', y, y, rows, cout, stats, ops.col_ws(rows, cout, x.device))
                 mi = _f32(2 * cout, device=x.device, zero=False)
             keep = keeps[i] if (keeps is not None and training) else None
             out = _f32(rows, cout, device=x.device, zero=False)
@@ -342,7 +342,7 @@ class ConvBNStack:
             dz = _f32(rows, cout, device=dy.device, zero=False)
             sums = _f32(2 * cout, device=dy.device, zero=False)
             call('gt_bn_act_drop_bwd1', dy, s['y'], s['mi'], P[bn + '.weight'], P[bn + '.bias'], rows, cout,
-                 self.acts[i], s['keep'], 0.5, dz, sums)
+                 self.acts[i], s['keep'], 0.5, dz, sums, ops.col_ws(rows, cout, dy.device))
             dconv = _f32(rows, cout, device=dy.device, zero=False)
             call('gt_bn_act_drop_bwd2', dz, s['y'], s['mi'], P[bn + '.weight'], sums, rows, cout, dconv,
                  G[bn + '.weight'], G[bn + '.bias'])

@@ -228,10 +228,15 @@ def linear_dw(dy, x, rows, N, K, dW, lddy=None, dy_offset=0, ldx=None, x_offset=
           ldc=ldc, accumulate=True, split_k=sk, c_offset=c_offset, bf16=BF16_GEMMS)
 
 
+def col_ws(rows, C, device):
+    """Scratch of the bit-reproducible column sums (gt_col_stats / gt_bn_act_drop_bwd1 with ws: BatchNorm statistics)."""
+    return torch.empty(int(lib().gt_col_ws_elems(rows, C)), device=device, dtype=torch.float32)
+
+
 def col_sums(x, rows, C):
     """Per-column sums of a (rows, C) matrix -> first C entries of a (2C,) tensor."""
     out = torch.empty(2 * C, device=x.device, dtype=torch.float32)
-    call('gt_col_stats', x, None, rows, C, out)
+    call('gt_col_stats', x, None, rows, C, out, None)
     return out[:C]
 
 

@@ -555,8 +555,12 @@ int gt_decoder_infer(const GtDecoderInfer* a, void* stream);
 /* per-column sums over rows: BatchNorm1d batch statistics incl. padding (model.py:123,176) and
  * bias gradients.  out[0..C) = sum x, out[C..2C) = sum x*y (sum x*x if y is NULL).  Passing
  * y == x selects the shifted form sum (x-K), sum (x-K)^2 with K = x[0][c] that
- * gt_bn_act_drop_fwd expects (no cancellation when |mean| >> std). */
-int gt_col_stats(const float* x, const float* y, int64_t rows, int32_t C, float* out2C,
+ * gt_bn_act_drop_fwd expects (no cancellation when |mean| >> std).
+ * ws == NULL: row blocks meet in fp32 atomics (the last bits depend on dispatch order);
+ * ws = gt_col_ws_elems(rows, C) floats of scratch: the last row block to arrive adds the others'
+ * partial sums in row order -- bit-reproducible (what BatchNorm statistics are computed with). */
+int64_t gt_col_ws_elems(int64_t rows, int32_t C);
+int gt_col_stats(const float* x, const float* y, int64_t rows, int32_t C, float* out2C, float* ws,
                  void* stream);
 /* BN(train) -> activation (0 none, 1 relu, 2 tanh) -> dropout; updates running stats.
  * stats = gt_col_stats output; saves mean/invstd (2C) for backward. */
@@ -570,7 +574,7 @@ int gt_bn_act_drop_fwd(const float* x, const float* stats, int64_t rows, int32_t
 int gt_bn_act_drop_bwd1(const float* dy, const float* x, const float* mean_invstd,
                         const float* gamma, const float* beta, int64_t rows, int32_t C,
                         int32_t act, const uint8_t* keep, float p_drop, float* dz, float* sums2C,
-                        void* stream);
+                        float* ws, void* stream);   /* ws: as gt_col_stats */
 int gt_bn_act_drop_bwd2(const float* dz, const float* x, const float* mean_invstd,
                         const float* gamma, const float* sums2C, int64_t rows, int32_t C,
                         float* dx, float* dgamma, float* dbeta, void* stream);

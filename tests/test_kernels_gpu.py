@@ -725,8 +725,9 @@ def test_attention_bwd_step_fused(dev, B, Ti, E):
 
 
 # ------------------------------------------------------------------------- BN / elementwise
+@pytest.mark.parametrize('det', [True, False])
 @pytest.mark.parametrize('rows,C,act', [(300, 24, 1), (1000, 80, 2), (77, 8, 0)])
-def test_bn_act_drop(dev, rows, C, act):
+def test_bn_act_drop(dev, rows, C, act, det):
     from gantron_amd import ops
     x = (g(rows, C) * 2 + 5).requires_grad_(True)
     gamma, beta = (1 + 0.1 * g(C, seed=1)).requires_grad_(True), (0.1 * g(C, seed=2)).requires_grad_(True)
@@ -740,7 +741,8 @@ def test_bn_act_drop(dev, rows, C, act):
     dy = g(rows, C, seed=5)
     gx, gg, gb = torch.autograd.grad(y, (x, gamma, beta), dy.double())
     xg = x.detach().to(dev); stats = torch.empty(2 * C, device=dev)
-    ops.call('gt_col_stats', xg, xg, rows, C, stats)
+    ws = ops.col_ws(rows, C, dev) if det else None
+    ops.call('gt_col_stats', xg, xg, rows, C, stats, ws)
     yo = torch.empty(rows, C, device=dev); mi = torch.empty(2 * C, device=dev)
     rmd, rvd = rm.clone().to(dev), rv.clone().to(dev)
     k8 = keep.to(torch.uint8).to(dev)
@@ -750,7 +752,8 @@ def test_bn_act_drop(dev, rows, C, act):
     close(rmd, 0.9 * rm + 0.1 * mean, rtol=1e-4, atol=1e-6, what='running mean')
     close(rvd, 0.9 * rv + 0.1 * xd.var(0, unbiased=True), rtol=1e-4, atol=1e-6, what='running var')
     dz = torch.empty(rows, C, device=dev); sums = torch.empty(2 * C, device=dev)
-    ops.call('gt_bn_act_drop_bwd1', dy.to(dev), xg, mi, gamma.detach().to(dev), beta.detach().to(dev), rows, C, act, k8, 0.5, dz, sums)
+    ops.call('gt_bn_act_drop_bwd1', dy.to(dev), xg, mi, gamma.detach().to(dev), beta.detach().to(dev), rows, C, act, k8, 0.5, dz, sums,
+             ops.col_ws(rows, C, dev) if det else None)
     dx = torch.empty(rows, C, device=dev); dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
     ops.call('gt_bn_act_drop_bwd2', dz, xg, mi, gamma.detach().to(dev), sums, rows, C, dx, dg, db)
     close(dx, gx, rtol=1e-3, atol=1e-5, what='bn dx')
@@ -907,3 +910,27 @@ def test_stft_mel(dev, golden_dir):
     close(mag, z['stft_mag'], rtol=1e-4, atol=1e-4, what='stft magnitude vs reference fixture')
     mel = stft.mel_spectrogram(audio.to(dev))
     close(mel, R.mel_spectrogram(audio), rtol=1e-4, atol=1e-3, what='mel vs oracle')
+
+
+def test_column_sums_are_bit_reproducible_with_a_workspace(dev):
+    """gt_col_stats / gt_bn_act_drop_bwd1 with their scratch (what BatchNorm runs on): the row blocks' partial sums are
+    added in row order by the last block to arrive, so the statistics carry the same bits in every run and under any
+    concurrent load -- here: 20 runs at the encoder's and the PostNet's sizes while a GEMM keeps another stream busy.
+    (With fp32 atomics the last bits follow the dispatch order; a pre-activation within rounding of the ReLU threshold
+    then flips between runs: tools/enc_grad_probe.py.)"""
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device=dev)
+    for rows, C in [(64 * 187, 512), (55680, 80), (1000, 24)]:
+        x = torch.randn(rows, C, device=dev) * 3 + 1
+        outs = []
+        for it in range(20):
+            if it % 2:
+                with torch.cuda.stream(side):
+                    ops.linear(a, a, 4096, 4096, 4096)
+            out = torch.empty(2 * C, device=dev)
+            ops.call('gt_col_stats', x, x, rows, C, out, ops.col_ws(rows, C, dev))
+            outs.append(out.clone())
+        torch.cuda.synchronize()
+        assert all(torch.equal(o, outs[0]) for o in outs[1:]), (rows, C)
+        ref = torch.stack(((x - x[0]).double().sum(0), ((x - x[0]).double() ** 2).sum(0))).reshape(-1)
+        close(outs[0], ref, rtol=1e-5, atol=1e-3, what=f'column sums {rows}x{C}')

@@ -23,12 +23,12 @@ rel = lambda a, b: float((a.double().cpu() - b).abs().max() / b.abs().max())
 yd, dyd, kd = y.to(dev), dy.to(dev), keep.to(torch.uint8).to(dev)
 gd, bd = gamma.to(dev), beta.to(dev)
 rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
-stats = torch.empty(2 * C, device=dev); call('gt_col_stats', yd, yd, rows, C, stats)
+stats = torch.empty(2 * C, device=dev); call('gt_col_stats', yd, yd, rows, C, stats, None)
 mi = torch.empty(2 * C, device=dev); o = torch.empty(rows, C, device=dev)
 call('gt_bn_act_drop_fwd', yd, stats, rows, C, gd, bd, rm, rv, 0.1, 1e-5, 1, kd, 0.5, o, mi, 1)
 print(f'rows={rows}: fwd {rel(o, out.detach()):.2e}  mean {rel(mi[:C], mean.detach()):.2e}')
 dz = torch.empty(rows, C, device=dev); sums = torch.empty(2 * C, device=dev)
-call('gt_bn_act_drop_bwd1', dyd, yd, mi, gd, bd, rows, C, 1, kd, 0.5, dz, sums)
+call('gt_bn_act_drop_bwd1', dyd, yd, mi, gd, bd, rows, C, 1, kd, 0.5, dz, sums, None)
 xhat = ((yr - mean) / torch.sqrt(var + 1e-5)).detach()
 print(f'   dz {rel(dz, dz_ref.detach()):.2e}  sum dz {rel(sums[:C], dz_ref.sum(0).detach()):.2e}  sum dz*xhat {rel(sums[C:], (dz_ref * xhat).sum(0).detach()):.2e}')
 dconv = torch.empty(rows, C, device=dev); Gg, Gb = torch.zeros(C, device=dev), torch.zeros(C, device=dev)

@@ -74,6 +74,10 @@ def main():
     def report(title, ga, gb, ta=None, tb=None):
         print(f'\n== {title}')
         if ta is not None:
+            for i, (xa, xb) in enumerate(zip(ta['enc_act'], tb['enc_act'])):
+                flips = int(((xa > 0) != (xb > 0)).sum())
+                print(f'   encoder block {i} forward output: {"bit-identical" if torch.equal(xa, xb) else "differs"}, '
+                      f'max-abs diff {float((xa - xb).abs().max()):.2e}, ReLU decisions that differ: {flips}')
             for k in ('dmem', 'dx3'):
                 print(f'   {k:55s} max-abs {rel(ta[k], tb[k])[0]:.2e}  rel-L2 {rel(ta[k], tb[k])[1]:.2e}')
         worst = 0.0
