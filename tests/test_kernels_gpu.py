@@ -918,6 +918,7 @@ def test_column_sums_are_bit_reproducible_with_a_workspace(dev):
     concurrent load -- here: 20 runs at the encoder's and the PostNet's sizes while a GEMM keeps another stream busy.
     (With fp32 atomics the last bits follow the dispatch order; a pre-activation within rounding of the ReLU threshold
     then flips between runs: tools/enc_grad_probe.py.)"""
+    from gantron_amd import ops
     side = torch.cuda.Stream()
     a = torch.randn(4096, 4096, device=dev)
     for rows, C in [(64 * 187, 512), (55680, 80), (1000, 24)]:

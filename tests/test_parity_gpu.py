@@ -543,10 +543,14 @@ def test_full_size_training_step_is_schedule_invariant(dev, monkeypatch):
     backward entirely inside the loop, separate cell and query launches: the code path the small-size oracle tests
     pin -- against the benchmark's schedule (two-chain pipelining over a ring of 16 buffers with batched hand-offs,
     6 backward chunks with leaf-stream GEMMs, hoisted attention gradients, fused cell+query kernels).  Differences are
-    summation order only: 1e-3 of each tensor's max-abs.  (With split-K atomics in the encoder's forward convolutions
-    two runs of the SAME schedule differ by up to 1.2e-2 in the encoder gradients: a pre-activation within rounding of
-    the ReLU threshold lands on either side depending on the order of the atomics.  Both runs here therefore use the
-    deterministic forward, GANTRON_FWD_SPLITK=0.)"""
+    summation order only: 1e-4 of each tensor's max-abs, encoder tensors included (measured: 1e-5 for the decoder's
+    tensors, 6e-7 for the encoder's, tools/enc_grad_probe.py).  Round 2 had to hold the encoder tensors to 1e-2 here: the
+    BatchNorm statistics were summed with fp32 atomics, whose order follows dispatch timing and therefore the schedule;
+    a pre-activation within rounding of the ReLU threshold then fell on the other side in one of the two runs and moved
+    a channel's slice of every gradient below it by percents (an exact float64 backward of the same inputs agreed to
+    3e-7, i.e. no amplification).  The statistics are now bit-reproducible (gt_col_stats with a workspace), the encoder
+    forward of the two schedules is bit-identical, and both runs use the deterministic forward convolutions
+    (GANTRON_FWD_SPLITK=0: split-K atomics in them are the one remaining run-to-run source of such flips)."""
     import bench
     from gantron_amd import engine
     from gantron_amd.hparams import HParams
@@ -572,7 +576,7 @@ def test_full_size_training_step_is_schedule_invariant(dev, monkeypatch):
 
     # deterministic activations in BOTH runs (no split-K atomics in the forward / input-gradient convolutions): the two
     # schedules then see bit-identical encoder pre-activations, no ReLU mask can differ, and a race in the leaf-stream /
-    # two-chain schedule cannot hide behind atomic-order noise -- every tensor is held to 1e-3
+    # two-chain schedule cannot hide behind atomic-order noise -- every tensor is held to 1e-4
     from gantron_amd import ops
     monkeypatch.setattr(ops, 'FWD_SPLITK', False)
     monkeypatch.setattr(engine, 'DEC_RING', 1)
@@ -591,16 +595,7 @@ def test_full_size_training_step_is_schedule_invariant(dev, monkeypatch):
     bad = []
     for k in g0:
         try:
-            if k.startswith(('encoder.convolutions.', 'embedding.')) and not k.endswith('.0.conv.bias'):     # (zero gradient there)
-                # the encoder's gradients pass through the whole decoder backward first and are the worst-conditioned of
-                # the step (test_midsize_against_oracle holds them to a relative L2 error for the same reason): between
-                # the two schedules the decoder LSTM's input product is a per-step fp32 product in one and a block GEMM
-                # in the other, i.e. two roundings of the same sums.  Relative L2 2e-3, max-abs 1e-2.
-                l2 = float((g1[k].double() - g0[k].double()).norm() / (g0[k].double().norm() + 1e-30))
-                assert l2 <= 2e-3, f'g_grad.{k}: relative L2 difference {l2:.3e}'
-                close(g1[k], g0[k], rtol=1e-2, atol=2e-6, what=f'g_grad.{k}')
-            else:
-                close(g1[k], g0[k], rtol=1e-3, atol=2e-6, what=f'g_grad.{k}')
+            close(g1[k], g0[k], rtol=1e-4, atol=2e-6, what=f'g_grad.{k}')
         except AssertionError as e:
             bad.append(str(e))
     assert not bad, '\n'.join(bad)
