@@ -12,6 +12,7 @@
 // the chip's fp32 peak).  Both operand tiles are staged k-major in LDS ([16][rows+4]) so that an
 // MFMA operand fetch is one conflict-free ds_read_b32 per lane; the next tile's global loads are
 // issued into registers before the current tile's MFMAs (register prefetch).
+#include <algorithm>
 #include "common.h"
 
 namespace {
@@ -24,6 +25,8 @@ struct OpDev {
 
 struct GemmDev {
     OpDev A, B;
+    const unsigned short* Ap; const unsigned short* Bp;     // pre-split bf16 planes of A / B (pgemm_kernel), else NULL
+    long a_ps, b_ps;                                         // elements between planes
     float* C;
     const float* bias;
     long ldc, a_bs, b_bs, c_bs;
@@ -715,6 +718,209 @@ __global__ __launch_bounds__(256) void xgemm_kernel(GemmDev g) {
         }
 }
 
+// =====================================================================================================================
+// The same three-plane product on operands that ARRIVE as bf16 planes (GtOperand.planes: plane i of element e at
+// planes + i * plane_stride + e, e indexed exactly like the fp32 operand).  The split -- ~180 vector instructions per thread
+// and k-tile in xgemm_kernel, repeated by every workgroup that shares an operand row -- is done once, where the operand
+// is produced (gt_split3, or the producing kernel's epilogue), and this kernel has no vector work left: each wave moves its
+// share of the tile global -> LDS with `global_load_lds_dwordx4` (1 KiB per instruction, no registers, no ds_write) and
+// issues MFMAs.  LDS-DMA writes lane l's 16 bytes at base + 16 l, so the IMAGE is lane-linear and the bank-conflict
+// swizzle sits on the per-lane SOURCE address plus the matching permutation of the fragment read:
+//   k-contiguous operand (KC / IM2COL_K): image [row][4 chunks of 8 k] (64-byte rows), chunk c of row r stored in slot
+//     c ^ ((r >> 2) & 3): the 16 rows of a ds_read_b128 lane group then cover all 16 bank quads;
+//   reduction-major operand (RC / IM2COL_R): image [k][BR / 8 chunks of 8 rows], chunk m of k-row k stored in slot
+//     (m + rot(k)) mod chunks with rot = 4 (k & 3) for 128-row tiles (k-rows 64 bytes apart mod 256) and 4 ((k >> 1) & 1)
+//     for 64-row tiles: the four k-rows of a ds_read_b64_tr_b16 lane group fall on disjoint banks.
+// One LDS buffer, every fragment of the k-tile in registers: read fragments -> barrier -> DMA of the next tile -> 48 MFMAs
+// -> barrier (the DMA has landed), so the transfer of tile k + 1 runs under the MFMAs of tile k without a second buffer
+// (48 KiB per workgroup: two workgroups per CU).  Conv taps outside [0, T) read 16 bytes of zeros (g_zero16).
+constexpr int BKP = 32;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+__device__ __attribute__((aligned(16))) unsigned short g_zero16[8];
+
+template <int MODE, int BR>
+struct TileDma {
+    static constexpr bool KT = is_ktype<MODE>();
+    static constexpr int PLANE = BR * BKP;                 // bf16 elements of one plane image (no padding)
+    static constexpr int NI = PLANE * 2 / 1024;            // wave instructions per plane: 8 (128 rows) / 4 (64 rows)
+    static constexpr int NJ = NI / 4;                      // ... per wave
+    static constexpr int CPR = BR / 8;                     // reduction-major: 16-byte chunks per k-row
+    static constexpr int KPI = 64 / CPR;                   // reduction-major: k-rows per instruction
+    long off[NJ];                                          // KC / RC: element offset of this lane's chunk in the next k-tile
+    int p0[NJ], p1[NJ], q0[NJ], q1[NJ];                    // im2col: fixed (row) and running (k) decompositions, as TileLoaderX
+
+    static __device__ __forceinline__ int rot(int kk) { return BR == 128 ? 4 * (kk & 3) : 4 * ((kk >> 1) & 1); }
+
+    __device__ __forceinline__ void init(const OpDev& o, int r0, int R, int kbeg, int lane, int wave) {
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            const int j = wave + 4 * jj;
+            p0[jj] = p1[jj] = q0[jj] = q1[jj] = 0;
+            off[jj] = 0;
+            if (KT) {
+                const int rl = 16 * j + (lane >> 2);
+                const int c = (lane & 3) ^ ((rl >> 2) & 3);
+                const int row = min(r0 + rl, R - 1);                 // rows beyond the matrix re-read its last row (never stored)
+                const int k = kbeg + 8 * c;
+                if (MODE == GT_OP_KC) off[jj] = (long)row * o.ld + k;
+                else { p0[jj] = row / o.T; p1[jj] = row - p0[jj] * o.T; q0[jj] = k / o.C; q1[jj] = k - q0[jj] * o.C; }
+            } else {
+                const int kk = KPI * j + lane / CPR;
+                const int m = ((lane % CPR) - rot(kk)) & (CPR - 1);
+                const int row = min(r0 + 8 * m, R - 8);
+                const int k = kbeg + kk;
+                if (MODE == GT_OP_RC) off[jj] = (long)k * o.ld + row;
+                else { p0[jj] = row / o.C; p1[jj] = row - p0[jj] * o.C; q0[jj] = k / o.T; q1[jj] = k - q0[jj] * o.T; }
+            }
+        }
+    }
+    // issue this wave's share of the next k-tile (3 planes x NJ instructions) and advance to the tile after it
+    __device__ __forceinline__ void issue(const OpDev& o, const unsigned short* base, long ps, unsigned short* S, int wave) {
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            const int j = wave + 4 * jj;
+            long e = off[jj];
+            bool ok = true;
+            if (MODE == GT_OP_IM2COL_K) {
+                const int tt = p1[jj] + q0[jj] * o.dil - o.pad;
+                ok = tt >= 0 && tt < o.T;
+                e = ((long)p0[jj] * o.T + (ok ? tt : p1[jj])) * o.C + q1[jj];
+                q1[jj] += BKP;
+                while (q1[jj] >= o.C) { q1[jj] -= o.C; ++q0[jj]; }
+            } else if (MODE == GT_OP_IM2COL_R) {
+                const int tt = q1[jj] + p0[jj] * o.dil - o.pad;
+                ok = tt >= 0 && tt < o.T;
+                e = ((long)q0[jj] * o.T + (ok ? tt : q1[jj])) * o.C + p1[jj];
+                q1[jj] += BKP;
+                while (q1[jj] >= o.T) { q1[jj] -= o.T; ++q0[jj]; }
+            } else {
+                off[jj] += MODE == GT_OP_KC ? (long)BKP : (long)BKP * o.ld;
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const unsigned short* src = ok ? base + p * ps + e : g_zero16;
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(S + p * PLANE + j * 512), 16, 0, 0);
+            }
+        }
+    }
+    // fragment of the 32x32x16 product for rows [w0 + 32 i, +32), k-step s, plane p (layouts: xgemm_kernel)
+    static __device__ __forceinline__ bf16x8_t frag(const unsigned short* S, int w0, int lane, int p, int i, int s) {
+        if (KT) {
+            const int r = w0 + 32 * i + (lane & 31), c = 2 * s + (lane >> 5);
+            return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(S + p * PLANE + r * BKP + 8 * (c ^ ((r >> 2) & 3))));
+        }
+        typedef __attribute__((address_space(3))) v4i16_t* lds_v4;
+        const int m0 = w0 + 32 * i + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+        const int kk = 16 * s + 8 * (lane >> 5) + ((lane & 15) >> 2);
+        const unsigned short* q = S + p * PLANE + kk * BR + 8 * (((m0 >> 3) + rot(kk)) & (CPR - 1)) + (m0 & 7);
+        const unsigned short* q4 = S + p * PLANE + (kk + 4) * BR + 8 * (((m0 >> 3) + rot(kk + 4)) & (CPR - 1)) + (m0 & 7);
+        const v4i16_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(q));
+        const v4i16_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(q4));
+        return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+};
+
+template <int BM, int BN, int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void pgemm_kernel(GemmDev g) {
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    typedef TileDma<AMODE, BM> LA;
+    typedef TileDma<BMODE, BN> LB;
+    __shared__ __attribute__((aligned(1024))) unsigned short smem[3 * (LA::PLANE + LB::PLANE)];
+    unsigned short* Ax = smem;
+    unsigned short* Bx = smem + 3 * LA::PLANE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int batch = blockIdx.z / g.split_k, kz = blockIdx.z - batch * g.split_k;
+    const int kbeg = kz * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    const unsigned short* Ab = g.Ap + (long)batch * g.a_bs;
+    const unsigned short* Bb = g.Bp + (long)batch * g.b_bs;
+    float* Cb = g.C + (long)batch * g.c_bs;
+
+    LA la;
+    LB lb;
+    la.init(g.A, m0, g.M, kbeg, lane, wave);
+    lb.init(g.B, n0, g.N, kbeg, lane, wave);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+    if (kbeg < kend) {
+        la.issue(g.A, Ab, g.a_ps, Ax, wave);
+        lb.issue(g.B, Bb, g.b_ps, Bx, wave);
+    }
+    __syncthreads();                      // (waits for the LDS-DMA in flight: vmcnt(0) + barrier)
+    for (int k0 = kbeg; k0 < kend; k0 += BKP) {
+        bf16x8_t a[2][3][TM], b[2][3][TN];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[s][p][i] = LA::frag(Ax, wm0, lane, p, i, s);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[s][p][j] = LB::frag(Bx, wn0, lane, p, j, s);
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();                  // every wave holds its fragments: the image may be overwritten
+        if (k0 + BKP < kend) {
+            la.issue(g.A, Ab, g.a_ps, Ax, wave);
+            lb.issue(g.B, Bb, g.b_ps, Bx, wave);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int ord = 2; ord >= 0; --ord)              // smallest terms first
+#pragma unroll
+                for (int pa = 0; pa <= ord; ++pa)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][pa][i], b[s][ord - pa][j], acc[i][j], 0, 0, 0);
+        __syncthreads();                  // the next tile has landed (vmcnt(0) + barrier)
+    }
+    // epilogue: as sgemm_kernel
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn0 + 32 * j + (lane & 31);
+            if (n >= g.N) continue;
+            const float bias = (g.bias != nullptr && kz == 0) ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= g.M) continue;
+                float* c = Cb + (long)m * g.ldc + n;
+                const float v = g.alpha * acc[i][j][r] + bias;
+                if (g.split_k > 1) atomicAdd(c, v);
+                else if (g.accumulate) *c += v;
+                else *c = v;
+            }
+        }
+}
+
+// x -> its three bf16 planes (x = p0 + p1 + p2 exactly, as split_all): 8 elements per thread, flat
+__global__ __launch_bounds__(256) void split3_kernel(const float* x, long n8, unsigned short* out, long ps) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        float4 reg[2] = {*reinterpret_cast<const float4*>(x + 8 * i), *reinterpret_cast<const float4*>(x + 8 * i + 4)};
+        unsigned lo[2][3], hi[2][3];
+        split_all<3, 2>(reg, lo, hi);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            *reinterpret_cast<uint4*>(out + p * ps + 8 * i) = make_uint4(lo[0][p], hi[0][p], lo[1][p], hi[1][p]);
+    }
+}
+
 // (Measured and not adopted: a producer / consumer form with 512 threads -- waves 4..7 load, split and store the next
 // k-tile into a second LDS buffer while waves 0..3 only issue MFMAs, two k-tiles of loads in flight.  182-186 TFLOP/s
 // against 191-193 for xgemm_kernel on the decoder weight gradients: SQ_VALU_MFMA_COEXEC_CYCLES stays at 1 %, the
@@ -732,7 +938,8 @@ int launch_tile(const GemmDev& d, dim3 grid, hipStream_t st, int lds_pad) {
     const int am = d.A.mode, bm = d.B.mode;
 #define GT_CASE(AM, BMD)                                                                                    \
     if (am == AM && bm == BMD) {                                                                            \
-        if (d.bf16 == 1) hipLaunchKernelGGL((hgemm_kernel<BM, BN, AM, BMD>), grid, dim3(256), lds_pad, st, d);           \
+        if (d.Ap != nullptr) hipLaunchKernelGGL((pgemm_kernel<BM, BN, AM, BMD>), grid, dim3(256), lds_pad, st, d);       \
+        else if (d.bf16 == 1) hipLaunchKernelGGL((hgemm_kernel<BM, BN, AM, BMD>), grid, dim3(256), lds_pad, st, d);      \
         else if (d.bf16 == 2) hipLaunchKernelGGL((xgemm_kernel<BM, BN, AM, BMD, 2>), grid, dim3(256), lds_pad, st, d);   \
         else if (d.bf16 == 3) hipLaunchKernelGGL((xgemm_kernel<BM, BN, AM, BMD, 3>), grid, dim3(256), lds_pad, st, d);   \
         else hipLaunchKernelGGL((sgemm_kernel<BM, BN, AM, BMD>), grid, dim3(256), lds_pad, st, d);                      \
@@ -749,7 +956,7 @@ int launch_tile(const GemmDev& d, dim3 grid, hipStream_t st, int lds_pad) {
 }
 
 int prep_operand(const GtOperand& s, OpDev& o, int rows, int K, const char* name) {
-    GT_REQUIRE(s.p != nullptr, GT_E_ARG, "gt_sgemm: operand %s is NULL", name);
+    GT_REQUIRE(s.p != nullptr || s.planes != nullptr, GT_E_ARG, "gt_sgemm: operand %s is NULL", name);
     o.p = s.p; o.mode = s.mode; o.T = s.T; o.C = s.C; o.dil = s.dil; o.pad = s.pad; o.ld = s.ld;
     switch (s.mode) {
         case GT_OP_KC:
@@ -780,6 +987,18 @@ int prep_operand(const GtOperand& s, OpDev& o, int rows, int K, const char* name
 
 int g_fp32_planes = 0;       // gt_sgemm_set_fp32_split: how GtGemm.bf16 == 0 products are computed
 
+// can pgemm_kernel address this operand's planes? (16-byte chunks of 8 bf16 that never straddle a row / tap / matrix end)
+bool planes_ok(const GtOperand& s, int rows) {
+    if (!aligned16(s.planes) || s.plane_stride % 8 != 0 || s.batch_stride % 8 != 0) return false;
+    switch (s.mode) {
+        case GT_OP_KC: return s.ld % 8 == 0;
+        case GT_OP_RC: return s.ld % 8 == 0 && rows % 8 == 0;
+        case GT_OP_IM2COL_K: return s.C % BKP == 0;
+        case GT_OP_IM2COL_R: return s.C % 8 == 0 && rows % 8 == 0;
+    }
+    return false;
+}
+
 }  // namespace
 
 extern "C" int gt_sgemm_set_fp32_split(int32_t planes) {
@@ -789,6 +1008,18 @@ extern "C" int gt_sgemm_set_fp32_split(int32_t planes) {
 }
 
 extern "C" int32_t gt_sgemm_get_fp32_split(void) { return g_fp32_planes; }
+
+extern "C" int gt_split3(const float* x, int64_t n, void* planes, int64_t plane_stride, void* stream) {
+    GT_REQUIRE(x != nullptr && planes != nullptr && n > 0 && n % 8 == 0 && plane_stride >= n && plane_stride % 8 == 0 &&
+                   aligned16(x) && aligned16(planes), GT_E_ARG,
+               "gt_split3: n (%ld) and plane_stride (%ld) must be multiples of 8, plane_stride >= n, 16-byte aligned buffers",
+               (long)n, (long)plane_stride);
+    const long n8 = n / 8;
+    const unsigned blocks = (unsigned)std::min<long>(cdiv64(n8, 256), 4096);
+    hipLaunchKernelGGL(split3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n8, (unsigned short*)planes, (long)plane_stride);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int gt_sgemm(const GtGemm* g, void* stream) {
     GT_REQUIRE(g != nullptr && g->C != nullptr, GT_E_ARG, "gt_sgemm: NULL argument");
@@ -805,6 +1036,16 @@ extern "C" int gt_sgemm(const GtGemm* g, void* stream) {
     d.split_k = g->split_k;
     GT_REQUIRE(g->bf16 >= 0 && g->bf16 <= 3, GT_E_ARG, "gt_sgemm: bf16 = %d (0 fp32, 1 bf16 operands, 2 / 3 split planes)", g->bf16);
     d.bf16 = g->bf16 != 0 ? g->bf16 : g_fp32_planes;
+    // operands that arrive as bf16 planes: the pure three-plane kernel, when the shapes allow whole 16-byte chunks and
+    // whole 32-wide k-tiles; otherwise the fp32 operands (which must then be there) go through xgemm_kernel's own split
+    d.Ap = d.Bp = nullptr; d.a_ps = d.b_ps = 0;
+    if (g->A.planes != nullptr && g->B.planes != nullptr && d.bf16 == 3 && g->K % BKP == 0 &&
+        planes_ok(g->A, g->M) && planes_ok(g->B, g->N)) {
+        d.Ap = (const unsigned short*)g->A.planes; d.Bp = (const unsigned short*)g->B.planes;
+        d.a_ps = g->A.plane_stride; d.b_ps = g->B.plane_stride;
+    } else {
+        GT_REQUIRE(g->A.p != nullptr && g->B.p != nullptr, GT_E_ARG, "gt_sgemm: plane operands of this shape need their fp32 original too");
+    }
     const int kstep = d.bf16 == 1 ? BKH : d.bf16 >= 2 ? BKX : BK;        // k-tile of the kernel: splits are whole k-tiles
     const int kblocks = cdiv(g->K, kstep);
     d.k_per_split = cdiv(kblocks, g->split_k) * kstep;

@@ -169,7 +169,7 @@ static int run_graphed(const void* args, size_t nbytes, hipStream_t stream, cons
 }
 
 static GtOperand op_kc(const float* p, int64_t ld) {
-    GtOperand o; o.p = p; o.mode = GT_OP_KC; o.T = o.C = o.dil = o.pad = 0; o.ld = ld; o.batch_stride = 0; return o;
+    GtOperand o = {}; o.p = p; o.mode = GT_OP_KC; o.T = o.C = o.dil = o.pad = 0; o.ld = ld; o.batch_stride = 0; return o;
 }
 static GtOperand op_rc(const float* p, int64_t ld) {
     GtOperand o = op_kc(p, ld); o.mode = GT_OP_RC; return o;
@@ -459,7 +459,7 @@ __global__ void gate_stop_kernel(const float* gate, int64_t ld, int B, float thr
 }
 
 static GtOperand kc(const float* p, int64_t ld) {
-    GtOperand o; o.p = p; o.mode = GT_OP_KC; o.T = o.C = o.dil = o.pad = 0; o.ld = ld; o.batch_stride = 0; return o;
+    GtOperand o = {}; o.p = p; o.mode = GT_OP_KC; o.T = o.C = o.dil = o.pad = 0; o.ld = ld; o.batch_stride = 0; return o;
 }
 static int small_linear(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
                         int M, int N, int K, void* stream) {

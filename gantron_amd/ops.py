@@ -117,18 +117,51 @@ def _require(t, dtype=torch.float32):
     return t
 
 
-class Operand:
-    """Addressing of one GEMM operand (see GtOperand)."""
+class Planes:
+    """An fp32 tensor as three bf16 planes x = x0 + x1 + x2 (exact; gt_split3): what the pure three-plane GEMM kernel
+    reads.  The planes are indexed like the flat fp32 tensor they were made from, so the element offsets / leading
+    dimensions of an Operand apply unchanged.  split(lo, hi) fills the planes of the flat element range [lo, hi)."""
 
-    def __init__(self, t, mode, ld=0, T=0, C=0, dil=1, pad=0, offset=0, batch_stride=0):
+    def __init__(self, src):
+        assert src.is_cuda and src.dtype == torch.float32 and src.is_contiguous() and src.numel() % 8 == 0, \
+            (src.dtype, src.is_contiguous(), src.numel())
+        self.src, self.n = src, src.numel()
+        self.t = torch.empty(3, self.n, device=src.device, dtype=torch.bfloat16)
+
+    def split(self, lo=0, hi=None):
+        hi = self.n if hi is None else hi
+        assert 0 <= lo < hi <= self.n and lo % 8 == 0 and (hi - lo) % 8 == 0, (lo, hi, self.n)
+        check(lib().gt_split3(ptr(self.src, lo), hi - lo, ptr(self.t, lo), self.n, _stream()), 'gt_split3')
+        return self
+
+
+def planes_of(t):
+    """Planes of a whole tensor, split now (None when plane GEMMs are off or the tensor cannot take them)."""
+    if not PLANE_GEMMS or BF16_GEMMS or FP32_SPLIT != 3 or t.numel() % 8 != 0:
+        return None
+    return Planes(t.contiguous()).split()
+
+
+# Operands of the large GEMMs are split into bf16 planes ONCE, where they are produced, and the GEMMs run the kernel that
+# has no split left to do (pgemm_kernel); GANTRON_PLANE_GEMMS=0 keeps the in-kernel split (xgemm_kernel) everywhere.
+PLANE_GEMMS = _os.environ.get('GANTRON_PLANE_GEMMS', '1') != '0'
+
+
+class Operand:
+    """Addressing of one GEMM operand (see GtOperand).  planes: a Planes of the tensor `t` is a view of (same offsets)."""
+
+    def __init__(self, t, mode, ld=0, T=0, C=0, dil=1, pad=0, offset=0, batch_stride=0, planes=None):
         self.t, self.mode, self.ld, self.T, self.C = t, mode, ld, T, C
         self.dil, self.pad, self.offset, self.batch_stride = dil, pad, offset, batch_stride
+        self.planes = planes
 
     def c(self):
         o = GtOperand()
         o.p = ptr(self.t, self.offset)
         o.mode, o.T, o.C, o.dil, o.pad = self.mode, self.T, self.C, self.dil, self.pad
         o.ld, o.batch_stride = self.ld, self.batch_stride
+        if self.planes is not None:
+            o.planes, o.plane_stride = ptr(self.planes.t, self.offset), self.planes.n
         return o
 
 
@@ -203,28 +236,30 @@ def pick_splits(K, want):
 
 
 # ---------------------------------------------------------------------------------- layers
-def linear(x, W, M, K, N, bias=None, out=None, ldw=None, w_offset=0, ldx=None, x_offset=0):
-    """out[M,N] = x[M,K] @ W[N,K]^T (+ bias)."""
+def linear(x, W, M, K, N, bias=None, out=None, ldw=None, w_offset=0, ldx=None, x_offset=0, x_planes=None, w_planes=None):
+    """out[M,N] = x[M,K] @ W[N,K]^T (+ bias).  *_planes: ops.Planes of the WHOLE tensors x / W (optional)."""
     if out is None:
         out = torch.empty(M, N, device=x.device, dtype=torch.float32)
-    sgemm(Operand(x, KC, ld=ldx or K, offset=x_offset), Operand(W, KC, ld=ldw or K, offset=w_offset), out, M, N, K,
-          bias=bias, bf16=BF16_GEMMS)
+    sgemm(Operand(x, KC, ld=ldx or K, offset=x_offset, planes=x_planes),
+          Operand(W, KC, ld=ldw or K, offset=w_offset, planes=w_planes), out, M, N, K, bias=bias, bf16=BF16_GEMMS)
     return out
 
 
-def linear_dx(dy, W, M, N, K, out=None, ldw=None, w_offset=0, lddy=None, dy_offset=0):
+def linear_dx(dy, W, M, N, K, out=None, ldw=None, w_offset=0, lddy=None, dy_offset=0, dy_planes=None, w_planes=None):
     """out[M,K] = dy[M,N] @ W[N,K]."""
     if out is None:
         out = torch.empty(M, K, device=dy.device, dtype=torch.float32)
-    sgemm(Operand(dy, KC, ld=lddy or N, offset=dy_offset), Operand(W, RC, ld=ldw or K, offset=w_offset), out, M, K, N,
-          bf16=BF16_GEMMS)
+    sgemm(Operand(dy, KC, ld=lddy or N, offset=dy_offset, planes=dy_planes),
+          Operand(W, RC, ld=ldw or K, offset=w_offset, planes=w_planes), out, M, K, N, bf16=BF16_GEMMS)
     return out
 
 
-def linear_dw(dy, x, rows, N, K, dW, lddy=None, dy_offset=0, ldx=None, x_offset=0, ldc=None, c_offset=0):
+def linear_dw(dy, x, rows, N, K, dW, lddy=None, dy_offset=0, ldx=None, x_offset=0, ldc=None, c_offset=0, dy_planes=None,
+              x_planes=None):
     """dW[N,K] += dy[rows,N]^T @ x[rows,K]  (split-K over rows when the output grid is small)."""
     sk = default_split_k(N, K, rows)
-    sgemm(Operand(dy, RC, ld=lddy or N, offset=dy_offset), Operand(x, RC, ld=ldx or K, offset=x_offset), dW, N, K, rows,
+    sgemm(Operand(dy, RC, ld=lddy or N, offset=dy_offset, planes=dy_planes),
+          Operand(x, RC, ld=ldx or K, offset=x_offset, planes=x_planes), dW, N, K, rows,
           ldc=ldc, accumulate=True, split_k=sk, c_offset=c_offset, bf16=BF16_GEMMS)
 
 
@@ -257,31 +292,31 @@ def conv_weight_bwd(W):
     return out
 
 
-def conv1d_fwd(x, Wf, bias, B, T, Cin, Cout, K, dil):
+def conv1d_fwd(x, Wf, bias, B, T, Cin, Cout, K, dil, x_planes=None, w_planes=None):
     """Channels-last Conv1d with 'same' padding: x (B*T, Cin) -> (B*T, Cout)."""
     pad = dil * (K - 1) // 2
     sk = forward_split_k(B * T, Cout, K * Cin)
     out = (torch.zeros if sk > 1 else torch.empty)(B * T, Cout, device=x.device, dtype=torch.float32)
-    sgemm(Operand(x, IM2COL_K, T=T, C=Cin, dil=dil, pad=pad), Operand(Wf, KC, ld=K * Cin), out, B * T, Cout, K * Cin,
-          bias=bias, accumulate=sk > 1, split_k=sk, bf16=BF16_GEMMS)
+    sgemm(Operand(x, IM2COL_K, T=T, C=Cin, dil=dil, pad=pad, planes=x_planes), Operand(Wf, KC, ld=K * Cin, planes=w_planes),
+          out, B * T, Cout, K * Cin, bias=bias, accumulate=sk > 1, split_k=sk, bf16=BF16_GEMMS)
     return out
 
 
-def conv1d_dx(dy, Wb, B, T, Cin, Cout, K, dil):
+def conv1d_dx(dy, Wb, B, T, Cin, Cout, K, dil, dy_planes=None, w_planes=None):
     pad = dil * (K - 1) // 2
     sk = forward_split_k(B * T, Cin, K * Cout)
     out = (torch.zeros if sk > 1 else torch.empty)(B * T, Cin, device=dy.device, dtype=torch.float32)
-    sgemm(Operand(dy, IM2COL_K, T=T, C=Cout, dil=dil, pad=pad), Operand(Wb, KC, ld=K * Cout), out, B * T, Cin, K * Cout,
-          accumulate=sk > 1, split_k=sk, bf16=BF16_GEMMS)
+    sgemm(Operand(dy, IM2COL_K, T=T, C=Cout, dil=dil, pad=pad, planes=dy_planes), Operand(Wb, KC, ld=K * Cout, planes=w_planes),
+          out, B * T, Cin, K * Cout, accumulate=sk > 1, split_k=sk, bf16=BF16_GEMMS)
     return out
 
 
-def conv1d_dw(dy, x, B, T, Cin, Cout, K, dil, dW):
+def conv1d_dw(dy, x, B, T, Cin, Cout, K, dil, dW, dy_planes=None, x_planes=None):
     """dW (Cout, Cin, K) += correlation of dy (B*T, Cout) with x (B*T, Cin)."""
     pad = dil * (K - 1) // 2
     tmp = torch.zeros(Cout, K * Cin, device=dy.device, dtype=torch.float32)
     sk = default_split_k(Cout, K * Cin, B * T)
-    sgemm(Operand(dy, RC, ld=Cout), Operand(x, IM2COL_R, T=T, C=Cin, dil=dil, pad=pad), tmp, Cout, K * Cin, B * T,
-          accumulate=True, split_k=sk, bf16=BF16_GEMMS)
+    sgemm(Operand(dy, RC, ld=Cout, planes=dy_planes), Operand(x, IM2COL_R, T=T, C=Cin, dil=dil, pad=pad, planes=x_planes),
+          tmp, Cout, K * Cin, B * T, accumulate=True, split_k=sk, bf16=BF16_GEMMS)
     # tmp[co][k][ci] -> dW[co][ci][k]
     call('gt_permute3', tmp, K * Cin, 1, Cin, Cout, Cin, K, dW, 0, 0, 1, 1.0)

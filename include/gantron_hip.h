@@ -84,6 +84,12 @@ typedef struct GtOperand {
     int32_t T, C, dil, pad;     /* im2col modes only */
     int64_t ld;                 /* KC / RC modes */
     int64_t batch_stride;       /* elements between batches (grid batching) */
+    const void* planes;         /* optional: the operand as three bf16 planes x = x0 + x1 + x2 (gt_split3): plane i of the
+                                   element that `p` addresses as p[e] is ((uint16_t*)planes)[i * plane_stride + e].  When
+                                   BOTH operands carry planes, the product is the exact three-plane one and the shapes
+                                   allow it (K % 32 == 0, ld % 8 == 0, im2col C % 32 / % 8 == 0), gt_sgemm runs the kernel
+                                   that has no split left to do; otherwise it uses p (p may be NULL only if planes suffice) */
+    int64_t plane_stride;
 } GtOperand;
 
 typedef struct GtGemm {
@@ -103,6 +109,9 @@ typedef struct GtGemm {
 } GtGemm;
 
 int gt_sgemm(const GtGemm* g, void* stream);
+/* x[0..n) -> three bf16 planes, plane i at planes + i * plane_stride (16-bit elements): x0 = bf16(x), x1 = bf16(x - x0),
+ * x2 = bf16(x - x0 - x1); x0 + x1 + x2 == x exactly (3 x 8 significand bits).  n, plane_stride multiples of 8. */
+int gt_split3(const float* x, int64_t n, void* planes, int64_t plane_stride, void* stream);
 
 /* How products with GtGemm.bf16 == 0 are computed (process-wide; default 0):
  *   0  v_mfma_f32_32x32x2_f32, the fp32 matrix pipe (157 TFLOP/s peak on MI355X);

@@ -130,6 +130,71 @@ def _sgemm_modes(dev, bf16):
     close(C2, rb(A2, bf16).t() @ rb(B2, bf16), **tol(bf16, 1e-4), what='rc/rc 128x128 tiles')
 
 
+def test_split3_planes_are_exact(dev):
+    """gt_split3: x0 + x1 + x2 == x bit for bit (three 8-bit significands hold fp32's 24), over ten decades of magnitude,
+    zeros and denormal-range residuals included."""
+    from gantron_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(8 * 5000, generator=gen) * torch.exp(torch.randn(8 * 5000, generator=gen) * 6)
+    x[::97] = 0
+    P = ops.Planes(x.to(dev)).split()
+    back = P.t.float().sum(0)                    # exact: each partial sum is representable
+    assert torch.equal(back.cpu(), x)
+    assert float((P.t[1].float().abs() > P.t[0].float().abs() * 2 ** -7).sum()) == 0       # plane 1 below plane 0's last bit
+
+
+@pytest.mark.parametrize('modes', ['kc/kc', 'kc/rc', 'rc/rc', 'rc/kc'])
+@pytest.mark.parametrize('M,N,K,sk', [(256, 192, 64, 1), (1536, 2048, 160, 1), (96, 136, 704, 5), (1024, 2048, 4096, 1)])
+def test_plane_gemm_matches_float64(dev, modes, M, N, K, sk):
+    """pgemm_kernel (operands pre-split by gt_split3, tiles moved by LDS-DMA, swizzled images): every operand mode pair,
+    64x64 and 128x128 tiles, ragged M / N (rows beyond the matrix re-read the last row), split-K with accumulation --
+    against float64, at the tolerance the fp32 pipe is held to; and the kernel REALLY ran (the in-kernel-split result of
+    the same call differs in summation order only, so equality of the two up to rounding is checked as well)."""
+    from gantron_amd import ops
+    am, bm = modes.split('/')
+    A, B = g(M, K, seed=3), g(N, K, seed=4)
+    ref = A.double() @ B.double().t()
+    Ad = (A if am == 'kc' else A.t().contiguous()).to(dev)
+    Bd = (B if bm == 'kc' else B.t().contiguous()).to(dev)
+
+    def run(planes):
+        oa = ops.Operand(Ad, ops.KC if am == 'kc' else ops.RC, ld=K if am == 'kc' else M, planes=ops.Planes(Ad).split() if planes else None)
+        ob = ops.Operand(Bd, ops.KC if bm == 'kc' else ops.RC, ld=K if bm == 'kc' else N, planes=ops.Planes(Bd).split() if planes else None)
+        C = torch.full((M, N), 0.5, device=dev)
+        ops.sgemm(oa, ob, C, M, N, K, accumulate=True, split_k=sk, bf16=3)
+        return C.cpu().double() - 0.5
+    got, inkernel = run(True), run(False)
+    close(got, ref, rtol=1e-5, atol=1e-4, what=f'plane gemm {modes}')
+    close(got, inkernel, rtol=2e-6, atol=2e-5, what=f'plane gemm vs in-kernel split {modes}')
+
+
+@pytest.mark.parametrize('B,T,Cin,Cout,K,dil', [(3, 37, 32, 64, 5, 1), (2, 9, 64, 96, 5, 2), (4, 150, 512, 512, 5, 1)])
+def test_plane_gemm_convolutions(dev, B, T, Cin, Cout, K, dil):
+    """The im2col operand modes of pgemm_kernel (taps outside [0, T) read zeros): Conv1d forward, input gradient and weight
+    gradient with pre-split activations / weights against float64."""
+    from gantron_amd import ops
+    x, W = g(B, Cin, T), g(Cout, Cin, K, seed=1, scale=0.2)
+    dy = g(B, Cout, T, seed=3)
+    pad = dil * (K - 1) // 2
+    xr, Wr = x.double().requires_grad_(True), W.double().requires_grad_(True)
+    y = F.conv1d(xr, Wr, None, padding=pad, dilation=dil)
+    gx, gw = torch.autograd.grad(y, (xr, Wr), dy.double())
+    xcl = x.permute(0, 2, 1).contiguous().view(B * T, Cin).to(dev)
+    dycl = dy.permute(0, 2, 1).contiguous().view(B * T, Cout).to(dev)
+    Wd = W.to(dev)
+    with ops.fp32_split(3):
+        assert ops.PLANE_GEMMS
+        Wf, Wb = ops.conv_weight_fwd(Wd), ops.conv_weight_bwd(Wd)
+        xp, dyp = ops.planes_of(xcl), ops.planes_of(dycl)
+        ycl = ops.conv1d_fwd(xcl, Wf, None, B, T, Cin, Cout, K, dil, x_planes=xp, w_planes=ops.planes_of(Wf))
+        close(ycl.view(B, T, Cout).permute(0, 2, 1), y, rtol=1e-5, atol=1e-4, what='conv fwd (planes)')
+        dx = ops.conv1d_dx(dycl, Wb, B, T, Cin, Cout, K, dil, dy_planes=dyp, w_planes=ops.planes_of(Wb))
+        close(dx.view(B, T, Cin).permute(0, 2, 1), gx, rtol=1e-5, atol=1e-4, what='conv dx (planes)')
+        dW = torch.zeros(Cout, Cin, K, device=dev)
+        ops.conv1d_dw(dycl, xcl, B, T, Cin, Cout, K, dil, dW, dy_planes=dyp, x_planes=xp)
+        close(dW, gw, rtol=1e-5, atol=1e-4, what='conv dw (planes)')
+
+
 @pytest.mark.parametrize('bf16', PRECISIONS)
 @pytest.mark.parametrize('B,T,Cin,Cout,K,dil', [(3, 37, 16, 24, 5, 1), (2, 9, 32, 48, 5, 2), (4, 150, 80, 512, 5, 1)])
 def test_conv1d_fwd_dx_dw(dev, B, T, Cin, Cout, K, dil, bf16):

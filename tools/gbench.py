@@ -27,6 +27,36 @@ def timeit(name, fn, flops):
 
 B, To, Bp = 64, 870, 64
 rows = B * To
+if os.environ.get('PLANES'):     # PLANES=1: the GEMMs of the step on pre-split operands (pgemm_kernel), split time listed apart
+    ops.set_fp32_split(3)
+    P = ops.Planes
+    dy = torch.randn(rows, 4096, device=dev); dyp = P(dy)
+    timeit('gt_split3 of dG (rows x 4096): GB/s = (4 + 6) B/element', lambda: dyp.split(), 0.0)
+    dyp.split()
+    for N in (2048, 3072):
+        x = torch.randn(rows, N, device=dev); xp = P(x).split(); out = torch.zeros(4096, N, device=dev)
+        timeit(f'decoder dW dG^T.X  M=4096 N={N} K=rows  [planes]', lambda: ops.linear_dw(dy, x, rows, 4096, N, out, dy_planes=dyp, x_planes=xp), 2.0 * 4096 * N * rows)
+        timeit(f'decoder dW dG^T.X  M=4096 N={N} K=rows  [in-kernel split]', lambda: ops.linear_dw(dy, x, rows, 4096, N, out), 2.0 * 4096 * N * rows)
+    W = torch.randn(4096, 2048, device=dev) * 0.05; Wp = P(W).split()
+    for blk in (16, 64):
+        M = blk * 64
+        xb = torch.randn(M, 2048, device=dev); xbp = P(xb).split()
+        timeit(f'block GEMM fwd X2.W2ih^T M={M} N=4096 K=2048 [planes]', lambda: ops.linear(xb, W, M, 2048, 4096, x_planes=xbp, w_planes=Wp), 2.0 * M * 4096 * 2048)
+        timeit(f'block GEMM fwd X2.W2ih^T M={M} N=4096 K=2048 [in-kernel]', lambda: ops.linear(xb, W, M, 2048, 4096), 2.0 * M * 4096 * 2048)
+        gb = torch.randn(M, 4096, device=dev); gbp = P(gb).split()
+        timeit(f'block GEMM bwd dG2.W2ih  M={M} N=2048 K=4096 [planes]', lambda: ops.linear_dx(gb, W, M, 4096, 2048, dy_planes=gbp, w_planes=Wp), 2.0 * M * 4096 * 2048)
+        timeit(f'block GEMM bwd dG2.W2ih  M={M} N=2048 K=4096 [in-kernel]', lambda: ops.linear_dx(gb, W, M, 4096, 2048), 2.0 * M * 4096 * 2048)
+    x = torch.randn(rows, 512, device=dev); Wc = torch.randn(512, 512, 5, device=dev) * 0.02
+    Wf, Wb = ops.conv_weight_fwd(Wc), ops.conv_weight_bwd(Wc)
+    xp, Wfp, Wbp = P(x).split(), P(Wf).split(), P(Wb).split()
+    fl = 2.0 * rows * 512 * 512 * 5
+    timeit('postnet conv fwd 512->512 k5 [planes]', lambda: ops.conv1d_fwd(x, Wf, None, B, To, 512, 512, 5, 1, x_planes=xp, w_planes=Wfp), fl)
+    timeit('postnet conv fwd 512->512 k5 [in-kernel]', lambda: ops.conv1d_fwd(x, Wf, None, B, To, 512, 512, 5, 1), fl)
+    timeit('postnet conv dx [planes]', lambda: ops.conv1d_dx(x, Wb, B, To, 512, 512, 5, 1, dy_planes=xp, w_planes=Wbp), fl)
+    dW = torch.zeros(512, 512, 5, device=dev)
+    timeit('postnet conv dW [planes]', lambda: ops.conv1d_dw(x, x, B, To, 512, 512, 5, 1, dW, dy_planes=xp, x_planes=xp), fl)
+    timeit('postnet conv dW [in-kernel]', lambda: ops.conv1d_dw(x, x, B, To, 512, 512, 5, 1, dW), fl)
+    sys.exit(0)
 # linear: M x K times N x K
 for name, M, K, N in (('pre1 (To*Bp x 256) . (4096 x 256)', rows, 256, 4096), ('proj dx (rows x 81) . W', rows, 81, 2048),
                       ('decoder dW dG^T.X  M=4096 N=2048 K=rows', 4096, rows, 2048), ('decoder dW M=4096 N=3072', 4096, rows, 3072)):
