@@ -13,6 +13,7 @@
 // MFMA operand fetch is one conflict-free ds_read_b32 per lane; the next tile's global loads are
 // issued into registers before the current tile's MFMAs (register prefetch).
 #include <algorithm>
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -32,6 +33,8 @@ struct GemmDev {
     long ldc, a_bs, b_bs, c_bs;
     int M, N, K, accumulate, split_k, k_per_split;
     int bf16;               // 0: fp32 MFMA, 1: operands rounded to bf16, 2 / 3: fp32 product from 2 / 3 bf16 planes (xgemm_kernel)
+    int dbg;                // GANTRON_PGEMM_DEBUG (diagnostics, pgemm_kernel): 1 = no DMA after the first tile, 2 = every tile
+                            // re-reads the first one's addresses (cache-hot sources), 4 = no MFMAs
     float alpha;
 };
 
@@ -775,33 +778,41 @@ struct TileDma {
             }
         }
     }
-    // issue this wave's share of the next k-tile (3 planes x NJ instructions) and advance to the tile after it
+    // source element offset of instruction slot jj for the NEXT k-tile (im2col: with its validity), then advance
+    __device__ __forceinline__ long next_source(const OpDev& o, int jj, bool& ok) {
+        long e = off[jj];
+        ok = true;
+        if (MODE == GT_OP_IM2COL_K) {
+            const int tt = p1[jj] + q0[jj] * o.dil - o.pad;
+            ok = tt >= 0 && tt < o.T;
+            e = ((long)p0[jj] * o.T + (ok ? tt : p1[jj])) * o.C + q1[jj];
+            q1[jj] += BKP;
+            while (q1[jj] >= o.C) { q1[jj] -= o.C; ++q0[jj]; }
+        } else if (MODE == GT_OP_IM2COL_R) {
+            const int tt = q1[jj] + p0[jj] * o.dil - o.pad;
+            ok = tt >= 0 && tt < o.T;
+            e = ((long)q0[jj] * o.T + (ok ? tt : q1[jj])) * o.C + p1[jj];
+            q1[jj] += BKP;
+            while (q1[jj] >= o.T) { q1[jj] -= o.T; ++q0[jj]; }
+        } else {
+            off[jj] += MODE == GT_OP_KC ? (long)BKP : (long)BKP * o.ld;
+        }
+        return e;
+    }
+    // one LDS-DMA instruction: plane p of instruction slot jj (1 KiB of the image)
+    static __device__ __forceinline__ void piece(const unsigned short* base, long ps, long e, bool ok, unsigned short* S, int wave,
+                                                 int jj, int p) {
+        const unsigned short* src = ok ? base + p * ps + e : g_zero16;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(S + p * PLANE + (wave + 4 * jj) * 512), 16, 0, 0);
+    }
+    // this wave's whole share of the next k-tile at once (prologue)
     __device__ __forceinline__ void issue(const OpDev& o, const unsigned short* base, long ps, unsigned short* S, int wave) {
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) {
-            const int j = wave + 4 * jj;
-            long e = off[jj];
-            bool ok = true;
-            if (MODE == GT_OP_IM2COL_K) {
-                const int tt = p1[jj] + q0[jj] * o.dil - o.pad;
-                ok = tt >= 0 && tt < o.T;
-                e = ((long)p0[jj] * o.T + (ok ? tt : p1[jj])) * o.C + q1[jj];
-                q1[jj] += BKP;
-                while (q1[jj] >= o.C) { q1[jj] -= o.C; ++q0[jj]; }
-            } else if (MODE == GT_OP_IM2COL_R) {
-                const int tt = q1[jj] + p0[jj] * o.dil - o.pad;
-                ok = tt >= 0 && tt < o.T;
-                e = ((long)q0[jj] * o.T + (ok ? tt : q1[jj])) * o.C + p1[jj];
-                q1[jj] += BKP;
-                while (q1[jj] >= o.T) { q1[jj] -= o.T; ++q0[jj]; }
-            } else {
-                off[jj] += MODE == GT_OP_KC ? (long)BKP : (long)BKP * o.ld;
-            }
+            bool ok;
+            const long e = next_source(o, jj, ok);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                const unsigned short* src = ok ? base + p * ps + e : g_zero16;
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(S + p * PLANE + j * 512), 16, 0, 0);
-            }
+            for (int p = 0; p < 3; ++p) piece(base, ps, e, ok, S, wave, jj, p);
         }
     }
     // fragment of the 32x32x16 product for rows [w0 + 32 i, +32), k-step s, plane p (layouts: xgemm_kernel)
@@ -831,7 +842,23 @@ __global__ __launch_bounds__(256) void pgemm_kernel(GemmDev g) {
     unsigned short* Bx = smem + 3 * LA::PLANE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so the ones that share an XCD (equal linear
+    // id mod 8) get a CONTIGUOUS range of tiles, walked in 8-wide column strips -- the 64 tiles an XCD holds at a time are
+    // then ~8 x 8 and its L2 serves 7 of 8 operand-panel reads (6 bytes per element make this kernel the first of the
+    // GEMMs here that is bound by what leaves L2; placement is a speed matter only)
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (!(g.dbg & 8)) {
+        const int nx = gridDim.x, ny = gridDim.y, nwg = nx * ny;
+        const int lin = by * nx + bx;
+        const int xcd = lin & 7, q = nwg >> 3, r = nwg & 7;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);       // bijective remap
+        const int strip = 8 * ny;                       // tiles per full 8-column strip
+        const int sidx = t / strip, rem = t - sidx * strip;
+        const int w = min(8, nx - 8 * sidx);            // width of this strip
+        by = rem / w;
+        bx = 8 * sidx + rem - by * w;
+    }
+    const int m0 = by * BM, n0 = bx * BN;
     const int batch = blockIdx.z / g.split_k, kz = blockIdx.z - batch * g.split_k;
     const int kbeg = kz * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
@@ -871,10 +898,15 @@ __global__ __launch_bounds__(256) void pgemm_kernel(GemmDev g) {
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();                  // every wave holds its fragments: the image may be overwritten
-        if (k0 + BKP < kend) {
+        // (Measured and not adopted: the next tile's LDS-DMA pieces issued BETWEEN the MFMAs, one per four, pinned with
+        // sched_barrier: 145 instead of 190 TFLOP/s on the decoder weight gradients -- the pins cost the MFMA stream more
+        // than the burst costs the pipe, the other workgroup of the CU computes while this one issues.)
+        if (k0 + BKP < kend && !(g.dbg & 1)) {
+            if (g.dbg & 2) { la.init(g.A, m0, g.M, kbeg, lane, wave); lb.init(g.B, n0, g.N, kbeg, lane, wave); }
             la.issue(g.A, Ab, g.a_ps, Ax, wave);
             lb.issue(g.B, Bb, g.b_ps, Bx, wave);
         }
+        if (!(g.dbg & 4))
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -1036,6 +1068,8 @@ extern "C" int gt_sgemm(const GtGemm* g, void* stream) {
     d.split_k = g->split_k;
     GT_REQUIRE(g->bf16 >= 0 && g->bf16 <= 3, GT_E_ARG, "gt_sgemm: bf16 = %d (0 fp32, 1 bf16 operands, 2 / 3 split planes)", g->bf16);
     d.bf16 = g->bf16 != 0 ? g->bf16 : g_fp32_planes;
+    static const int pgemm_dbg = getenv("GANTRON_PGEMM_DEBUG") ? atoi(getenv("GANTRON_PGEMM_DEBUG")) : 0;
+    d.dbg = pgemm_dbg;
     // operands that arrive as bf16 planes: the pure three-plane kernel, when the shapes allow whole 16-byte chunks and
     // whole 32-wide k-tiles; otherwise the fp32 operands (which must then be there) go through xgemm_kernel's own split
     d.Ap = d.Bp = nullptr; d.a_ps = d.b_ps = 0;
