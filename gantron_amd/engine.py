@@ -973,20 +973,39 @@ class GeneratorEngine:
         g1ih, g1hh = G['decoder.attention_rnn.weight_ih'], G['decoder.attention_rnn.weight_hh']
         g2ih, g2hh = G['decoder.decoder_rnn.weight_ih'], G['decoder.decoder_rnn.weight_hh']
 
+        # Operands of the deferred weight-gradient GEMMs as bf16 planes (ops.Planes): the forward histories are split once,
+        # on the leaf stream, under the PostNet / projection backward; a chunk's gate gradients when the chunk's loop
+        # steps are done.  The GEMMs then run the kernel that has no split left to do (pgemm_kernel).
+        pl = {}
+        if ops.PLANE_GEMMS and not self.bf16 and ops.FP32_SPLIT == 3 and Bp % 8 == 0:
+            def split_histories():
+                for k, t in (('p2', sv['p2']), ('hatt', hist['hatt']), ('HC', hist['HC'])):
+                    pl[k] = ops.Planes(t).split()
+            LEAF.run(split_histories, sv['p2'], hist['hatt'], hist['HC'])
+            pl['dG1'], pl['dG2'] = ops.Planes(dG1), ops.Planes(dG2)
+
         def leaf_decoder(lo, hi):
             """Weight gradients contributed by decoder steps lo..hi (dW = dGates^T . inputs, K = rows)."""
             n, o = (hi - lo + 1) * Bp, lo * Bp
-            ops.linear_dw(dG1, sv['p2'], n, 4 * Ha, Pd, g1ih, dy_offset=o * 4 * Ha, x_offset=o * Pd, ldc=Pd + E)
-            ops.linear_dw(dG2, hist['hatt'], n, 4 * Hd, Ha, g2ih, dy_offset=o * 4 * Hd, x_offset=o * Ha, ldc=Ha + E)
+            if pl:
+                pl['dG1'].split(o * 4 * Ha, (o + n) * 4 * Ha)
+                pl['dG2'].split(o * 4 * Hd, (o + n) * 4 * Hd)
+            g1p, g2p, p2p, hap, hcp = (pl.get(k) for k in ('dG1', 'dG2', 'p2', 'hatt', 'HC'))
+            ops.linear_dw(dG1, sv['p2'], n, 4 * Ha, Pd, g1ih, dy_offset=o * 4 * Ha, x_offset=o * Pd, ldc=Pd + E,
+                          dy_planes=g1p, x_planes=p2p)
+            ops.linear_dw(dG2, hist['hatt'], n, 4 * Hd, Ha, g2ih, dy_offset=o * 4 * Hd, x_offset=o * Ha, ldc=Ha + E,
+                          dy_planes=g2p, x_planes=hap)
             ops.linear_dw(dG2, hist['HC'], n, 4 * Hd, E, g2ih, dy_offset=o * 4 * Hd, ldx=hc, x_offset=o * hc + Hd,
-                          ldc=Ha + E, c_offset=Ha)
+                          ldc=Ha + E, c_offset=Ha, dy_planes=g2p, x_planes=hcp)
             l1 = max(lo, 1)                      # pairs (t, t-1): gradients of the recurrent inputs
             if hi >= l1:
                 n1, o1, p1_ = (hi - l1 + 1) * Bp, l1 * Bp, (l1 - 1) * Bp
                 ops.linear_dw(dG1, hist['HC'], n1, 4 * Ha, E, g1ih, dy_offset=o1 * 4 * Ha, ldx=hc,
-                              x_offset=p1_ * hc + Hd, ldc=Pd + E, c_offset=Pd)
-                ops.linear_dw(dG1, hist['hatt'], n1, 4 * Ha, Ha, g1hh, dy_offset=o1 * 4 * Ha, x_offset=p1_ * Ha)
-                ops.linear_dw(dG2, hist['HC'], n1, 4 * Hd, Hd, g2hh, dy_offset=o1 * 4 * Hd, ldx=hc, x_offset=p1_ * hc)
+                              x_offset=p1_ * hc + Hd, ldc=Pd + E, c_offset=Pd, dy_planes=g1p, x_planes=hcp)
+                ops.linear_dw(dG1, hist['hatt'], n1, 4 * Ha, Ha, g1hh, dy_offset=o1 * 4 * Ha, x_offset=p1_ * Ha,
+                              dy_planes=g1p, x_planes=hap)
+                ops.linear_dw(dG2, hist['HC'], n1, 4 * Hd, Hd, g2hh, dy_offset=o1 * 4 * Hd, ldx=hc, x_offset=p1_ * hc,
+                              dy_planes=g2p, x_planes=hcp)
             s1 = ops.col_sums(dG1[lo:hi + 1], n, 4 * Ha)
             acc_add(G['decoder.attention_rnn.bias_ih'], s1)
             acc_add(G['decoder.attention_rnn.bias_hh'], s1)

@@ -135,16 +135,12 @@ class Planes:
         return self
 
 
-def planes_of(t):
-    """Planes of a whole tensor, split now (None when plane GEMMs are off or the tensor cannot take them)."""
-    if not PLANE_GEMMS or BF16_GEMMS or FP32_SPLIT != 3 or t.numel() % 8 != 0:
-        return None
-    return Planes(t.contiguous()).split()
-
-
-# Operands of the large GEMMs are split into bf16 planes ONCE, where they are produced, and the GEMMs run the kernel that
-# has no split left to do (pgemm_kernel); GANTRON_PLANE_GEMMS=0 keeps the in-kernel split (xgemm_kernel) everywhere.
-PLANE_GEMMS = _os.environ.get('GANTRON_PLANE_GEMMS', '1') != '0'
+# GANTRON_PLANE_GEMMS=1: operands of the decoder's weight-gradient GEMMs are split into bf16 planes ONCE (gt_split3 on the
+# leaf stream) and those GEMMs run the kernel that has no split left to do (pgemm_kernel).  Measured on MI355X (round 3,
+# DESIGN.md section 3) and NOT adopted: stand-alone the two kernels tie (190-197 vs 191-202 TFLOP/s on the decoder shapes: with
+# 6 instead of 4 bytes per element the plane kernel is bound by what moves L2 -> LDS, 43.8 GB per GEMM, not by the split),
+# and in the step the split passes cost what nothing pays back: 135.2-135.7 vs 133.8-133.9 ms per pair.  Off by default.
+PLANE_GEMMS = _os.environ.get('GANTRON_PLANE_GEMMS', '0') != '0'
 
 
 class Operand:

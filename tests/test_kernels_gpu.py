@@ -183,12 +183,11 @@ def test_plane_gemm_convolutions(dev, B, T, Cin, Cout, K, dil):
     dycl = dy.permute(0, 2, 1).contiguous().view(B * T, Cout).to(dev)
     Wd = W.to(dev)
     with ops.fp32_split(3):
-        assert ops.PLANE_GEMMS
         Wf, Wb = ops.conv_weight_fwd(Wd), ops.conv_weight_bwd(Wd)
-        xp, dyp = ops.planes_of(xcl), ops.planes_of(dycl)
-        ycl = ops.conv1d_fwd(xcl, Wf, None, B, T, Cin, Cout, K, dil, x_planes=xp, w_planes=ops.planes_of(Wf))
+        xp, dyp = ops.Planes(xcl).split(), ops.Planes(dycl).split()
+        ycl = ops.conv1d_fwd(xcl, Wf, None, B, T, Cin, Cout, K, dil, x_planes=xp, w_planes=ops.Planes(Wf).split())
         close(ycl.view(B, T, Cout).permute(0, 2, 1), y, rtol=1e-5, atol=1e-4, what='conv fwd (planes)')
-        dx = ops.conv1d_dx(dycl, Wb, B, T, Cin, Cout, K, dil, dy_planes=dyp, w_planes=ops.planes_of(Wb))
+        dx = ops.conv1d_dx(dycl, Wb, B, T, Cin, Cout, K, dil, dy_planes=dyp, w_planes=ops.Planes(Wb).split())
         close(dx.view(B, T, Cin).permute(0, 2, 1), gx, rtol=1e-5, atol=1e-4, what='conv dx (planes)')
         dW = torch.zeros(Cout, Cin, K, device=dev)
         ops.conv1d_dw(dycl, xcl, B, T, Cin, Cout, K, dil, dW, dy_planes=dyp, x_planes=xp)

@@ -189,6 +189,15 @@ def test_fused_attention_backward_step_against_oracle(dev, monkeypatch):
     _midsize_against_oracle(dev, 'full_dims_b20')
 
 
+def test_plane_gemms_against_oracle(dev, monkeypatch):
+    """The opt-in pre-split operand path of the decoder's weight-gradient GEMMs (GANTRON_PLANE_GEMMS: gt_split3 +
+    pgemm_kernel) through a whole pair at the reference's dimensions, 64 rows, several backward chunks."""
+    from gantron_amd import ops
+    monkeypatch.setattr(ops, 'PLANE_GEMMS', True)
+    with ops.fp32_split(3):
+        _midsize_against_oracle(dev, 'full_dims_b64_t200')
+
+
 def test_fused_decoder_lstm_backward_against_oracle(dev, monkeypatch):
     """The opt-in one-launch decoder-LSTM backward step (GANTRON_REC_CELL bit 5: gt_rec_cellbwd) through a whole generator +
     discriminator pair at the reference's dimensions, against the oracle."""
