@@ -25,6 +25,7 @@ extern "C" int64_t gt_abi_sizeof(int32_t which) {
         case 5: return sizeof(GtDecoderBwd);
         case 6: return sizeof(GtBiLstm);
         case 7: return sizeof(GtDecoderInfer);
+        case 8: return sizeof(GtPlstm);
         default: return -1;
     }
 }

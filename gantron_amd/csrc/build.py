@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
-SOURCES = ['api.hip', 'gemm.hip', 'recurrent.hip', 'recurrent_bf16.hip', 'recurrent_fused.hip', 'cell_query.hip', 'attention.hip', 'attention_mfma.hip', 'elementwise.hip', 'loss_optim.hip', 'loops.hip']
+SOURCES = ['api.hip', 'gemm.hip', 'recurrent.hip', 'recurrent_bf16.hip', 'recurrent_fused.hip', 'cell_query.hip', 'attention.hip', 'attention_mfma.hip', 'elementwise.hip', 'loss_optim.hip', 'loops.hip', 'plstm.hip']
 LIB = os.path.join(PKG, 'libgantron_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
          '-fno-gpu-rdc', '-DNDEBUG']

@@ -226,6 +226,8 @@ static int decoder_fwd_hoisted(const GtDecoderFwd* a, void* stream) {
                "gt_decoder_fwd: W1c / W2hc need Wq + partq, Ha %% 32 == 0, Hd %% 16 == 0, E %% 4 == 0 and their counters");
     const bool attn_step = a->row_cnt != nullptr && gt_attn_step_supported(d) && wpack != nullptr && a->ld1 % 4 == 0 &&
                            a->ld2 % 4 == 0 && a->ldE % 4 == 0 && (a->Hd % 4 == 0) && a->To < (1 << 24);
+    const bool persistB = a->W2hh != nullptr && a->pl_counters != nullptr && a->pl_timeout != nullptr && !a->bf16 &&
+                          gt_plstm_supported(a->Bp, a->Hd) && hc_ld % 4 == 0 && a->pre2 == a->gates2;
     const int64_t x1_slot = fusedA ? (int64_t)a->Bp * a->ld1 : 0;      // operand ping-pong (see GtDecoderFwd::W1c)
     const int64_t xh_slot = fusedB ? (int64_t)a->Bp * a->ldh : 0;
     int nblock = 0;
@@ -290,6 +292,19 @@ static int decoder_fwd_hoisted(const GtDecoderFwd* a, void* stream) {
         // ---- decoder LSTM (stream B): input pre-activations of the block, then its recurrence
         GT_TRY(block_gemm(op_kc(a->X2 + (int64_t)t0 * xa_step, a->ld2), op_kc(a->W2ih, a->ldw2), a->bias2,
                           a->pre2 + (int64_t)t0 * a->Bp * N2, N2, (t1 - t0) * a->Bp, N2, a->Ha + a->E, 0, a->bf16, sB));
+        if (persistB) {
+            // the block's recurrence as ONE persistent launch: h_dec_t is published into HC[t] and read from there
+            GtPlstm q = {};
+            q.B = a->B; q.Bp = a->Bp; q.H = a->Hd; q.T = a->To; q.ndir = 1; q.s_lo = t0; q.s_hi = t1; q.hx_ring = 0;
+            q.p_drop = a->dec_keep ? a->p_dec : 0.f;
+            q.Whh = a->W2hh; q.pre = a->pre2; q.gates = a->gates2; q.c = a->c2; q.hs = nullptr;
+            q.hx = a->HC; q.hx_step = (int64_t)a->Bp * hc_ld; q.hx_ld = hc_ld;
+            q.keep = a->dec_keep; q.active = nullptr; q.counters = a->pl_counters; q.timeout_flag = a->pl_timeout;
+            GT_TRY(gt_plstm_fwd(&q, sB));
+            t0 = t1;
+            ++nblock;
+            continue;
+        }
         for (int t = t0; t < t1; ++t) {
             const uint8_t* k2 = a->dec_keep ? a->dec_keep + (int64_t)t * a->Bp * a->Hd : nullptr;
             float* hc_t = a->HC + (int64_t)t * a->Bp * hc_ld;

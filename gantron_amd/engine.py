@@ -24,7 +24,7 @@ import torch
 
 from . import ops
 from .ops import (ACT_NONE, ACT_RELU, ACT_TANH, IM2COL_K, IM2COL_R, KC, RC, Operand, call, ptr, roundup, sgemm)
-from ._lib import GtBiLstm, GtDecoderBwd, GtDecoderFwd, GtDecoderInfer, check, lib
+from ._lib import GtBiLstm, GtDecoderBwd, GtDecoderFwd, GtDecoderInfer, GtPlstm, check, lib
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 # ---- switches (environment, read once at import; the defaults are the measured-best configuration)
@@ -56,6 +56,15 @@ DEC_BLK_BWD = int(_os.environ.get('GANTRON_DEC_BLK_BWD', '16'))
 # (it only follows / feeds the attention chain): fewer, longer workgroups leave the CUs to the critical chain.
 S2_FWD = int(_os.environ.get('GANTRON_S2_FWD', '0'))
 S2_BWD = int(_os.environ.get('GANTRON_S2_BWD', '0'))
+# Persistent, weight-resident LSTM recurrences (gt_plstm_fwd, csrc/plstm.hip): bit 0 = the encoder BiLSTM forward (ONE launch
+# for all steps of both directions), bit 1 = the decoder LSTM's h_dec recurrence of a block of steps (hoisted mode, fp32).
+# Measured on MI355X (round 3) and NOT adopted: the encoder launch takes 9.8 us per step against ~10 for
+# the per-step fused launches it replaces (1.84 vs 1.9 ms per forward); the decoder block runs at 33 us per step on 64 CUs --
+# fast enough for the chain it feeds, but the attention chain's 256-workgroup kernels then run on 192 CUs (its fused step
+# 27 instead of 20 us): pair 134.0-134.6 ms with both on against 133.3-134.2 without; forward loop 41.3 (with 3 K-splits
+# for the attention LSTM) / 42.7 / 42.5 ms.  Off by default, parity-tested with the bits on.
+PLSTM = int(_os.environ.get('GANTRON_PLSTM', '0'))
+S1_FWD = int(_os.environ.get('GANTRON_S1_FWD', '0'))       # diagnostics: K-splits of the attention LSTM's forward product
 DEC_BLK = int(_os.environ.get('GANTRON_DEC_BLK', '16'))       # steps per block in that mode (measured: 8: 160.6 ms per pair,
                                                               # 12: 157.9, 16: 157.9, 32: 160.5, 48: 160.9, 64: 165.7)
 
@@ -402,19 +411,25 @@ class GeneratorEngine:
     def step_major_index(lengths, T, Bp):
         """Row maps of the packed BiLSTM.  fwd_idx/rev_idx: (T*Bp,) source row b*T+t of step-major row
         (s,b) (or -1); inverse maps (B*T,) give the step-major row of (b,t) for each direction."""
+        import numpy as np
         B = len(lengths)
-        fwd = torch.full((T, Bp), -1, dtype=torch.int32)
-        rev = torch.full((T, Bp), -1, dtype=torch.int32)
-        ifwd = torch.full((B, T), -1, dtype=torch.int32)
-        irev = torch.full((B, T), -1, dtype=torch.int32)
-        active = torch.zeros(T, Bp, dtype=torch.int32)
-        for b, L in enumerate(lengths):
-            s = torch.arange(L, dtype=torch.int32)
-            fwd[:L, b] = b * T + s
-            rev[:L, b] = b * T + (L - 1 - s)
-            ifwd[b, :L] = s * Bp + b
-            irev[b, :L] = (L - 1 - s) * Bp + b
-            active[:L, b] = 1
+        L = np.asarray(lengths, dtype=np.int64)[None, :]                 # (1, B)
+        s = np.arange(T, dtype=np.int64)[:, None]                        # (T, 1)
+        b = np.arange(B, dtype=np.int64)[None, :]
+        live = s < L                                                     # (T, B): step s of item b exists
+        fwd = np.full((T, Bp), -1, dtype=np.int32)
+        rev = np.full((T, Bp), -1, dtype=np.int32)
+        active = np.zeros((T, Bp), dtype=np.int32)
+        fwd[:, :B] = np.where(live, b * T + s, -1)
+        rev[:, :B] = np.where(live, b * T + (L - 1 - s), -1)
+        active[:, :B] = live
+        # inverse maps, (B, T): step-major row of position t of item b in each direction
+        t = np.arange(T, dtype=np.int64)[None, :]
+        Lc = np.asarray(lengths, dtype=np.int64)[:, None]
+        bb = np.arange(B, dtype=np.int64)[:, None]
+        ifwd = np.where(t < Lc, t * Bp + bb, -1).astype(np.int32)
+        irev = np.where(t < Lc, (Lc - 1 - t) * Bp + bb, -1).astype(np.int32)
+        fwd, rev, ifwd, irev, active = (torch.from_numpy(a) for a in (fwd, rev, ifwd, irev, active))
         return fwd.reshape(-1), rev.reshape(-1), ifwd.reshape(-1), irev.reshape(-1), active
 
     def _encode(self, P, text, in_lens, rng, speaker_ids, emotions, training, sv):
@@ -447,7 +462,14 @@ class GeneratorEngine:
         PHASES.mark('f.enc_conv')
         # ---- packed BiLSTM, step-major
         fwd_i, rev_i, ifwd, irev, active = self.step_major_index(in_lens, Ti, Bp)
-        idx = {k: v.to(dev) for k, v in dict(fwd=fwd_i, rev=rev_i, ifwd=ifwd, irev=irev, active=active).items()}
+        # one non-blocking copy for the five maps (ops.h2d: no host stall)
+        maps = dict(fwd=fwd_i, rev=rev_i, ifwd=ifwd, irev=irev, active=active.reshape(-1))
+        flat = ops.h2d(torch.cat([v.reshape(-1) for v in maps.values()]), torch.int32, dev)
+        idx, o = {}, 0
+        for k, v in maps.items():
+            idx[k] = flat[o:o + v.numel()]
+            o += v.numel()
+        idx['active'] = idx['active'].view(Ti, Bp)
         sv['idx'] = idx
         C = self.enc_dim
         Xs = _f32(2, Ti * Bp, C, device=dev, zero=False)
@@ -461,13 +483,28 @@ class GeneratorEngine:
             ops.linear(Xs[d], P['encoder.lstm.weight_ih_l0' + sfx], Ti * Bp, C, 4 * H, bias=bias, out=pre[d])
             Whp.append(pack_rec(P['encoder.lstm.weight_hh_l0' + sfx], 4 * H, 4 * H, H))
         Whp = torch.stack(Whp)
+        gates = _f32(2, Ti, Bp, 4 * H, device=dev, zero=False)
+        cst = _f32(2, Ti + 1, Bp, H, device=dev)
+        hs = _f32(2, Ti, Bp, H, device=dev, zero=False)
+        if (PLSTM & 1) and lib().gt_plstm_supported(Bp, H):
+            # the whole recurrence of both directions as ONE persistent launch (W_hh resident in registers, 2 x H/16 workgroups)
+            Whh = torch.stack([P['encoder.lstm.weight_hh_l0' + sfx] for sfx in ('', '_reverse')]).contiguous()
+            q = GtPlstm()
+            q.B, q.Bp, q.H, q.T, q.ndir, q.s_lo, q.s_hi, q.hx_ring = B, Bp, H, Ti, 2, 0, Ti, 2
+            hx = _f32(2, 2, Bp, H, device=dev, zero=False)
+            counters = torch.zeros(2, dtype=torch.int32, device=dev)
+            q.Whh, q.w_dstride, q.pre, q.pre_dstride = ptr(Whh), Whh.stride(0), ptr(pre), pre.stride(0)
+            q.gates, q.gates_dstride, q.c, q.c_dstride, q.hs, q.hs_dstride = ptr(gates), gates.stride(0), ptr(cst), cst.stride(0), \
+                ptr(hs), hs.stride(0)
+            q.hx, q.hx_dstride, q.hx_step, q.hx_ld = ptr(hx), hx.stride(0), hx.stride(1), H
+            q.active, q.counters, q.timeout_flag = ptr(idx['active']), ptr(counters), ptr(handoff_flag(dev))
+            _run('gt_plstm_fwd', q)
+            sv.update(Xs=Xs, enc_gates=gates, enc_c=cst, enc_hs=hs)
+            return self._encode_memory(P, sv, hs, idx, rng, speaker_ids, emotions, B, Ti, Bp, dev)
         ldx = roundup(H, 16)
         S = rec_splits(4 * H, H, nz=2)
         a = GtBiLstm()
         a.B, a.Bp, a.T, a.H, a.S, a.backward = B, Bp, Ti, H, S, 0
-        gates = _f32(2, Ti, Bp, 4 * H, device=dev, zero=False)
-        cst = _f32(2, Ti + 1, Bp, H, device=dev)
-        hs = _f32(2, Ti, Bp, H, device=dev, zero=False)
         fused_enc = bool(REC_CELL & 4) and H % 16 == 0         # product + cell of a BiLSTM step as one launch
         if fused_enc and ENC_SPLITS:
             S = a.S = ops.pick_splits(H, ENC_SPLITS)
@@ -482,7 +519,12 @@ class GeneratorEngine:
         a.X, a.ldx, a.part, a.gates, a.c, a.hs = ptr(Xst), ldx, ptr(part), ptr(gates), ptr(cst), ptr(hs)
         _run('gt_bilstm_run', a)
         sv.update(Xs=Xs, enc_gates=gates, enc_c=cst, enc_hs=hs)
+        return self._encode_memory(P, sv, hs, idx, rng, speaker_ids, emotions, B, Ti, Bp, dev)
 
+    def _encode_memory(self, P, sv, hs, idx, rng, speaker_ids, emotions, B, Ti, Bp, dev):
+        """The decoder memory [encoder outputs | speaker | labels | style noise] and its attention projection."""
+        hp = self.hp
+        H, E, Ep, A = self.H, self.E, self.Ep, self.A
         PHASES.mark('f.bilstm')
         # ---- decoder memory = [encoder outputs | speaker | labels | style noise]
         memory = _f32(B, Ti, Ep, device=dev)                 # columns [E, Ep) stay zero
@@ -587,6 +629,8 @@ class GeneratorEngine:
             d.S1, d.S2 = split(4 * Ha, K1), split(4 * Hd, Hd)
             if S2_FWD and not self.bf16:
                 d.S2 = ops.pick_splits(Hd, S2_FWD)
+            if S1_FWD and not self.bf16:
+                d.S1 = ops.pick_splits(K1, S1_FWD)
             # fused product + cell launches (gt_rec_cell_fwd) take their own packing
             use_c1 = bool(REC_CELL & (8 if self.bf16 else 1)) and CELL_QUERY and Ha % 32 == 0
             use_c2 = bool(REC_CELL & (16 if self.bf16 else 2)) and Hd % 16 == 0 and Hd % 4 == 0
@@ -603,7 +647,7 @@ class GeneratorEngine:
             keep_t.update(W1g=pack_gates(W1cat, Ha, K1), W2g=pack_gates(W2cat, Hd, K2))
         else:
             keep_t.update(W1p=pack_rec(W1cat, 4 * Ha, 4 * Ha, K1), W2p=pack_rec(W2cat, 4 * Hd, 4 * Hd, K2))
-        lens32 = torch.tensor(in_lens, dtype=torch.int32, device=dev)
+        lens32 = ops.h2d(in_lens, torch.int32, dev)
         ld1, ld2 = (int(lib().gt_fused_k_padded(K1)), int(lib().gt_fused_k_padded(K2))) if fused else \
             (roundup(K1, 16), roundup(K2, 16))
         if hoist2:
@@ -657,6 +701,10 @@ class GeneratorEngine:
             if use_c2:
                 ws['counters2'] = torch.zeros(nzb * (Hd // 16), dtype=torch.int32, device=dev)
                 d.W2hc, d.counters2 = ptr(keep_t['W2hc']), ptr(ws['counters2'])
+        if hoist2 and (PLSTM & 2) and not self.bf16 and lib().gt_plstm_supported(Bp, Hd):
+            keep_t['W2hh_raw'] = W2hh.contiguous()
+            ws['pl_counters'] = torch.zeros(1, dtype=torch.int32, device=dev)
+            d.W2hh, d.pl_counters, d.pl_timeout = ptr(keep_t['W2hh_raw']), ptr(ws['pl_counters']), ptr(handoff_flag(dev))
         if hoist2 and ATTN_STEP and lib().gt_attn_step_supported(ops.attn_dims(B, Ti, Ep, A, self.F, self.Kc)):
             ws['row_cnt'] = torch.zeros(B, dtype=torch.int32, device=dev)
             d.row_cnt, d.attn_timeout = ptr(ws['row_cnt']), ptr(handoff_flag(dev))
@@ -696,7 +744,7 @@ class GeneratorEngine:
         mel_post = mel.clone()
         call('gt_permute3', post_cl, To * n_mel, 1, n_mel, B, n_mel, To, mel_post, 0, 0, 1, 1.0)
         if mask_padding:
-            ol = torch.tensor(out_lens, dtype=torch.int64, device=dev)
+            ol = ops.h2d(out_lens, torch.int64, dev)
             call('gt_mask_outputs', mel, mel_post, gate, ol, B, n_mel, To)
             # the reference masks `mel` in place after the PostNet consumed it: the first PostNet
             # conv's weight gradient therefore sees the MASKED frames (model.py:638-640)
@@ -1331,8 +1379,8 @@ class LinearDiscriminatorEngine:
                 rows.extend(range(b * T + s0, b * T + s0 + win))
             weights.extend([1.0 / (B * len(st))] * len(st))
         NW = len(weights)
-        idx = torch.tensor(rows, dtype=torch.int32, device=dev)
-        wgt = torch.tensor(weights, dtype=torch.float32, device=dev)
+        idx = ops.h2d(rows, torch.int32, dev)
+        wgt = ops.h2d(weights, torch.float32, dev)
         frames = _f32(B * T, n_mel, device=dev, zero=False)                 # (b, t) rows of n_mel
         call('gt_permute3', mel.contiguous(), n_mel * T, 1, T, B, T, n_mel, frames, 0, 0, 0, 1.0)
         x = _f32(NW, win * n_mel, device=dev, zero=False)

@@ -99,6 +99,19 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def h2d(data, dtype, device):
+    """Small host -> device copy that does NOT stall the host: `torch.tensor(data, device=...)` and `.to(device)` from
+    pageable memory synchronise the stream after the copy, i.e. the host waits until the GPU has drained everything issued
+    so far and the kernels issued next start from an idle device (measured in a kernel trace of the step: ~12 such points
+    per G+D pair, ~14 ms of idle GPU per pair under the profiler).  Pinned staging + non_blocking copy instead; the caching
+    host allocator keeps the staging block alive until the copy has run."""
+    t = data if isinstance(data, torch.Tensor) else torch.tensor(data, dtype=dtype)
+    t = t.to(dtype).contiguous()
+    if torch.device(device).type != 'cuda':
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def ptr(t, offset=0):
     """Device address of element `offset` of tensor t (None -> NULL)."""
     if t is None:

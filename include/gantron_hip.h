@@ -443,6 +443,13 @@ typedef struct GtDecoderFwd {
      * attn_timeout (int32, may be NULL) is raised if an in-launch wait gives up. */
     uint32_t* row_cnt;
     int32_t* attn_timeout;
+    /* W2hh != NULL (hoisted mode, fp32, gt_plstm_supported(Bp, Hd)): the decoder LSTM's recurrence of a whole block of
+     * steps is ONE persistent launch (gt_plstm_fwd: W_hh resident in registers on Hd / 16 workgroups, h exchanged through
+     * the HC history itself) instead of one product + cell launch per step.  W2hh = decoder_rnn.weight_hh (4Hd, Hd) in
+     * PyTorch layout, pl_counters one word, pl_timeout as attn_timeout (not NULL). */
+    const float* W2hh;
+    uint32_t* pl_counters;
+    int32_t* pl_timeout;
 } GtDecoderFwd;
 
 typedef struct GtDecoderBwd {
@@ -528,6 +535,37 @@ typedef struct GtBiLstm {
     const float* Whc;
     uint32_t* counters;
 } GtBiLstm;
+
+/* Persistent, weight-resident LSTM recurrence: ONE launch walks steps [s_lo, s_hi) of
+ *   G_s = pre_s + h_{s-1} . W_hh^T,  cell,  h_s = dropout(o tanh c_s)
+ * for ndir independent problems, each on H / 16 workgroups that keep W_hh in registers and exchange h through `hx`
+ * (csrc/plstm.hip).  Used for the encoder BiLSTM (ndir = 2, packed-sequence semantics through `active`: model.py:202-210)
+ * and for the decoder LSTM's h_dec recurrence inside a block of steps (ndir = 1, hx = the HC history itself: model.py:406-409).
+ * Bp must be 64 and H 256 or 1024 (gt_plstm_supported).  Direction d of every per-direction buffer lies *_dstride
+ * elements behind direction 0. */
+typedef struct GtPlstm {
+    int32_t B, Bp, H, T, ndir, s_lo, s_hi, hx_ring;
+    float p_drop;              /* dropout probability of `keep` (0: none) */
+    const float* Whh;          /* (4H, H) PyTorch layout, gate order i f g o */
+    int64_t w_dstride;
+    const float* pre;          /* (T, Bp, 4H) input projections + both biases */
+    int64_t pre_dstride;
+    float* gates;              /* (T, Bp, 4H) gate values kept for the backward pass; may alias pre */
+    int64_t gates_dstride;
+    float* c;                  /* (T + 1, Bp, H); slice s_lo is read, slices s_lo + 1 .. s_hi are written */
+    int64_t c_dstride;
+    float* hs;                 /* (T, Bp, H) emitted h (zero for inactive rows), or NULL */
+    int64_t hs_dstride;
+    float* hx;                 /* exchange: h_s is published at slot (hx_ring ? s % hx_ring : s) * hx_step, rows of hx_ld;
+                                  h_{s_lo - 1} is read from there when s_lo > 0.  hx_ring = 0 or >= 2 */
+    int64_t hx_dstride, hx_step, hx_ld;
+    const uint8_t* keep;       /* (T, Bp, H) keep mask of the dropout on h, or NULL */
+    const int32_t* active;     /* (T, Bp): rows with 0 pass their state through and emit zeros, or NULL */
+    uint32_t* counters;        /* ndir words (zeroed by the call) */
+    int32_t* timeout_flag;     /* raised when a bounded wait gives up (results invalid) */
+} GtPlstm;
+int32_t gt_plstm_supported(int32_t Bp, int32_t H);
+int gt_plstm_fwd(const GtPlstm* a, void* stream);
 
 /* Free-running decoder of Decoder.inference (model.py:456-497): every step feeds the previous mel
  * frame back through the Prenet (dropout always on, model.py:104), runs the decode step of

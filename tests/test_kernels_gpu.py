@@ -999,3 +999,94 @@ def test_column_sums_are_bit_reproducible_with_a_workspace(dev):
         assert all(torch.equal(o, outs[0]) for o in outs[1:]), (rows, C)
         ref = torch.stack(((x - x[0]).double().sum(0), ((x - x[0]).double() ** 2).sum(0))).reshape(-1)
         close(outs[0], ref, rtol=1e-5, atol=1e-3, what=f'column sums {rows}x{C}')
+
+
+def _lstm_reference(pre, Whh, keep, active, c0):
+    """fp64 recurrence G_s = pre_s + h_{s-1} Whh^T with packed-sequence pass-through; returns gates, c (T+1), h_raw, h_carried."""
+    T, Bp, N = pre.shape
+    H = N // 4
+    c, h = c0.double().clone(), torch.zeros(Bp, H, dtype=torch.float64)
+    gates, cs, hraw, hcar = [], [c.clone()], [], []
+    for s in range(T):
+        G = pre[s].double() + h @ Whh.double().t()
+        i, f, g, o = torch.sigmoid(G[:, :H]), torch.sigmoid(G[:, H:2 * H]), torch.tanh(G[:, 2 * H:3 * H]), torch.sigmoid(G[:, 3 * H:])
+        cn = f * c + i * g
+        hn = o * torch.tanh(cn)
+        if keep is not None:
+            hn = hn * keep[s].double() * (1.0 / 0.9)
+        a = torch.ones(Bp, 1, dtype=torch.float64) if active is None else active[s].double()[:, None]
+        gates.append(torch.cat((i, f, g, o), 1))
+        c = a * cn + (1 - a) * c
+        hraw.append(a * hn)
+        h = a * hn + (1 - a) * h
+        cs.append(c.clone())
+        hcar.append(h.clone())
+    return torch.stack(gates), torch.stack(cs), torch.stack(hraw), torch.stack(hcar)
+
+
+def _plstm(dev, H, ndir, T, blocks, packed, dropout, B):
+    import ctypes
+    from gantron_amd import engine
+    from gantron_amd._lib import GtPlstm, check, lib
+    from gantron_amd.ops import ptr
+    Bp, N = 64, 4 * H
+    assert lib().gt_plstm_supported(Bp, H)
+    gen = torch.Generator().manual_seed(H + T)
+    Whh = torch.randn(ndir, N, H, generator=gen) * (1.5 / math.sqrt(H))
+    pre = torch.randn(ndir, T, Bp, N, generator=gen)
+    pre[:, :, B:] = 0
+    keep = (torch.rand(T, Bp, H, generator=gen) >= 0.1).to(torch.uint8) if dropout else None
+    lens = torch.randint(1, T + 1, (Bp,), generator=gen)
+    lens[0] = T
+    active = (torch.arange(T)[:, None] < lens[None, :]).to(torch.int32) if packed else None
+    if active is not None:
+        active[:, B:] = 0
+    ld = 2 * H if not packed else H                   # decoder use: h lives in columns [0, H) of the (T, Bp, 2H) HC history
+    d = lambda t: None if t is None else t.contiguous().to(dev)
+    Wd, pred, keepd, actd = d(Whh), d(pre), d(keep), d(active)
+    gates = torch.full((ndir, T, Bp, N), float('nan'), device=dev)
+    c = torch.full((ndir, T + 1, Bp, H), float('nan'), device=dev)
+    c[:, 0] = 0
+    hs = torch.full((ndir, T, Bp, H), float('nan'), device=dev) if packed else None
+    ring = 2 if packed else 0
+    hx = torch.full((ndir, ring if ring else T, Bp, ld), float('nan'), device=dev)
+    cnt = torch.zeros(ndir, dtype=torch.int32, device=dev)
+    q = GtPlstm()
+    q.B, q.Bp, q.H, q.T, q.ndir, q.hx_ring, q.p_drop = B, Bp, H, T, ndir, ring, 0.1 if dropout else 0.0
+    q.Whh, q.w_dstride, q.pre, q.pre_dstride = ptr(Wd), Wd.stride(0), ptr(pred), pred.stride(0)
+    q.gates, q.gates_dstride, q.c, q.c_dstride = ptr(gates), gates.stride(0), ptr(c), c.stride(0)
+    if hs is not None:
+        q.hs, q.hs_dstride = ptr(hs), hs.stride(0)
+    q.hx, q.hx_dstride, q.hx_step, q.hx_ld = ptr(hx), hx.stride(0), hx.stride(1), ld
+    q.keep, q.active, q.counters, q.timeout_flag = ptr(keepd), ptr(actd), ptr(cnt), ptr(engine.handoff_flag(dev))
+    s = 0
+    for n in blocks:                                   # several launches: state is picked up from c / hx of the step before
+        q.s_lo, q.s_hi = s, s + n
+        check(lib().gt_plstm_fwd(ctypes.byref(q), torch.cuda.current_stream().cuda_stream), 'gt_plstm_fwd')
+        s += n
+    assert s == T
+    torch.cuda.synchronize()
+    engine.check_handoffs()
+    for dd in range(ndir):
+        g_ref, c_ref, hraw_ref, hcar_ref = _lstm_reference(pre[dd], Whh[dd], keep, active, torch.zeros(Bp, H))
+        close(gates[dd, :, :B], g_ref[:, :B], rtol=1e-5, atol=1e-5, what=f'gates dir {dd}')
+        close(c[dd, :, :B], c_ref[:, :B], rtol=1e-5, atol=1e-5, what=f'c dir {dd}')
+        if hs is not None:
+            close(hs[dd, :, :B], hraw_ref[:, :B], rtol=1e-5, atol=1e-5, what=f'emitted h dir {dd}')
+            close(hx[dd, (T - 1) % 2, :B], hcar_ref[T - 1, :B], rtol=1e-5, atol=1e-5, what=f'carried h dir {dd}')
+        else:
+            close(hx[dd, :, :B, :H], hcar_ref[:, :B], rtol=1e-5, atol=1e-5, what=f'h history dir {dd}')
+        assert B == Bp or float(c[dd, :, B:].abs().max()) == 0.0           # pad rows stay zero
+
+
+@pytest.mark.parametrize('B', [64, 50])
+def test_plstm_encoder_bilstm(dev, B):
+    """gt_plstm_fwd as the encoder BiLSTM runs it: two directions in one persistent launch, H = 256, packed-sequence
+    pass-through (ragged lengths), 57 steps -- gates, cell states, emitted and carried h against a float64 recurrence."""
+    _plstm(dev, 256, 2, 57, [57], packed=True, dropout=False, B=B)
+
+
+def test_plstm_decoder_lstm_blocks(dev):
+    """gt_plstm_fwd as the decoder loop runs it: H = 1024 (W_hh resident in 64 workgroups' registers), one launch per
+    block of steps with the state picked up from the histories, dropout on h, h published into a (T, Bp, 2H) history."""
+    _plstm(dev, 1024, 1, 40, [16, 16, 4, 4], packed=False, dropout=True, B=64)

@@ -189,6 +189,21 @@ def test_fused_attention_backward_step_against_oracle(dev, monkeypatch):
     _midsize_against_oracle(dev, 'full_dims_b20')
 
 
+@pytest.mark.parametrize('case', ['full_dims_b64_t200', 'full_dims_b64_poison', 'vesus_b64'])
+def test_persistent_lstm_recurrences_against_oracle(dev, monkeypatch, case):
+    """The opt-in persistent recurrences (GANTRON_PLSTM = 3: gt_plstm_fwd for the encoder BiLSTM -- both directions, packed
+    sequences, one launch -- and for the decoder LSTM's h_dec recurrence, one launch per block of 16 steps with W_hh
+    resident in registers) through whole pairs at the reference's dimensions, 64 rows: ragged text lengths, several blocks,
+    NaN-poisoned histories, and the VESUS memory width (HC rows of 1024 + 1096 columns)."""
+    from gantron_amd import engine
+    monkeypatch.setattr(engine, 'PLSTM', 3)
+    if case.endswith('_poison'):
+        monkeypatch.setattr(engine, 'POISON', True)
+        case = case[:-len('_poison')]
+    _midsize_against_oracle(dev, case)
+    engine.check_handoffs()
+
+
 def test_plane_gemms_against_oracle(dev, monkeypatch):
     """The opt-in pre-split operand path of the decoder's weight-gradient GEMMs (GANTRON_PLANE_GEMMS: gt_split3 +
     pgemm_kernel) through a whole pair at the reference's dimensions, 64 rows, several backward chunks."""
