@@ -742,23 +742,23 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 __device__ __attribute__((aligned(16))) unsigned short g_zero16[8];
 
-template <int MODE, int BR>
+template <int MODE, int BR, int NW = 4>
 struct TileDma {
     static constexpr bool KT = is_ktype<MODE>();
     static constexpr int PLANE = BR * BKP;                 // bf16 elements of one plane image (no padding)
-    static constexpr int NI = PLANE * 2 / 1024;            // wave instructions per plane: 8 (128 rows) / 4 (64 rows)
-    static constexpr int NJ = NI / 4;                      // ... per wave
+    static constexpr int NI = PLANE * 2 / 1024;            // wave instructions per plane: 16 / 8 / 4 for 256 / 128 / 64 rows
+    static constexpr int NJ = NI / NW;                     // ... per wave (NW waves share the tile)
     static constexpr int CPR = BR / 8;                     // reduction-major: 16-byte chunks per k-row
     static constexpr int KPI = 64 / CPR;                   // reduction-major: k-rows per instruction
     long off[NJ];                                          // KC / RC: element offset of this lane's chunk in the next k-tile
     int p0[NJ], p1[NJ], q0[NJ], q1[NJ];                    // im2col: fixed (row) and running (k) decompositions, as TileLoaderX
 
-    static __device__ __forceinline__ int rot(int kk) { return BR == 128 ? 4 * (kk & 3) : 4 * ((kk >> 1) & 1); }
+    static __device__ __forceinline__ int rot(int kk) { return BR >= 128 ? 4 * (kk & 3) : 4 * ((kk >> 1) & 1); }
 
     __device__ __forceinline__ void init(const OpDev& o, int r0, int R, int kbeg, int lane, int wave) {
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) {
-            const int j = wave + 4 * jj;
+            const int j = wave + NW * jj;
             p0[jj] = p1[jj] = q0[jj] = q1[jj] = 0;
             off[jj] = 0;
             if (KT) {
@@ -803,7 +803,7 @@ struct TileDma {
     static __device__ __forceinline__ void piece(const unsigned short* base, long ps, long e, bool ok, unsigned short* S, int wave,
                                                  int jj, int p) {
         const unsigned short* src = ok ? base + p * ps + e : g_zero16;
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(S + p * PLANE + (wave + 4 * jj) * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(S + p * PLANE + (wave + NW * jj) * 512), 16, 0, 0);
     }
     // this wave's whole share of the next k-tile at once (prologue)
     __device__ __forceinline__ void issue(const OpDev& o, const unsigned short* base, long ps, unsigned short* S, int wave) {
@@ -941,6 +941,146 @@ __global__ __launch_bounds__(256) void pgemm_kernel(GemmDev g) {
         }
 }
 
+// ---- the same product on 256 x 128 tiles: 8 waves (4 x 2, wave tile 64 x 64), TWO LDS stages of 72 KiB, one workgroup per
+// CU.  The DMA of tile k + 1 is issued before the fragment reads of tile k and lands under its 48 MFMAs per wave; ONE barrier
+// per k-tile (it closes the reads of stage k & 1 and, behind vmcnt(0), opens stage (k + 1) & 1).  Against pgemm_kernel: a
+// quarter less operand traffic per flop (384 instead of 512 rows staged per 128 x 256 outputs), 9 instead of 12 DMA
+// instructions per wave and tile, half the barriers, and the second wave of each SIMD computes while the first one issues.
+template <int AMODE, int BMODE>
+__global__ __launch_bounds__(512) void pgemm2_kernel(GemmDev g) {
+    constexpr int BM = 256, BN = 128, NW = 8;
+    typedef TileDma<AMODE, BM, NW> LA;
+    typedef TileDma<BMODE, BN, NW> LB;
+    constexpr int STAGE = 3 * (LA::PLANE + LB::PLANE);             // bf16 elements per stage (72 KiB)
+    extern __shared__ __attribute__((aligned(1024))) unsigned short smem2[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bx = blockIdx.x, by = blockIdx.y;
+    {   // XCD-aware tile order (as pgemm_kernel)
+        const int nx = gridDim.x, ny = gridDim.y, nwg = nx * ny;
+        const int lin = by * nx + bx;
+        const int xcd = lin & 7, q = nwg >> 3, r = nwg & 7;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+        const int strip = 8 * ny;
+        const int sidx = t / strip, rem = t - sidx * strip;
+        const int w = min(8, nx - 8 * sidx);
+        by = rem / w;
+        bx = 8 * sidx + rem - by * w;
+    }
+    const int m0 = by * BM, n0 = bx * BN;
+    const int batch = blockIdx.z / g.split_k, kz = blockIdx.z - batch * g.split_k;
+    const int kbeg = kz * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    const unsigned short* Ab = g.Ap + (long)batch * g.a_bs;
+    const unsigned short* Bb = g.Bp + (long)batch * g.b_bs;
+    float* Cb = g.C + (long)batch * g.c_bs;
+
+    LA la;
+    LB lb;
+    la.init(g.A, m0, g.M, kbeg, lane, wave);
+    lb.init(g.B, n0, g.N, kbeg, lane, wave);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    if (kbeg < kend) {
+        la.issue(g.A, Ab, g.a_ps, smem2, wave);
+        lb.issue(g.B, Bb, g.b_ps, smem2 + 3 * LA::PLANE, wave);
+    }
+    __syncthreads();                      // vmcnt(0) + barrier: stage 0 is there
+    // (Measured and not adopted: a software-pipelined form -- fragments of the next k-step read under the MFMAs of the
+    // current one, the barrier between the two k-steps, the DMA of tile k + 2 issued by waves 0..3 and 4..7 at different
+    // times: 254 registers, 192 instead of 205 TFLOP/s on the decoder weight gradients, 78 instead of 181 on the PostNet
+    // convolutions, whose im2col address arithmetic then sits inside the MFMA stream.)
+    int st = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BKP, st ^= 1) {
+        const unsigned short* Ax = smem2 + st * STAGE;
+        const unsigned short* Bx = Ax + 3 * LA::PLANE;
+        if (k0 + BKP < kend && !(g.dbg & 1)) {     // stage st ^ 1 was last read one iteration ago, behind the barrier below
+            if (g.dbg & 2) { la.init(g.A, m0, g.M, kbeg, lane, wave); lb.init(g.B, n0, g.N, kbeg, lane, wave); }
+            unsigned short* An = smem2 + (st ^ 1) * STAGE;
+            la.issue(g.A, Ab, g.a_ps, An, wave);
+            lb.issue(g.B, Bb, g.b_ps, An + 3 * LA::PLANE, wave);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8_t a[3][2], b[3][2];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[p][i] = LA::frag(Ax, wm0, lane, p, i, s);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[p][j] = LB::frag(Bx, wn0, lane, p, j, s);
+            }
+            if (g.dbg & 4) {              // knock-out: keep the fragment reads alive, no MFMAs
+#pragma unroll
+                for (int p = 0; p < 3; ++p) { asm volatile("" :: "v"(a[p][0]), "v"(a[p][1]), "v"(b[p][0]), "v"(b[p][1])); }
+                continue;
+            }
+#pragma unroll
+            for (int ord = 2; ord >= 0; --ord)
+#pragma unroll
+                for (int pa = 0; pa <= ord; ++pa)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa][i], b[ord - pa][j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();                  // reads of stage st done everywhere; (vmcnt(0)) stage st ^ 1 has landed
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn0 + 32 * j + (lane & 31);
+            if (n >= g.N) continue;
+            const float bias = (g.bias != nullptr && kz == 0) ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= g.M) continue;
+                float* c = Cb + (long)m * g.ldc + n;
+                const float v = g.alpha * acc[i][j][r] + bias;
+                if (g.split_k > 1) atomicAdd(c, v);
+                else if (g.accumulate) *c += v;
+                else *c = v;
+            }
+        }
+}
+
+template <int AM, int BMD>
+int launch_pgemm2_modes(const GemmDev& d, dim3 grid, hipStream_t st) {
+    constexpr int LDS = 2 * 3 * (256 + 128) * BKP * 2;            // 147 456 bytes
+    static bool once = false;
+    if (!once) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pgemm2_kernel<AM, BMD>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        once = true;
+    }
+    hipLaunchKernelGGL((pgemm2_kernel<AM, BMD>), grid, dim3(512), LDS, st, d);
+    return 0;
+}
+int launch_pgemm2(const GemmDev& d, dim3 grid, hipStream_t st) {
+    const int am = d.A.mode, bm = d.B.mode;
+#define GT_CASE2(AM, BMD) if (am == AM && bm == BMD) return launch_pgemm2_modes<AM, BMD>(d, grid, st);
+    GT_CASE2(GT_OP_KC, GT_OP_KC)
+    GT_CASE2(GT_OP_KC, GT_OP_RC)
+    GT_CASE2(GT_OP_RC, GT_OP_RC)
+    GT_CASE2(GT_OP_RC, GT_OP_KC)
+    GT_CASE2(GT_OP_IM2COL_K, GT_OP_KC)
+    GT_CASE2(GT_OP_RC, GT_OP_IM2COL_R)
+#undef GT_CASE2
+    return GT_E_ARG;
+}
+
 // x -> its three bf16 planes (x = p0 + p1 + p2 exactly, as split_all): 8 elements per thread, flat
 __global__ __launch_bounds__(256) void split3_kernel(const float* x, long n8, unsigned short* out, long ps) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
@@ -1018,6 +1158,7 @@ int prep_operand(const GtOperand& s, OpDev& o, int rows, int K, const char* name
 }
 
 int g_fp32_planes = 0;       // gt_sgemm_set_fp32_split: how GtGemm.bf16 == 0 products are computed
+int g_last_kernel = -1;      // gt_sgemm_last_kernel (tests): 0 sgemm, 1 hgemm, 2 xgemm, 3 pgemm, 4 pgemm2
 
 // can pgemm_kernel address this operand's planes? (16-byte chunks of 8 bf16 that never straddle a row / tap / matrix end)
 bool planes_ok(const GtOperand& s, int rows) {
@@ -1040,6 +1181,7 @@ extern "C" int gt_sgemm_set_fp32_split(int32_t planes) {
 }
 
 extern "C" int32_t gt_sgemm_get_fp32_split(void) { return g_fp32_planes; }
+extern "C" int32_t gt_sgemm_last_kernel(void) { const int k = g_last_kernel; g_last_kernel = -1; return k; }
 
 extern "C" int gt_split3(const float* x, int64_t n, void* planes, int64_t plane_stride, void* stream) {
     GT_REQUIRE(x != nullptr && planes != nullptr && n > 0 && n % 8 == 0 && plane_stride >= n && plane_stride % 8 == 0 &&
@@ -1098,7 +1240,14 @@ extern "C" int gt_sgemm(const GtGemm* g, void* stream) {
     // CU's register file) capped at one workgroup per CU while the loops run: 146.9 vs 134.0 ms -- the GEMMs slow down by
     // more than the loop kernels gain.)
     const int lds_pad = 0;
-    if (big) {
+    static const int pgemm2_on = getenv("GANTRON_PGEMM2") ? atoi(getenv("GANTRON_PGEMM2")) : 1;
+    const long tiles256 = (long)cdiv(g->M, 256) * cdiv(g->N, 128) * gz;
+    if (d.Ap != nullptr && pgemm2_on && g->M >= 256 && g->N >= 128 && tiles256 >= 128) {
+        dim3 grid(cdiv(g->N, 128), cdiv(g->M, 256), (unsigned)gz);
+        GT_REQUIRE(grid.y <= 65535, GT_E_LIMIT, "gt_sgemm: M too large for grid.y");
+        rc = launch_pgemm2(d, grid, st);
+        g_last_kernel = 4;
+    } else if (big) {
         dim3 grid(cdiv(g->N, 128), cdiv(g->M, 128), (unsigned)gz);
         GT_REQUIRE(grid.y <= 65535, GT_E_LIMIT, "gt_sgemm: M too large for grid.y");
         rc = launch_tile<128, 128>(d, grid, st, lds_pad);
@@ -1108,6 +1257,7 @@ extern "C" int gt_sgemm(const GtGemm* g, void* stream) {
         rc = launch_tile<64, 64>(d, grid, st, lds_pad);
     }
     GT_REQUIRE(rc == 0, rc, "gt_sgemm: unsupported operand mode pair (%d,%d)", g->A.mode, g->B.mode);
+    if (g_last_kernel != 4 || d.Ap == nullptr) g_last_kernel = d.Ap != nullptr ? 3 : d.bf16 >= 2 ? 2 : d.bf16;
     GT_LAUNCH_CHECK();
     return 0;
 }

@@ -112,6 +112,10 @@ int gt_sgemm(const GtGemm* g, void* stream);
 /* x[0..n) -> three bf16 planes, plane i at planes + i * plane_stride (16-bit elements): x0 = bf16(x), x1 = bf16(x - x0),
  * x2 = bf16(x - x0 - x1); x0 + x1 + x2 == x exactly (3 x 8 significand bits).  n, plane_stride multiples of 8. */
 int gt_split3(const float* x, int64_t n, void* planes, int64_t plane_stride, void* stream);
+/* which kernel the last gt_sgemm call of this thread's process launched (tests): 0 fp32 pipe, 1 bf16 operands, 2 in-kernel
+ * plane split, 3 pre-split planes on 128 x 128 / 64 x 64 tiles, 4 pre-split planes on 256 x 128 tiles; -1 none since the
+ * last query */
+int32_t gt_sgemm_last_kernel(void);
 
 /* How products with GtGemm.bf16 == 0 are computed (process-wide; default 0):
  *   0  v_mfma_f32_32x32x2_f32, the fp32 matrix pipe (157 TFLOP/s peak on MI355X);

@@ -144,7 +144,8 @@ def test_split3_planes_are_exact(dev):
 
 
 @pytest.mark.parametrize('modes', ['kc/kc', 'kc/rc', 'rc/rc', 'rc/kc'])
-@pytest.mark.parametrize('M,N,K,sk', [(256, 192, 64, 1), (1536, 2048, 160, 1), (96, 136, 704, 5), (1024, 2048, 4096, 1)])
+@pytest.mark.parametrize('M,N,K,sk', [(256, 192, 64, 1), (1536, 2048, 160, 1), (96, 136, 704, 5), (1024, 2048, 4096, 1),
+                                      (2048, 2048, 160, 1), (1000, 1016, 704, 4)])      # the last two: 256 x 128 tiles (pgemm2)
 def test_plane_gemm_matches_float64(dev, modes, M, N, K, sk):
     """pgemm_kernel (operands pre-split by gt_split3, tiles moved by LDS-DMA, swizzled images): every operand mode pair,
     64x64 and 128x128 tiles, ragged M / N (rows beyond the matrix re-read the last row), split-K with accumulation --
@@ -162,13 +163,15 @@ def test_plane_gemm_matches_float64(dev, modes, M, N, K, sk):
         ob = ops.Operand(Bd, ops.KC if bm == 'kc' else ops.RC, ld=K if bm == 'kc' else N, planes=ops.Planes(Bd).split() if planes else None)
         C = torch.full((M, N), 0.5, device=dev)
         ops.sgemm(oa, ob, C, M, N, K, accumulate=True, split_k=sk, bf16=3)
+        big = -(-M // 256) * -(-N // 128) * sk >= 128 and M >= 256 and N >= 128
+        assert int(ops.lib().gt_sgemm_last_kernel()) == ((4 if big else 3) if planes else 2)
         return C.cpu().double() - 0.5
     got, inkernel = run(True), run(False)
     close(got, ref, rtol=1e-5, atol=1e-4, what=f'plane gemm {modes}')
     close(got, inkernel, rtol=2e-6, atol=2e-5, what=f'plane gemm vs in-kernel split {modes}')
 
 
-@pytest.mark.parametrize('B,T,Cin,Cout,K,dil', [(3, 37, 32, 64, 5, 1), (2, 9, 64, 96, 5, 2), (4, 150, 512, 512, 5, 1)])
+@pytest.mark.parametrize('B,T,Cin,Cout,K,dil', [(3, 37, 32, 64, 5, 1), (2, 9, 64, 96, 5, 2), (4, 160, 512, 512, 5, 1), (8, 1024, 64, 512, 5, 1)])
 def test_plane_gemm_convolutions(dev, B, T, Cin, Cout, K, dil):
     """The im2col operand modes of pgemm_kernel (taps outside [0, T) read zeros): Conv1d forward, input gradient and weight
     gradient with pre-split activations / weights against float64."""
@@ -186,12 +189,18 @@ def test_plane_gemm_convolutions(dev, B, T, Cin, Cout, K, dil):
         Wf, Wb = ops.conv_weight_fwd(Wd), ops.conv_weight_bwd(Wd)
         xp, dyp = ops.Planes(xcl).split(), ops.Planes(dycl).split()
         ycl = ops.conv1d_fwd(xcl, Wf, None, B, T, Cin, Cout, K, dil, x_planes=xp, w_planes=ops.Planes(Wf).split())
+        kinds = [int(ops.lib().gt_sgemm_last_kernel())]
         close(ycl.view(B, T, Cout).permute(0, 2, 1), y, rtol=1e-5, atol=1e-4, what='conv fwd (planes)')
         dx = ops.conv1d_dx(dycl, Wb, B, T, Cin, Cout, K, dil, dy_planes=dyp, w_planes=ops.Planes(Wb).split())
         close(dx.view(B, T, Cin).permute(0, 2, 1), gx, rtol=1e-5, atol=1e-4, what='conv dx (planes)')
         dW = torch.zeros(Cout, Cin, K, device=dev)
         ops.conv1d_dw(dycl, xcl, B, T, Cin, Cout, K, dil, dW, dy_planes=dyp, x_planes=xp)
+        kinds.append(int(ops.lib().gt_sgemm_last_kernel()))
         close(dW, gw, rtol=1e-5, atol=1e-4, what='conv dw (planes)')
+        if (B * T) % 32 == 0:
+            assert all(k in (3, 4) for k in kinds), kinds              # the pre-split kernels really ran
+        if (B, T) == (8, 1024):
+            assert kinds[0] == 4                                       # ... the 256 x 128 one for the big forward
 
 
 @pytest.mark.parametrize('bf16', PRECISIONS)
