@@ -216,6 +216,55 @@ def cpu_baseline(seconds_budget=45.0):
                        f'median {t:.2f} s per pair')
 
 
+def data_path_figures(hp, dev, out_lens, n_batches=6):
+    """SURVEY 8(a) S1 / 8(f)-1 side figures, OUTSIDE the timed region: can the data path feed the step?
+    * stft: TacotronSTFT.mel_spectrogram_batch (reflect pad, windowed DFT as a GEMM over overlapping frames, magnitude, mel
+      filterbank GEMM, log, collate; reference layers.py:97-114, stft.py:77-105) on 64 clips whose lengths give exactly the
+      bench batch's frame counts -- valid frames / s, and the algorithmic TFLOP/s of its two GEMMs;
+    * loader: gantron_amd.data_utils.DeviceBatches over an in-memory stream of TextAudioCollate-shaped host batches (pinned
+      H2D of 57 MB of raw audio per batch on a side stream + the batched STFT-mel) -- batches / s with nothing else running."""
+    from gantron_amd.data_utils import DeviceBatches
+    from gantron_amd.stft import TacotronSTFT
+    stft = TacotronSTFT(hp.filter_length, hp.hop_length, hp.win_length, hp.n_mel_channels, hp.sampling_rate, hp.mel_fmin,
+                        hp.mel_fmax).to(dev)
+    hop, N, nm = hp.hop_length, hp.filter_length, hp.n_mel_channels
+    B = len(out_lens)
+    rs = np.random.default_rng(7)
+    alen = torch.tensor([(f - 1) * hop + hop // 2 for f in out_lens], dtype=torch.int64)       # alen // hop + 1 == frames
+    audio = torch.zeros(B, int(alen.max()))
+    for b in range(B):
+        audio[b, :alen[b]] = torch.from_numpy(rs.uniform(-0.5, 0.5, int(alen[b])).astype(np.float32))
+    audio_d, alen_d = audio.to(dev), alen.to(dev)
+    F = audio.shape[1] // hop + 1
+    for _ in range(2):
+        stft.mel_spectrogram_batch(audio_d, alen_d)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    e0.record()
+    for _ in range(reps):
+        stft.mel_spectrogram_batch(audio_d, alen_d)
+    e1.record()
+    torch.cuda.synchronize()
+    stft_ms = e0.elapsed_time(e1) / reps
+    flops = B * F * (2.0 * (2 * (N // 2 + 1)) * N + 2.0 * (N // 2 + 1) * nm)
+    text = torch.zeros(B, 187, dtype=torch.long)
+    host = [(text, torch.full((B,), 187, dtype=torch.long), audio.pin_memory(), alen, torch.zeros(B), torch.zeros(B, 5))
+            for _ in range(n_batches)]
+    for _ in DeviceBatches(host[:2], stft, dev):
+        pass
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in DeviceBatches(host, stft, dev):
+        pass
+    torch.cuda.synchronize()
+    loader_s = (time.perf_counter() - t0) / n_batches
+    return dict(stft_frames_per_s=sum(out_lens) / (stft_ms * 1e-3), stft_ms_per_batch=stft_ms, stft_tflops=flops / (stft_ms * 1e-3) / 1e12,
+                stft_padded_frames=B * F, loader_batches_per_s=1.0 / loader_s, loader_ms_per_batch=loader_s * 1e3,
+                note='outside the timed region: batched STFT-mel of 64 clips with the bench batch\'s frame counts; DeviceBatches '
+                     'over in-memory raw-audio host batches (pinned H2D + STFT-mel on a side stream), nothing else running')
+
+
 def self_launch(world):
     """`python bench.py --gpus N` without a launcher: one child process per GPU with the torchrun environment
     (gantron_amd.multiproc.worker_env: RANK / LOCAL_RANK / WORLD_SIZE, MASTER_ADDR=127.0.0.1, a free port, dmabuf IPC),
@@ -246,6 +295,7 @@ def main():
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--fixed-shape', action='store_true', help='nominal Ti=150, To=800 for every item')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-data-path', action='store_true', help='skip the STFT-mel / loader side figures (config.data_path)')
     ap.add_argument('--bf16', action='store_true',
                     help='BASELINE config 3 (hparams.fp16_run): bf16 operands in the decoder LSTM products and the layer '
                          'GEMMs, fp32 accumulation and master weights; NOT the headline metric, the default line is fp32')
@@ -332,9 +382,9 @@ def main():
     frames = sum(out_lens)
     _lib.check(_lib.lib().gt_prof_set_context_rows(sum(in_lens)), 'gt_prof_set_context_rows')
 
-    # GANTRON_GRAPH=1 (hipGraph replay of the decoder loops) cannot capture on the legacy default stream: the step then
+    # GANTRON_EXPERIMENTAL=graph (hipGraph replay of the decoder loops) cannot capture on the legacy default stream: the step then
     # runs on a stream of its own
-    side = torch.cuda.Stream() if os.environ.get('GANTRON_GRAPH', '0') != '0' else None
+    side = torch.cuda.Stream() if 'graph' in os.environ.get('GANTRON_EXPERIMENTAL', '') else None
 
     def on_step_stream(fn):
         if side is None:
@@ -483,6 +533,16 @@ def main():
                                               gbs=round(r['bytes'] / max(r['ms'], 1e-9) / 1e6, 1)) for r in fam})
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()
+        # tile GEMMs run on the bf16 matrix pipe (three planes: 6 of the 16 bf16 MFMAs an fp32 product would cost, i.e. a
+        # ceiling of 2500 / 6 TFLOP/s of fp32 work), the recurrent / attention products on the fp32 pipe: the pair is bound
+        # by the SUM of the two pipes' times, not by all of its flops on the fp32 peak
+        sg = next(r for r in fam if r['name'] == 'sgemm')
+        gemm_flops_pair = (sg['flops'] / max(sg['launches'], 1)) * sg['seen'] / args.steps if sg['launches'] else 0.0
+        gemm_peak = (BF16_MFMA_PEAK_TFLOPS if args.bf16 else
+                     {0: FP32_MFMA_PEAK_TFLOPS, 3: BF16_MFMA_PEAK_TFLOPS / 6, 2: BF16_MFMA_PEAK_TFLOPS / 3}[_ops.FP32_SPLIT])
+        roof['families']['sgemm'].update(peak=round(gemm_peak, 1), frac=round(roof['families']['sgemm']['tflops'] / gemm_peak, 3),
+                                         pipe='bf16 MFMA' if (args.bf16 or _ops.FP32_SPLIT) else 'fp32 MFMA',
+                                         est_tflop_per_pair=round(gemm_flops_pair / 1e12, 3))
     if use_dist:
         dist.barrier()
 
@@ -490,6 +550,17 @@ def main():
         Ti, To = max(in_lens), max(out_lens)
         ms = elapsed / args.steps * 1e3
         fl = pair_flops(hp, in_lens, out_lens)
+        rec_peak = BF16_MFMA_PEAK_TFLOPS if args.bf16 else FP32_MFMA_PEAK_TFLOPS
+        gemm_fl = min(gemm_flops_pair, fl)
+        bound_s = gemm_fl / (gemm_peak * 1e12) + (fl - gemm_fl) / (rec_peak * 1e12)
+        data_path = None
+        if world == 1 and not args.no_data_path and not args.vesus:
+            try:
+                data_path = data_path_figures(hp, dev, out_lens)
+                data_path['feeds_step'] = data_path['loader_ms_per_batch'] < ms
+            except Exception as e:                                   # a side figure must never cost the headline line
+                data_path = dict(error=repr(e))
+        import hashlib
         line = dict(metric='mel-frames/sec (gen+disc step) LJSpeech bs=64', value=total_frames * args.steps / elapsed,
                     unit='mel-frames/s', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms,
                     higher_is_better=True, scaling='weak', vs_baseline=None,
@@ -506,7 +577,13 @@ def main():
                                 padded_frames_per_s=args.batch * To * world * args.steps / elapsed,
                                 g_step_ms=g_s * 1e3, d_step_ms=d_s * 1e3,
                                 schedule_2g1d_frames_per_s=2 * total_frames / (2 * g_s + d_s),
-                                pair_mfma_frac=fl / (elapsed / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS),
+                                pair_mfma_frac=fl / (elapsed / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                pair_blended_frac=bound_s / (elapsed / args.steps),
+                                pair_blended_note=f'{gemm_fl / 1e12:.2f} TFLOP of tile GEMMs on {gemm_peak:.0f} TFLOP/s + '
+                                                  f'{(fl - gemm_fl) / 1e12:.2f} TFLOP of recurrent / attention products on '
+                                                  f'{rec_peak:.1f} TFLOP/s = {bound_s * 1e3:.1f} ms of matrix-pipe time per pair',
+                                data_path=data_path, cmd='python bench.py ' + ' '.join(sys.argv[1:]),
+                                bench_py_sha16=hashlib.sha256(open(os.path.abspath(__file__), 'rb').read()).hexdigest()[:16]),
                     roofline=roof, cpu_baseline=cpu, dist=dist_info)
         print(json.dumps(line))
     if use_dist:

@@ -1,5 +1,6 @@
 // Error reporting and version of the C ABI.
 #include <stdarg.h>
+#include <stdlib.h>
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -12,6 +13,23 @@ void gt_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* gt_last_error_string(void) { return g_err; }
+
+int gt_env_item(const char* var, const char* key, int dflt) {
+    const char* e = getenv(var);
+    if (e == nullptr) return dflt;
+    const size_t n = strlen(key);
+    for (const char* p = e; *p;) {
+        while (*p == ',' || *p == ';' || *p == ' ') ++p;
+        const char* q = p;
+        while (*q && *q != ',' && *q != ';') ++q;
+        if ((size_t)(q - p) >= n && strncmp(p, key, n) == 0) {
+            if (p + n == q) return 1;
+            if (p[n] == '=') return atoi(p + n + 1);
+        }
+        p = q;
+    }
+    return dflt;
+}
 extern "C" int gt_version(void) { return 100; }
 
 // sizeof of every struct that crosses the ABI, so a binding can verify its layout at load time

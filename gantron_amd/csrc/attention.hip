@@ -553,7 +553,7 @@ int check_dims(const GtAttnDims& d, const char* who) {
 
 extern "C" int32_t gt_attn_chunks(int32_t Ti) { return cdiv(Ti, CT); }
 
-static bool use_mfma(const GtAttnDims& d) { return d.A == 128 && d.F == 32 && d.Kc == 31 && !getenv("GANTRON_ATTN_VALU"); }
+static bool use_mfma(const GtAttnDims& d) { return d.A == 128 && d.F == 32 && d.Kc == 31 && !gt_env_item("GANTRON_DEBUG", "attn_valu", 0); }
 
 extern "C" int64_t gt_attn_acc_elems(GtAttnDims d) {
     // per workgroup: the logical [dv | dWd | dWc] block, or the matrix-core kernel's register-order block
@@ -602,7 +602,7 @@ extern "C" int gt_attn_energies_fwd_u(GtAttnDims d, GtSlabs qpart, const float* 
 #define GT_EF(NIT, CA, CF, CK)                                                                                   \
     hipLaunchKernelGGL((attn_energies_fwd_kernel<NIT, CA, CF, CK>), grid, dim3(256), 0, (hipStream_t)stream, d,  \
                        qpart, w_prev, w_cum, pm, Wc, Wd, v, lengths, q_out, energies)
-    if (d.A == 128 && d.F == 32 && d.Kc == 31 && !getenv("GANTRON_ATTN_VALU")) {
+    if (d.A == 128 && d.F == 32 && d.Kc == 31 && !gt_env_item("GANTRON_DEBUG", "attn_valu", 0)) {
         gt_launch_attn_energies_fwd_mfma(d, qpart, w_prev, w_cum, pm, Wc, Wd, v, lengths, q_out, energies, wpack,
                                          (hipStream_t)stream, u_out);      // the reference's default hparams
     } else if (d.A == 128 && d.F == 32 && d.Kc == 31) {
@@ -726,7 +726,7 @@ extern "C" int gt_attn_energies_bwd_w(GtAttnDims d, const float* dw, const float
 #define GT_EB(NIT, CA, CF, CK)                                                                                   \
     hipLaunchKernelGGL((attn_energies_bwd_kernel<NIT, CA, CF, CK>), grid, dim3(256), 0, (hipStream_t)stream, d,  \
                        dw, w, q, w_prev, w_cum, pm, Wc, Wd, v, lengths, dq, (long)ld_dq, dpm, dwcat_out, acc)
-    if (d.A == 128 && d.F == 32 && d.Kc == 31 && !getenv("GANTRON_ATTN_VALU")) {
+    if (d.A == 128 && d.F == 32 && d.Kc == 31 && !gt_env_item("GANTRON_DEBUG", "attn_valu", 0)) {
         gt_launch_attn_energies_bwd_mfma(d, dw, w, q, w_prev, w_cum, pm, Wc, Wd, v, lengths, dq, (long)ld_dq, dpm, dwcat_out, acc,
                                          wpack, (hipStream_t)stream);
     } else if (d.A == 128 && d.F == 32 && d.Kc == 31) {

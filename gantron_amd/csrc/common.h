@@ -11,6 +11,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 void gt_set_error(const char* fmt, ...);
+// value of `key` in the comma list `key[=int]` of environment variable `var` (gantron_amd/switches.py documents the lists);
+// a bare key counts as 1, an absent one as `dflt`
+int gt_env_item(const char* var, const char* key, int dflt);
 
 #define GT_REQUIRE(cond, code, ...)                 \
     do {                                            \
@@ -36,7 +39,7 @@ __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / 
 enum { GT_FAM_REC_GEMM = 0, GT_FAM_SGEMM = 1, GT_FAM_ATTN_E_FWD = 2, GT_FAM_ATTN_C_FWD = 3, GT_FAM_ATTN_C_BWD = 4,
        GT_FAM_ATTN_E_BWD = 5, GT_FAM_CELL_FWD = 6, GT_FAM_CELL_BWD = 7, GT_FAM_REC_CELL = 8, GT_FAM_COUNT = 9 };
 extern bool g_gt_prof_on;
-extern bool g_gt_capturing;          // loops.hip: stream capture in progress (GANTRON_GRAPH)
+extern bool g_gt_capturing;          // loops.hip: stream capture in progress (GANTRON_EXPERIMENTAL=graph)
 extern double g_gt_prof_ctx_rows;   // valid attention-memory rows of the current batch (0: unknown, charge B*Ti)
 bool gt_prof_sample(int family);      // true for every `stride`-th launch of the family while profiling
 void gt_prof_mark(int family, double flops, double bytes, hipStream_t st, bool begin);

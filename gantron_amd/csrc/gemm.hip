@@ -33,7 +33,7 @@ struct GemmDev {
     long ldc, a_bs, b_bs, c_bs;
     int M, N, K, accumulate, split_k, k_per_split;
     int bf16;               // 0: fp32 MFMA, 1: operands rounded to bf16, 2 / 3: fp32 product from 2 / 3 bf16 planes (xgemm_kernel)
-    int dbg;                // GANTRON_PGEMM_DEBUG (diagnostics, pgemm_kernel): 1 = no DMA after the first tile, 2 = every tile
+    int dbg;                // GANTRON_DEBUG=pgemm=<bits> (diagnostics, pgemm_kernel): 1 = no DMA after the first tile, 2 = every tile
                             // re-reads the first one's addresses (cache-hot sources), 4 = no MFMAs
     float alpha;
 };
@@ -1157,7 +1157,7 @@ int prep_operand(const GtOperand& s, OpDev& o, int rows, int K, const char* name
     return 0;
 }
 
-int g_fp32_planes = 0;       // gt_sgemm_set_fp32_split: how GtGemm.bf16 == 0 products are computed
+int g_fp32_planes = 3;       // gt_sgemm_set_fp32_split: how GtGemm.bf16 == 0 products are computed
 int g_last_kernel = -1;      // gt_sgemm_last_kernel (tests): 0 sgemm, 1 hgemm, 2 xgemm, 3 pgemm, 4 pgemm2
 
 // can pgemm_kernel address this operand's planes? (16-byte chunks of 8 bf16 that never straddle a row / tap / matrix end)
@@ -1210,7 +1210,7 @@ extern "C" int gt_sgemm(const GtGemm* g, void* stream) {
     d.split_k = g->split_k;
     GT_REQUIRE(g->bf16 >= 0 && g->bf16 <= 3, GT_E_ARG, "gt_sgemm: bf16 = %d (0 fp32, 1 bf16 operands, 2 / 3 split planes)", g->bf16);
     d.bf16 = g->bf16 != 0 ? g->bf16 : g_fp32_planes;
-    static const int pgemm_dbg = getenv("GANTRON_PGEMM_DEBUG") ? atoi(getenv("GANTRON_PGEMM_DEBUG")) : 0;
+    static const int pgemm_dbg = gt_env_item("GANTRON_DEBUG", "pgemm", 0);
     d.dbg = pgemm_dbg;
     // operands that arrive as bf16 planes: the pure three-plane kernel, when the shapes allow whole 16-byte chunks and
     // whole 32-wide k-tiles; otherwise the fp32 operands (which must then be there) go through xgemm_kernel's own split
@@ -1240,7 +1240,7 @@ extern "C" int gt_sgemm(const GtGemm* g, void* stream) {
     // CU's register file) capped at one workgroup per CU while the loops run: 146.9 vs 134.0 ms -- the GEMMs slow down by
     // more than the loop kernels gain.)
     const int lds_pad = 0;
-    static const int pgemm2_on = getenv("GANTRON_PGEMM2") ? atoi(getenv("GANTRON_PGEMM2")) : 1;
+    static const int pgemm2_on = !gt_env_item("GANTRON_EXPERIMENTAL", "no_pgemm2", 0);
     const long tiles256 = (long)cdiv(g->M, 256) * cdiv(g->N, 128) * gz;
     if (d.Ap != nullptr && pgemm2_on && g->M >= 256 && g->N >= 128 && tiles256 >= 128) {
         dim3 grid(cdiv(g->N, 128), cdiv(g->M, 256), (unsigned)gz);

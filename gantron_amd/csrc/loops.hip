@@ -76,10 +76,10 @@ static int loop_ctx(LoopCtx** out) {
     return 0;
 }
 
-// steps between cross-stream hand-offs for a ring of R buffers (GANTRON_SYNC_EVERY overrides, clamped so that
+// steps between cross-stream hand-offs for a ring of R buffers (GANTRON_DEBUG=sync_every=<n> overrides, clamped so that
 // the follower's allowed lag R - k + 1 still covers a burst of k steps)
 static int sync_every(int R) {
-    static const int env = getenv("GANTRON_SYNC_EVERY") ? atoi(getenv("GANTRON_SYNC_EVERY")) : 0;
+    static const int env = gt_env_item("GANTRON_DEBUG", "sync_every", 0);
     int k = env > 0 ? env : R / 2;
     if (k > (R + 1) / 2) k = (R + 1) / 2;
     return k < 1 ? 1 : k;
@@ -124,13 +124,13 @@ struct AuxJoin {
         GT_REQUIRE(e__ == hipSuccess, (int)e__, "%s failed: %s", #call, hipGetErrorString(e__)); \
     } while (0)
 
-// ---- hipGraph replay of a whole loop call (GANTRON_GRAPH=1; BASELINE config 5 names it) --------------------------------
+// ---- hipGraph replay of a whole loop call (GANTRON_EXPERIMENTAL=graph; BASELINE config 5 names it) --------------------------------
 // The launches of a loop call -- both streams, their hand-off events included -- are captured once into a graph and the
 // graph is replayed whenever a call arrives with byte-identical arguments (same buffers, same sizes: the steady state of a
 // training run whose allocator hands back the same blocks).  Host issue time drops from ~19 ms to one graph launch; what
 // it does to the GPU-side duration is recorded in DESIGN.md (the loops are bound by dependent-kernel latency, not by issue).
 static int graph_mode() {
-    static const int v = getenv("GANTRON_GRAPH") ? atoi(getenv("GANTRON_GRAPH")) : 0;
+    static const int v = gt_env_item("GANTRON_EXPERIMENTAL", "graph", 0);
     return v;
 }
 struct GraphEntry { std::vector<unsigned char> key; hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; };
@@ -581,9 +581,9 @@ static int decoder_bwd_hoisted(const GtDecoderBwd* a, void* stream) {
     }
     const int blk = block_steps(a->blk);
     int nblock = 0;
-    // GANTRON_BLOCK_TIMING=1 (diagnostic): events around the B-chain block, its block GEMM and the A-chain block; printed
+    // GANTRON_DEBUG=block_timing (diagnostic): events around the B-chain block, its block GEMM and the A-chain block; printed
     // at the end of the call (synchronises)
-    static const bool block_timing = getenv("GANTRON_BLOCK_TIMING") != nullptr;
+    static const bool block_timing = gt_env_item("GANTRON_DEBUG", "block_timing", 0) != 0;
     struct BT_ { hipEvent_t b0, b1, g1, a0, a1; int steps; };
     std::vector<BT_> bts;
     auto mark = [&](hipEvent_t* e, hipStream_t st) { if (block_timing) { (void)hipEventCreate(e); (void)hipEventRecord(*e, st); } };

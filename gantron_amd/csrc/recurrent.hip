@@ -89,7 +89,7 @@ struct RecW {                             // weight fragments of this wave's hal
     }
 };
 
-// DBG (diagnostics, GANTRON_REC_DEBUG): bit 0 = no weight loads, bit 1 = no MFMAs, bit 2 = no activation staging
+// DBG (diagnostics, GANTRON_DEBUG=rec=<bits>): bit 0 = no weight loads, bit 1 = no MFMAs, bit 2 = no activation staging
 // One workgroup of the product: 64 columns starting at column group `cg`, K-slice [kb0, kb1) of 16-wide blocks;
 // `out` is the slab this K-slice writes (row stride N).
 constexpr int EP_LD = 68;                 // epilogue tile row stride: 4 rows apart = 16 banks apart, conflict-free scalar writes
@@ -557,11 +557,11 @@ int gt_rec_gemm_prio(const float* X, int64_t ldx, const float* Wp, float* part, 
                      4.0 * nz * ((double)N * K + 16.0 * mtiles * K + 16.0 * mtiles * N * splits), st, true);
     // reserve enough LDS that at most ONE workgroup fits a CU: the grid is sized to the CU count and
     // two co-resident workgroups would serialise on one CU's matrix pipes while another CU idles
-    static const int lds_pad = getenv("GANTRON_REC_LDS_PAD") ? atoi(getenv("GANTRON_REC_LDS_PAD")) : 0;
+    static const int lds_pad = gt_env_item("GANTRON_DEBUG", "rec_lds_pad", 0);
 #define GT_REC(MT)                                                                                    \
     hipExtLaunchKernelGGL((rec_gemm_kernel<MT>), grid, dim3(REC_THREADS), lds_pad, st, prof.e0, prof.e1, 0, X, (long)ldx, \
                           Wp, part, N, KB, KBS, (long)x_zstride, (long)w_zstride, (long)part_zstride, (long)part_sstride, prio)
-    static const int dbg = getenv("GANTRON_REC_DEBUG") ? atoi(getenv("GANTRON_REC_DEBUG")) : 0;
+    static const int dbg = gt_env_item("GANTRON_DEBUG", "rec", 0);
     if (dbg && mtiles == 4) {   // diagnostic variants (wrong results by construction)
 #define GT_RECD(D)                                                                                       \
     hipExtLaunchKernelGGL((rec_gemm_kernel<4, D>), grid, dim3(REC_THREADS), lds_pad, st, prof.e0, prof.e1, 0, X, (long)ldx, \

@@ -39,7 +39,7 @@ struct FusedCell {
     int B;                                // valid rows (rows >= B are not written)
 };
 
-// DBG (diagnostics, GANTRON_FUSED_DEBUG): bit 0 = no weight loads, bit 1 = no MFMAs, bit 2 = no activation staging,
+// DBG (diagnostics, GANTRON_DEBUG=fused=<bits>): bit 0 = no weight loads, bit 1 = no MFMAs, bit 2 = no activation staging,
 // bit 3 = no chunk rotation
 template <int MT, int DBG = 0>
 __global__ __launch_bounds__(FC_THREADS) void rec_gemm_cell_kernel(FusedCell a) {
@@ -230,7 +230,7 @@ extern "C" int gt_lstm_step_fused(const float* X, int64_t ldx, const float* Wg, 
         case 2: hipLaunchKernelGGL((rec_gemm_cell_kernel<2>), grid, dim3(FC_THREADS), 0, st, a); break;
         case 3: hipLaunchKernelGGL((rec_gemm_cell_kernel<3>), grid, dim3(FC_THREADS), 0, st, a); break;
         default: {
-            static const int dbg = getenv("GANTRON_FUSED_DEBUG") ? atoi(getenv("GANTRON_FUSED_DEBUG")) : 0;
+            static const int dbg = gt_env_item("GANTRON_DEBUG", "fused", 0);
             switch (dbg) {      // diagnostic variants give wrong results by construction
                 case 1: hipLaunchKernelGGL((rec_gemm_cell_kernel<4, 1>), grid, dim3(FC_THREADS), 0, st, a); break;
                 case 2: hipLaunchKernelGGL((rec_gemm_cell_kernel<4, 2>), grid, dim3(FC_THREADS), 0, st, a); break;

@@ -21,6 +21,7 @@ import torch
 import torch.distributed as dist
 from torch.autograd import Variable
 
+from . import switches as sw
 from .optim import flatten_module
 
 
@@ -68,8 +69,8 @@ def apply_gradient_allreduce(module):
     for buf in module.buffers():
         dist.broadcast(buf, 0)
 
-    timing = os.environ.get('GANTRON_DIST_TIMING') == '1'      # diagnostics: synchronising per-phase timer
-    overlap = os.environ.get('GANTRON_DIST_OVERLAP', '1') != '0'
+    timing = bool(sw.debug('dist_timing'))      # diagnostics: synchronising per-phase timer
+    overlap = sw.schedule_on('dist_overlap')
     state = {'queued': False, 'comm': None}
 
     def allreduce_params():

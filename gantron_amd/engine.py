@@ -23,39 +23,40 @@ import time as _time
 import torch
 
 from . import ops
+from . import switches as sw
 from .ops import (ACT_NONE, ACT_RELU, ACT_TANH, IM2COL_K, IM2COL_R, KC, RC, Operand, call, ptr, roundup, sgemm)
 from ._lib import GtBiLstm, GtDecoderBwd, GtDecoderFwd, GtDecoderInfer, GtPlstm, check, lib
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 # ---- switches (environment, read once at import; the defaults are the measured-best configuration)
-REC_SPLITS_OVERRIDE = int(_os.environ.get("GANTRON_REC_SPLITS", "0"))     # diagnostics: force the K-split count
+REC_SPLITS_OVERRIDE = sw.debug('rec_splits')     # diagnostics: force the K-split count
 # forward LSTM steps as ONE fused launch (gt_lstm_step_fused).  Stand-alone it beats product + cell (20.4 vs 23.2 us,
 # 25.5 vs 28.1 us) but every workgroup stages the whole activation matrix (4x the L2->LDS traffic), which slows the
 # kernels of the other chain in the two-stream loop: 69 ms per forward loop instead of 62.  Off by default.
-FUSED_CELL = _os.environ.get('GANTRON_FUSED_CELL', '0') != '0'
-HOST_TIMING = _os.environ.get('GANTRON_HOST_TIMING') == '1'      # diagnostics: host time spent issuing each loop
-CELL_QUERY = _os.environ.get('GANTRON_CELL_QUERY', '1') != '0'    # attention cell + query product in one launch
-BWD_CHUNKS = int(_os.environ.get("GANTRON_BWD_CHUNKS", "12"))
+FUSED_CELL = bool(sw.experimental('fused_cell'))
+HOST_TIMING = bool(sw.debug('host_timing'))      # diagnostics: host time spent issuing each loop
+CELL_QUERY = sw.schedule_on('cell_query')    # attention cell + query product in one launch
+BWD_CHUNKS = 12
 # hoisted attention backward (gt_attn_param_grads): keep tanh(.) of every step (B*Ti*A floats each) so that the loop
 # only computes the recurrent terms of the energies backward
-ATTN_HOIST = _os.environ.get('GANTRON_ATTN_HOIST', '1') != '0'
-DEC_RING = int(_os.environ.get('GANTRON_DEC_RING', '16'))     # ring of hand-off buffers between the two decoder chains;
+ATTN_HOIST = sw.schedule_on('attn_hoist')
+DEC_RING = 16     # ring of hand-off buffers between the two decoder chains;
                                                              # cross-stream syncs happen every ring/2 steps (loops.hip)
 # hoisted decoder-LSTM input product (GtDecoderFwd.W2hp / GtDecoderBwd.W2hTp): [h_att | ctx] . W2ih of a block of steps
 # is one tiled GEMM, only h_dec . W2hh stays in the per-step loops
-HOIST2 = _os.environ.get('GANTRON_HOIST2', '1') != '0'
+HOIST2 = sw.schedule_on('hoist2')
 # one launch per backward attention step (gt_attn_bwd_step) instead of context + energies backward; needs ATTN_HOIST, HOIST2
-ATTN_BWD_FUSED = _os.environ.get('GANTRON_ATTN_BWD_FUSED', '0') == '1'     # measured slower: off
+ATTN_BWD_FUSED = bool(sw.experimental('attn_bwd_fused'))     # measured slower: off
 # fused product + cell (+ query) launches of the forward loops (gt_rec_cell_fwd): bit 0 = attention LSTM, bit 1 = decoder LSTM,
 # bit 2 = encoder BiLSTM; bits 3 / 4 = attention / decoder LSTM in bf16 mode (gt_rec_cell_fwd_bf16); bit 5 = the decoder
 # LSTM's backward product + cell backward (gt_rec_cellbwd; measured 0.3 ms slower per pair than two launches: off)
-REC_CELL = int(_os.environ.get('GANTRON_REC_CELL', '31'))
-ENC_SPLITS = int(_os.environ.get('GANTRON_ENC_SPLITS', '0'))   # K-splits of the fused BiLSTM step (0: cost model)
-DEC_BLK_BWD = int(_os.environ.get('GANTRON_DEC_BLK_BWD', '16'))
+REC_CELL = (31 if sw.schedule_on('rec_cell') else 0) | (32 if sw.experimental('rec_cellbwd') else 0)
+ENC_SPLITS = sw.debug('enc_splits')   # K-splits of the fused BiLSTM step (0: cost model)
+DEC_BLK_BWD = 16
 # K-splits of the decoder LSTM's small recurrent products in the hoisted mode (0: cost model).  That chain has slack
 # (it only follows / feeds the attention chain): fewer, longer workgroups leave the CUs to the critical chain.
-S2_FWD = int(_os.environ.get('GANTRON_S2_FWD', '0'))
-S2_BWD = int(_os.environ.get('GANTRON_S2_BWD', '0'))
+S2_FWD = sw.debug('s2_fwd')
+S2_BWD = sw.debug('s2_bwd')
 # Persistent, weight-resident LSTM recurrences (gt_plstm_fwd, csrc/plstm.hip): bit 0 = the encoder BiLSTM forward (ONE launch
 # for all steps of both directions), bit 1 = the decoder LSTM's h_dec recurrence of a block of steps (hoisted mode, fp32).
 # Measured on MI355X (round 3) and NOT adopted: the encoder launch takes 9.8 us per step against ~10 for
@@ -63,16 +64,16 @@ S2_BWD = int(_os.environ.get('GANTRON_S2_BWD', '0'))
 # fast enough for the chain it feeds, but the attention chain's 256-workgroup kernels then run on 192 CUs (its fused step
 # 27 instead of 20 us): pair 134.0-134.6 ms with both on against 133.3-134.2 without; forward loop 41.3 (with 3 K-splits
 # for the attention LSTM) / 42.7 / 42.5 ms.  Off by default, parity-tested with the bits on.
-PLSTM = int(_os.environ.get('GANTRON_PLSTM', '0'))
-S1_FWD = int(_os.environ.get('GANTRON_S1_FWD', '0'))       # diagnostics: K-splits of the attention LSTM's forward product
-DEC_BLK = int(_os.environ.get('GANTRON_DEC_BLK', '16'))       # steps per block in that mode (measured: 8: 160.6 ms per pair,
+PLSTM = sw.experimental('plstm')
+S1_FWD = sw.debug('s1_fwd')       # diagnostics: K-splits of the attention LSTM's forward product
+DEC_BLK = 16       # steps per block in that mode (measured: 8: 160.6 ms per pair,
                                                               # 12: 157.9, 16: 157.9, 32: 160.5, 48: 160.9, 64: 165.7)
 
 
 # energies + softmax + context of a forward step as one launch (gt_attn_step_fwd: the row's workgroups meet inside it).
 # Measured slower than the two launches it replaces (20.8 vs 11.1 + 6.5 us stand-alone, forward loop 49.5 vs 45.7 ms): the
 # in-launch wait costs what the kernel boundary cost and the context phase loses its prefetch.  Off by default.
-ATTN_STEP = _os.environ.get('GANTRON_ATTN_STEP', '0') != '0'
+ATTN_STEP = bool(sw.experimental('attn_step'))
 _HANDOFF_FLAGS = {}
 
 
@@ -92,7 +93,7 @@ def check_handoffs():
         if int(flag.item()) != 0:
             flag.zero_()
             raise RuntimeError(f'an in-launch hand-off of a decoder-loop kernel timed out on cuda:{key}: results since the '
-                               'last check are invalid (GANTRON_ATTN_STEP=0 selects the two-launch attention step)')
+                               'last check are invalid (the attn_step experiment is off by default: two launches)')
 
 
 # GANTRON_POISON=1 (tests): buffers that are NOT zero-initialised start as NaN, so that a read of anything the kernels have
@@ -130,11 +131,11 @@ def _run(name, struct):
 
 
 class PhaseTimer:
-    """Optional wall-clock phase breakdown (GANTRON_PHASE_TIMING=1): synchronises at every mark, so it
+    """Optional wall-clock phase breakdown (GANTRON_DEBUG=phase_timing): synchronises at every mark, so it
     serialises the streams -- a development aid, never on in a measured run."""
 
     def __init__(self):
-        self.on = _os.environ.get('GANTRON_PHASE_TIMING', '0') == '1'
+        self.on = bool(sw.debug('phase_timing'))
         self.t = None
         self.acc = {}
 
@@ -166,10 +167,10 @@ class LeafStream:
     def __init__(self):
         self.stream = None
         self.keep = []
-        self.enabled = _os.environ.get('GANTRON_LEAF_STREAM', '1') != '0'
-        # GANTRON_LEAF_DEFER=1: queue the leaves and run them on the main stream at flush() / join(), after the loop they
+        self.enabled = sw.schedule_on('leaf_stream')
+        # experimental leaf_defer: queue the leaves and run them on the main stream at flush() / join(), after the loop they
         # would otherwise share the chip with
-        self.defer = _os.environ.get('GANTRON_LEAF_DEFER', '0') == '1'
+        self.defer = bool(sw.experimental('leaf_defer'))
         self.queue = []
 
     def flush(self):
@@ -233,7 +234,7 @@ def rec_splits(N, K, nz=1):
 # chunks per K-slice of the bf16 product.  4 is allowed by the kernel but its 210 VGPRs x 512 threads fill a CU's
 # register file, so nothing of the other chain can share the CU; measured per pair (B=64): 1 chunk 154.5 ms,
 # 2: 150.2, 3: 149.4, 4: 153.1
-BF16_MAX_CHUNKS = int(_os.environ.get('GANTRON_BF16_MAXCH', '3'))
+BF16_MAX_CHUNKS = 3
 
 
 def rec_splits_bf16(N, K):

@@ -11,6 +11,7 @@ import os as _os
 import torch
 
 from . import _lib
+from . import switches as sw
 from ._lib import GtAttnDims, GtGemm, GtOperand, GtSlabs, check, lib
 
 KC, RC, IM2COL_K, IM2COL_R = 0, 1, 2, 3
@@ -19,10 +20,10 @@ KC, RC, IM2COL_K, IM2COL_R = 0, 1, 2, 3
 # fp32-pipe kernel liked ~1024: postnet conv dW 41 -> 103 TFLOP/s; pair 133.3 -> 131.9 ms with 512 and 12 backward chunks);
 # the same setting for the GEMMs that run on the leaf stream UNDER the decoder backward loop makes the pair 2 ms
 # slower (they crowd out the latency-bound loop kernels), so the engine lowers the target there.
-SPLITK_EXPOSED = int(_os.environ.get('GANTRON_SPLITK_TARGET', '512'))
-SPLITK_OVERLAPPED = int(_os.environ.get('GANTRON_SPLITK_OVERLAPPED', '128'))
+SPLITK_EXPOSED = 512
+SPLITK_OVERLAPPED = 128
 SPLITK_TARGET = SPLITK_EXPOSED
-FWD_SPLITK = _os.environ.get('GANTRON_FWD_SPLITK', '1') != '0'
+FWD_SPLITK = sw.schedule_on('fwd_splitk')
 
 
 class splitk_target:
@@ -148,12 +149,12 @@ class Planes:
         return self
 
 
-# GANTRON_PLANE_GEMMS=1: operands of the decoder's weight-gradient GEMMs are split into bf16 planes ONCE (gt_split3 on the
+# GANTRON_EXPERIMENTAL=plane_gemms: operands of the decoder's weight-gradient GEMMs are split into bf16 planes ONCE (gt_split3 on the
 # leaf stream) and those GEMMs run the kernel that has no split left to do (pgemm_kernel).  Measured on MI355X (round 3,
 # DESIGN.md section 3) and NOT adopted: stand-alone the two kernels tie (190-197 vs 191-202 TFLOP/s on the decoder shapes: with
 # 6 instead of 4 bytes per element the plane kernel is bound by what moves L2 -> LDS, 43.8 GB per GEMM, not by the split),
 # and in the step the split passes cost what nothing pays back: 135.2-135.7 vs 133.8-133.9 ms per pair.  Off by default.
-PLANE_GEMMS = _os.environ.get('GANTRON_PLANE_GEMMS', '0') != '0'
+PLANE_GEMMS = bool(sw.experimental('plane_gemms'))
 
 
 class Operand:

@@ -1,0 +1,49 @@
+"""Every run-time switch of the package, in one place.  Five environment variables, read once at import:
+
+GANTRON_FP32_SPLIT     0 / 2 / 3 (default 3): how the tiled fp32 GEMMs are computed -- the fp32 matrix pipe, or two / three
+                       bf16 planes per operand on the bf16 pipe (3 = fp32-exact).
+GANTRON_POISON=1       tests: buffers that are not zero-initialised start as NaN.
+GANTRON_EXPERIMENTAL   comma list `name[=int]` of paths that were built, are parity-tested and measured SLOWER or no faster
+                       than the default ("measured and not adopted"); nothing here is needed for
+                       correctness and the default path never runs them:
+                         fused_cell, attn_step, attn_bwd_fused, leaf_defer, rec_cellbwd (the decoder LSTM's fused backward
+                         step), plane_gemms (pre-split GEMM operands), plstm=<bits> (persistent LSTM recurrences: 1 encoder,
+                         2 decoder), graph[=2] (hipGraph replay of the decoder loops; 2 also reports capture / replay),
+                         no_pgemm2 (keep the plane GEMMs on 128 x 128 tiles).
+GANTRON_SCHEDULE       comma list switching OFF parts of the default schedule (what the schedule-invariance test toggles
+                       through the module attributes instead): no_cell_query, no_attn_hoist, no_hoist2, no_leaf_stream,
+                       no_fwd_splitk, no_rec_cell (per-step product + cell launches instead of the fused ones),
+                       no_dist_overlap.
+GANTRON_DEBUG          comma list of diagnostics: phase_timing, host_timing, block_timing, dist_timing, attn_valu,
+                       rec=<bits> / fused=<bits> / pgemm=<bits> (kernel knock-outs), rec_splits=<n>, s1_fwd=<n>, s2_fwd=<n>,
+                       s2_bwd=<n>, enc_splits=<n>, sync_every=<n>, rec_lds_pad=<n>.
+(The C side parses the same variables: csrc/api.hip, gt_env_item.)  bench.py / the tests additionally use
+GANTRON_FORCE_DIST, GANTRON_BENCH_DEVICE and GANTRON_BENCH_BACKEND for the one-GPU rehearsals of the multi-rank paths.
+Tuned constants (block sizes, split-K targets, ring depth ...) are plain module attributes of engine.py / ops.py."""
+import os as _os
+
+
+def _parse(var):
+    out = {}
+    for item in _os.environ.get(var, '').replace(';', ',').split(','):
+        item = item.strip()
+        if item:
+            k, _, v = item.partition('=')
+            out[k.strip()] = int(v) if v.strip() else 1
+    return out
+
+
+EXPERIMENTAL, SCHEDULE, DEBUG = _parse('GANTRON_EXPERIMENTAL'), _parse('GANTRON_SCHEDULE'), _parse('GANTRON_DEBUG')
+
+
+def experimental(name, default=0):
+    return EXPERIMENTAL.get(name, default)
+
+
+def schedule_on(name):
+    """True unless GANTRON_SCHEDULE lists no_<name>."""
+    return not SCHEDULE.get('no_' + name, 0)
+
+
+def debug(name, default=0):
+    return DEBUG.get(name, default)

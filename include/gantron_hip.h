@@ -109,15 +109,8 @@ typedef struct GtGemm {
 } GtGemm;
 
 int gt_sgemm(const GtGemm* g, void* stream);
-/* x[0..n) -> three bf16 planes, plane i at planes + i * plane_stride (16-bit elements): x0 = bf16(x), x1 = bf16(x - x0),
- * x2 = bf16(x - x0 - x1); x0 + x1 + x2 == x exactly (3 x 8 significand bits).  n, plane_stride multiples of 8. */
-int gt_split3(const float* x, int64_t n, void* planes, int64_t plane_stride, void* stream);
-/* which kernel the last gt_sgemm call of this thread's process launched (tests): 0 fp32 pipe, 1 bf16 operands, 2 in-kernel
- * plane split, 3 pre-split planes on 128 x 128 / 64 x 64 tiles, 4 pre-split planes on 256 x 128 tiles; -1 none since the
- * last query */
-int32_t gt_sgemm_last_kernel(void);
 
-/* How products with GtGemm.bf16 == 0 are computed (process-wide; default 0):
+/* How products with GtGemm.bf16 == 0 are computed (process-wide; default 3, the same as the Python package):
  *   0  v_mfma_f32_32x32x2_f32, the fp32 matrix pipe (157 TFLOP/s peak on MI355X);
  *   3  every fp32 operand x is staged as three bf16 planes x0 + x1 + x2 = x (exact: 3 x 8 significand bits) and
  *      a . b = a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0) runs as six bf16 MFMAs with fp32 accumulation: each
@@ -165,16 +158,6 @@ int gt_rec_cell_fwd(const float* X, int64_t ldx, const float* Wp, float* part, u
                     const float* Wq, int64_t ldwq, float* qpart, int64_t q_sstride, int32_t A, int32_t Apad,
                     int32_t prio, void* stream);
 
-/* Backward counterpart for a recurrence whose only per-step product is d h_{t-1} = dG_t . W_hh (the decoder LSTM in the
- * hoisted mode, model.py:406-409): ONE launch per step = that product (Wp: gt_pack_rec_weight of W_hh^T, i.e. [H] x [4H],
- * K = 4H; X = dG_t (Bp, ldx)) + the cell backward of step t - 1 in the last-arriving workgroup of every 64-unit column
- * group: d h = product + dh_direct (gradient of the emitted h_{t-1}), dropout, gate derivatives -> dgates = dG_{t-1}
- * (Bp, 4H), dc (Bp, H) replaced by the gradient carried on.  gates / c_new / c_prev / keep are step t - 1's.  H % 64 == 0,
- * splits <= 16; `part` (splits x Bp x H) and `counters` ((Bp > 64 ? Bp/64 : 1) x H/64, zeroed once) as in gt_rec_cell_fwd. */
-int gt_rec_cellbwd(const float* X, int64_t ldx, const float* Wp, float* part, uint32_t* counters, int32_t Bp,
-                   int32_t B, int32_t H, int32_t K, int32_t splits, const float* dh_direct, int64_t ld_direct, float* dc,
-                   const float* gates, const float* c_new, const float* c_prev, const uint8_t* keep, float p_drop,
-                   float* dgates, int32_t prio, void* stream);
 
 /* bf16-operand variant (hparams.fp16_run, the reference's apex path train.py:246-250 -> bf16 MFMA with fp32
  * accumulation on MI355X): the weights are packed as bf16 fragments of v_mfma_f32_16x16x32_bf16
@@ -199,27 +182,7 @@ int gt_rec_cell_fwd_bf16(const float* X, int64_t ldx, const void* Wp, float* par
                          const float* Wq, int64_t ldwq, float* qpart, int64_t q_sstride, int32_t A, int32_t Apad,
                          int32_t prio, void* stream);
 
-/* Two products with their own shapes (both with 16*mtiles rows) in ONE launch: the decoder loops issue the
- * attention-LSTM and decoder-LSTM products of a step together so that they share the device as co-resident
- * workgroups without cross-stream synchronisation.  Arguments per problem as in gt_rec_gemm (nz = 1). */
-int gt_rec_gemm2(const float* X0, int64_t ldx0, const float* Wp0, float* part0, int32_t N0, int32_t K0,
-                 int32_t splits0, int64_t sstride0, const float* X1, int64_t ldx1, const float* Wp1,
-                 float* part1, int32_t N1, int32_t K1, int32_t splits1, int64_t sstride1, int32_t mtiles,
-                 void* stream);
 
-/* One whole LSTMCell step forward in a single launch: gates = X.W^T + pre, pointwise cell, dropout, h
- * written to up to three operand buffers (model.py:391-394, 406-409).  Wg is the gate-interleaved packing
- * (gt_pack_rec_weight mode 2) of the (4H, K) weight matching X's column order; pre (row stride ld_pre, 0 = one
- * bias row) is added to the pre-activations; gates (Bp,4H), c_out, h_raw in the layouts of gt_lstm_cell_fwd.
- * One workgroup per 4 hidden units sees all of K: no K-split slabs, no second launch.
- * The loop is branch-free: Wg is packed by gt_pack_gates for Kp = gt_fused_k_padded(K) columns (K rounded up
- * to a multiple of 512, zeros beyond K) and X needs ldx >= Kp zero-padded columns. */
-int64_t gt_fused_k_padded(int32_t K);
-int gt_pack_gates(const float* W, int64_t ldw, int32_t H, int32_t K, float* Wg, void* stream);   /* Wg: 4H*Kp floats */
-int gt_lstm_step_fused(const float* X, int64_t ldx, const float* Wg, int32_t K, const float* pre,
-                       int64_t ld_pre, const float* c_prev, const uint8_t* keep, float p_drop, float* gates,
-                       float* c_out, float* h_raw, float* h0, int64_t ld0, float* h1, int64_t ld1, float* h2,
-                       int64_t ld2, int32_t B, int32_t Bp, int32_t H, void* stream);
 
 /* ------------------------------------------------------------------------------------ LSTM cell
  * nn.LSTMCell pointwise part + dropout (model.py:391-394,406-409); gate order i,f,g,o.
@@ -251,13 +214,6 @@ int gt_cell_bwd_query(GtSlabs dh_a, GtSlabs dh_c, const float* dq, int64_t ld_dq
                       const uint8_t* keep, float p_drop, float* dgates, float* dc_prev, int32_t B, int32_t Bp,
                       int32_t H, int32_t A, void* stream);
 
-/* the same with a corrected query gradient dq - s dq2, s[m] = sum of row m's n_sum entries of dq_sum (B, n_sum): the
- * consumer side of the fused backward attention step (gt_attn_bwd_step); dq2 laid out like dq.  dq_sum = dq2 = NULL:
- * gt_cell_bwd_query. */
-int gt_cell_bwd_query_c(GtSlabs dh_a, GtSlabs dh_c, const float* dq, int64_t ld_dq, const float* dq_sum, int32_t n_sum,
-                        const float* dq2, const float* Wq, int64_t ldwq, const float* dc_next, const float* gates,
-                        const float* c_new, const float* c_prev, const uint8_t* keep, float p_drop, float* dgates,
-                        float* dc_prev, int32_t B, int32_t Bp, int32_t H, int32_t A, void* stream);
 
 /* dh = (sum of up to three slab sources + direct) ; returns pre-activation gate grads + dc_prev. */
 int gt_lstm_cell_bwd(GtSlabs dh_a, GtSlabs dh_b, GtSlabs dh_c, const float* dh_direct,
@@ -331,49 +287,10 @@ int gt_attn_param_grads(GtAttnDims d, int32_t nsteps, const float* u, const floa
                         const float* w_cum, int64_t step_stride, const float* Wc, const float* Wd,
                         const float* v, const int32_t* lengths, float* dpm, float* acc, const float* wpack,
                         void* stream);
-/* Fused backward attention step ((128, 32, 31) dimensions, Ti <= 512).  The softmax backward needs one scalar per batch
- * row, s = sum_t w dw, but everything after it is linear in de = w dw - s w.  With M[t][d] = v[d] (1 - u[t][d]^2) and
- * P = (M . Wd) . Wc (62 columns per position, stored 64 wide), functions of forward quantities only:
- *     dq[d] = sum_t de[t] M[t][d],   d[w_prev; w_cum][c][t0 + p - 15] = sum_k de[p - k] P[p - k][(c, k)].
- *  gt_attn_bwd_wterms : for `nsteps` steps in ONE launch: p_hist[t] = P ((B, Ti, 64) per step), dq2[t] = Lq(w_t) (step
- *                       stride dq2_step_stride, rows ld_dq2 apart) and dwcat2[t] = Lw(w_t) ((2, B, Ti) per step); dq2 /
- *                       dwcat2 zero-initialised by the caller; w advances by w_step_stride per step, u by B*Ti*A.
- *  gt_attn_bwd_step   : gt_attn_context_bwd's inputs (dctx sources, memory, carried planes dwcat_in / dcum_acc, dw_extern,
- *                       dctx_out) + the step's w, u and P rows.  Writes e1 = w dw to e1_out (B, Ti), the tile sums of e1 to
- *                       sum_out (B, gt_attn_chunks(Ti)), and ADDS Lq(e1) to dq (zeroed by the caller) and Lw(e1) to
- *                       dwcat_out.  sum_prev / dwcat2_prev (both or neither): the previous call's sum_out and that step's
- *                       dwcat2 -- the carried planes are read as dwcat_in - s_prev dwcat2_prev.
- *  gt_attn_bwd_fixup  : de[t] = e1[t] - s_t w_t and dq[t] -= s_t dq2[t] for `nsteps` steps (sum: (nsteps, B, chunks)).
- * The attention cell backward takes the correction on the fly (gt_cell_bwd_query_c). */
-int gt_attn_bwd_wterms(GtAttnDims d, int32_t nsteps, const float* w, int64_t w_step_stride, const float* u,
-                       const float* Wc, const float* Wd, const float* v, const int32_t* lengths, float* dq2,
-                       int64_t dq2_step_stride, int64_t ld_dq2, float* dwcat2, float* p_hist, const float* wpack,
-                       void* stream);
-int gt_attn_bwd_step(GtAttnDims d, GtSlabs dctx_a, GtSlabs dctx_b, const float* dctx_direct, int64_t ld_direct,
-                     const float* memory, int64_t ld_mem, const int32_t* lengths, float* dwcat_in, float* dcum_acc,
-                     const float* dw_extern, float* dctx_out, int64_t ld_dctx_out, const float* w, const float* u,
-                     const float* v, const float* p, const float* sum_prev, const float* dwcat2_prev, float* sum_out,
-                     float* dq, int64_t ld_dq, float* dwcat_out, float* e1_out, void* stream);
-int gt_attn_bwd_fixup(GtAttnDims d, int32_t nsteps, const float* sum, const float* w, int64_t w_step_stride,
-                      float* de, float* dq, int64_t dq_step_stride, int64_t ld_dq, const float* dq2, void* stream);
 int64_t gt_attn_acc_elems(GtAttnDims d);     /* size of `acc` (dv | dWd | dWc per workgroup) */
 int gt_attn_acc_reduce(GtAttnDims d, const float* acc, float* dv, float* dWd, float* dWc,
                        void* stream);
 int32_t gt_attn_chunks(int32_t Ti);
-/* One launch for a whole forward attention step = gt_attn_energies_fwd_u + gt_attn_context_fwd (model.py:70-91), for the
- * dimensions gt_attn_step_supported() accepts ((128, 32, 31), Ti <= 256, E % 4 == 0).  The workgroups of a batch row
- * exchange their energies INSIDE the launch: `erow` (B, Ti) receives them (write-through), `row_cnt` (B) uint32 arrival
- * counters -- zero-initialised ONCE per loop, monotonic -- tell a row's workgroups when the row is complete for step
- * number `step1` = t + 1 (1, 2, 3, ... in launch order); then every workgroup normalises the row and accumulates the
- * context for its slice of the E columns.  The wait is bounded: on time-out *timeout_flag (int32, may be NULL) is set
- * to 1 and the step's result is undefined.  Other arguments as in the two calls it replaces. */
-int32_t gt_attn_step_supported(GtAttnDims d);
-int gt_attn_step_fwd(GtAttnDims d, GtSlabs qpart, const float* w_prev, const float* w_cum, const float* pm,
-                     const float* Wc, const float* Wd, const float* v, const int32_t* lengths, float* q_out,
-                     const float* wpack, float* u_out, float* erow, uint32_t* row_cnt, uint32_t step1,
-                     int32_t* timeout_flag, const float* memory, int64_t ld_mem, float* w_out, const float* cum_in,
-                     float* cum_out, float* c0, int64_t ld0, float* c1, int64_t ld1, float* c2, int64_t ld2,
-                     void* stream);
 
 /* ------------------------------------------------------------------------- sequential loops
  * gt_decoder_fwd / gt_decoder_bwd: the teacher-forced decoder loop (Decoder.forward + decode,
@@ -540,36 +457,6 @@ typedef struct GtBiLstm {
     uint32_t* counters;
 } GtBiLstm;
 
-/* Persistent, weight-resident LSTM recurrence: ONE launch walks steps [s_lo, s_hi) of
- *   G_s = pre_s + h_{s-1} . W_hh^T,  cell,  h_s = dropout(o tanh c_s)
- * for ndir independent problems, each on H / 16 workgroups that keep W_hh in registers and exchange h through `hx`
- * (csrc/plstm.hip).  Used for the encoder BiLSTM (ndir = 2, packed-sequence semantics through `active`: model.py:202-210)
- * and for the decoder LSTM's h_dec recurrence inside a block of steps (ndir = 1, hx = the HC history itself: model.py:406-409).
- * Bp must be 64 and H 256 or 1024 (gt_plstm_supported).  Direction d of every per-direction buffer lies *_dstride
- * elements behind direction 0. */
-typedef struct GtPlstm {
-    int32_t B, Bp, H, T, ndir, s_lo, s_hi, hx_ring;
-    float p_drop;              /* dropout probability of `keep` (0: none) */
-    const float* Whh;          /* (4H, H) PyTorch layout, gate order i f g o */
-    int64_t w_dstride;
-    const float* pre;          /* (T, Bp, 4H) input projections + both biases */
-    int64_t pre_dstride;
-    float* gates;              /* (T, Bp, 4H) gate values kept for the backward pass; may alias pre */
-    int64_t gates_dstride;
-    float* c;                  /* (T + 1, Bp, H); slice s_lo is read, slices s_lo + 1 .. s_hi are written */
-    int64_t c_dstride;
-    float* hs;                 /* (T, Bp, H) emitted h (zero for inactive rows), or NULL */
-    int64_t hs_dstride;
-    float* hx;                 /* exchange: h_s is published at slot (hx_ring ? s % hx_ring : s) * hx_step, rows of hx_ld;
-                                  h_{s_lo - 1} is read from there when s_lo > 0.  hx_ring = 0 or >= 2 */
-    int64_t hx_dstride, hx_step, hx_ld;
-    const uint8_t* keep;       /* (T, Bp, H) keep mask of the dropout on h, or NULL */
-    const int32_t* active;     /* (T, Bp): rows with 0 pass their state through and emit zeros, or NULL */
-    uint32_t* counters;        /* ndir words (zeroed by the call) */
-    int32_t* timeout_flag;     /* raised when a bounded wait gives up (results invalid) */
-} GtPlstm;
-int32_t gt_plstm_supported(int32_t Bp, int32_t H);
-int gt_plstm_fwd(const GtPlstm* a, void* stream);
 
 /* Free-running decoder of Decoder.inference (model.py:456-497): every step feeds the previous mel
  * frame back through the Prenet (dropout always on, model.py:104), runs the decode step of
@@ -718,6 +605,133 @@ int gt_collate_mel(const float* rows, const int64_t* frames, int32_t B, int32_t 
 int gt_stft_magnitude(const float* ft /* rows x 2*cutoff */, int64_t rows, int32_t cutoff,
                       float* mag, void* stream);
 int gt_log_clamp(const float* x, int64_t n, float clip, float* out, void* stream);
+
+
+/* ================================================================================================ GtExperimental
+ * Everything below was built, is covered by kernel and parity tests, was MEASURED on MI355X and is NOT on the default path
+ * ("measured and not adopted"; the switches are listed in gantron_amd/switches.py under
+ * GANTRON_EXPERIMENTAL).  A binding that only wants the training step's path can ignore this section. */
+
+/* x[0..n) -> three bf16 planes, plane i at planes + i * plane_stride (16-bit elements): x0 = bf16(x), x1 = bf16(x - x0),
+ * x2 = bf16(x - x0 - x1); x0 + x1 + x2 == x exactly (3 x 8 significand bits).  n, plane_stride multiples of 8. */
+int gt_split3(const float* x, int64_t n, void* planes, int64_t plane_stride, void* stream);
+/* which kernel the last gt_sgemm call of this thread's process launched (tests): 0 fp32 pipe, 1 bf16 operands, 2 in-kernel
+ * plane split, 3 pre-split planes on 128 x 128 / 64 x 64 tiles, 4 pre-split planes on 256 x 128 tiles; -1 none since the
+ * last query */
+int32_t gt_sgemm_last_kernel(void);
+
+/* Backward counterpart for a recurrence whose only per-step product is d h_{t-1} = dG_t . W_hh (the decoder LSTM in the
+ * hoisted mode, model.py:406-409): ONE launch per step = that product (Wp: gt_pack_rec_weight of W_hh^T, i.e. [H] x [4H],
+ * K = 4H; X = dG_t (Bp, ldx)) + the cell backward of step t - 1 in the last-arriving workgroup of every 64-unit column
+ * group: d h = product + dh_direct (gradient of the emitted h_{t-1}), dropout, gate derivatives -> dgates = dG_{t-1}
+ * (Bp, 4H), dc (Bp, H) replaced by the gradient carried on.  gates / c_new / c_prev / keep are step t - 1's.  H % 64 == 0,
+ * splits <= 16; `part` (splits x Bp x H) and `counters` ((Bp > 64 ? Bp/64 : 1) x H/64, zeroed once) as in gt_rec_cell_fwd. */
+int gt_rec_cellbwd(const float* X, int64_t ldx, const float* Wp, float* part, uint32_t* counters, int32_t Bp,
+                   int32_t B, int32_t H, int32_t K, int32_t splits, const float* dh_direct, int64_t ld_direct, float* dc,
+                   const float* gates, const float* c_new, const float* c_prev, const uint8_t* keep, float p_drop,
+                   float* dgates, int32_t prio, void* stream);
+
+/* Two products with their own shapes (both with 16*mtiles rows) in ONE launch: the decoder loops issue the
+ * attention-LSTM and decoder-LSTM products of a step together so that they share the device as co-resident
+ * workgroups without cross-stream synchronisation.  Arguments per problem as in gt_rec_gemm (nz = 1). */
+int gt_rec_gemm2(const float* X0, int64_t ldx0, const float* Wp0, float* part0, int32_t N0, int32_t K0,
+                 int32_t splits0, int64_t sstride0, const float* X1, int64_t ldx1, const float* Wp1,
+                 float* part1, int32_t N1, int32_t K1, int32_t splits1, int64_t sstride1, int32_t mtiles,
+                 void* stream);
+
+/* One whole LSTMCell step forward in a single launch: gates = X.W^T + pre, pointwise cell, dropout, h
+ * written to up to three operand buffers (model.py:391-394, 406-409).  Wg is the gate-interleaved packing
+ * (gt_pack_rec_weight mode 2) of the (4H, K) weight matching X's column order; pre (row stride ld_pre, 0 = one
+ * bias row) is added to the pre-activations; gates (Bp,4H), c_out, h_raw in the layouts of gt_lstm_cell_fwd.
+ * One workgroup per 4 hidden units sees all of K: no K-split slabs, no second launch.
+ * The loop is branch-free: Wg is packed by gt_pack_gates for Kp = gt_fused_k_padded(K) columns (K rounded up
+ * to a multiple of 512, zeros beyond K) and X needs ldx >= Kp zero-padded columns. */
+int64_t gt_fused_k_padded(int32_t K);
+int gt_pack_gates(const float* W, int64_t ldw, int32_t H, int32_t K, float* Wg, void* stream);   /* Wg: 4H*Kp floats */
+int gt_lstm_step_fused(const float* X, int64_t ldx, const float* Wg, int32_t K, const float* pre,
+                       int64_t ld_pre, const float* c_prev, const uint8_t* keep, float p_drop, float* gates,
+                       float* c_out, float* h_raw, float* h0, int64_t ld0, float* h1, int64_t ld1, float* h2,
+                       int64_t ld2, int32_t B, int32_t Bp, int32_t H, void* stream);
+
+/* the same with a corrected query gradient dq - s dq2, s[m] = sum of row m's n_sum entries of dq_sum (B, n_sum): the
+ * consumer side of the fused backward attention step (gt_attn_bwd_step); dq2 laid out like dq.  dq_sum = dq2 = NULL:
+ * gt_cell_bwd_query. */
+int gt_cell_bwd_query_c(GtSlabs dh_a, GtSlabs dh_c, const float* dq, int64_t ld_dq, const float* dq_sum, int32_t n_sum,
+                        const float* dq2, const float* Wq, int64_t ldwq, const float* dc_next, const float* gates,
+                        const float* c_new, const float* c_prev, const uint8_t* keep, float p_drop, float* dgates,
+                        float* dc_prev, int32_t B, int32_t Bp, int32_t H, int32_t A, void* stream);
+
+/* Fused backward attention step ((128, 32, 31) dimensions, Ti <= 512).  The softmax backward needs one scalar per batch
+ * row, s = sum_t w dw, but everything after it is linear in de = w dw - s w.  With M[t][d] = v[d] (1 - u[t][d]^2) and
+ * P = (M . Wd) . Wc (62 columns per position, stored 64 wide), functions of forward quantities only:
+ *     dq[d] = sum_t de[t] M[t][d],   d[w_prev; w_cum][c][t0 + p - 15] = sum_k de[p - k] P[p - k][(c, k)].
+ *  gt_attn_bwd_wterms : for `nsteps` steps in ONE launch: p_hist[t] = P ((B, Ti, 64) per step), dq2[t] = Lq(w_t) (step
+ *                       stride dq2_step_stride, rows ld_dq2 apart) and dwcat2[t] = Lw(w_t) ((2, B, Ti) per step); dq2 /
+ *                       dwcat2 zero-initialised by the caller; w advances by w_step_stride per step, u by B*Ti*A.
+ *  gt_attn_bwd_step   : gt_attn_context_bwd's inputs (dctx sources, memory, carried planes dwcat_in / dcum_acc, dw_extern,
+ *                       dctx_out) + the step's w, u and P rows.  Writes e1 = w dw to e1_out (B, Ti), the tile sums of e1 to
+ *                       sum_out (B, gt_attn_chunks(Ti)), and ADDS Lq(e1) to dq (zeroed by the caller) and Lw(e1) to
+ *                       dwcat_out.  sum_prev / dwcat2_prev (both or neither): the previous call's sum_out and that step's
+ *                       dwcat2 -- the carried planes are read as dwcat_in - s_prev dwcat2_prev.
+ *  gt_attn_bwd_fixup  : de[t] = e1[t] - s_t w_t and dq[t] -= s_t dq2[t] for `nsteps` steps (sum: (nsteps, B, chunks)).
+ * The attention cell backward takes the correction on the fly (gt_cell_bwd_query_c). */
+int gt_attn_bwd_wterms(GtAttnDims d, int32_t nsteps, const float* w, int64_t w_step_stride, const float* u,
+                       const float* Wc, const float* Wd, const float* v, const int32_t* lengths, float* dq2,
+                       int64_t dq2_step_stride, int64_t ld_dq2, float* dwcat2, float* p_hist, const float* wpack,
+                       void* stream);
+int gt_attn_bwd_step(GtAttnDims d, GtSlabs dctx_a, GtSlabs dctx_b, const float* dctx_direct, int64_t ld_direct,
+                     const float* memory, int64_t ld_mem, const int32_t* lengths, float* dwcat_in, float* dcum_acc,
+                     const float* dw_extern, float* dctx_out, int64_t ld_dctx_out, const float* w, const float* u,
+                     const float* v, const float* p, const float* sum_prev, const float* dwcat2_prev, float* sum_out,
+                     float* dq, int64_t ld_dq, float* dwcat_out, float* e1_out, void* stream);
+int gt_attn_bwd_fixup(GtAttnDims d, int32_t nsteps, const float* sum, const float* w, int64_t w_step_stride,
+                      float* de, float* dq, int64_t dq_step_stride, int64_t ld_dq, const float* dq2, void* stream);
+
+/* One launch for a whole forward attention step = gt_attn_energies_fwd_u + gt_attn_context_fwd (model.py:70-91), for the
+ * dimensions gt_attn_step_supported() accepts ((128, 32, 31), Ti <= 256, E % 4 == 0).  The workgroups of a batch row
+ * exchange their energies INSIDE the launch: `erow` (B, Ti) receives them (write-through), `row_cnt` (B) uint32 arrival
+ * counters -- zero-initialised ONCE per loop, monotonic -- tell a row's workgroups when the row is complete for step
+ * number `step1` = t + 1 (1, 2, 3, ... in launch order); then every workgroup normalises the row and accumulates the
+ * context for its slice of the E columns.  The wait is bounded: on time-out *timeout_flag (int32, may be NULL) is set
+ * to 1 and the step's result is undefined.  Other arguments as in the two calls it replaces. */
+int32_t gt_attn_step_supported(GtAttnDims d);
+int gt_attn_step_fwd(GtAttnDims d, GtSlabs qpart, const float* w_prev, const float* w_cum, const float* pm,
+                     const float* Wc, const float* Wd, const float* v, const int32_t* lengths, float* q_out,
+                     const float* wpack, float* u_out, float* erow, uint32_t* row_cnt, uint32_t step1,
+                     int32_t* timeout_flag, const float* memory, int64_t ld_mem, float* w_out, const float* cum_in,
+                     float* cum_out, float* c0, int64_t ld0, float* c1, int64_t ld1, float* c2, int64_t ld2,
+                     void* stream);
+
+/* Persistent, weight-resident LSTM recurrence: ONE launch walks steps [s_lo, s_hi) of
+ *   G_s = pre_s + h_{s-1} . W_hh^T,  cell,  h_s = dropout(o tanh c_s)
+ * for ndir independent problems, each on H / 16 workgroups that keep W_hh in registers and exchange h through `hx`
+ * (csrc/plstm.hip).  Used for the encoder BiLSTM (ndir = 2, packed-sequence semantics through `active`: model.py:202-210)
+ * and for the decoder LSTM's h_dec recurrence inside a block of steps (ndir = 1, hx = the HC history itself: model.py:406-409).
+ * Bp must be 64 and H 256 or 1024 (gt_plstm_supported).  Direction d of every per-direction buffer lies *_dstride
+ * elements behind direction 0. */
+typedef struct GtPlstm {
+    int32_t B, Bp, H, T, ndir, s_lo, s_hi, hx_ring;
+    float p_drop;              /* dropout probability of `keep` (0: none) */
+    const float* Whh;          /* (4H, H) PyTorch layout, gate order i f g o */
+    int64_t w_dstride;
+    const float* pre;          /* (T, Bp, 4H) input projections + both biases */
+    int64_t pre_dstride;
+    float* gates;              /* (T, Bp, 4H) gate values kept for the backward pass; may alias pre */
+    int64_t gates_dstride;
+    float* c;                  /* (T + 1, Bp, H); slice s_lo is read, slices s_lo + 1 .. s_hi are written */
+    int64_t c_dstride;
+    float* hs;                 /* (T, Bp, H) emitted h (zero for inactive rows), or NULL */
+    int64_t hs_dstride;
+    float* hx;                 /* exchange: h_s is published at slot (hx_ring ? s % hx_ring : s) * hx_step, rows of hx_ld;
+                                  h_{s_lo - 1} is read from there when s_lo > 0.  hx_ring = 0 or >= 2 */
+    int64_t hx_dstride, hx_step, hx_ld;
+    const uint8_t* keep;       /* (T, Bp, H) keep mask of the dropout on h, or NULL */
+    const int32_t* active;     /* (T, Bp): rows with 0 pass their state through and emit zeros, or NULL */
+    uint32_t* counters;        /* ndir words (zeroed by the call) */
+    int32_t* timeout_flag;     /* raised when a bounded wait gives up (results invalid) */
+} GtPlstm;
+int32_t gt_plstm_supported(int32_t Bp, int32_t H);
+int gt_plstm_fwd(const GtPlstm* a, void* stream);
 
 #ifdef __cplusplus
 }

@@ -112,7 +112,7 @@ def test_tiny_pair_matches_reference_golden(dev, golden_dir, name):
 
 
 def test_tiny_pair_with_fused_lstm_steps(dev, golden_dir, monkeypatch):
-    """The opt-in fused product+cell forward path (GANTRON_FUSED_CELL=1, gt_lstm_step_fused with ping-pong operand
+    """The opt-in fused product+cell forward path (GANTRON_EXPERIMENTAL=fused_cell, gt_lstm_step_fused with ping-pong operand
     buffers) must reproduce the same golden outputs and gradients."""
     from gantron_amd import engine
     monkeypatch.setattr(engine, 'FUSED_CELL', True)
@@ -180,7 +180,7 @@ def test_midsize_against_oracle(dev, case, monkeypatch):
 
 
 def test_fused_attention_backward_step_against_oracle(dev, monkeypatch):
-    """The opt-in one-launch backward attention step (GANTRON_ATTN_BWD_FUSED: gt_attn_bwd_wterms + gt_attn_bwd_step +
+    """The opt-in one-launch backward attention step (GANTRON_EXPERIMENTAL=attn_bwd_fused: gt_attn_bwd_wterms + gt_attn_bwd_step +
     gt_cell_bwd_query_c + gt_attn_bwd_fixup) through a whole generator + discriminator pair at the reference's attention
     dimensions, against the oracle."""
     from gantron_amd import engine
@@ -191,7 +191,7 @@ def test_fused_attention_backward_step_against_oracle(dev, monkeypatch):
 
 @pytest.mark.parametrize('case', ['full_dims_b64_t200', 'full_dims_b64_poison', 'vesus_b64'])
 def test_persistent_lstm_recurrences_against_oracle(dev, monkeypatch, case):
-    """The opt-in persistent recurrences (GANTRON_PLSTM = 3: gt_plstm_fwd for the encoder BiLSTM -- both directions, packed
+    """The opt-in persistent recurrences (GANTRON_EXPERIMENTAL=plstm=3: gt_plstm_fwd for the encoder BiLSTM -- both directions, packed
     sequences, one launch -- and for the decoder LSTM's h_dec recurrence, one launch per block of 16 steps with W_hh
     resident in registers) through whole pairs at the reference's dimensions, 64 rows: ragged text lengths, several blocks,
     NaN-poisoned histories, and the VESUS memory width (HC rows of 1024 + 1096 columns)."""
@@ -205,7 +205,7 @@ def test_persistent_lstm_recurrences_against_oracle(dev, monkeypatch, case):
 
 
 def test_plane_gemms_against_oracle(dev, monkeypatch):
-    """The opt-in pre-split operand path of the decoder's weight-gradient GEMMs (GANTRON_PLANE_GEMMS: gt_split3 +
+    """The opt-in pre-split operand path of the decoder's weight-gradient GEMMs (GANTRON_EXPERIMENTAL=plane_gemms: gt_split3 +
     pgemm_kernel) through a whole pair at the reference's dimensions, 64 rows, several backward chunks."""
     from gantron_amd import ops
     monkeypatch.setattr(ops, 'PLANE_GEMMS', True)
@@ -214,7 +214,7 @@ def test_plane_gemms_against_oracle(dev, monkeypatch):
 
 
 def test_fused_decoder_lstm_backward_against_oracle(dev, monkeypatch):
-    """The opt-in one-launch decoder-LSTM backward step (GANTRON_REC_CELL bit 5: gt_rec_cellbwd) through a whole generator +
+    """The opt-in one-launch decoder-LSTM backward step (GANTRON_EXPERIMENTAL=rec_cellbwd: gt_rec_cellbwd) through a whole generator +
     discriminator pair at the reference's dimensions, against the oracle."""
     from gantron_amd import engine
     monkeypatch.setattr(engine, 'REC_CELL', engine.REC_CELL | 32)
@@ -574,7 +574,7 @@ def test_full_size_training_step_is_schedule_invariant(dev, monkeypatch):
     a channel's slice of every gradient below it by percents (an exact float64 backward of the same inputs agreed to
     3e-7, i.e. no amplification).  The statistics are now bit-reproducible (gt_col_stats with a workspace), the encoder
     forward of the two schedules is bit-identical, and both runs use the deterministic forward convolutions
-    (GANTRON_FWD_SPLITK=0: split-K atomics in them are the one remaining run-to-run source of such flips)."""
+    (GANTRON_SCHEDULE=no_fwd_splitk: split-K atomics in them are the one remaining run-to-run source of such flips)."""
     import bench
     from gantron_amd import engine
     from gantron_amd.hparams import HParams
@@ -644,7 +644,7 @@ print('graph worker OK')
 
 @pytest.mark.parametrize('case', ['full_dims_b20', 'full_dims_b64_t200'])
 def test_graph_replayed_decoder_loops_against_oracle(dev, tmp_path, case):
-    """BASELINE config 5 names a "hipGraph-captured decoder inner loop": GANTRON_GRAPH makes gt_decoder_fwd / gt_decoder_bwd
+    """BASELINE config 5 names a "hipGraph-captured decoder inner loop": GANTRON_EXPERIMENTAL=graph makes gt_decoder_fwd / gt_decoder_bwd
     capture a loop call (both streams and their hand-off events) into a hipGraph and replay it (loops.hip: run_graphed).
     The switch is read once per process, so the case runs in a child process: a whole generator + discriminator pair at the
     reference's dimensions against the oracle, twice, with every loop call going through capture + launch.  (Measured
@@ -654,7 +654,7 @@ def test_graph_replayed_decoder_loops_against_oracle(dev, tmp_path, case):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / 'graph_worker.py'
     script.write_text(_GRAPH_WORKER)
-    env = dict(os.environ, GANTRON_GRAPH='2')          # 2: also report capture / replay on stderr
+    env = dict(os.environ, GANTRON_EXPERIMENTAL='graph=2')          # 2: also report capture / replay on stderr
     out = subprocess.run([sys.executable, str(script), root, case], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
     assert 'graph worker OK' in out.stdout

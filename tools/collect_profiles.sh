@@ -8,7 +8,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline"
 ARGS1="bench.py --steps 1 --warmup 1 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o r02k -- python3 $ARGS > "$OUT/stats.log" 2>&1 && echo "stats pass done" &&
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o r03k -- python3 $ARGS > "$OUT/stats.log" 2>&1 && echo "stats pass done" &&
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -o fetch -- python3 $ARGS1 > "$OUT/fetch.log" 2>&1 && echo "fetch pass done" &&
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -o write -- python3 $ARGS1 > "$OUT/write.log" 2>&1 && echo "write pass done" &&
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d "$OUT/mfma" -o mfma -- python3 $ARGS1 > "$OUT/mfma.log" 2>&1 && echo "mfma pass done" &&

@@ -3,7 +3,7 @@ serialised duration of each call (development tool; synchronises around every GE
 import collections, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ['GANTRON_LEAF_STREAM'] = '0'
+os.environ['GANTRON_SCHEDULE'] = 'no_leaf_stream'
 import bench
 from gantron_amd import ops
 from gantron_amd.hparams import HParams
