@@ -583,31 +583,37 @@ class GeneratorEngine:
                   text=text)
 
         PHASES.mark(None)
-        memory, mem2, pm = self._encode(P, text, in_lens, rng, speaker_ids, emotions, training, sv)
-        idx = sv['idx']
-
-        # ---- prenet over all teacher-forcing frames (go frame + mel[:, :, :To-1]), step-major (To, Bp, .)
-        x0 = _f32(To, Bp, n_mel, device=dev)
-        if To > 1:
-            check(lib().gt_permute3(ptr(mels), 1, n_mel * To, To, To - 1, B, n_mel, ptr(x0, Bp * n_mel), Bp * n_mel,
-                                    n_mel, 0, 1.0, ops._stream()), 'gt_permute3')
+        # ---- prenet over all teacher-forcing frames (go frame + mel[:, :, :To-1]), step-major (To, Bp, .), and its
+        # projection into the attention LSTM
         Pd = self.P
-        W0, W1 = P['decoder.prenet.layers.0.linear_layer.weight'], P['decoder.prenet.layers.1.linear_layer.weight']
-        pk = rng['prenet_keep']
-        p1 = ops.linear(x0, W0, To * Bp, n_mel, Pd)
-        call('gt_bias_act_drop_fwd', p1, None, To * Bp, Pd, ACT_RELU, 0, pk[0], 0.5, p1)
-        p2 = ops.linear(p1, W1, To * Bp, Pd, Pd)
-        call('gt_bias_act_drop_fwd', p2, None, To * Bp, Pd, ACT_RELU, 0, pk[1], 0.5, p2)
-        sv.update(x0=x0, p1=p1, p2=p2)
-
         Ha, Hd = self.Ha, self.Hd
         W1ih, W1hh = P['decoder.attention_rnn.weight_ih'], P['decoder.attention_rnn.weight_hh']
         W2ih, W2hh = P['decoder.decoder_rnn.weight_ih'], P['decoder.decoder_rnn.weight_hh']
-        bias1 = _f32(4 * Ha, device=dev, zero=False)
-        call('gt_axpby', P['decoder.attention_rnn.bias_ih'], 1.0, P['decoder.attention_rnn.bias_hh'], 1.0, bias1, 4 * Ha)
-        bias2 = _f32(4 * Hd, device=dev, zero=False)
-        call('gt_axpby', P['decoder.decoder_rnn.bias_ih'], 1.0, P['decoder.decoder_rnn.bias_hh'], 1.0, bias2, 4 * Hd)
-        pre1 = ops.linear(p2, W1ih, To * Bp, Pd, 4 * Ha, bias=bias1, ldw=Pd + E)
+        pk = rng['prenet_keep']
+
+        def decoder_inputs():
+            x0 = _f32(To, Bp, n_mel, device=dev)
+            if To > 1:
+                check(lib().gt_permute3(ptr(mels), 1, n_mel * To, To, To - 1, B, n_mel, ptr(x0, Bp * n_mel), Bp * n_mel,
+                                        n_mel, 0, 1.0, ops._stream()), 'gt_permute3')
+            W0, W1 = P['decoder.prenet.layers.0.linear_layer.weight'], P['decoder.prenet.layers.1.linear_layer.weight']
+            p1 = ops.linear(x0, W0, To * Bp, n_mel, Pd)
+            call('gt_bias_act_drop_fwd', p1, None, To * Bp, Pd, ACT_RELU, 0, pk[0], 0.5, p1)
+            p2 = ops.linear(p1, W1, To * Bp, Pd, Pd)
+            call('gt_bias_act_drop_fwd', p2, None, To * Bp, Pd, ACT_RELU, 0, pk[1], 0.5, p2)
+            bias1 = _f32(4 * Ha, device=dev, zero=False)
+            call('gt_axpby', P['decoder.attention_rnn.bias_ih'], 1.0, P['decoder.attention_rnn.bias_hh'], 1.0, bias1, 4 * Ha)
+            bias2 = _f32(4 * Hd, device=dev, zero=False)
+            call('gt_axpby', P['decoder.decoder_rnn.bias_ih'], 1.0, P['decoder.decoder_rnn.bias_hh'], 1.0, bias2, 4 * Hd)
+            pre1 = ops.linear(p2, W1ih, To * Bp, Pd, 4 * Ha, bias=bias1, ldw=Pd + E)
+            return x0, p1, p2, bias2, pre1
+
+        # (Measured and not adopted: these launches on a side stream beside the encoder -- 133.1-133.5 against 133.0-133.8 ms
+        # per pair; the host is far enough ahead that the encoder's small launches are already queued back to back.)
+        memory, mem2, pm = self._encode(P, text, in_lens, rng, speaker_ids, emotions, training, sv)
+        idx = sv['idx']
+        x0, p1, p2, bias2, pre1 = decoder_inputs()
+        sv.update(x0=x0, p1=p1, p2=p2)
 
         # ---- decoder loop
         K1, K2 = Ep + Ha, Ha + Ep + Hd             # loop operands are Ep wide in their ctx part (zero columns beyond E)
@@ -1101,14 +1107,17 @@ class GeneratorEngine:
         gentle.__exit__()
         PHASES.mark('b.dec_loop+dW')
 
-        # ---- prenet backward
-        dp2 = ops.linear_dx(dG1, W1ih, rows, 4 * Ha, Pd, ldw=Pd + E)
-        pk = sv['prenet_keep']
-        call('gt_bias_act_drop_bwd', dp2, sv['p2'], rows, Pd, ACT_RELU, 0, pk[1], 0.5, dp2)
-        LEAF.run(lambda: ops.linear_dw(dp2, sv['p1'], rows, Pd, Pd, G['decoder.prenet.layers.1.linear_layer.weight']), dp2)
-        dp1 = ops.linear_dx(dp2, P['decoder.prenet.layers.1.linear_layer.weight'], rows, Pd, Pd)
-        call('gt_bias_act_drop_bwd', dp1, sv['p1'], rows, Pd, ACT_RELU, 0, pk[0], 0.5, dp1)
-        LEAF.run(lambda: ops.linear_dw(dp1, sv['x0'], rows, Pd, n_mel, G['decoder.prenet.layers.0.linear_layer.weight']), dp1)
+        # ---- prenet backward: a leaf of the graph as a whole (nothing below depends on it) -- it runs on the leaf stream
+        # beside d(memory), the BiLSTM backward and the encoder convolutions, which are latency-bound launch chains
+        def leaf_prenet():
+            dp2 = ops.linear_dx(dG1, W1ih, rows, 4 * Ha, Pd, ldw=Pd + E)
+            pk = sv['prenet_keep']
+            call('gt_bias_act_drop_bwd', dp2, sv['p2'], rows, Pd, ACT_RELU, 0, pk[1], 0.5, dp2)
+            ops.linear_dw(dp2, sv['p1'], rows, Pd, Pd, G['decoder.prenet.layers.1.linear_layer.weight'])
+            dp1 = ops.linear_dx(dp2, P['decoder.prenet.layers.1.linear_layer.weight'], rows, Pd, Pd)
+            call('gt_bias_act_drop_bwd', dp1, sv['p1'], rows, Pd, ACT_RELU, 0, pk[0], 0.5, dp1)
+            ops.linear_dw(dp1, sv['x0'], rows, Pd, n_mel, G['decoder.prenet.layers.0.linear_layer.weight'])
+        LEAF.run(leaf_prenet, dG1)
 
         # ---- d(memory) = sum_t w_t^T dctx_t (batched over b) + dpm @ Wmem ;  dWmem = dpm^T memory
         Wmem = P[al + 'memory_layer.linear_layer.weight']
