@@ -479,6 +479,234 @@ __global__ __launch_bounds__(256) void attn_step_fwd_mfma(AttnStepFwd a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Forward attention step as ONE launch WITHOUT any in-launch wait (gt_attn_step2_fwd): every (row, 32-position chunk)
+// workgroup
+//   0. requests its 32 x E tile of the attention memory straight away -- it depends on nothing of this step --
+//   1. computes the energies of its positions (as attn_energies_fwd_mfma),
+//   2. turns them into softmax NUMERATORS relative to the chunk's own maximum, p_i = exp(e_i - m_c), s_c = sum p_i, and
+//      forms the chunk's PARTIAL context sum_i p_i memory_i from the tile that arrived meanwhile,
+//   3. publishes (partial context, p, m_c, s_c) with write-through stores, drains, and draws a ticket on its row's counter;
+//   4. the LAST arriver of the row combines: M = max m_c, ctx = sum_c e^{m_c - M} part_c / sum_c e^{m_c - M} s_c, the
+//      normalised weights w_i = p_i e^{m_c - M} / S and the cumulative weights, and writes the step's outputs.
+// No workgroup ever waits for another (the hand-off form of rec_cell.h: sc1 stores, every storing wave drained, one
+// agent-scope add per workgroup, the last adder reads with sc1 loads), the memory stream runs under the energies phase
+// instead of after a kernel boundary, and the softmax is the usual online form: results equal the two-launch path up to
+// rounding.  Counters are monotonic over a loop call (ticket NCv * step - 1 is the last arriver's), zeroed once by the caller.
+struct AttnStep2Fwd {
+    GtAttnDims d; GtSlabs qpart;
+    const float* w_prev; const float* w_cum; const float* pm; const float* Wc; const float* Wd; const float* v;
+    const int* lengths; float* q_out; const float* wpack; float* u_out;
+    float* xbuf; long xs; unsigned* row_cnt; unsigned step1;
+    const float* memory; long ld_mem; float* w_out; const float* cum_in; float* cum_out;
+    float* c0; long ld0; float* c1; long ld1; float* c2; long ld2;
+    int NC;
+    int dbg;       // GANTRON_DEBUG=attn2=<bits> (timing knock-outs, results wrong): 1 no memory tile, 2 stop after the energies,
+                   // 4 stop after the ticket (no combine)
+};
+
+typedef unsigned au32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t at_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+
+__global__ __launch_bounds__(256) void attn_step2_fwd_mfma(AttnStep2Fwd a) {
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ SharedM S;
+    const GtAttnDims& d = a.d;
+    // workgroup id -> (row, chunk): groups of 8 rows; inside a group id = chunk * 8 + (row % 8): a row's chunks share an XCD
+    const int L = blockIdx.x;
+    const int grp = L / (8 * a.NC), rem = L - grp * 8 * a.NC;
+    const int chunk = rem >> 3, b = grp * 8 + (rem & 7);
+    if (b >= d.B) return;
+    const int t0 = chunk * CT;
+    const int Tv = a.lengths != nullptr ? min(a.lengths[b], d.Ti) : d.Ti;      // valid positions of this row
+    if (t0 >= Tv) return;                                                    // chunk entirely in the padding: not a member
+    const int NCv = (Tv + CT - 1) / CT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, kq = lane >> 4;
+    const int E4 = d.E >> 2;
+    const int c4 = min(tid, E4 - 1);
+    // ---- 1. energies of positions [t0, t0 + 32)  (as attn_energies_fwd_mfma)
+    float4 pm4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + 256 * i, tl = f >> 5, cc = f & 31;
+        pm4[i] = *reinterpret_cast<const float4*>(a.pm + ((long)b * d.Ti + min(t0 + tl, d.Ti - 1)) * A + 4 * cc);
+    }
+    const bool qvec = ((a.qpart.ld | a.qpart.slab_stride) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.qpart.p) & 15) == 0;
+    float qv = 0.f;
+    if (qvec) {
+        const int sg = tid >> 5, cc = tid & 31;
+        const float* qp = a.qpart.p + (long)b * a.qpart.ld + 4 * cc;
+        float4 qa = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int base = 0; base < a.qpart.n; base += 64) {
+            float4 t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = *reinterpret_cast<const float4*>(qp + (long)min(base + sg + 8 * j, a.qpart.n - 1) * a.qpart.slab_stride);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float w = base + sg + 8 * j < a.qpart.n ? 1.f : 0.f;
+                qa.x += w * t[j].x; qa.y += w * t[j].y; qa.z += w * t[j].z; qa.w += w * t[j].w;
+            }
+        }
+        *reinterpret_cast<float4*>(&S.g[sg * A + 4 * cc]) = qa;
+    } else {
+        const float* qp = a.qpart.p + (long)b * a.qpart.ld + (tid & (A - 1));
+#pragma unroll 8
+        for (int s2 = 0; s2 < a.qpart.n; ++s2) qv += qp[(long)s2 * a.qpart.slab_stride];
+    }
+    stage_common(S, d, a.Wc, a.Wd, a.v, a.w_prev, a.w_cum, b, t0, a.wpack);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + 256 * i, tl = f >> 5, cc = f & 31;
+        *reinterpret_cast<float4*>(&S.ds[tl * LDS_ + 4 * cc]) = pm4[i];
+    }
+    if (qvec) {
+        __syncthreads();
+        if (tid < A) {
+            qv = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qv += S.g[j * A + tid];
+        }
+    }
+    if (tid < A) {
+        S.q[tid] = qv;
+        if (chunk == 0 && a.q_out != nullptr) a.q_out[(long)b * A + tid] = qv;
+    }
+    // ---- 0. the memory tile: thread c4 owns float4 column c4 of the chunk's 32 rows (E <= 1024: host check).  Requested
+    // HERE, behind the energies phase's own loads (vector loads return in order: issued first, the 128 KB tile would hold
+    // up the query slabs and the processed-memory tile the phase starts with), and consumed after the phase.
+    float4 mem4[CT];
+    {
+        const float* mp = a.memory + ((long)b * d.Ti) * a.ld_mem + 4 * c4;
+#pragma unroll
+        for (int l = 0; l < CT; ++l)
+            mem4[l] = (a.dbg & 1) ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(mp + (long)min(t0 + l, Tv - 1) * a.ld_mem);
+    }
+    __syncthreads();
+    conv_tile(S, wave, lane);
+    __syncthreads();
+    f32x4 acc[2][2];
+    dense_tiles(S, wave, lane, acc);
+    float ep[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float sum = 0.f;
+#pragma unroll
+            for (int nl = 0; nl < 2; ++nl) {
+                const int dd = 32 * wave + 16 * nl + r;
+                const float u = tanhf(acc[mt][nl][e] + S.q[dd] + S.ds[(16 * mt + 4 * kq + e) * LDS_ + dd]);
+                sum += S.v[dd] * u;
+                if (a.u_out != nullptr && t0 + 16 * mt + 4 * kq + e < d.Ti)
+                    a.u_out[((long)b * d.Ti + t0 + 16 * mt + 4 * kq + e) * A + dd] = u;
+            }
+            sum += __shfl_xor(sum, 1, 64);
+            sum += __shfl_xor(sum, 2, 64);
+            sum += __shfl_xor(sum, 4, 64);
+            sum += __shfl_xor(sum, 8, 64);
+            ep[mt][e] = sum;
+        }
+    if (r == 0) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) S.epart[wave][16 * mt + 4 * kq + e] = ep[mt][e];
+    }
+    __syncthreads();
+    if (a.dbg & 2) return;
+    // ---- 2. softmax numerators relative to the chunk's own maximum (wave 0), then the partial context
+    float* pl = S.de;                                   // CT numerators
+    if (wave == 0) {
+        const bool valid = lane < CT && t0 + lane < Tv;
+        const float e = valid ? (S.epart[0][lane & 31] + S.epart[1][lane & 31]) + (S.epart[2][lane & 31] + S.epart[3][lane & 31]) : -INFINITY;
+        const float m = wave_max(e);                    // finite: position t0 is valid
+        const float pv = valid ? __expf(e - m) : 0.f;
+        const float sm = wave_sum(pv);
+        if (lane < CT) pl[lane] = pv;
+        if (lane == 0) { S.red[0] = m; S.red[1] = sm; }
+    }
+    __syncthreads();
+    float4 part = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int l = 0; l < CT; ++l) {
+        const float pv = pl[l];
+        part.x += pv * mem4[l].x; part.y += pv * mem4[l].y; part.z += pv * mem4[l].z; part.w += pv * mem4[l].w;
+    }
+    // ---- 3. publish (write-through), drain, ticket
+    float* xrow = a.xbuf + ((long)b * a.NC + chunk) * a.xs;      // [E partial context | 32 numerators | m | s | pad]
+    {
+        const __amdgpu_buffer_rsrc_t wr = at_rsrc(xrow);
+        if (tid < E4) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(au32x4, part), wr, tid * 16, 0, 16);
+        if (wave == 3 && lane < 9) {                    // 8 x 16 B of numerators + one of (m, s)
+            const float4 v4 = lane < 8 ? *reinterpret_cast<const float4*>(&pl[4 * lane]) : make_float4(S.red[0], S.red[1], 0.f, 0.f);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(au32x4, v4), wr, (d.E + 4 * lane) * 4, 0, 16);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // EVERY storing wave drains (its u_out stores too)
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned ticket = __hip_atomic_fetch_add(a.row_cnt + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        S.red[2] = ticket == (unsigned)NCv * a.step1 - 1u ? 1.f : 0.f;
+    }
+    __syncthreads();
+    if (S.red[2] == 0.f || (a.dbg & 4)) return;                    // not the row's last arriver
+    // ---- 4. last arriver: everything the other members published is requested at once (one round trip): their
+    // statistics, their partial contexts, their numerators
+    float* stat = S.g;                                             // [NCv][2] (m_c, s_c)
+    const float* xb = a.xbuf + (long)b * a.NC * a.xs;
+    float4 ms = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < NCv) {
+        const __amdgpu_buffer_rsrc_t rd = at_rsrc(xb + (long)tid * a.xs);
+        ms = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rd, (d.E + CT) * 4, 0, 16));
+    }
+    float4 others[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int c = j + (j >= chunk ? 1 : 0);                     // every member but this one
+        const int cc = min(c, NCv - 1);
+        const __amdgpu_buffer_rsrc_t rd = at_rsrc(xb + (long)cc * a.xs);
+        others[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rd, c4 * 16, 0, 16));
+    }
+    const int tw = min(tid, Tv - 1), cw = tw >> 5;                  // position tid of the row (Ti <= 256)
+    float pw = __hip_atomic_load(xb + (long)cw * a.xs + d.E + (tw & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cw == chunk) pw = pl[tw & 31];
+    if (tid < NCv) {
+        stat[2 * tid] = tid == chunk ? S.red[0] : ms.x;
+        stat[2 * tid + 1] = tid == chunk ? S.red[1] : ms.y;
+    }
+    __syncthreads();
+    float M = -INFINITY;
+    for (int c = 0; c < NCv; ++c) M = fmaxf(M, stat[2 * c]);
+    float Stot = 0.f;
+    for (int c = 0; c < NCv; ++c) Stot += __expf(stat[2 * c] - M) * stat[2 * c + 1];
+    const float inv = 1.0f / Stot;
+    {
+        const float sc = __expf(S.red[0] - M);
+        float4 ctx = make_float4(sc * part.x, sc * part.y, sc * part.z, sc * part.w);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int c = j + (j >= chunk ? 1 : 0);
+            const float so = c < NCv ? __expf(stat[2 * min(c, NCv - 1)] - M) : 0.f;
+            ctx.x += so * others[j].x; ctx.y += so * others[j].y; ctx.z += so * others[j].z; ctx.w += so * others[j].w;
+        }
+        ctx.x *= inv; ctx.y *= inv; ctx.z *= inv; ctx.w *= inv;
+        if (tid < E4) {
+            const int col = 4 * tid;
+            if (a.c0 != nullptr) *reinterpret_cast<float4*>(a.c0 + (long)b * a.ld0 + col) = ctx;
+            if (a.c1 != nullptr) *reinterpret_cast<float4*>(a.c1 + (long)b * a.ld1 + col) = ctx;
+            if (a.c2 != nullptr) *reinterpret_cast<float4*>(a.c2 + (long)b * a.ld2 + col) = ctx;
+        }
+    }
+    if (tid < d.Ti) {
+        const float wt = tid < Tv ? pw * __expf(stat[2 * cw] - M) * inv : 0.f;
+        a.w_out[(long)b * d.Ti + tid] = wt;
+        if (a.cum_out != nullptr) a.cum_out[(long)b * d.Ti + tid] = a.cum_in[(long)b * d.Ti + tid] + wt;
+    }
+}
+
 __global__ __launch_bounds__(256) void attn_energies_bwd_mfma(GtAttnDims d, const float* dw, const float* w,
                                                               const float* q, const float* w_prev, const float* w_cum,
                                                               const float* pm, const float* Wc, const float* Wd,
@@ -1224,6 +1452,23 @@ void gt_launch_attn_step_fwd_mfma(GtAttnDims d, GtSlabs qpart, const float* w_pr
     a.NC = cdiv(d.Ti, CT);
     const int groups = cdiv(d.B, 8);
     hipLaunchKernelGGL(attn_step_fwd_mfma, dim3(groups * 8 * a.NC), dim3(256), 0, st, a);
+}
+
+void gt_launch_attn_step2_fwd_mfma(GtAttnDims d, GtSlabs qpart, const float* w_prev, const float* w_cum, const float* pm,
+                                   const float* Wc, const float* Wd, const float* v, const int* lengths, float* q_out,
+                                   const float* wpack, float* u_out, float* xbuf, long xs, unsigned* row_cnt, unsigned step1,
+                                   const float* memory, long ld_mem, float* w_out, const float* cum_in, float* cum_out,
+                                   float* c0, long ld0, float* c1, long ld1, float* c2, long ld2, hipStream_t st) {
+    AttnStep2Fwd a;
+    a.d = d; a.qpart = qpart; a.w_prev = w_prev; a.w_cum = w_cum; a.pm = pm; a.Wc = Wc; a.Wd = Wd; a.v = v; a.lengths = lengths;
+    a.q_out = q_out; a.wpack = wpack; a.u_out = u_out; a.xbuf = xbuf; a.xs = xs; a.row_cnt = row_cnt; a.step1 = step1;
+    a.memory = memory; a.ld_mem = ld_mem; a.w_out = w_out; a.cum_in = cum_in; a.cum_out = cum_out;
+    a.c0 = c0; a.ld0 = ld0; a.c1 = c1; a.ld1 = ld1; a.c2 = c2; a.ld2 = ld2;
+    a.NC = cdiv(d.Ti, CT);
+    static const int dbg = gt_env_item("GANTRON_DEBUG", "attn2", 0);
+    a.dbg = dbg;
+    const int groups = cdiv(d.B, 8);
+    hipLaunchKernelGGL(attn_step2_fwd_mfma, dim3(groups * 8 * a.NC), dim3(256), 0, st, a);
 }
 
 void gt_launch_attn_energies_bwd_rec_mfma(GtAttnDims d, const float* dw, const float* w, const float* u, const float* Wc,

@@ -224,10 +224,12 @@ static int decoder_fwd_hoisted(const GtDecoderFwd* a, void* stream) {
     const bool fusedB = a->W2hc != nullptr && a->counters2 != nullptr && a->Hd % 16 == 0 && (a->Hd + a->E) % 4 == 0;
     GT_REQUIRE((a->W1c == nullptr || fusedA) && (a->W2hc == nullptr || fusedB), GT_E_ARG,
                "gt_decoder_fwd: W1c / W2hc need Wq + partq, Ha %% 32 == 0, Hd %% 16 == 0, E %% 4 == 0 and their counters");
-    const bool attn_step = a->row_cnt != nullptr && gt_attn_step_supported(d) && wpack != nullptr && a->ld1 % 4 == 0 &&
+    const bool attn_step = a->row_cnt != nullptr && a->attn_xbuf == nullptr && gt_attn_step_supported(d) && wpack != nullptr && a->ld1 % 4 == 0 &&
                            a->ld2 % 4 == 0 && a->ldE % 4 == 0 && (a->Hd % 4 == 0) && a->To < (1 << 24);
     const bool persistB = a->W2hh != nullptr && a->pl_counters != nullptr && a->pl_timeout != nullptr && !a->bf16 &&
                           gt_plstm_supported(a->Bp, a->Hd) && hc_ld % 4 == 0 && a->pre2 == a->gates2;
+    const bool attn_step2 = a->attn_xbuf != nullptr && a->row_cnt != nullptr && gt_attn_step2_supported(d) && wpack != nullptr &&
+                            a->ld1 % 4 == 0 && a->ld2 % 4 == 0 && a->ldE % 4 == 0 && (a->Hd % 4 == 0) && a->To < (1 << 24);
     const int64_t x1_slot = fusedA ? (int64_t)a->Bp * a->ld1 : 0;      // operand ping-pong (see GtDecoderFwd::W1c)
     const int64_t xh_slot = fusedB ? (int64_t)a->Bp * a->ldh : 0;
     int nblock = 0;
@@ -268,6 +270,15 @@ static int decoder_fwd_hoisted(const GtDecoderFwd* a, void* stream) {
             }
             const GtSlabs qs = cq ? slabs(a->partq, a->Ha / (fusedA ? 16 : 32), (int64_t)a->Bp * a->Apad, a->Apad)
                                   : slabs(a->part, a->Sq, (int64_t)a->Bp * a->Apad, a->Apad);
+            if (attn_step2) {       // energies + softmax + context: one launch, partial contexts, the row's last arriver combines
+                GT_TRY(gt_attn_step2_fwd(d, qs, a->w_hist + (int64_t)t * BT, a->cum_hist + (int64_t)t * BT, a->pm, a->Wc, a->Wd,
+                                         a->v, a->lengths, a->q_hist + (int64_t)t * a->B * a->A, wpack,
+                                         a->u_hist ? a->u_hist + (int64_t)t * BT * a->A : nullptr, a->attn_xbuf, a->row_cnt,
+                                         (uint32_t)(t + 1), a->memory, a->ldE, a->w_hist + (int64_t)(t + 1) * BT,
+                                         a->cum_hist + (int64_t)t * BT, a->cum_hist + (int64_t)(t + 1) * BT, X1n, a->ld1,
+                                         XAt + a->Ha, a->ld2, hc_t + a->Hd, hc_ld, sA));
+                continue;
+            }
             if (attn_step) {        // energies + softmax + context: one launch, the row's workgroups meet inside it
                 GT_TRY(gt_attn_step_fwd(d, qs, a->w_hist + (int64_t)t * BT, a->cum_hist + (int64_t)t * BT, a->pm, a->Wc, a->Wd,
                                         a->v, a->lengths, a->q_hist + (int64_t)t * a->B * a->A, wpack,

@@ -74,6 +74,8 @@ DEC_BLK = 16       # steps per block in that mode (measured: 8: 160.6 ms per pai
 # Measured slower than the two launches it replaces (20.8 vs 11.1 + 6.5 us stand-alone, forward loop 49.5 vs 45.7 ms): the
 # in-launch wait costs what the kernel boundary cost and the context phase loses its prefetch.  Off by default.
 ATTN_STEP = bool(sw.experimental('attn_step'))
+# the same step as one launch WITHOUT a wait: per-chunk partial contexts, the row's last arriver combines (gt_attn_step2_fwd)
+ATTN_STEP2 = sw.schedule_on('attn_step2')
 _HANDOFF_FLAGS = {}
 
 
@@ -712,7 +714,13 @@ class GeneratorEngine:
             keep_t['W2hh_raw'] = W2hh.contiguous()
             ws['pl_counters'] = torch.zeros(1, dtype=torch.int32, device=dev)
             d.W2hh, d.pl_counters, d.pl_timeout = ptr(keep_t['W2hh_raw']), ptr(ws['pl_counters']), ptr(handoff_flag(dev))
-        if hoist2 and ATTN_STEP and lib().gt_attn_step_supported(ops.attn_dims(B, Ti, Ep, A, self.F, self.Kc)):
+        dims_f = ops.attn_dims(B, Ti, Ep, A, self.F, self.Kc)
+        if hoist2 and ATTN_STEP2 and lib().gt_attn_step2_supported(dims_f):
+            nch = int(lib().gt_attn_chunks(Ti))
+            ws['row_cnt'] = torch.zeros(B, dtype=torch.int32, device=dev)
+            ws['attn_xbuf'] = _f32(B * nch * int(lib().gt_attn_step2_xstride(dims_f)), device=dev, zero=False)
+            d.row_cnt, d.attn_xbuf = ptr(ws['row_cnt']), ptr(ws['attn_xbuf'])
+        elif hoist2 and ATTN_STEP and lib().gt_attn_step_supported(ops.attn_dims(B, Ti, Ep, A, self.F, self.Kc)):
             ws['row_cnt'] = torch.zeros(B, dtype=torch.int32, device=dev)
             d.row_cnt, d.attn_timeout = ptr(ws['row_cnt']), ptr(handoff_flag(dev))
         if ATTN_HOIST and training and lib().gt_attn_hoist_supported(ops.attn_dims(B, Ti, Ep, A, self.F, self.Kc)):

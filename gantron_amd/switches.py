@@ -12,7 +12,8 @@ GANTRON_EXPERIMENTAL   comma list `name[=int]` of paths that were built, are par
                          no_pgemm2 (keep the plane GEMMs on 128 x 128 tiles).
 GANTRON_SCHEDULE       comma list switching OFF parts of the default schedule (what the schedule-invariance test toggles
                        through the module attributes instead): no_cell_query, no_attn_hoist, no_hoist2, no_leaf_stream,
-                       no_fwd_splitk, no_rec_cell (per-step product + cell launches instead of the fused ones),
+                       no_fwd_splitk, no_rec_cell (per-step product + cell launches instead of the fused ones), no_attn_step2 (energies
+                       and softmax + context of a forward step as two launches instead of gt_attn_step2_fwd),
                        no_dist_overlap.
 GANTRON_DEBUG          comma list of diagnostics: phase_timing, host_timing, block_timing, dist_timing, attn_valu,
                        rec=<bits> / fused=<bits> / pgemm=<bits> (kernel knock-outs), rec_splits=<n>, s1_fwd=<n>, s2_fwd=<n>,

@@ -243,6 +243,20 @@ int gt_attn_energies_fwd_w(GtAttnDims d, GtSlabs qpart, const float* w_prev, con
                          const int32_t* lengths, float* q_out, float* energies, const float* wpack, void* stream);
 int64_t gt_attn_wpack_elems(GtAttnDims d);
 int gt_attn_pack_weights(GtAttnDims d, const float* Wc, const float* Wd, float* wpack, void* stream);
+/* One launch for a whole forward attention step (model.py:70-91) WITHOUT an in-launch wait: every (row, 32-position chunk)
+ * workgroup requests its tile of `memory` at once, computes its energies (as gt_attn_energies_fwd_u), softmax numerators
+ * relative to the chunk's own maximum and the chunk's partial context, publishes them in `xbuf` (write-through) and draws a
+ * ticket on row_cnt[b]; the row's LAST arriver combines the partials (online softmax), normalises and writes w_out, cum_out
+ * and the context to up to three destinations.  xbuf: B * ceil(Ti / 32) rows of gt_attn_step2_xstride(d) floats; row_cnt: B
+ * words zeroed once per loop; step1 = 1, 2, ... counts the calls since then.  Attention dims (128, 32, 31), Ti <= 256,
+ * E % 4 == 0, E <= 1024 (gt_attn_step2_supported). */
+int32_t gt_attn_step2_supported(GtAttnDims d);
+int64_t gt_attn_step2_xstride(GtAttnDims d);
+int gt_attn_step2_fwd(GtAttnDims d, GtSlabs qpart, const float* w_prev, const float* w_cum, const float* pm,
+                      const float* Wc, const float* Wd, const float* v, const int32_t* lengths, float* q_out,
+                      const float* wpack, float* u_out, float* xbuf, uint32_t* row_cnt, uint32_t step1,
+                      const float* memory, int64_t ld_mem, float* w_out, const float* cum_in, float* cum_out,
+                      float* c0, int64_t ld0, float* c1, int64_t ld1, float* c2, int64_t ld2, void* stream);
 int gt_attn_context_fwd(GtAttnDims d, const float* energies, const float* memory, int64_t ld_mem,
                         const int32_t* lengths, float* w_out, const float* cum_in, float* cum_out,
                         float* c0, int64_t ld0, float* c1, int64_t ld1, float* c2, int64_t ld2,
@@ -371,6 +385,9 @@ typedef struct GtDecoderFwd {
     const float* W2hh;
     uint32_t* pl_counters;
     int32_t* pl_timeout;
+    /* attn_xbuf != NULL (with row_cnt, and gt_attn_step2_supported): energies + softmax + context of a step are ONE launch
+     * with NO in-launch wait (gt_attn_step2_fwd): B * ceil(Ti / 32) rows of gt_attn_step2_xstride(d) floats. */
+    float* attn_xbuf;
 } GtDecoderFwd;
 
 typedef struct GtDecoderBwd {

@@ -686,6 +686,78 @@ def test_attention_step_fused(dev, B, Ti, E, nslabs):
     assert torch.equal(cnt.cpu(), want)          # every member workgroup of every step arrived exactly once
 
 
+@pytest.mark.parametrize('B,Ti,E,nslabs', [(64, 187, 1024, 64), (9, 150, 1024, 5), (5, 77, 512, 1), (2, 33, 1024, 64), (17, 256, 640, 3)])
+def test_attention_step2_partial_contexts(dev, B, Ti, E, nslabs):
+    """gt_attn_step2_fwd = gt_attn_energies_fwd_u + gt_attn_context_fwd in ONE launch with NO in-launch wait: every chunk
+    workgroup forms softmax numerators against its own maximum and a partial context, the row's last arriver combines
+    them (online softmax).  Weights, cumulative weights, context (three destinations), query and tanh history against the
+    oracle's attention_step and against the two-launch path, for three consecutive steps on the same tickets (ragged
+    lengths: rows with 1 .. NC member workgroups; one row with a huge energy spread between its chunks)."""
+    from gantron_amd import ops
+    from gantron_amd._lib import lib
+    from oracle import gantron_ref as R
+    A, Fn, Kc = 128, 32, 31
+    d = ops.attn_dims(B, Ti, E, A, Fn, Kc)
+    assert lib().gt_attn_step2_supported(d)
+    pre = 'decoder.attention_layer.'
+    P = {pre + 'query_layer.linear_layer.weight': g(A, 16, scale=0.3),
+         pre + 'location_layer.location_conv.conv.weight': g(Fn, 2, Kc, seed=1, scale=0.3),
+         pre + 'location_layer.location_dense.linear_layer.weight': g(A, Fn, seed=2, scale=0.3),
+         pre + 'v.linear_layer.weight': g(1, A, seed=3, scale=0.5)}
+    gen = torch.Generator().manual_seed(B * 1000 + Ti)
+    lens = torch.randint(1, Ti + 1, (B,), generator=gen)
+    lens[0] = Ti
+    if B > 1:
+        lens[1] = 1
+    memory = g(B, Ti, E, seed=4)
+    pm = g(B, Ti, A, seed=5, scale=0.5)
+    if Ti > 64:
+        pm[0, 40:64] += 4.0          # chunk 1 of row 0 far above the others: the combine must rescale by e^{m_c - M}
+    pad = ~R.length_mask(lens, Ti)
+    f32 = lambda t: t.detach().float().contiguous().to(dev)
+    Wc, Wd, v = (f32(P[pre + 'location_layer.location_conv.conv.weight']),
+                 f32(P[pre + 'location_layer.location_dense.linear_layer.weight']), f32(P[pre + 'v.linear_layer.weight']))
+    wpack = torch.empty(int(lib().gt_attn_wpack_elems(d)), device=dev)
+    ops.call('gt_attn_pack_weights', d, Wc, Wd, wpack)
+    lens32 = lens.to(torch.int32).to(dev)
+    mem_d, pm_d = f32(memory), f32(pm)
+    nch = int(lib().gt_attn_chunks(Ti))
+    xbuf = torch.full((B * nch * int(lib().gt_attn_step2_xstride(d)),), float('nan'), device=dev)
+    cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+    for step in range(3):
+        query = g(B, 16, seed=60 + step)
+        w_prev = torch.softmax(g(B, Ti, seed=70 + step), 1) * (~pad)
+        w_cum = torch.softmax(g(B, Ti, seed=80 + step), 1) * 3 * (~pad)
+        ctx, w = R.attention_step({k: t.double() for k, t in P.items()}, query.double(), memory.double(), pm.double(),
+                                  w_prev.double(), w_cum.double(), pad)
+        q_ref = query.double() @ P[pre + 'query_layer.linear_layer.weight'].double().t()
+        parts = torch.randn(nslabs, B, A, generator=gen) * 0.1
+        parts[0] += q_ref.float() - parts.sum(0)
+        qd = parts.contiguous().to(dev)
+        q_out = torch.empty(B, A, device=dev); u_out = torch.zeros(B, Ti, A, device=dev)
+        w_out = torch.full((B, Ti), float('nan'), device=dev); cum_out = torch.full((B, Ti), float('nan'), device=dev)
+        c0 = torch.full((B, E), float('nan'), device=dev); c1 = torch.zeros(B, E + 8, device=dev); c2 = torch.zeros(B, E, device=dev)
+        ops.call('gt_attn_step2_fwd', d, ops.slabs(qd, nslabs, B * A, A), f32(w_prev), f32(w_cum), pm_d, Wc, Wd, v, lens32, q_out,
+                 wpack, u_out, xbuf, cnt, step + 1, mem_d, E, w_out, f32(w_cum), cum_out, c0, E, ops.ptr(c1, 8), E + 8, c2, E)
+        close(w_out, w, rtol=1e-4, atol=1e-6, what=f'attention weights (step {step})')
+        close(c0, ctx, rtol=1e-4, atol=1e-5, what=f'context (step {step})')
+        close(c1[:, 8:], ctx, rtol=1e-4, atol=1e-5, what='context strided')
+        close(c2, ctx, rtol=1e-4, atol=1e-5, what='context third destination')
+        close(cum_out, w_cum.double() + w, rtol=1e-4, atol=1e-6, what='cumulative')
+        close(q_out, q_ref, rtol=1e-4, atol=1e-5, what='query')
+        q2 = torch.empty(B, A, device=dev); en = torch.empty(B, Ti, device=dev); u2 = torch.zeros(B, Ti, A, device=dev)
+        ops.call('gt_attn_energies_fwd_u', d, ops.slabs(qd, nslabs, B * A, A), f32(w_prev), f32(w_cum), pm_d, Wc, Wd, v, lens32, q2, en,
+                 wpack, u2)
+        w2 = torch.empty(B, Ti, device=dev); cu2 = torch.empty(B, Ti, device=dev); cc = torch.empty(B, E, device=dev)
+        ops.call('gt_attn_context_fwd', d, en, mem_d, E, lens32, w2, f32(w_cum), cu2, cc, E, None, 0, None, 0)
+        close(w_out, w2, rtol=1e-5, atol=1e-8, what='weights vs two-launch path')
+        close(c0, cc, rtol=1e-5, atol=1e-6, what='context vs two-launch path')
+        valid = (~pad)[:, :, None].to(dev)
+        close(u_out * valid, u2 * valid, rtol=0, atol=0, what='tanh history')
+    want = ((lens + 31) // 32 * 3).to(torch.int32)
+    assert torch.equal(cnt.cpu(), want)          # every member workgroup of every step drew exactly one ticket
+
+
 @pytest.mark.parametrize('B,Ti', [(3, 150), (5, 77), (2, 33)])
 def test_attention_hoisted_backward_equals_in_loop(dev, B, Ti):
     """gt_attn_energies_fwd_u + gt_attn_energies_bwd_rec per step + ONE gt_attn_param_grads over the steps == the

@@ -32,10 +32,20 @@ def fused():
     step[0] += 1
     ops.call('gt_attn_step_fwd', d, qs, w_prev, w_cum, pm, Wc, Wd, v, lens32, q_out, wpack, u_out, en, cnt, step[0], tf, memory, E,
              w_out, w_cum, cum_out, c0, E, c1, 2 * E, c2, 2 * E)
+nch = int(lib().gt_attn_chunks(Ti))
+xbuf = torch.empty(B * nch * int(lib().gt_attn_step2_xstride(d)), device=dev)
+cnt2 = torch.zeros(B, dtype=torch.int32, device=dev)
+step2 = [0]
+def fused2():
+    step2[0] += 1
+    ops.call('gt_attn_step2_fwd', d, qs, w_prev, w_cum, pm, Wc, Wd, v, lens32, q_out, wpack, u_out, xbuf, cnt2, step2[0], memory, E,
+             w_out, w_cum, cum_out, c0, E, c1, 2 * E, c2, 2 * E)
+def energies_only():
+    ops.call('gt_attn_energies_fwd_u', d, qs, w_prev, w_cum, pm, Wc, Wd, v, lens32, q_out, en, wpack, u_out)
 def two():
     ops.call('gt_attn_energies_fwd_u', d, qs, w_prev, w_cum, pm, Wc, Wd, v, lens32, q_out, en, wpack, u_out)
     ops.call('gt_attn_context_fwd', d, en, memory, E, lens32, w_out, w_cum, cum_out, c0, E, c1, 2 * E, c2, 2 * E)
-for name, fn in (('two launches', two), ('fused', fused)):
+for name, fn in (('two launches', two), ('energies only', energies_only), ('fused (wait)', fused), ('fused2 (no wait)', fused2)):
     for _ in range(10):
         fn()
     torch.cuda.synchronize()
