@@ -59,11 +59,12 @@ S2_FWD = sw.debug('s2_fwd')
 S2_BWD = sw.debug('s2_bwd')
 # Persistent, weight-resident LSTM recurrences (gt_plstm_fwd, csrc/plstm.hip): bit 0 = the encoder BiLSTM forward (ONE launch
 # for all steps of both directions), bit 1 = the decoder LSTM's h_dec recurrence of a block of steps (hoisted mode, fp32).
-# Measured on MI355X (round 3) and NOT adopted: the encoder launch takes 9.8 us per step against ~10 for
-# the per-step fused launches it replaces (1.84 vs 1.9 ms per forward); the decoder block runs at 33 us per step on 64 CUs --
-# fast enough for the chain it feeds, but the attention chain's 256-workgroup kernels then run on 192 CUs (its fused step
-# 27 instead of 20 us): pair 134.0-134.6 ms with both on against 133.3-134.2 without; forward loop 41.3 (with 3 K-splits
-# for the attention LSTM) / 42.7 / 42.5 ms.  Off by default, parity-tested with the bits on.
+# Measured on MI355X (round 3): the encoder launch takes 9.8 us per step against ~10 for the per-step
+# fused launches it replaces; the decoder block runs at 33 us per step on 64 CUs -- fast enough for the chain it feeds, but
+# the attention chain's 256-workgroup kernels then run on 192 CUs: pair 134.0-134.6 ms with both on against 133.3-134.2
+# without.  With the attention LSTM re-split for the 192 CUs that are left (3 K-splits instead of 4, done automatically
+# below) and the one-launch attention step: 131.2-132.1 against 133.0.  A 1 % gain against a launch whose 64 + 32
+# workgroups must all be resident together: kept opt-in (GANTRON_EXPERIMENTAL=plstm=3), parity-tested with the bits on.
 PLSTM = sw.experimental('plstm')
 S1_FWD = sw.debug('s1_fwd')       # diagnostics: K-splits of the attention LSTM's forward product
 DEC_BLK = 16       # steps per block in that mode (measured: 8: 160.6 ms per pair,
@@ -640,6 +641,8 @@ class GeneratorEngine:
                 d.S2 = ops.pick_splits(Hd, S2_FWD)
             if S1_FWD and not self.bf16:
                 d.S1 = ops.pick_splits(K1, S1_FWD)
+            elif (PLSTM & 2) and not self.bf16 and lib().gt_plstm_supported(Bp, Hd) and 4 * Ha == 4096 and d.S1 == 4:
+                d.S1 = 3        # the persistent decoder-LSTM launch holds 64 CUs: 64 column groups x 3 K-splits = the other 192
             # fused product + cell launches (gt_rec_cell_fwd) take their own packing
             use_c1 = bool(REC_CELL & (8 if self.bf16 else 1)) and CELL_QUERY and Ha % 32 == 0
             use_c2 = bool(REC_CELL & (16 if self.bf16 else 2)) and Hd % 16 == 0 and Hd % 4 == 0
