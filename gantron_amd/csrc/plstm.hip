@@ -17,7 +17,9 @@
 //     (unit = lane & 15, rows 4 (lane >> 4) + 0..3) in one lane, so the cell runs in registers and c never leaves them.
 // Residency: every workgroup of a problem waits for its peers, so all of them must be resident together.  The grid is at
 // most 64 workgroups on a 256-CU device and no other kernel ever waits on this one while holding a CU, so each workgroup
-// is dispatched eventually; every wait is bounded and raises `timeout_flag` instead of hanging (results are then invalid:
+// is dispatched eventually (the other kernels of the step run as dependent launches: between two of them their CUs are
+// empty, and the auxiliary stream this launch sits on has the higher queue priority); every wait is bounded and raises
+// `timeout_flag` instead of hanging, and a raised flag ends all further waiting (results are then invalid:
 // engine.check_handoffs()).
 #include "common.h"
 
@@ -116,9 +118,13 @@ __global__ __launch_bounds__(256) void plstm_fwd_kernel(PlstmDev a) {
                 if (tid == 0) {
                     const unsigned want = (unsigned)a.NW * (unsigned)(s - a.s_lo);
                     int spins = 0;
+                    // bounded, and STICKY: once any wait of any launch has given up (the flag stays raised until the host
+                    // reads it), nobody spins any more -- a run that is already invalid ends quickly instead of paying
+                    // one time-out per step
                     while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                         __builtin_amdgcn_s_sleep(1);
-                        if (++spins > (1 << 24)) { atomicExch(a.timeout_flag, 1); break; }       // ~ seconds: give up, flag it
+                        if ((++spins & 1023) == 0 && __hip_atomic_load(a.timeout_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                        if (spins > (1 << 21)) { atomicExch(a.timeout_flag, 1); break; }        // ~ seconds: give up, flag it
                     }
                 }
                 __syncthreads();

@@ -60,12 +60,12 @@ S2_BWD = sw.debug('s2_bwd')
 # Persistent, weight-resident LSTM recurrences (gt_plstm_fwd, csrc/plstm.hip): bit 0 = the encoder BiLSTM forward (ONE launch
 # for all steps of both directions), bit 1 = the decoder LSTM's h_dec recurrence of a block of steps (hoisted mode, fp32).
 # Measured on MI355X (round 3): the encoder launch takes 9.8 us per step against ~10 for the per-step
-# fused launches it replaces; the decoder block runs at 33 us per step on 64 CUs -- fast enough for the chain it feeds, but
-# the attention chain's 256-workgroup kernels then run on 192 CUs: pair 134.0-134.6 ms with both on against 133.3-134.2
-# without.  With the attention LSTM re-split for the 192 CUs that are left (3 K-splits instead of 4, done automatically
-# below) and the one-launch attention step: 131.2-132.1 against 133.0.  A 1 % gain against a launch whose 64 + 32
-# workgroups must all be resident together: kept opt-in (GANTRON_EXPERIMENTAL=plstm=3), parity-tested with the bits on.
-PLSTM = sw.experimental('plstm')
+# fused launches it replaces; the decoder block runs at 33 us per step on 64 CUs -- fast enough for the chain it feeds.  On
+# their own they changed nothing (the attention chain's 256-workgroup kernels then ran on 192 CUs: 134.0-134.6 vs
+# 133.3-134.2 ms per pair); with the attention LSTM re-split for the 192 CUs that are left (3 K-splits instead of 4, done
+# below) and the one-launch attention step: 131.0-132.1 against 133.0-133.4.  On by default (GANTRON_SCHEDULE=no_plstm or
+# GANTRON_EXPERIMENTAL=plstm=<bits> to change it).
+PLSTM = sw.experimental('plstm', 3 if sw.schedule_on('plstm') else 0)
 S1_FWD = sw.debug('s1_fwd')       # diagnostics: K-splits of the attention LSTM's forward product
 DEC_BLK = 16       # steps per block in that mode (measured: 8: 160.6 ms per pair,
                                                               # 12: 157.9, 16: 157.9, 32: 160.5, 48: 160.9, 64: 165.7)

@@ -7,13 +7,14 @@ GANTRON_EXPERIMENTAL   comma list `name[=int]` of paths that were built, are par
                        than the default ("measured and not adopted"); nothing here is needed for
                        correctness and the default path never runs them:
                          fused_cell, attn_step, attn_bwd_fused, leaf_defer, rec_cellbwd (the decoder LSTM's fused backward
-                         step), plane_gemms (pre-split GEMM operands), plstm=<bits> (persistent LSTM recurrences: 1 encoder,
-                         2 decoder), graph[=2] (hipGraph replay of the decoder loops; 2 also reports capture / replay),
+                         step), plane_gemms (pre-split GEMM operands), plstm=<bits> (persistent LSTM recurrences, default 3: 1
+                         encoder, 2 decoder; 0 = per-step launches), graph[=2] (hipGraph replay of the decoder loops; 2 also reports capture / replay),
                          no_pgemm2 (keep the plane GEMMs on 128 x 128 tiles).
 GANTRON_SCHEDULE       comma list switching OFF parts of the default schedule (what the schedule-invariance test toggles
                        through the module attributes instead): no_cell_query, no_attn_hoist, no_hoist2, no_leaf_stream,
                        no_fwd_splitk, no_rec_cell (per-step product + cell launches instead of the fused ones), no_attn_step2 (energies
-                       and softmax + context of a forward step as two launches instead of gt_attn_step2_fwd),
+                       and softmax + context of a forward step as two launches instead of gt_attn_step2_fwd), no_plstm (per-step
+                       launches instead of the persistent LSTM recurrences),
                        no_dist_overlap.
 GANTRON_DEBUG          comma list of diagnostics: phase_timing, host_timing, block_timing, dist_timing, attn_valu,
                        rec=<bits> / fused=<bits> / pgemm=<bits> (kernel knock-outs), rec_splits=<n>, s1_fwd=<n>, s2_fwd=<n>,

@@ -197,11 +197,21 @@ def test_persistent_lstm_recurrences_against_oracle(dev, monkeypatch, case):
     NaN-poisoned histories, and the VESUS memory width (HC rows of 1024 + 1096 columns)."""
     from gantron_amd import engine
     monkeypatch.setattr(engine, 'PLSTM', 3)
+    assert engine.lib().gt_plstm_supported(64, 1024) and engine.lib().gt_plstm_supported(64, 256)
     if case.endswith('_poison'):
         monkeypatch.setattr(engine, 'POISON', True)
         case = case[:-len('_poison')]
     _midsize_against_oracle(dev, case)
     engine.check_handoffs()
+
+
+@pytest.mark.parametrize('case', ['full_dims_b64', 'vesus_b64'])
+def test_per_step_lstm_launches_against_oracle(dev, monkeypatch, case):
+    """The per-step fused product + cell launches that the persistent recurrences replace at 64 rows (GANTRON_SCHEDULE=
+    no_plstm; still what every other batch size and bf16 mode run) at the reference's dimensions."""
+    from gantron_amd import engine
+    monkeypatch.setattr(engine, 'PLSTM', 0)
+    _midsize_against_oracle(dev, case)
 
 
 def test_plane_gemms_against_oracle(dev, monkeypatch):
@@ -609,10 +619,11 @@ def test_full_size_training_step_is_schedule_invariant(dev, monkeypatch):
     monkeypatch.setattr(engine, 'CELL_QUERY', False)
     monkeypatch.setattr(engine, 'HOIST2', False)
     monkeypatch.setattr(engine.LEAF, 'enabled', False)
+    monkeypatch.setattr(engine, 'PLSTM', 0)
     out0, g0 = run()
     monkeypatch.undo()
     monkeypatch.setattr(ops, 'FWD_SPLITK', False)
-    assert engine.DEC_RING > 1 and engine.BWD_CHUNKS > 1 and engine.ATTN_HOIST and engine.LEAF.enabled and engine.HOIST2
+    assert engine.DEC_RING > 1 and engine.BWD_CHUNKS > 1 and engine.ATTN_HOIST and engine.LEAF.enabled and engine.HOIST2 and engine.PLSTM == 3
     out1, g1 = run()
     for name, a, b in zip(('mel', 'mel_post', 'gate', 'align'), out1, out0):
         close(a, b, rtol=1e-4, atol=1e-6, what=f'out.{name}')
