@@ -88,7 +88,7 @@ def lib():
             fn = getattr(handle, name)        # AttributeError here = header/library drift
             fn.restype, fn.argtypes = restype, argtypes
         for which, sname in enumerate(('GtOperand', 'GtGemm', 'GtSlabs', 'GtAttnDims', 'GtDecoderFwd',
-                                       'GtDecoderBwd', 'GtBiLstm', 'GtDecoderInfer', 'GtPlstm')):
+                                       'GtDecoderBwd', 'GtBiLstm', 'GtDecoderInfer', 'GtPlstm', 'GtPlstmBwd')):
             want, got = handle.gt_abi_sizeof(which), ctypes.sizeof(STRUCTS[sname])
             if want != got:
                 raise GantronHipError(f'ABI mismatch: sizeof({sname}) is {want} in the library, {got} in the binding')

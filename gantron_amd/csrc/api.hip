@@ -44,6 +44,7 @@ extern "C" int64_t gt_abi_sizeof(int32_t which) {
         case 6: return sizeof(GtBiLstm);
         case 7: return sizeof(GtDecoderInfer);
         case 8: return sizeof(GtPlstm);
+        case 9: return sizeof(GtPlstmBwd);
         default: return -1;
     }
 }

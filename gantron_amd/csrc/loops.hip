@@ -607,7 +607,21 @@ static int decoder_bwd_hoisted(const GtDecoderBwd* a, void* stream) {
         // ---- decoder LSTM chain (stream B, leads), steps b1 .. b0
         // countersB != NULL: the product of step t + 1 and the cell backward of step t are ONE launch (gt_rec_cellbwd)
         const bool fusedB = a->countersB != nullptr && !a->bf16 && a->Hd % 64 == 0 && a->S2 <= 16;
-        for (int t = b1; t >= b0; --t) {
+        const bool persistB = a->W2hh != nullptr && a->pl_xbuf != nullptr && a->pl_counters != nullptr && a->pl_timeout != nullptr &&
+                              !a->bf16 && gt_plstm_supported(a->Bp, a->Hd) && hc_ld % 4 == 0;
+        if (persistB) {
+            // the block's backward recurrence as ONE persistent launch; the exchange tiles of step b1 + 1 are in pl_xbuf
+            GtPlstmBwd q = {};
+            q.B = a->B; q.Bp = a->Bp; q.H = a->Hd; q.T = a->To; q.ndir = 1; q.s_lo = b0; q.s_hi = b1 + 1;
+            q.recurrent_in = b1 < a->To - 1 ? 1 : 0;
+            q.p_drop = a->dec_keep ? a->p_dec : 0.f;
+            q.Whh = a->W2hh; q.gates = a->gates2; q.c = a->c2;
+            q.dh_direct = a->dHC; q.dd_step = (int64_t)a->Bp * hc_ld; q.dd_ld = hc_ld;
+            q.dG = a->dG2; q.dc = a->dc2; q.xbuf = a->pl_xbuf;
+            q.keep = a->dec_keep; q.active = nullptr; q.counters = a->pl_counters; q.timeout_flag = a->pl_timeout;
+            GT_TRY(gt_plstm_bwd(&q, sB));
+        }
+        for (int t = b1; t >= b0 && !persistB; --t) {
             const bool last = (t == a->To - 1);
             const uint8_t* k2 = a->dec_keep ? a->dec_keep + (int64_t)t * a->Bp * a->Hd : nullptr;
             const float* dhc_t = a->dHC + (int64_t)t * a->Bp * hc_ld;

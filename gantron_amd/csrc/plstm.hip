@@ -216,6 +216,172 @@ __global__ __launch_bounds__(256) void plstm_fwd_kernel(PlstmDev a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward counterpart (gt_plstm_bwd): ONE launch walks steps s_hi - 1 .. s_lo of
+//   dh_s = dh_direct_s + dG_{s+1} . W_hh,   cell backward -> dG_s (gate pre-activation gradients), dc carried on.
+// Same decomposition (workgroup w owns 16 hidden units = 64 gate columns = 64 ROWS of W_hh, resident in registers), but the
+// product runs the other way round: the workgroup's own dG block (64 batch rows x 64 gate columns, produced locally by the
+// cell backward, staged in LDS) times its 64 x H block of W_hh is a PARTIAL of dh for ALL H units, so the exchange is a
+// reduce-scatter: the partial is cut into H / 16 tiles of (64 rows x 16 units), tile d goes to workgroup d's inbox
+// (xbuf[slot][d][w], 4 KiB, written through), and at the next step every workgroup adds the H / 16 tiles of its inbox.
+// The four waves split the OUTPUT columns (H / 4 each, i.e. H / 64 destination workgroups per wave), so no fold is needed.
+struct PlstmBwdDev {
+    const float* Whh; long w_dstride;
+    const float* gates; long gates_dstride;      // (T, Bp, 4H) gate values of the forward pass
+    const float* c_hist; long c_dstride;         // (T + 1, Bp, H)
+    const float* dh_direct; long dd_dstride; long dd_step; long dd_ld;       // gradient of the emitted h of step s
+    float* dG; long dG_dstride;                  // (T, Bp, 4H) out
+    float* dc; long dc_dstride;                  // (Bp, H) carried cell-state gradient, read at the start, written at the end
+    float* xbuf; long x_dstride;                 // (2 slots, NW dest, NW src, 64, 16) per direction
+    const uint8_t* keep; float scale;
+    const int* active;
+    unsigned* cnt; int* timeout_flag;
+    int B, H, s_lo, s_hi, NW, recurrent_in;
+};
+
+template <int KW>       // KW = H / 4 output columns per wave
+__global__ __launch_bounds__(256) void plstm_bwd_kernel(PlstmBwdDev a) {
+    constexpr int NCT = KW / 16;                 // destination workgroups (column tiles) per wave
+    constexpr int LDA = 68;                      // dG tile row stride in LDS (floats): conflict-free float4 fragment reads
+    __shared__ __attribute__((aligned(16))) float dgs[PL_ROWS * LDA];         // [row][64 own gate columns]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.x / a.NW, w = blockIdx.x - dir * a.NW;
+    const int H = a.H, N = 4 * H;
+    const int u0 = 16 * w;
+    const int ln = lane & 15, lq = lane >> 4;
+    const float* Whh = a.Whh + dir * a.w_dstride;
+    const float* gates = a.gates + dir * a.gates_dstride;
+    const float* c_hist = a.c_hist + dir * a.c_dstride;
+    const float* dd = a.dh_direct + dir * a.dd_dstride;
+    float* dG = a.dG + dir * a.dG_dstride;
+    float* dcp = a.dc + dir * a.dc_dstride;
+    float* xbuf = a.xbuf + dir * a.x_dstride;
+    unsigned* cnt = a.cnt + dir;
+    const long tile = (long)PL_ROWS * 16;                            // floats of one (64 x 16) tile
+    const long slot_stride = (long)a.NW * a.NW * tile;
+
+    // ---- this wave's block of W_hh, resident: B operand lane (n = ln, k-quad lq) of column tile ct, gate j (= k-group):
+    //      k = 16 j + 4 lq + i  <->  row j H + u0 + 4 lq + i of W_hh;  n <-> column wave KW + 16 ct + ln
+    float4 wreg[NCT][4];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float* wp = Whh + (long)(j * H + u0 + 4 * lq) * H + wave * KW + 16 * ct + ln;
+            wreg[ct][j] = make_float4(wp[0], wp[H], wp[2 * (long)H], wp[3 * (long)H]);
+        }
+
+    // ---- cell phase layout: thread (row = tid >> 2, units 4 (tid & 3) .. + 3), float4 everywhere
+    const int crow = tid >> 2, uq = tid & 3;
+    const int cu = u0 + 4 * uq;
+    float4 dcv = *reinterpret_cast<const float4*>(dcp + (long)crow * H + cu);
+
+    for (int s = a.s_hi - 1; s >= a.s_lo; --s) {
+        // ---- inputs that do not depend on the exchange
+        const float* gt = gates + ((long)s * PL_ROWS + crow) * N + cu;
+        const float4 gi = *reinterpret_cast<const float4*>(gt), gf = *reinterpret_cast<const float4*>(gt + H);
+        const float4 gg = *reinterpret_cast<const float4*>(gt + 2 * (long)H), go = *reinterpret_cast<const float4*>(gt + 3 * (long)H);
+        const float4 cn = *reinterpret_cast<const float4*>(c_hist + ((long)(s + 1) * PL_ROWS + crow) * H + cu);
+        const float4 cp = *reinterpret_cast<const float4*>(c_hist + ((long)s * PL_ROWS + crow) * H + cu);
+        float4 dh = *reinterpret_cast<const float4*>(dd + (long)s * a.dd_step + (long)crow * a.dd_ld + cu);
+        uchar4 kp = make_uchar4(1, 1, 1, 1);
+        if (a.keep != nullptr) kp = *reinterpret_cast<const uchar4*>(a.keep + ((long)s * PL_ROWS + crow) * H + cu);
+        const bool act = crow < a.B && (a.active == nullptr || a.active[(long)s * PL_ROWS + crow] != 0);
+        // ---- recurrent part: the H / 16 tiles of this workgroup's inbox, published while step s + 1 ran
+        const bool have_in = s + 1 < a.s_hi || a.recurrent_in;
+        if (have_in) {
+            if (s + 1 < a.s_hi) {
+                if (tid == 0) {
+                    const unsigned want = (unsigned)a.NW * (unsigned)(a.s_hi - 1 - s);
+                    int spins = 0;
+                    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if ((++spins & 1023) == 0 && __hip_atomic_load(a.timeout_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                        if (spins > (1 << 21)) { atomicExch(a.timeout_flag, 1); break; }
+                    }
+                }
+                __syncthreads();
+            }
+            const float* inbox = xbuf + ((s + 1) & 1) * slot_stride + (long)w * a.NW * tile;      // [src][64][16]
+            const __amdgpu_buffer_rsrc_t rd = pl_rsrc(inbox);
+            for (int s0 = 0; s0 < a.NW; s0 += 16) {               // 16 tiles in flight per thread
+                float4 t[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    t[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                        rd, (int)(((long)(s0 + j) * tile + crow * 16 + 4 * uq) * 4), 0, SC1));
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { dh.x += t[j].x; dh.y += t[j].y; dh.z += t[j].z; dh.w += t[j].w; }
+            }
+        }
+        // ---- cell backward (rec_cell.h / lstm_cell_bwd_kernel), thread = (row, 4 units)
+        float4 dgi = make_float4(0.f, 0.f, 0.f, 0.f), dgf = dgi, dgg = dgi, dgo = dgi;
+        if (act) {
+            const float dhv[4] = {dh.x, dh.y, dh.z, dh.w}, giv[4] = {gi.x, gi.y, gi.z, gi.w}, gfv[4] = {gf.x, gf.y, gf.z, gf.w};
+            const float ggv[4] = {gg.x, gg.y, gg.z, gg.w}, gov[4] = {go.x, go.y, go.z, go.w};
+            const float cnv[4] = {cn.x, cn.y, cn.z, cn.w}, cpv[4] = {cp.x, cp.y, cp.z, cp.w};
+            const float dcn[4] = {dcv.x, dcv.y, dcv.z, dcv.w};
+            const unsigned char kpv[4] = {kp.x, kp.y, kp.z, kp.w};
+            float o[5][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float d = dhv[e];
+                if (a.keep != nullptr) d *= kpv[e] ? a.scale : 0.f;
+                const float tc = tanhf(cnv[e]);
+                const float dcell = dcn[e] + d * gov[e] * (1.f - tc * tc);
+                o[0][e] = dcell * ggv[e] * giv[e] * (1.f - giv[e]);
+                o[1][e] = dcell * cpv[e] * gfv[e] * (1.f - gfv[e]);
+                o[2][e] = dcell * giv[e] * (1.f - ggv[e] * ggv[e]);
+                o[3][e] = d * tc * gov[e] * (1.f - gov[e]);
+                o[4][e] = dcell * gfv[e];
+            }
+            dgi = make_float4(o[0][0], o[0][1], o[0][2], o[0][3]); dgf = make_float4(o[1][0], o[1][1], o[1][2], o[1][3]);
+            dgg = make_float4(o[2][0], o[2][1], o[2][2], o[2][3]); dgo = make_float4(o[3][0], o[3][1], o[3][2], o[3][3]);
+            dcv = make_float4(o[4][0], o[4][1], o[4][2], o[4][3]);
+        }
+        {
+            float* dg = dG + ((long)s * PL_ROWS + crow) * N + cu;
+            *reinterpret_cast<float4*>(dg) = dgi; *reinterpret_cast<float4*>(dg + H) = dgf;
+            *reinterpret_cast<float4*>(dg + 2 * (long)H) = dgg; *reinterpret_cast<float4*>(dg + 3 * (long)H) = dgo;
+            float* ds = dgs + crow * LDA + 4 * uq;                   // k = 16 gate + unit
+            *reinterpret_cast<float4*>(ds) = dgi; *reinterpret_cast<float4*>(ds + 16) = dgf;
+            *reinterpret_cast<float4*>(ds + 32) = dgg; *reinterpret_cast<float4*>(ds + 48) = dgo;
+        }
+        if (s == 0) break;                                           // nothing consumes a product behind step 0 (a later launch picks
+                                                                     // the tiles of step s_lo up: recurrent_in)
+        __syncthreads();
+        // ---- partial of dh_{s-1} for this wave's H / 4 units, TRANSPOSED: C^T = W_block^T (units x k) . dG^T (k x rows), so the
+        //      C layout (lane (ln, lq) holds rows 4 lq .. 4 lq + 3 of column ln) leaves four consecutive UNITS of batch row ln
+        //      in one lane: one 16-byte write-through store per lane per (16 rows x 16 units) patch, no transpose
+        float* outbox = xbuf + (s & 1) * slot_stride;
+#pragma unroll 1
+        for (int rt = 0; rt < 4; ++rt) {
+            float4 af[4];                                            // dG^T fragments: row 16 rt + ln, k = 16 j + 4 lq ..
+#pragma unroll
+            for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const float4*>(dgs + (16 * rt + ln) * LDA + 16 * j + 4 * lq);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[ct][j].x, af[j].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[ct][j].y, af[j].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[ct][j].z, af[j].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[ct][j].w, af[j].w, acc, 0, 0, 0);
+                }
+                const int d = wave * NCT + ct;                       // destination workgroup (units 16 d .. 16 d + 15)
+                const __amdgpu_buffer_rsrc_t wr = pl_rsrc(outbox + ((long)d * a.NW + w) * tile);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), wr, ((16 * rt + ln) * 16 + 4 * lq) * 4, 0, SC1);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    *reinterpret_cast<float4*>(dcp + (long)crow * H + cu) = dcv;
+}
+
 }  // namespace
 
 extern "C" int gt_plstm_supported(int32_t Bp, int32_t H) { return Bp == PL_ROWS && (H == 256 || H == 1024) ? 1 : 0; }
@@ -248,6 +414,42 @@ extern "C" int gt_plstm_fwd(const GtPlstm* q, void* stream) {
                      4.0 * q->ndir * (4.0 * q->H * q->H + steps * PL_ROWS * 10.0 * q->H), st);
     if (q->H == 256) hipLaunchKernelGGL(plstm_fwd_kernel<64>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(plstm_fwd_kernel<256>, grid, dim3(256), 0, st, a);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int64_t gt_plstm_bwd_xbuf_elems(int32_t H) { return 2L * (H / 16) * (H / 16) * PL_ROWS * 16; }
+
+extern "C" int gt_plstm_bwd(const GtPlstmBwd* q, void* stream) {
+    GT_REQUIRE(q != nullptr, GT_E_ARG, "gt_plstm_bwd: NULL");
+    GT_REQUIRE(gt_plstm_supported(q->Bp, q->H), GT_E_LIMIT, "gt_plstm_bwd: Bp = %d, H = %d (needs Bp = 64 and H = 256 or 1024)", q->Bp, q->H);
+    GT_REQUIRE(q->B > 0 && q->B <= q->Bp && q->ndir >= 1 && q->ndir <= 2 && q->s_lo >= 0 && q->s_lo < q->s_hi && q->s_hi <= q->T,
+               GT_E_ARG, "gt_plstm_bwd: bad sizes B=%d ndir=%d steps [%d,%d) of %d", q->B, q->ndir, q->s_lo, q->s_hi, q->T);
+    GT_REQUIRE(q->Whh && q->gates && q->c && q->dh_direct && q->dG && q->dc && q->xbuf && q->counters && q->timeout_flag, GT_E_ARG,
+               "gt_plstm_bwd: NULL pointer");
+    GT_REQUIRE(q->dd_ld >= q->H && q->dd_ld % 4 == 0 && aligned16(q->dh_direct) && aligned16(q->xbuf) && aligned16(q->dc) &&
+                   aligned16(q->dG) && aligned16(q->gates) && aligned16(q->c), GT_E_ALIGN, "gt_plstm_bwd: 16-byte aligned buffers, dd_ld %% 4 == 0");
+    GT_REQUIRE(!q->recurrent_in || q->s_hi < q->T, GT_E_ARG, "gt_plstm_bwd: recurrent_in needs a step s_hi whose partials were published");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(q->counters, 0, sizeof(unsigned) * q->ndir, st);
+    GT_REQUIRE(e == hipSuccess, (int)e, "gt_plstm_bwd: memset failed");
+    PlstmBwdDev a;
+    a.Whh = q->Whh; a.w_dstride = q->w_dstride;
+    a.gates = q->gates; a.gates_dstride = q->gates_dstride;
+    a.c_hist = q->c; a.c_dstride = q->c_dstride;
+    a.dh_direct = q->dh_direct; a.dd_dstride = q->dd_dstride; a.dd_step = q->dd_step; a.dd_ld = q->dd_ld;
+    a.dG = q->dG; a.dG_dstride = q->dG_dstride;
+    a.dc = q->dc; a.dc_dstride = q->dc_dstride;
+    a.xbuf = q->xbuf; a.x_dstride = q->x_dstride;
+    a.keep = q->p_drop > 0.f ? q->keep : nullptr; a.scale = q->p_drop > 0.f ? 1.0f / (1.0f - q->p_drop) : 1.0f;
+    a.active = q->active; a.cnt = q->counters; a.timeout_flag = q->timeout_flag;
+    a.B = q->B; a.H = q->H; a.s_lo = q->s_lo; a.s_hi = q->s_hi; a.NW = q->H / 16; a.recurrent_in = q->recurrent_in;
+    const dim3 grid(q->ndir * a.NW);
+    const double steps = q->s_hi - q->s_lo;
+    GtProfScope prof(GT_FAM_REC_GEMM, 2.0 * q->ndir * PL_ROWS * 4.0 * q->H * q->H * steps,
+                     4.0 * q->ndir * (4.0 * q->H * q->H + steps * PL_ROWS * 14.0 * q->H), st);
+    if (q->H == 256) hipLaunchKernelGGL(plstm_bwd_kernel<64>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(plstm_bwd_kernel<256>, grid, dim3(256), 0, st, a);
     GT_LAUNCH_CHECK();
     return 0;
 }

@@ -25,7 +25,7 @@ import torch
 from . import ops
 from . import switches as sw
 from .ops import (ACT_NONE, ACT_RELU, ACT_TANH, IM2COL_K, IM2COL_R, KC, RC, Operand, call, ptr, roundup, sgemm)
-from ._lib import GtBiLstm, GtDecoderBwd, GtDecoderFwd, GtDecoderInfer, GtPlstm, check, lib
+from ._lib import GtBiLstm, GtDecoderBwd, GtDecoderFwd, GtDecoderInfer, GtPlstm, GtPlstmBwd, check, lib
 
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 # ---- switches (environment, read once at import; the defaults are the measured-best configuration)
@@ -57,16 +57,20 @@ DEC_BLK_BWD = 16
 # (it only follows / feeds the attention chain): fewer, longer workgroups leave the CUs to the critical chain.
 S2_FWD = sw.debug('s2_fwd')
 S2_BWD = sw.debug('s2_bwd')
-# Persistent, weight-resident LSTM recurrences (gt_plstm_fwd, csrc/plstm.hip): bit 0 = the encoder BiLSTM forward (ONE launch
-# for all steps of both directions), bit 1 = the decoder LSTM's h_dec recurrence of a block of steps (hoisted mode, fp32).
-# Measured on MI355X (round 3): the encoder launch takes 9.8 us per step against ~10 for the per-step
-# fused launches it replaces; the decoder block runs at 33 us per step on 64 CUs -- fast enough for the chain it feeds.  On
-# their own they changed nothing (the attention chain's 256-workgroup kernels then ran on 192 CUs: 134.0-134.6 vs
-# 133.3-134.2 ms per pair); with the attention LSTM re-split for the 192 CUs that are left (3 K-splits instead of 4, done
-# below) and the one-launch attention step: 131.0-132.1 against 133.0-133.4.  On by default (GANTRON_SCHEDULE=no_plstm or
-# GANTRON_EXPERIMENTAL=plstm=<bits> to change it).
-PLSTM = sw.experimental('plstm', 3 if sw.schedule_on('plstm') else 0)
+# Persistent, weight-resident LSTM recurrences (gt_plstm_fwd / gt_plstm_bwd, csrc/plstm.hip): bit 0 = the encoder BiLSTM
+# forward (ONE launch for all steps of both directions), bit 1 = the decoder LSTM's h_dec recurrence of a block of steps
+# (hoisted mode, fp32), bit 2 = the encoder BiLSTM backward (one launch), bit 3 = the decoder LSTM's backward recurrence of a
+# block.  Measured on MI355X (round 3): the encoder launch takes 9.8 us per step against ~10 for the
+# per-step fused launches it replaces; the decoder block runs at 33 us per step on 64 CUs -- fast enough for the chain it
+# feeds.  On their own bits 0-1 changed nothing (the attention chain's 256-workgroup kernels then ran on 192 CUs:
+# 134.0-134.6 vs 133.3-134.2 ms per pair); with the attention LSTM re-split for the 192 CUs that are left (3 K-splits
+# instead of 4, done below) and the one-launch attention step: 131.0-132.1 against 133.0-133.4.  Bit 2: the BiLSTM backward
+# phase 2.9 -> 2.35 ms (pair 130.4 against 130.9).  Bit 3 LOSES (132.0): in the backward loop the 64 CUs it holds for the
+# whole block are taken from the weight-gradient GEMMs that fill the chip beside the attention chain; it stays opt-in
+# (GANTRON_EXPERIMENTAL=plstm=15).  Default 7 (GANTRON_SCHEDULE=no_plstm or GANTRON_EXPERIMENTAL=plstm=<bits> to change it).
+PLSTM = sw.experimental('plstm', 7 if sw.schedule_on('plstm') else 0)
 S1_FWD = sw.debug('s1_fwd')       # diagnostics: K-splits of the attention LSTM's forward product
+S1_BWD = sw.debug('s1_bwd')       # diagnostics: K-splits of its backward product when the decoder LSTM's backward is persistent
 DEC_BLK = 16       # steps per block in that mode (measured: 8: 160.6 ms per pair,
                                                               # 12: 157.9, 16: 157.9, 32: 160.5, 48: 160.9, 64: 165.7)
 
@@ -969,6 +973,8 @@ class GeneratorEngine:
             b.S2 = (rec_splits_bf16 if self.bf16 else rec_splits)(Hdpad, 4 * Hd)
             if S2_BWD and not self.bf16:
                 b.S2 = ops.pick_splits(4 * Hd, S2_BWD)
+        if S1_BWD and not self.bf16:
+            b.S1 = S1_BWD
         b.N1pad, b.N2pad = N1pad, N2pad
         if CELL_QUERY and Ha % 16 == 0:
             b.Wq = ptr(P['decoder.attention_layer.query_layer.linear_layer.weight'])
@@ -999,6 +1005,11 @@ class GeneratorEngine:
             b.W2hTp, b.W2ih, b.ldw2, b.ldxa, b.blk = ptr(W2hTp), ptr(W2ih_c), W2ih_c.stride(0), ldxa, DEC_BLK_BWD
             if (REC_CELL & 32) and not self.bf16 and Hd % 64 == 0 and b.S2 <= 16:
                 buf['countersB'] = torch.zeros((Bp // 64 if Bp > 64 else 1) * (Hd // 64), dtype=torch.int32, device=dev)
+            if (PLSTM & 8) and not self.bf16 and lib().gt_plstm_supported(Bp, Hd) and hc % 4 == 0:
+                # the decoder LSTM's backward recurrence of a block of steps as ONE persistent launch (gt_plstm_bwd)
+                buf.update(W2hh=W2hh.contiguous(), pl_xbuf=_f32(int(lib().gt_plstm_bwd_xbuf_elems(Hd)), device=dev, zero=False),
+                           pl_counters=torch.zeros(1, dtype=torch.int32, device=dev))
+                b.pl_timeout = ptr(handoff_flag(dev))
         b.memory, b.pm, b.Wc, b.Wd, b.v = ptr(sv['memory']), ptr(sv['pm']), ptr(Wc), ptr(Wd), ptr(v)
         b.lengths = ptr(sv['lens32'])
         b.att_keep, b.dec_keep = ptr(sv['att_keep']), ptr(sv['dec_keep'])
@@ -1160,18 +1171,34 @@ class GeneratorEngine:
         call('gt_gather_rows', dm2, Ep, idx['fwd'], Ti * Bp, H, dhs[0], H, 0)
         check(lib().gt_gather_rows(ptr(dmem, H), Ep, ptr(idx['rev']), Ti * Bp, H, ptr(dhs[1]), H, 0, ops._stream()),
               'gt_gather_rows')
-        Hpad = roundup(H, 16)
-        WhT = torch.stack([pack_rec(P['encoder.lstm.weight_hh_l0' + sfx], Hpad, H, 4 * H, transposed=True)
-                           for sfx in ('', '_reverse')])
-        S = rec_splits(Hpad, 4 * H, nz=2)
-        a = GtBiLstm()
-        a.B, a.Bp, a.T, a.H, a.S, a.backward, a.Hpad = B, Bp, Ti, H, S, 1, Hpad
-        dG = _f32(2, Ti * Bp, 4 * H, device=dev)
         dc = _f32(2, Bp, H, device=dev)
-        part = _f32(2, S, Bp, Hpad, device=dev)
-        a.Whp, a.w_zstride, a.active = ptr(WhT), WhT.stride(0), ptr(idx['active'])
-        a.part, a.gates, a.c, a.dhs, a.dG, a.dc = ptr(part), ptr(sv['enc_gates']), ptr(sv['enc_c']), ptr(dhs), ptr(dG), ptr(dc)
-        _run('gt_bilstm_run', a)
+        if (PLSTM & 4) and lib().gt_plstm_supported(Bp, H):
+            # the whole backward recurrence of both directions as ONE persistent launch (csrc/plstm.hip)
+            Whh = torch.stack([P['encoder.lstm.weight_hh_l0' + sfx] for sfx in ('', '_reverse')]).contiguous()
+            dG = _f32(2, Ti * Bp, 4 * H, device=dev, zero=False)
+            xbuf = _f32(2, lib().gt_plstm_bwd_xbuf_elems(H), device=dev, zero=False)
+            counters = torch.zeros(2, dtype=torch.int32, device=dev)
+            q = GtPlstmBwd()
+            q.B, q.Bp, q.H, q.T, q.ndir, q.s_lo, q.s_hi, q.recurrent_in = B, Bp, H, Ti, 2, 0, Ti, 0
+            q.Whh, q.w_dstride, q.gates, q.gates_dstride = ptr(Whh), Whh.stride(0), ptr(sv['enc_gates']), sv['enc_gates'].stride(0)
+            q.c, q.c_dstride, q.dh_direct, q.dd_dstride, q.dd_step, q.dd_ld = ptr(sv['enc_c']), sv['enc_c'].stride(0), ptr(dhs), \
+                dhs.stride(0), Bp * H, H
+            q.dG, q.dG_dstride, q.dc, q.dc_dstride, q.xbuf, q.x_dstride = ptr(dG), dG.stride(0), ptr(dc), dc.stride(0), ptr(xbuf), \
+                xbuf.stride(0)
+            q.active, q.counters, q.timeout_flag = ptr(idx['active']), ptr(counters), ptr(handoff_flag(dev))
+            _run('gt_plstm_bwd', q)
+        else:
+            Hpad = roundup(H, 16)
+            WhT = torch.stack([pack_rec(P['encoder.lstm.weight_hh_l0' + sfx], Hpad, H, 4 * H, transposed=True)
+                               for sfx in ('', '_reverse')])
+            S = rec_splits(Hpad, 4 * H, nz=2)
+            a = GtBiLstm()
+            a.B, a.Bp, a.T, a.H, a.S, a.backward, a.Hpad = B, Bp, Ti, H, S, 1, Hpad
+            dG = _f32(2, Ti * Bp, 4 * H, device=dev)
+            part = _f32(2, S, Bp, Hpad, device=dev)
+            a.Whp, a.w_zstride, a.active = ptr(WhT), WhT.stride(0), ptr(idx['active'])
+            a.part, a.gates, a.c, a.dhs, a.dG, a.dc = ptr(part), ptr(sv['enc_gates']), ptr(sv['enc_c']), ptr(dhs), ptr(dG), ptr(dc)
+            _run('gt_bilstm_run', a)
         hs, Xs = sv['enc_hs'], sv['Xs']
         dXs = _f32(2, Ti * Bp, C, device=dev, zero=False)
         for d_, sfx in enumerate(('', '_reverse')):

@@ -448,6 +448,14 @@ typedef struct GtDecoderBwd {
     /* hoisted mode, fp32, Hd % 64 == 0: the decoder LSTM's per-step product and the cell backward of the step before it as
      * ONE launch (gt_rec_cellbwd); (Bp > 64 ? Bp/64 : 1) x Hd/64 tickets, zero-initialised; NULL: two launches */
     uint32_t* countersB;
+    /* W2hh != NULL (hoisted mode, fp32, gt_plstm_supported(Bp, Hd)): the decoder LSTM's backward recurrence of a whole block
+     * of steps is ONE persistent launch (gt_plstm_bwd) instead of one product + cell-backward launch per step.  W2hh =
+     * decoder_rnn.weight_hh (4Hd, Hd) in PyTorch layout, pl_xbuf gt_plstm_bwd_xbuf_elems(Hd) floats (persists between the
+     * calls of a chunked loop), pl_counters one word, pl_timeout as GtDecoderFwd's. */
+    const float* W2hh;
+    float* pl_xbuf;
+    uint32_t* pl_counters;
+    int32_t* pl_timeout;
 } GtDecoderBwd;
 
 typedef struct GtBiLstm {
@@ -749,6 +757,36 @@ typedef struct GtPlstm {
 } GtPlstm;
 int32_t gt_plstm_supported(int32_t Bp, int32_t H);
 int gt_plstm_fwd(const GtPlstm* a, void* stream);
+
+/* Backward counterpart: ONE launch walks steps s_hi - 1 .. s_lo of  dh_s = dh_direct_s + dG_{s+1} . W_hh,  cell backward ->
+ * dG_s, dc carried on (csrc/plstm.hip).  The recurrent term travels between the H / 16 workgroups of a problem as a
+ * reduce-scatter of (64 x 16) tiles through `xbuf` (gt_plstm_bwd_xbuf_elems(H) floats per direction, two step slots);
+ * recurrent_in = 1: the tiles of step s_hi were published by an earlier call (a loop issued in blocks, highest steps
+ * first).  dc (Bp, H) is read at the start and holds the carried gradient at the end. */
+typedef struct GtPlstmBwd {
+    int32_t B, Bp, H, T, ndir, s_lo, s_hi, recurrent_in;
+    float p_drop;
+    const float* Whh;          /* (4H, H) PyTorch layout */
+    int64_t w_dstride;
+    const float* gates;        /* (T, Bp, 4H) gate values of the forward pass */
+    int64_t gates_dstride;
+    const float* c;            /* (T + 1, Bp, H) */
+    int64_t c_dstride;
+    const float* dh_direct;    /* gradient of the h emitted by step s at dh_direct + s * dd_step, rows of dd_ld */
+    int64_t dd_dstride, dd_step, dd_ld;
+    float* dG;                 /* (T, Bp, 4H) gate pre-activation gradients (out) */
+    int64_t dG_dstride;
+    float* dc;                 /* (Bp, H) */
+    int64_t dc_dstride;
+    float* xbuf;
+    int64_t x_dstride;
+    const uint8_t* keep;       /* (T, Bp, H) dropout keep mask of the forward pass, or NULL */
+    const int32_t* active;     /* (T, Bp), or NULL */
+    uint32_t* counters;        /* ndir words (zeroed by the call) */
+    int32_t* timeout_flag;
+} GtPlstmBwd;
+int64_t gt_plstm_bwd_xbuf_elems(int32_t H);
+int gt_plstm_bwd(const GtPlstmBwd* a, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1171,3 +1171,78 @@ def test_plstm_decoder_lstm_blocks(dev):
     """gt_plstm_fwd as the decoder loop runs it: H = 1024 (W_hh resident in 64 workgroups' registers), one launch per
     block of steps with the state picked up from the histories, dropout on h, h published into a (T, Bp, 2H) history."""
     _plstm(dev, 1024, 1, 40, [16, 16, 4, 4], packed=False, dropout=True, B=64)
+
+
+def _plstm_bwd(dev, H, ndir, T, blocks, packed, dropout, B):
+    """gt_plstm_bwd against a float64 restatement of the LSTM backward recurrence (model.py:233-236, 340-343 through autograd:
+    dh_s = direct + dG_{s+1} W_hh, the cell's gate gradients, dc carried; rows past their length leave dG = 0, dc as is)."""
+    import ctypes
+    from gantron_amd import engine
+    from gantron_amd._lib import GtPlstmBwd, check, lib
+    from gantron_amd.ops import ptr
+    Bp, N = 64, 4 * H
+    gen = torch.Generator().manual_seed(3 * H + T)
+    Whh = torch.randn(ndir, N, H, generator=gen) * (1.5 / math.sqrt(H))
+    sg = torch.sigmoid(torch.randn(ndir, T, Bp, N, generator=gen))
+    gates = sg.clone()
+    gates[..., 2 * H:3 * H] = 2 * sg[..., 2 * H:3 * H] - 1
+    c = torch.randn(ndir, T + 1, Bp, H, generator=gen)
+    ld = 2 * H if not packed else H                   # decoder use: the direct gradient lives in columns [0, H) of a (T, Bp, 2H) history
+    dd = torch.randn(ndir, T, Bp, ld, generator=gen)
+    keep = (torch.rand(T, Bp, H, generator=gen) >= 0.1).to(torch.uint8) if dropout else None
+    lens = torch.randint(1, T + 1, (Bp,), generator=gen)
+    lens[0] = T
+    active = (torch.arange(T)[:, None] < lens[None, :]).to(torch.int32) if packed else None
+    if active is not None:
+        active[:, B:] = 0
+    dc0 = torch.randn(ndir, Bp, H, generator=gen) * 0.1
+    d = lambda t: None if t is None else t.contiguous().to(dev)
+    Wd, gd, cd, ddd, keepd, actd, dcd = d(Whh), d(gates), d(c), d(dd), d(keep), d(active), d(dc0)
+    dG = torch.full((ndir, T, Bp, N), float('nan'), device=dev)
+    xe = lib().gt_plstm_bwd_xbuf_elems(H)
+    xbuf = torch.full((ndir, xe), float('nan'), device=dev)
+    cnt = torch.zeros(ndir, dtype=torch.int32, device=dev)
+    q = GtPlstmBwd()
+    q.B, q.Bp, q.H, q.T, q.ndir, q.p_drop = B, Bp, H, T, ndir, 0.1 if dropout else 0.0
+    q.Whh, q.w_dstride, q.gates, q.gates_dstride, q.c, q.c_dstride = ptr(Wd), Wd.stride(0), ptr(gd), gd.stride(0), ptr(cd), cd.stride(0)
+    q.dh_direct, q.dd_dstride, q.dd_step, q.dd_ld = ptr(ddd), ddd.stride(0), ddd.stride(1), ld
+    q.dG, q.dG_dstride, q.dc, q.dc_dstride, q.xbuf, q.x_dstride = ptr(dG), dG.stride(0), ptr(dcd), dcd.stride(0), ptr(xbuf), xbuf.stride(0)
+    q.keep, q.active, q.counters, q.timeout_flag = ptr(keepd), ptr(actd), ptr(cnt), ptr(engine.handoff_flag(dev))
+    s = T
+    for n in blocks:                                   # highest steps first; later launches pick the exchange tiles up
+        q.s_lo, q.s_hi, q.recurrent_in = s - n, s, int(s < T)
+        check(lib().gt_plstm_bwd(ctypes.byref(q), torch.cuda.current_stream().cuda_stream), 'gt_plstm_bwd')
+        s -= n
+    assert s == 0
+    torch.cuda.synchronize()
+    engine.check_handoffs()
+    dG, dcd = dG.cpu(), dcd.cpu()
+    for k in range(ndir):
+        W, g, cc = Whh[k].double(), gates[k].double(), c[k].double()
+        dcr, dGn = dc0[k].double().clone(), torch.zeros(Bp, N, dtype=torch.float64)
+        for s in range(T - 1, -1, -1):
+            dh = dd[k, s, :, :H].double() + dGn @ W
+            if keep is not None:
+                dh = dh * keep[s].double() * (1.0 / 0.9)
+            i, f, gg, o = g[s, :, :H], g[s, :, H:2 * H], g[s, :, 2 * H:3 * H], g[s, :, 3 * H:]
+            tc = torch.tanh(cc[s + 1])
+            dcell = dcr + dh * o * (1 - tc * tc)
+            a = torch.zeros(Bp, 1, dtype=torch.float64)
+            a[:B] = 1.0 if active is None else active[s, :B].double()[:, None]
+            dGn = a * torch.cat((dcell * gg * i * (1 - i), dcell * cc[s] * f * (1 - f), dcell * i * (1 - gg * gg),
+                                 dh * tc * o * (1 - o)), 1)
+            dcr = a * dcell * f + (1 - a) * dcr
+            close(dG[k, s], dGn, rtol=2e-5, atol=2e-5 * float(dGn.abs().max()) + 1e-12, what=f'dG dir {k} step {s}')
+        close(dcd[k], dcr, rtol=2e-5, atol=2e-5 * float(dcr.abs().max()) + 1e-12, what=f'carried dc dir {k}')
+
+
+@pytest.mark.parametrize('B', [64, 50])
+def test_plstm_bwd_encoder_bilstm(dev, B):
+    """gt_plstm_bwd as the encoder BiLSTM backward runs it: two directions in one persistent launch, H = 256, ragged lengths."""
+    _plstm_bwd(dev, 256, 2, 57, [57], packed=True, dropout=False, B=B)
+
+
+def test_plstm_bwd_decoder_lstm_blocks(dev):
+    """gt_plstm_bwd as the decoder backward loop runs it: H = 1024, one launch per block of steps (highest first) with the
+    exchange tiles of the previous launch picked up, dropout on h, the direct gradient in a (T, Bp, 2H) history."""
+    _plstm_bwd(dev, 1024, 1, 40, [4, 4, 16, 16], packed=False, dropout=True, B=64)

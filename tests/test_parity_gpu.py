@@ -189,14 +189,16 @@ def test_fused_attention_backward_step_against_oracle(dev, monkeypatch):
     _midsize_against_oracle(dev, 'full_dims_b20')
 
 
-@pytest.mark.parametrize('case', ['full_dims_b64', 'full_dims_b64_poison', 'vesus_b64'])
-def test_persistent_lstm_recurrences_against_oracle(dev, monkeypatch, case):
-    """The opt-in persistent recurrences (GANTRON_EXPERIMENTAL=plstm=3: gt_plstm_fwd for the encoder BiLSTM -- both directions, packed
-    sequences, one launch -- and for the decoder LSTM's h_dec recurrence, one launch per block of 16 steps with W_hh
-    resident in registers) through whole pairs at the reference's dimensions, 64 rows: ragged text lengths, two blocks,
-    NaN-poisoned histories, and the VESUS memory width (HC rows of 1024 + 1096 columns)."""
+@pytest.mark.parametrize('case,bits', [('full_dims_b64', 15), ('full_dims_b64_poison', 15), ('vesus_b64', 15), ('full_dims_b64', 3),
+                                       ('full_dims_b64', 12)])
+def test_persistent_lstm_recurrences_against_oracle(dev, monkeypatch, case, bits):
+    """The persistent recurrences (gt_plstm_fwd for the encoder BiLSTM -- both directions, packed sequences, one launch -- and
+    for the decoder LSTM's h_dec recurrence, one launch per block of 16 steps with W_hh resident in registers; gt_plstm_bwd
+    for the BiLSTM backward and, opt-in, the decoder LSTM's backward blocks) through whole pairs at the reference's
+    dimensions, 64 rows: ragged text lengths, two blocks, NaN-poisoned histories, the VESUS memory width (HC rows of
+    1024 + 1096 columns); forward kernels only, backward kernels only, and all four."""
     from gantron_amd import engine
-    monkeypatch.setattr(engine, 'PLSTM', 3)
+    monkeypatch.setattr(engine, 'PLSTM', bits)      # 1 | 2: gt_plstm_fwd encoder / decoder, 4 | 8: gt_plstm_bwd encoder / decoder
     assert engine.lib().gt_plstm_supported(64, 1024) and engine.lib().gt_plstm_supported(64, 256)
     if case.endswith('_poison'):
         monkeypatch.setattr(engine, 'POISON', True)
@@ -623,7 +625,7 @@ def test_full_size_training_step_is_schedule_invariant(dev, monkeypatch):
     out0, g0 = run()
     monkeypatch.undo()
     monkeypatch.setattr(ops, 'FWD_SPLITK', False)
-    assert engine.DEC_RING > 1 and engine.BWD_CHUNKS > 1 and engine.ATTN_HOIST and engine.LEAF.enabled and engine.HOIST2 and engine.PLSTM == 3
+    assert engine.DEC_RING > 1 and engine.BWD_CHUNKS > 1 and engine.ATTN_HOIST and engine.LEAF.enabled and engine.HOIST2 and engine.PLSTM == 7
     out1, g1 = run()
     for name, a, b in zip(('mel', 'mel_post', 'gate', 'align'), out1, out0):
         close(a, b, rtol=1e-4, atol=1e-6, what=f'out.{name}')
