@@ -37,7 +37,7 @@ __host__ __device__ static inline int64_t cdiv64(int64_t a, int64_t b) { return 
 __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // ---- optional per-launch timing (HIP events on the launch stream), enabled by gt_prof_begin()
 enum { GT_FAM_REC_GEMM = 0, GT_FAM_SGEMM = 1, GT_FAM_ATTN_E_FWD = 2, GT_FAM_ATTN_C_FWD = 3, GT_FAM_ATTN_C_BWD = 4,
-       GT_FAM_ATTN_E_BWD = 5, GT_FAM_CELL_FWD = 6, GT_FAM_CELL_BWD = 7, GT_FAM_REC_CELL = 8, GT_FAM_COUNT = 9 };
+       GT_FAM_ATTN_E_BWD = 5, GT_FAM_CELL_FWD = 6, GT_FAM_CELL_BWD = 7, GT_FAM_REC_CELL = 8, GT_FAM_PLSTM = 9, GT_FAM_COUNT = 10 };
 extern bool g_gt_prof_on;
 extern bool g_gt_capturing;          // loops.hip: stream capture in progress (GANTRON_EXPERIMENTAL=graph)
 extern double g_gt_prof_ctx_rows;   // valid attention-memory rows of the current batch (0: unknown, charge B*Ti)

@@ -63,15 +63,18 @@ struct LoopCtx {
     std::vector<hipEvent_t> events;
 };
 static std::mutex g_ctx_mu;
-static std::map<int, LoopCtx*> g_ctx;
+static std::map<std::pair<int, void*>, LoopCtx*> g_ctx;
 
-static int loop_ctx(LoopCtx** out) {
+// one context (auxiliary stream, events, issue lock) per device AND caller stream: loops issued on different streams of a
+// device are independent of each other
+static int loop_ctx(LoopCtx** out, void* stream) {
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);
     GT_REQUIRE(e == hipSuccess, (int)e, "decoder loop: hipGetDevice failed");
     std::lock_guard<std::mutex> lk(g_ctx_mu);
-    auto it = g_ctx.find(dev);
-    if (it == g_ctx.end()) it = g_ctx.emplace(dev, new LoopCtx()).first;
+    const auto key = std::make_pair(dev, stream);
+    auto it = g_ctx.find(key);
+    if (it == g_ctx.end()) it = g_ctx.emplace(key, new LoopCtx()).first;
     *out = it->second;
     return 0;
 }
@@ -202,7 +205,7 @@ static int decoder_fwd_hoisted(const GtDecoderFwd* a, void* stream) {
     hipStream_t sA = (hipStream_t)stream, sB = sA;
     hipEvent_t ev;
     LoopCtx* ctx = nullptr;
-    GT_TRY(loop_ctx(&ctx));
+    GT_TRY(loop_ctx(&ctx, stream));
     std::lock_guard<std::mutex> lk(ctx->mu);
     AuxJoin join{ctx, sA, sB, false};
     if (two) {
@@ -372,7 +375,7 @@ int gt_decoder_fwd(const GtDecoderFwd* a, void* stream) {
     float* partB = two ? a->part2 : a->part;
     hipEvent_t ev;
     LoopCtx* ctx = nullptr;
-    GT_TRY(loop_ctx(&ctx));
+    GT_TRY(loop_ctx(&ctx, stream));
     std::lock_guard<std::mutex> lk(ctx->mu);
     AuxJoin join{ctx, sA, sB, false};
     if (two) {
@@ -572,7 +575,7 @@ static int decoder_bwd_hoisted(const GtDecoderBwd* a, void* stream) {
     hipStream_t sA = (hipStream_t)stream, sB = sA;
     hipEvent_t ev;
     LoopCtx* ctx = nullptr;
-    GT_TRY(loop_ctx(&ctx));
+    GT_TRY(loop_ctx(&ctx, stream));
     std::lock_guard<std::mutex> lk(ctx->mu);
     AuxJoin join{ctx, sA, sB, false};
     if (two) {
@@ -761,7 +764,7 @@ int gt_decoder_bwd(const GtDecoderBwd* a, void* stream) {
     hipStream_t sA = (hipStream_t)stream, sB = sA;
     hipEvent_t ev;
     LoopCtx* ctx = nullptr;
-    GT_TRY(loop_ctx(&ctx));
+    GT_TRY(loop_ctx(&ctx, stream));
     std::lock_guard<std::mutex> lk(ctx->mu);
     AuxJoin join{ctx, sA, sB, false};
     if (two) {

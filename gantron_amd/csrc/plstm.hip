@@ -410,7 +410,7 @@ extern "C" int gt_plstm_fwd(const GtPlstm* q, void* stream) {
     a.B = q->B; a.H = q->H; a.s_lo = q->s_lo; a.s_hi = q->s_hi; a.NW = q->H / 16;
     const dim3 grid(q->ndir * a.NW);
     const double steps = q->s_hi - q->s_lo;
-    GtProfScope prof(GT_FAM_REC_CELL, 2.0 * q->ndir * PL_ROWS * 4.0 * q->H * q->H * steps,
+    GtProfScope prof(GT_FAM_PLSTM, 2.0 * q->ndir * PL_ROWS * 4.0 * q->H * q->H * steps,
                      4.0 * q->ndir * (4.0 * q->H * q->H + steps * PL_ROWS * 10.0 * q->H), st);
     if (q->H == 256) hipLaunchKernelGGL(plstm_fwd_kernel<64>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(plstm_fwd_kernel<256>, grid, dim3(256), 0, st, a);
@@ -446,7 +446,7 @@ extern "C" int gt_plstm_bwd(const GtPlstmBwd* q, void* stream) {
     a.B = q->B; a.H = q->H; a.s_lo = q->s_lo; a.s_hi = q->s_hi; a.NW = q->H / 16; a.recurrent_in = q->recurrent_in;
     const dim3 grid(q->ndir * a.NW);
     const double steps = q->s_hi - q->s_lo;
-    GtProfScope prof(GT_FAM_REC_GEMM, 2.0 * q->ndir * PL_ROWS * 4.0 * q->H * q->H * steps,
+    GtProfScope prof(GT_FAM_PLSTM, 2.0 * q->ndir * PL_ROWS * 4.0 * q->H * q->H * steps,
                      4.0 * q->ndir * (4.0 * q->H * q->H + steps * PL_ROWS * 14.0 * q->H), st);
     if (q->H == 256) hipLaunchKernelGGL(plstm_bwd_kernel<64>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(plstm_bwd_kernel<256>, grid, dim3(256), 0, st, a);

@@ -39,20 +39,21 @@ int64_t gt_abi_sizeof(int32_t which);
 
 /* Optional per-launch timing with HIP events recorded on the launch stream (bench.py's roofline
  * leg).  Between gt_prof_begin() and gt_prof_end() every launch of a profiled kernel family is
- * bracketed by two events; gt_prof_end waits for them and fills, per family f of the GT_PROF_FAMILIES = 9 families
+ * bracketed by two events; gt_prof_end waits for them and fills, per family f of the GT_PROF_FAMILIES = 10 families
  * (0 rec_gemm, 1 sgemm, 2 attn_energies_fwd, 3 attn_context_fwd, 4 attn_context_bwd, 5 attn_energies_bwd,
- * 6 lstm_cell_fwd, 7 lstm_cell_bwd, 8 rec_cell = the fused product + cell launches): out[4f] bracketed launches,
+ * 6 lstm_cell_fwd, 7 lstm_cell_bwd, 8 rec_cell = the fused product + cell launches, 9 plstm = the persistent multi-step
+ * recurrences): out[4f] bracketed launches,
  * out[4f+1] their total ms, out[4f+2] their algorithmic flops, out[4f+3] their algorithmic bytes, and
  * out[4*GT_PROF_FAMILIES + f] ALL launches of the family issued while profiling (bracketed or not); with sampling,
  * every 4th bracket is followed by the same bracket around an EMPTY kernel on the same stream:
  * out[5*GT_PROF_FAMILIES] their count, out[5*GT_PROF_FAMILIES + 1] their total ms.  `out` is a HOST array of
- * GT_PROF_DOUBLES = 56 doubles.  Not thread-safe.  A bracket = kernel duration (dispatch begin to end) + event latency
+ * GT_PROF_DOUBLES = 62 doubles.  Not thread-safe.  A bracket = kernel duration (dispatch begin to end) + event latency
  * (+ what the dispatch waited for), so the duration of a sampled kernel is bracket - (empty-kernel bracket -
  * empty-kernel duration), the latter from gt_prof_calibrate.  The two recurrent-product families (0 and 8) are not
  * bracketed: their sampled launches carry their own start / stop events (hipExtLaunchKernelGGL), stamped with the
  * dispatch's begin and end -- the duration a profiler reports; out[5*GT_PROF_FAMILIES + 2 + f] counts, per family, the
  * timed launches of that kind (no latency to subtract for them). */
-#define GT_PROF_FAMILIES 9
+#define GT_PROF_FAMILIES 10
 #define GT_PROF_DOUBLES (6 * GT_PROF_FAMILIES + 2)
 int gt_prof_begin(void);
 /* the attention context kernels skip padded memory rows: tell the profiler how many rows of the current batch are valid
