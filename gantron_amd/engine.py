@@ -52,7 +52,8 @@ ATTN_BWD_FUSED = bool(sw.experimental('attn_bwd_fused'))     # measured slower (
 # LSTM's backward product + cell backward (gt_rec_cellbwd; measured 0.3 ms slower per pair than two launches: off)
 REC_CELL = (31 if sw.schedule_on('rec_cell') else 0) | (32 if sw.experimental('rec_cellbwd') else 0)
 ENC_SPLITS = sw.debug('enc_splits')   # K-splits of the fused BiLSTM step (0: cost model)
-DEC_BLK_BWD = 16
+DEC_BLK_BWD = 24  # steps per block of the backward loop (round 3, with the forward's persistent recurrences on: 16: 130.4-130.7 ms per
+                  # pair, 20: 130.4, 24: 128.7-129.6, 28: 130.1, 32: 129.3-131.0; chunk boundaries on whole blocks: no difference)
 # K-splits of the decoder LSTM's small recurrent products in the hoisted mode (0: cost model).  That chain has slack
 # (it only follows / feeds the attention chain): fewer, longer workgroups leave the CUs to the critical chain.
 S2_FWD = sw.debug('s2_fwd')
