@@ -50,7 +50,7 @@ int gt_rec_gemm_prio(const float* X, int64_t ldx, const float* Wp, float* part, 
                      int64_t part_zstride, int prio, void* stream);
 int gt_rec_gemm_bf16_prio(const float* X, int64_t ldx, const void* Wp, float* part, int32_t mtiles, int32_t N, int32_t K,
                           int32_t splits, int64_t part_sstride, int32_t nz, int64_t x_zstride, int64_t w_zstride,
-                          int64_t part_zstride, int prio, void* stream);
+                          int64_t part_zstride, int prio, void* stream, int planes = 1);
 
 // Timing of a sampled launch.  Default: two events recorded on the stream around the launch (a bracket = kernel duration +
 // event latency + whatever the dispatch waits for).  exact = true: nothing is recorded here; the launch itself carries the

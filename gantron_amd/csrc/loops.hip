@@ -33,10 +33,11 @@ static const GtSlabs kNoSlabs = {nullptr, 0, 0, 0};
 // prio: 1 for the products of the attention chain (the loops' serial critical path): raised wave priority.
 static int rec_rows(const float* X, int64_t ldx, const float* Wp, float* part, int Bp, int N, int K, int S,
                     void* stream, int bf16 = 0, int prio = 0) {
-    if (bf16) {         // Wp is a bf16 fragment image (gt_pack_rec_weight_bf16)
-        if (Bp <= 64) return gt_rec_gemm_bf16_prio(X, ldx, Wp, part, Bp / 16, N, K, S, (int64_t)Bp * N, 1, 0, 0, 0, prio, stream);
+    if (bf16) {         // Wp is a bf16 fragment image (gt_pack_rec_weight_bf16), or three planes of them (bf16 == 3: _x3)
+        const int planes = bf16 == 3 ? 3 : 1;
+        if (Bp <= 64) return gt_rec_gemm_bf16_prio(X, ldx, Wp, part, Bp / 16, N, K, S, (int64_t)Bp * N, 1, 0, 0, 0, prio, stream, planes);
         return gt_rec_gemm_bf16_prio(X, ldx, Wp, part, 4, N, K, S, (int64_t)Bp * N, Bp / 64, 64 * ldx, 0, (int64_t)64 * N, prio,
-                                     stream);
+                                     stream, planes);
     }
     if (Bp <= 64) return gt_rec_gemm_prio(X, ldx, Wp, part, Bp / 16, N, K, S, (int64_t)Bp * N, 1, 0, 0, 0, prio, stream);
     return gt_rec_gemm_prio(X, ldx, Wp, part, 4, N, K, S, (int64_t)Bp * N, Bp / 64, 64 * ldx, 0, (int64_t)64 * N, prio, stream);
@@ -248,7 +249,7 @@ static int decoder_fwd_hoisted(const GtDecoderFwd* a, void* stream) {
             float* X1c = a->X1 + (t & 1) * x1_slot;            // [ctx_{t-1} | h_att_{t-1}]
             float* X1n = a->X1 + ((t + 1) & 1) * x1_slot;      // receives h_att_t (cell) and ctx_t (context kernel)
             if (fusedA) {       // product + cell + dropout + query slabs: one launch
-                GT_TRY(gt_rec_cell_fwd_z(X1c, a->ld1, a->W1c, a->bf16, a->part, a->counters1, a->Bp, a->B, a->Ha, K1, a->S1,
+                GT_TRY(gt_rec_cell_fwd_z(X1c, a->ld1, a->W1c, a->bf16 ? 1 : (a->rec_x3 ? 3 : 0), a->part, a->counters1, a->Bp, a->B, a->Ha, K1, a->S1,
                                        a->pre1 + (int64_t)t * a->Bp * N1, N1, a->c1 + (int64_t)t * a->Bp * a->Ha, k1, a->p_att,
                                        a->gates1 + (int64_t)t * a->Bp * N1, a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha,
                                        a->hatt + (int64_t)t * a->Bp * a->Ha, X1n + a->E, a->ld1, XAt, a->ld2, nullptr, 0, a->Wq,
@@ -686,7 +687,7 @@ static int decoder_bwd_hoisted(const GtDecoderBwd* a, void* stream) {
                                            a->gates1 + (int64_t)t * a->Bp * N1, a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha,
                                            a->c1 + (int64_t)t * a->Bp * a->Ha, k1, a->p_att, dG1_t, a->dc1, a->B, a->Bp, a->Ha,
                                            a->A, sA));
-                if (t > 0) GT_TRY(rec_rows(dG1_t, N1, a->W1Tp, a->partX1, a->Bp, a->N1pad, N1, a->S1, sA, a->bf16, two ? kPrioA : 0));
+                if (t > 0) GT_TRY(rec_rows(dG1_t, N1, a->W1Tp, a->partX1, a->Bp, a->N1pad, N1, a->S1, sA, a->bf16 ? 1 : (a->rec_x3 ? 3 : 0), two ? kPrioA : 0));
                 continue;
             }
             GT_TRY(gt_attn_context_bwd(d, slabs(dXA_t + a->Ha, 1, 0, a->ldxa),
@@ -717,7 +718,7 @@ static int decoder_bwd_hoisted(const GtDecoderBwd* a, void* stream) {
                                         a->c1 + (int64_t)t * a->Bp * a->Ha, k1, a->p_att, nullptr, dG1_t, a->dc1, nullptr, a->B,
                                         a->Ha, sA));
             }
-            if (t > 0) GT_TRY(rec_rows(dG1_t, N1, a->W1Tp, a->partX1, a->Bp, a->N1pad, N1, a->S1, sA, a->bf16, two ? kPrioA : 0));
+            if (t > 0) GT_TRY(rec_rows(dG1_t, N1, a->W1Tp, a->partX1, a->Bp, a->N1pad, N1, a->S1, sA, a->bf16 ? 1 : (a->rec_x3 ? 3 : 0), two ? kPrioA : 0));
         }
         mark(&bt.a1, sA);
         if (block_timing) bts.push_back(bt);
@@ -836,7 +837,7 @@ int gt_decoder_bwd(const GtDecoderBwd* a, void* stream) {
             GT_TRY(evA(t, &e2));
             GT_HIP(hipEventRecord(e2, sA));
         }
-        if (t > 0) GT_TRY(rec_rows(dG1_t, N1, a->W1Tp, a->partX1, a->Bp, a->N1pad, N1, a->S1, sA, a->bf16, two ? kPrioA : 0));
+        if (t > 0) GT_TRY(rec_rows(dG1_t, N1, a->W1Tp, a->partX1, a->Bp, a->N1pad, N1, a->S1, sA, a->bf16 ? 1 : (a->rec_x3 ? 3 : 0), two ? kPrioA : 0));
         return 0;
     };
     int a_next = t_hi, last_wait_a = -1;

@@ -606,7 +606,7 @@ extern "C" int gt_pack_rec_cell_weight(const float* W, int64_t ldw, int32_t H, i
 struct RecCellEpi;
 int gt_launch_rec_cell_bf16(const float* X, int64_t ldx, const void* Wp, float* part, int32_t Bp, int32_t N, int32_t K,
                             int32_t splits, int32_t ndir, int prio, const RecCellEpi& e, hipEvent_t e0, hipEvent_t e1,
-                            void* stream);      // recurrent_bf16.hip
+                            void* stream, int planes);      // recurrent_bf16.hip
 
 int gt_rec_cell_fwd_z(const float* X, int64_t ldx, const void* Wpv, int wbf16, float* part, uint32_t* counters, int32_t Bp, int32_t B,
                       int32_t H, int32_t K, int32_t splits, const float* pre, int64_t ld_pre, const float* c_prev,
@@ -650,9 +650,9 @@ int gt_rec_cell_fwd_z(const float* X, int64_t ldx, const void* Wpv, int wbf16, f
     dim3 grid(N / 64, splits, nzb * ndir);
     hipStream_t st = (hipStream_t)stream;
     GtProfScope prof(GT_FAM_REC_CELL, ndir * (2.0 * Bp * (double)N * K + (Wq ? 2.0 * Bp * (double)H * A : 0.0)),
-                     ndir * ((wbf16 ? 2.0 : 4.0) * (double)N * K +
+                     ndir * ((wbf16 == 3 ? 6.0 : wbf16 ? 2.0 : 4.0) * (double)N * K +
                              4.0 * ((double)Bp * K + (double)Bp * N * (splits > 1 ? 2 * splits - 1 : 0) + (double)B * H * 12)), st, true);
-    if (wbf16) return gt_launch_rec_cell_bf16(X, ldx, Wpv, part, Bp, N, K, splits, ndir, prio, e, prof.e0, prof.e1, stream);
+    if (wbf16) return gt_launch_rec_cell_bf16(X, ldx, Wpv, part, Bp, N, K, splits, ndir, prio, e, prof.e0, prof.e1, stream, wbf16 == 3 ? 3 : 1);
     const long ps = (long)Bp * N;
 #define GT_RC(MT)                                                                                                      \
     hipExtLaunchKernelGGL((rec_cell_kernel<MT>), grid, dim3(REC_THREADS), 0, st, prof.e0, prof.e1, 0, X, (long)ldx, Wp, part,  \
@@ -686,6 +686,17 @@ extern "C" int gt_rec_cell_fwd_bf16(const float* X, int64_t ldx, const void* Wp,
                                     const float* Wq, int64_t ldwq, float* qpart, int64_t q_sstride, int32_t A, int32_t Apad,
                                     int32_t prio, void* stream) {
     return gt_rec_cell_fwd_z(X, ldx, Wp, 1, part, counters, Bp, B, H, K, splits, pre, ld_pre, c_prev, keep, p_drop, gates, c_out,
+                             h_raw, h0, ld0, h1, ld1, h2, ld2, Wq, ldwq, qpart, q_sstride, A, Apad, nullptr, nullptr, 0, 1,
+                             nullptr, prio, stream);
+}
+
+extern "C" int gt_rec_cell_fwd_x3(const float* X, int64_t ldx, const void* Wp, float* part, uint32_t* counters, int32_t Bp,
+                                  int32_t B, int32_t H, int32_t K, int32_t splits, const float* pre, int64_t ld_pre,
+                                  const float* c_prev, const uint8_t* keep, float p_drop, float* gates, float* c_out,
+                                  float* h_raw, float* h0, int64_t ld0, float* h1, int64_t ld1, float* h2, int64_t ld2,
+                                  const float* Wq, int64_t ldwq, float* qpart, int64_t q_sstride, int32_t A, int32_t Apad,
+                                  int32_t prio, void* stream) {
+    return gt_rec_cell_fwd_z(X, ldx, Wp, 3, part, counters, Bp, B, H, K, splits, pre, ld_pre, c_prev, keep, p_drop, gates, c_out,
                              h_raw, h0, ld0, h1, ld1, h2, ld2, Wq, ldwq, qpart, q_sstride, A, Apad, nullptr, nullptr, 0, 1,
                              nullptr, prio, stream);
 }

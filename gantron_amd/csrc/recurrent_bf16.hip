@@ -9,6 +9,14 @@
 // in LDS) -- are issued before the first MFMA, then the chunks are converted, published and multiplied in turn.
 // Same decomposition as gt_rec_gemm otherwise: 64 gate columns per workgroup, wave w owns columns [16*(w&3), +16)
 // and the k-blocks of half (w>>2) of every chunk, K split over blockIdx.y into slabs.
+//
+// NP = 3 ("x3", gt_rec_gemm_x3 / gt_rec_cell_fwd_x3): the SAME kernels as an exact fp32 product.  The weights are packed as
+// three bf16 planes w = w0 + w1 + w2 (w0 = bf16(w), w1 = bf16(w - w0), w2 = bf16(w - w0 - w1): all 24 significand bits),
+// the activations are split the same way while they are staged through LDS, and a . b = a0 b0 + (a0 b1 + a1 b0) +
+// (a0 b2 + a1 b1 + a2 b0) runs as six v_mfma_f32_16x16x32_bf16 with fp32 accumulation, smallest terms first -- every
+// product exact, dropped terms <= 2^-24 |a||b|, the arithmetic of xgemm_kernel (gemm.hip).  At M = 64 rows the fp32 pipe
+// needs 6.8 us for a workgroup's 64 columns x 512 k (v_mfma_f32_16x16x4_f32: 256 flop per clock and CU); the six bf16
+// products take 2.6 us.  K-slices of at most 2 chunks (the three weight planes of a slice live in registers).
 #include <stdint.h>
 #include "common.h"
 #include "rec_cell.h"
@@ -34,8 +42,9 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 // holds B[k = 32 kb + 8 (l >> 4) + j][column 16 nb + (l & 15)], j = 0..7, zero padded.
 // cellH > 0 (gt_pack_rec_cell_weight_bf16): W is a (4 cellH x K) LSTM weight and packed column 64 cg + 16 g + u is its row
 // g * cellH + 16 cg + u, so that a 64-column group holds the four gates of 16 hidden units (gt_rec_cell_fwd_bf16).
+// planes = 3: block (nb, kb) is followed by its second and third plane (residuals), ((nb KB + kb) planes + p) 64 + lane.
 __global__ __launch_bounds__(256) void pack_rec_weight_bf16_kernel(const float* W, long ldw, int transposed, int N,
-                                                                   int n_valid, int K, int KB, int cellH, uint4* Wp) {
+                                                                   int n_valid, int K, int KB, int cellH, uint4* Wp, int planes) {
     const long total = (long)(N / 16) * KB * 64;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int lane = (int)(idx & 63);
@@ -50,7 +59,33 @@ __global__ __launch_bounds__(256) void pack_rec_weight_bf16_kernel(const float* 
             const int kk = k + j;
             v[j] = (kk < K && n < n_valid) ? (transposed ? W[(long)kk * ldw + n] : W[(long)n * ldw + kk]) : 0.f;
         }
-        Wp[idx] = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+        for (int p = 0; p < planes; ++p) {
+            const uint4 o = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+            Wp[(blk * planes + p) * 64 + lane] = o;
+            const unsigned u[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {          // residuals (exact in fp32)
+                v[2 * j] -= __uint_as_float(u[j] << 16);
+                v[2 * j + 1] -= __uint_as_float(u[j] & 0xffff0000u);
+            }
+        }
+    }
+}
+
+// float4 -> its NP bf16 planes, (x, y) packed in .x and (z, w) in .y of plane p
+template <int NP>
+__device__ __forceinline__ void split_planes(float4 x, uint2 (&out)[NP]) {
+    float v[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        unsigned u0 = pack2(v[0], v[1]), u1 = pack2(v[2], v[3]);
+        asm("" : "+v"(u0));                      // keep the pair packed (otherwise every element is converted twice)
+        asm("" : "+v"(u1));
+        out[p] = make_uint2(u0, u1);
+        if (p + 1 < NP) {
+            v[0] -= __uint_as_float(u0 << 16); v[1] -= __uint_as_float(u0 & 0xffff0000u);
+            v[2] -= __uint_as_float(u1 << 16); v[3] -= __uint_as_float(u1 & 0xffff0000u);
+        }
     }
 }
 
@@ -63,9 +98,10 @@ __device__ __forceinline__ void rb_setprio(int prio) {
 
 // One workgroup's [MT*16 rows x 64 columns] tile of X . W^T over the k-blocks [kb0, kb1) of packed weights Wz: returns it
 // folded over the two K-halves in LDS (row stride REC_EP_LD floats, at the start of the staging array Xs), after a barrier.
-template <int MT, int NCH>
+template <int MT, int NCH, int NP>
 __device__ __forceinline__ float* rec_bf16_tile(unsigned short* Xs, const float* __restrict__ Xz, long ldx, int kvalid,
                                                 const uint4* __restrict__ Wz, int N, int KB, int kb0, int kb1, int cg) {
+    constexpr int PL = MT * 16 * RB_LD;      // bf16 elements per activation plane in LDS
     constexpr int XV = MT * 2;         // float4 per thread per chunk (MT*16 rows x 64 float4 / 512 threads)
     constexpr int XR = NCH < RB_XR ? NCH : RB_XR;
     constexpr int EP_LD = REC_EP_LD;
@@ -75,11 +111,11 @@ __device__ __forceinline__ float* rec_bf16_tile(unsigned short* Xs, const float*
     int nb = cg * 4 + (wave & 3);
     const bool active = nb * 16 < N;   // inactive waves (N % 64 != 0) still stage and join the barriers
     if (!active) nb = 0;
-    const uint4* wp = Wz + ((long)nb * KB) * 64 + lane;
+    const uint4* wp = Wz + ((long)nb * KB) * 64 * NP + lane;
 
     // ---- every load of the slice, issued together.  Out-of-range blocks are clamped to a valid address and
     // zeroed by a select (a predicated load would put s_waitcnt vmcnt(0) in front of everything behind it).
-    uint4 w[NCH][RB_HB];
+    uint4 w[NCH][RB_HB][NP];
     float4 x[XR][XV];
     auto xload = [&](float4 (&dst)[XV], int c) __attribute__((always_inline)) {
 #pragma unroll
@@ -94,8 +130,11 @@ __device__ __forceinline__ float* rec_bf16_tile(unsigned short* Xs, const float*
 #pragma unroll
         for (int u = 0; u < RB_HB; ++u) {
             const int kb = kb0 + c * RB_CB + half * RB_HB + u;
-            const uint4 t = wp[(long)min(kb, kb1 - 1) * 64];
-            w[c][u] = kb < kb1 ? t : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const uint4 t = wp[((long)min(kb, kb1 - 1) * NP + p) * 64];
+                w[c][u][p] = kb < kb1 ? t : make_uint4(0u, 0u, 0u, 0u);
+            }
         }
         if (c < XR) xload(x[c], c);
     }
@@ -110,19 +149,30 @@ __device__ __forceinline__ float* rec_bf16_tile(unsigned short* Xs, const float*
             for (int i = 0; i < XV; ++i) {
                 const int f = tid + RB_THREADS * i, row = f >> 6, c4 = f & 63;
                 // activations beyond the valid columns meet zero weights; the clamped load keeps them finite
-                const float4 xv = x[c % XR][i];
-                *reinterpret_cast<uint2*>(&Xs[row * RB_LD + 4 * c4]) = make_uint2(pack2(xv.x, xv.y), pack2(xv.z, xv.w));
+                uint2 pl[NP];
+                split_planes<NP>(x[c % XR][i], pl);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(&Xs[p * PL + row * RB_LD + 4 * c4]) = pl[p];
             }
             if (c + XR < NCH) xload(x[c % XR], c + XR);      // registers of this chunk are free again
             __syncthreads();
 #pragma unroll
             for (int u = 0; u < RB_HB; ++u) {
-                const bf16x8 b = __builtin_bit_cast(bf16x8, w[c][u]);
+                bf16x8 a[NP][MT];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xs + mt * 16 * RB_LD + u * 32));
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[mt], 0, 0, 0);
-                }
+                for (int p = 0; p < NP; ++p)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        a[p][mt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xs + p * PL + mt * 16 * RB_LD + u * 32));
+                // plane products of order < NP, smallest terms first; the MT row tiles lie between two MFMAs on one accumulator
+#pragma unroll
+                for (int ord = NP - 1; ord >= 0; --ord)
+#pragma unroll
+                    for (int pa = 0; pa <= ord; ++pa) {
+                        const bf16x8 b = __builtin_bit_cast(bf16x8, w[c][u][ord - pa]);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[pa][mt], b, acc[mt], 0, 0, 0);
+                    }
             }
             __syncthreads();
         }
@@ -147,16 +197,16 @@ __device__ __forceinline__ float* rec_bf16_tile(unsigned short* Xs, const float*
     return red;
 }
 
-template <int MT, int NCH>
+template <int MT, int NCH, int NP>
 __global__ __launch_bounds__(RB_THREADS) void rec_gemm_bf16_kernel(const float* __restrict__ X, long ldx, int kvalid,
                                                                    const uint4* __restrict__ Wp, float* __restrict__ part,
                                                                    int N, int KB, int KBS, long xz, long wz, long pz,
                                                                    long ps, int prio) {
     rb_setprio(prio);
-    __shared__ __attribute__((aligned(16))) unsigned short Xs[MT * 16 * RB_LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Xs[NP * MT * 16 * RB_LD];
     const int s = blockIdx.y, z = blockIdx.z, cg = blockIdx.x;
     const int kb0 = s * KBS;
-    const float* red = rec_bf16_tile<MT, NCH>(Xs, X + (long)z * xz, ldx, kvalid, Wp + (long)z * wz, N, KB, kb0, min(KB, kb0 + KBS), cg);
+    const float* red = rec_bf16_tile<MT, NCH, NP>(Xs, X + (long)z * xz, ldx, kvalid, Wp + (long)z * wz, N, KB, kb0, min(KB, kb0 + KBS), cg);
     constexpr int EP_LD = REC_EP_LD;
     const int tid = threadIdx.x;
     float* out = part + (long)z * pz + (long)s * ps + (long)cg * 64;
@@ -172,12 +222,12 @@ __global__ __launch_bounds__(RB_THREADS) void rec_gemm_bf16_kernel(const float* 
 
 // gt_rec_cell_fwd_bf16: the product above with the fused cell epilogue of rec_cell.h (gate-grouped packing, last-arriver
 // split-K).  Same launch geometry as the fp32 rec_cell_kernel: blockIdx = (column group, K-slice, direction * nzb + row block).
-template <int MT, int NCH>
+template <int MT, int NCH, int NP>
 __global__ __launch_bounds__(RB_THREADS) void rec_cell_bf16_kernel(const float* __restrict__ X, long ldx, int kvalid,
                                                                    const uint4* __restrict__ Wp, float* part, int N, int KB,
                                                                    int KBS, long xz, long pz, long ps, int prio, RecCellEpi e) {
     rb_setprio(prio);
-    __shared__ __attribute__((aligned(16))) unsigned short Xs[MT * 16 * RB_LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Xs[NP * MT * 16 * RB_LD];
     const int cg = blockIdx.x, s = blockIdx.y, z = blockIdx.z;
     const int dir = z / e.nzb, rb = z - dir * e.nzb;
     const int kb0 = s * KBS;
@@ -185,7 +235,7 @@ __global__ __launch_bounds__(RB_THREADS) void rec_cell_bf16_kernel(const float* 
         X += e.dX; Wp += e.dW / 8; part += e.dPart;          // dW counts bf16 elements
         rec_cell_dir1(e);
     }
-    float* red = rec_bf16_tile<MT, NCH>(Xs, X + (long)rb * xz, ldx, kvalid, Wp, N, KB, kb0, min(KB, kb0 + KBS), cg);
+    float* red = rec_bf16_tile<MT, NCH, NP>(Xs, X + (long)rb * xz, ldx, kvalid, Wp, N, KB, kb0, min(KB, kb0 + KBS), cg);
     rec_cell_epilogue<MT>(red, e, part + (long)rb * pz, ps, N, cg, s, rb, e.counters + (long)z * gridDim.x + cg);
 }
 
@@ -194,36 +244,54 @@ __global__ __launch_bounds__(RB_THREADS) void rec_cell_bf16_kernel(const float* 
 extern "C" int64_t gt_rec_weight_bf16_elems(int32_t N, int32_t K) {
     return (int64_t)(N / 16) * cdiv(K, 32) * 64 * 8;
 }
+extern "C" int64_t gt_rec_weight_x3_elems(int32_t N, int32_t K) { return 3 * gt_rec_weight_bf16_elems(N, K); }
 
 extern "C" int32_t gt_rec_bf16_min_splits(int32_t K) { return cdiv(cdiv(K, 32), RB_NCH * RB_CB); }
+constexpr int RB_NCH_X3 = 2;           // chunks per K-slice with three weight planes in registers
+extern "C" int32_t gt_rec_x3_min_splits(int32_t K) { return cdiv(cdiv(K, 32), RB_NCH_X3 * RB_CB); }
 
-extern "C" int gt_pack_rec_weight_bf16(const float* W, int64_t ldw, int32_t transposed, int32_t N, int32_t n_valid,
-                                       int32_t K, void* Wp, void* stream) {
+static int pack_rec_planes(const char* what, const float* W, int64_t ldw, int32_t transposed, int32_t N, int32_t n_valid,
+                           int32_t K, int32_t cellH, void* Wp, int planes, void* stream) {
     GT_REQUIRE(W && Wp && N > 0 && K > 0 && N % 16 == 0 && n_valid > 0 && n_valid <= N && (transposed == 0 || transposed == 1),
-               GT_E_ARG, "gt_pack_rec_weight_bf16: N=%d must be a multiple of 16 and 0 < n_valid=%d <= N", N, n_valid);
-    GT_REQUIRE(aligned16(Wp), GT_E_ALIGN, "gt_pack_rec_weight_bf16: Wp must be 16-byte aligned");
+               GT_E_ARG, "%s: N=%d must be a multiple of 16 and 0 < n_valid=%d <= N", what, N, n_valid);
+    GT_REQUIRE(aligned16(Wp), GT_E_ALIGN, "%s: Wp must be 16-byte aligned", what);
     const int KB = cdiv(K, 32);
     const long total = (long)(N / 16) * KB * 64;
     const int blocks = (int)std::min<long>(cdiv64(total, 256), 4096);
     hipLaunchKernelGGL(pack_rec_weight_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, W, (long)ldw,
-                       transposed, N, n_valid, K, KB, 0, reinterpret_cast<uint4*>(Wp));
+                       transposed, N, n_valid, K, KB, cellH, reinterpret_cast<uint4*>(Wp), planes);
     GT_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int gt_pack_rec_weight_bf16(const float* W, int64_t ldw, int32_t transposed, int32_t N, int32_t n_valid,
+                                       int32_t K, void* Wp, void* stream) {
+    return pack_rec_planes("gt_pack_rec_weight_bf16", W, ldw, transposed, N, n_valid, K, 0, Wp, 1, stream);
+}
+extern "C" int gt_pack_rec_weight_x3(const float* W, int64_t ldw, int32_t transposed, int32_t N, int32_t n_valid,
+                                     int32_t K, void* Wp, void* stream) {
+    return pack_rec_planes("gt_pack_rec_weight_x3", W, ldw, transposed, N, n_valid, K, 0, Wp, 3, stream);
 }
 
 extern "C" int gt_rec_gemm_bf16(const float* X, int64_t ldx, const void* Wp, float* part, int32_t mtiles, int32_t N,
                                 int32_t K, int32_t splits, int64_t part_sstride, int32_t nz, int64_t x_zstride,
                                 int64_t w_zstride, int64_t part_zstride, void* stream) {
     return gt_rec_gemm_bf16_prio(X, ldx, Wp, part, mtiles, N, K, splits, part_sstride, nz, x_zstride, w_zstride, part_zstride, 0,
-                                 stream);
+                                 stream, 1);
+}
+extern "C" int gt_rec_gemm_x3(const float* X, int64_t ldx, const void* Wp, float* part, int32_t mtiles, int32_t N,
+                              int32_t K, int32_t splits, int64_t part_sstride, int32_t nz, int64_t x_zstride,
+                              int64_t w_zstride, int64_t part_zstride, void* stream) {
+    return gt_rec_gemm_bf16_prio(X, ldx, Wp, part, mtiles, N, K, splits, part_sstride, nz, x_zstride, w_zstride, part_zstride, 0,
+                                 stream, 3);
 }
 
 int gt_rec_gemm_bf16_prio(const float* X, int64_t ldx, const void* Wp, float* part, int32_t mtiles, int32_t N, int32_t K,
                           int32_t splits, int64_t part_sstride, int32_t nz, int64_t x_zstride, int64_t w_zstride,
-                          int64_t part_zstride, int prio, void* stream) {
+                          int64_t part_zstride, int prio, void* stream, int planes) {
     GT_REQUIRE(X && Wp && part, GT_E_ARG, "gt_rec_gemm_bf16: NULL pointer");
-    GT_REQUIRE(mtiles >= 1 && mtiles <= 4 && N > 0 && N % 16 == 0 && K >= 4 && splits >= 1 && nz >= 1, GT_E_ARG,
-               "gt_rec_gemm_bf16: bad sizes mtiles=%d N=%d K=%d splits=%d", mtiles, N, K, splits);
+    GT_REQUIRE(mtiles >= 1 && mtiles <= 4 && N > 0 && N % 16 == 0 && K >= 4 && splits >= 1 && nz >= 1 && (planes == 1 || planes == 3),
+               GT_E_ARG, "gt_rec_gemm_bf16: bad sizes mtiles=%d N=%d K=%d splits=%d planes=%d", mtiles, N, K, splits, planes);
     const int KB = cdiv(K, 32);
     const int kvalid = cdiv(K, 16) * 16;        // columns the caller guarantees (zero padded beyond K), as gt_rec_gemm
     GT_REQUIRE(ldx >= kvalid && ldx % 4 == 0 && aligned16(X) && aligned16(Wp) && x_zstride % 4 == 0 && w_zstride % 8 == 0,
@@ -231,25 +299,29 @@ int gt_rec_gemm_bf16_prio(const float* X, int64_t ldx, const void* Wp, float* pa
     GT_REQUIRE(part_sstride >= (int64_t)mtiles * 16 * N && aligned16(part) && part_sstride % 4 == 0 && part_zstride % 4 == 0,
                GT_E_ARG, "gt_rec_gemm_bf16: part slabs too small or misaligned");
     const int KBS = cdiv(KB, splits);
+    const int max_nch = planes == 3 ? RB_NCH_X3 : RB_NCH;
     GT_REQUIRE(cdiv(KB, KBS) == splits, GT_E_ARG, "gt_rec_gemm_bf16: splits=%d leaves empty slabs for K=%d", splits, K);
-    GT_REQUIRE(KBS <= RB_NCH * RB_CB, GT_E_ARG, "gt_rec_gemm_bf16: K-slice of %d exceeds %d (use >= %d splits)", KBS * 32,
-               RB_NCH * RB_CB * 32, cdiv(KB, RB_NCH * RB_CB));
+    GT_REQUIRE(KBS <= max_nch * RB_CB, GT_E_ARG, "gt_rec_gemm_bf16: K-slice of %d exceeds %d (use >= %d splits)", KBS * 32,
+               max_nch * RB_CB * 32, cdiv(KB, max_nch * RB_CB));
     dim3 grid(cdiv(N, 64), splits, nz);
     hipStream_t st = (hipStream_t)stream;
     GtProfScope prof(GT_FAM_REC_GEMM, 2.0 * 16 * mtiles * (double)N * K * nz,
-                     (double)nz * (2.0 * N * K + 4.0 * (16.0 * mtiles * K + 16.0 * mtiles * N * splits)), st, true);
+                     (double)nz * (2.0 * planes * N * K + 4.0 * (16.0 * mtiles * K + 16.0 * mtiles * N * splits)), st, true);
     const uint4* wp = reinterpret_cast<const uint4*>(Wp);
     const int nch = cdiv(KBS, RB_CB);           // chunks of a slice: one instantiation each (all loads issued up front)
-#define GT_RECB(MT, NCH)                                                                                              \
-    hipExtLaunchKernelGGL((rec_gemm_bf16_kernel<MT, NCH>), grid, dim3(RB_THREADS), 0, st, prof.e0, prof.e1, 0, X, (long)ldx, \
+#define GT_RECB(MT, NCH, NP)                                                                                          \
+    hipExtLaunchKernelGGL((rec_gemm_bf16_kernel<MT, NCH, NP>), grid, dim3(RB_THREADS), 0, st, prof.e0, prof.e1, 0, X, (long)ldx, \
                           kvalid, wp, part, N, KB, KBS, (long)x_zstride, (long)(w_zstride / 8), (long)part_zstride,        \
                           (long)part_sstride, prio)
-#define GT_RECB_M(MT)                        \
-    switch (nch) {                           \
-        case 1: GT_RECB(MT, 1); break;       \
-        case 2: GT_RECB(MT, 2); break;       \
-        case 3: GT_RECB(MT, 3); break;       \
-        default: GT_RECB(MT, 4); break;      \
+#define GT_RECB_M(MT)                                  \
+    if (planes == 3) {                                 \
+        if (nch == 1) GT_RECB(MT, 1, 3);               \
+        else GT_RECB(MT, 2, 3);                        \
+    } else switch (nch) {                              \
+        case 1: GT_RECB(MT, 1, 1); break;              \
+        case 2: GT_RECB(MT, 2, 1); break;              \
+        case 3: GT_RECB(MT, 3, 1); break;              \
+        default: GT_RECB(MT, 4, 1); break;             \
     }
     switch (mtiles) {
         case 1: GT_RECB_M(1); break;
@@ -263,29 +335,29 @@ int gt_rec_gemm_bf16_prio(const float* X, int64_t ldx, const void* Wp, float* pa
     return 0;
 }
 
-// packing for gt_rec_cell_fwd_bf16: W is the (4H x K) LSTM weight in PyTorch gate order
+// packing for gt_rec_cell_fwd_bf16 / _x3: W is the (4H x K) LSTM weight in PyTorch gate order
 extern "C" int gt_pack_rec_cell_weight_bf16(const float* W, int64_t ldw, int32_t H, int32_t K, void* Wp, void* stream) {
-    GT_REQUIRE(W && Wp && H > 0 && H % 16 == 0 && K > 0, GT_E_ARG, "gt_pack_rec_cell_weight_bf16: H=%d must be a multiple of 16", H);
-    GT_REQUIRE(aligned16(Wp), GT_E_ALIGN, "gt_pack_rec_cell_weight_bf16: Wp must be 16-byte aligned");
-    const int N = 4 * H, KB = cdiv(K, 32);
-    const long total = (long)(N / 16) * KB * 64;
-    const int blocks = (int)std::min<long>(cdiv64(total, 256), 4096);
-    hipLaunchKernelGGL(pack_rec_weight_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, W, (long)ldw, 0, N, N, K, KB,
-                       H, reinterpret_cast<uint4*>(Wp));
-    GT_LAUNCH_CHECK();
-    return 0;
+    GT_REQUIRE(H > 0 && H % 16 == 0, GT_E_ARG, "gt_pack_rec_cell_weight_bf16: H=%d must be a multiple of 16", H);
+    return pack_rec_planes("gt_pack_rec_cell_weight_bf16", W, ldw, 0, 4 * H, 4 * H, K, H, Wp, 1, stream);
+}
+extern "C" int gt_pack_rec_cell_weight_x3(const float* W, int64_t ldw, int32_t H, int32_t K, void* Wp, void* stream) {
+    GT_REQUIRE(H > 0 && H % 16 == 0, GT_E_ARG, "gt_pack_rec_cell_weight_x3: H=%d must be a multiple of 16", H);
+    return pack_rec_planes("gt_pack_rec_cell_weight_x3", W, ldw, 0, 4 * H, 4 * H, K, H, Wp, 3, stream);
 }
 
-// launch of the bf16-operand fused product + cell; arguments already validated by gt_rec_cell_fwd_z (recurrent.hip)
+// launch of the bf16-operand (planes = 1) or three-plane fp32 (planes = 3) fused product + cell; arguments already
+// validated by gt_rec_cell_fwd_z (recurrent.hip)
 int gt_launch_rec_cell_bf16(const float* X, int64_t ldx, const void* Wp, float* part, int32_t Bp, int32_t N, int32_t K,
                             int32_t splits, int32_t ndir, int prio, const RecCellEpi& e, hipEvent_t e0, hipEvent_t e1,
-                            void* stream) {
+                            void* stream, int planes) {
     const int KB = cdiv(K, 32);
     const int kvalid = cdiv(K, 16) * 16;
     const int KBS = cdiv(KB, splits);
+    const int max_nch = planes == 3 ? RB_NCH_X3 : RB_NCH;
+    GT_REQUIRE(planes == 1 || planes == 3, GT_E_ARG, "gt_rec_cell_fwd_bf16: planes");
     GT_REQUIRE(cdiv(KB, KBS) == splits, GT_E_ARG, "gt_rec_cell_fwd_bf16: splits=%d leaves empty slabs for K=%d", splits, K);
-    GT_REQUIRE(KBS <= RB_NCH * RB_CB, GT_E_ARG, "gt_rec_cell_fwd_bf16: K-slice of %d exceeds %d (use >= %d splits)", KBS * 32,
-               RB_NCH * RB_CB * 32, cdiv(KB, RB_NCH * RB_CB));
+    GT_REQUIRE(KBS <= max_nch * RB_CB, GT_E_ARG, "gt_rec_cell_fwd_bf16: K-slice of %d exceeds %d (use >= %d splits)", KBS * 32,
+               max_nch * RB_CB * 32, cdiv(KB, max_nch * RB_CB));
     GT_REQUIRE(e.dW % 8 == 0, GT_E_ALIGN, "gt_rec_cell_fwd_bf16: direction offset of the weights must be a multiple of 8");
     const int mt = Bp <= 64 ? Bp / 16 : 4, nzb = Bp <= 64 ? 1 : Bp / 64;
     dim3 grid(N / 64, splits, nzb * ndir);
@@ -293,15 +365,18 @@ int gt_launch_rec_cell_bf16(const float* X, int64_t ldx, const void* Wp, float* 
     const uint4* wp = reinterpret_cast<const uint4*>(Wp);
     const long ps = (long)Bp * N;
     const int nch = cdiv(KBS, RB_CB);
-#define GT_RCB(MT, NCH)                                                                                                  \
-    hipExtLaunchKernelGGL((rec_cell_bf16_kernel<MT, NCH>), grid, dim3(RB_THREADS), 0, st, e0, e1, 0, X, (long)ldx, kvalid, wp, \
+#define GT_RCB(MT, NCH, NP)                                                                                              \
+    hipExtLaunchKernelGGL((rec_cell_bf16_kernel<MT, NCH, NP>), grid, dim3(RB_THREADS), 0, st, e0, e1, 0, X, (long)ldx, kvalid, wp, \
                           part, N, KB, KBS, (long)(64 * ldx), (long)64 * N, ps, prio, e)
-#define GT_RCB_M(MT)                         \
-    switch (nch) {                           \
-        case 1: GT_RCB(MT, 1); break;        \
-        case 2: GT_RCB(MT, 2); break;        \
-        case 3: GT_RCB(MT, 3); break;        \
-        default: GT_RCB(MT, 4); break;       \
+#define GT_RCB_M(MT)                                   \
+    if (planes == 3) {                                 \
+        if (nch == 1) GT_RCB(MT, 1, 3);                \
+        else GT_RCB(MT, 2, 3);                         \
+    } else switch (nch) {                              \
+        case 1: GT_RCB(MT, 1, 1); break;               \
+        case 2: GT_RCB(MT, 2, 1); break;               \
+        case 3: GT_RCB(MT, 3, 1); break;               \
+        default: GT_RCB(MT, 4, 1); break;              \
     }
     switch (mt) {
         case 1: GT_RCB_M(1); break;

@@ -70,6 +70,11 @@ S2_BWD = sw.debug('s2_bwd')
 # whole block are taken from the weight-gradient GEMMs that fill the chip beside the attention chain; it stays opt-in
 # (GANTRON_EXPERIMENTAL=plstm=15).  Default 7 (GANTRON_SCHEDULE=no_plstm or GANTRON_EXPERIMENTAL=plstm=<bits> to change it).
 PLSTM = sw.experimental('plstm', 7 if sw.schedule_on('plstm') else 0)
+# The attention LSTM's per-step products as exact fp32 products on the bf16 matrix pipe (three bf16 planes, csrc/recurrent_bf16.hip
+# NP = 3): bit 0 = the forward fused product + cell (gt_rec_cell_fwd_x3), bit 1 = the backward product (gt_rec_gemm_x3).
+# Measured (round 3) and not adopted: 31.1 us per forward launch against 26.7, 25.6 per backward product against 19.6, pair
+# 141.0-141.4 ms against 127.9-128.4 -- the launches follow their weight bytes (6 per weight instead of 4), not their MFMAs.
+REC_X3 = sw.experimental('rec_x3', 0)
 S1_FWD = sw.debug('s1_fwd')       # diagnostics: K-splits of the attention LSTM's forward product
 S1_BWD = sw.debug('s1_bwd')       # diagnostics: K-splits of its backward product when the decoder LSTM's backward is persistent
 DEC_BLK = 16       # steps per block in that mode (measured: 8: 160.6 ms per pair,
@@ -286,9 +291,31 @@ def pack_rec_bf16(W2d, N, n_valid, K, transposed=False):
     return out
 
 
+def pack_rec_x3(W2d, N, n_valid, K, transposed=False):
+    """Pack a (n_valid x K) [or (K x n_valid) when transposed] matrix as three bf16 planes of MFMA fragments for gt_rec_gemm_x3."""
+    out = torch.empty(int(lib().gt_rec_weight_x3_elems(N, K)), device=W2d.device, dtype=torch.bfloat16)
+    call('gt_pack_rec_weight_x3', W2d, W2d.stride(0), int(transposed), N, n_valid, K, out)
+    return out
+
+
+def rec_splits_x3(N, K, cus=256):
+    """K-splits of the three-plane products (K-slices of at most 512, gt_rec_x3_min_splits): the fewest splits whose
+    workgroups (64 columns x one slice, one per CU: 101 KB of LDS) fill `cus` CUs once; at least the minimum."""
+    kb = -(-K // 32)
+    groups = -(-N // 64)
+    lo = int(lib().gt_rec_x3_min_splits(K))
+    ok = [s for s in range(lo, min(16, kb) + 1) if -(-kb // -(-kb // s)) == s]
+    fit = [s for s in ok if groups * s <= cus]
+    return max(fit) if fit else ok[0]
+
+
 def pack_rec_cell(W2d, H, K, bf16=False):
-    """Pack a (4H x K) LSTM weight for gt_rec_cell_fwd / gt_rec_cell_fwd_bf16 (a workgroup's 64 columns = the four gates
-    of 16 hidden units)."""
+    """Pack a (4H x K) LSTM weight for gt_rec_cell_fwd / gt_rec_cell_fwd_bf16 / gt_rec_cell_fwd_x3 (bf16 = 3) (a
+    workgroup's 64 columns = the four gates of 16 hidden units)."""
+    if bf16 == 3 and bf16 is not True:
+        out = torch.empty(int(lib().gt_rec_weight_x3_elems(4 * H, K)), device=W2d.device, dtype=torch.bfloat16)
+        call('gt_pack_rec_cell_weight_x3', W2d, W2d.stride(0), H, K, out)
+        return out
     if bf16:
         out = torch.empty(int(lib().gt_rec_weight_bf16_elems(4 * H, K)), device=W2d.device, dtype=torch.bfloat16)
         call('gt_pack_rec_cell_weight_bf16', W2d, W2d.stride(0), H, K, out)
@@ -652,7 +679,11 @@ class GeneratorEngine:
             use_c1 = bool(REC_CELL & (8 if self.bf16 else 1)) and CELL_QUERY and Ha % 32 == 0
             use_c2 = bool(REC_CELL & (16 if self.bf16 else 2)) and Hd % 16 == 0 and Hd % 4 == 0
             keep_t['W2ih'] = W2ihp
-            keep_t['W1c' if use_c1 else 'W1p'] = pack_rec_cell(W1cat, Ha, K1, self.bf16) if use_c1 else \
+            x3 = bool(REC_X3 & 1) and use_c1 and not self.bf16 and Bp <= 64
+            if x3:      # the attention LSTM's product on the bf16 pipe, exactly (three planes): K-slices of at most 512
+                d.rec_x3 = 1
+                d.S1 = rec_splits_x3(4 * Ha, K1, 192 if ((PLSTM & 2) and lib().gt_plstm_supported(Bp, Hd)) else 256)
+            keep_t['W1c' if use_c1 else 'W1p'] = pack_rec_cell(W1cat, Ha, K1, 3 if x3 else self.bf16) if use_c1 else \
                 pack(W1cat, 4 * Ha, 4 * Ha, K1)
             keep_t['W2hc' if use_c2 else 'W2hp'] = pack_rec_cell(W2hh, Hd, Hd, self.bf16) if use_c2 else \
                 pack(W2hh, 4 * Hd, 4 * Hd, Hd)
@@ -959,7 +990,8 @@ class GeneratorEngine:
         packT = pack_rec_bf16 if self.bf16 else pack_rec
         hoist2 = HOIST2 and not FUSED_CELL
         Hdpad = roundup(Hd, 16)
-        W1Tp = packT(W1cat, N1pad, K1, 4 * Ha, transposed=True)
+        x3b = bool(REC_X3 & 2) and not self.bf16 and Bp <= 64 and N1pad % 64 == 0
+        W1Tp = pack_rec_x3(W1cat, N1pad, K1, 4 * Ha, transposed=True) if x3b else packT(W1cat, N1pad, K1, 4 * Ha, transposed=True)
         W2Tp = None if hoist2 else packT(W2cat, N2pad, K2, 4 * Hd, transposed=True)
         W2hTp = packT(W2hh, Hdpad, Hd, 4 * Hd, transposed=True) if hoist2 else None
         WqTp = pack_rec(Wq, Ha, Ha, A, transposed=True)
@@ -974,6 +1006,9 @@ class GeneratorEngine:
             b.S2 = (rec_splits_bf16 if self.bf16 else rec_splits)(Hdpad, 4 * Hd)
             if S2_BWD and not self.bf16:
                 b.S2 = ops.pick_splits(4 * Hd, S2_BWD)
+        if x3b:
+            b.rec_x3 = 1
+            b.S1 = rec_splits_x3(N1pad, 4 * Ha)
         if S1_BWD and not self.bf16:
             b.S1 = S1_BWD
         b.N1pad, b.N2pad = N1pad, N2pad

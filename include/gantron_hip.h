@@ -185,6 +185,7 @@ int gt_rec_cell_fwd_bf16(const float* X, int64_t ldx, const void* Wp, float* par
 
 
 
+
 /* ------------------------------------------------------------------------------------ LSTM cell
  * nn.LSTMCell pointwise part + dropout (model.py:391-394,406-409); gate order i,f,g,o.
  * gates_pre = sum_s part[s] + pre (pre holds the non-recurrent input projection and both biases).
@@ -389,6 +390,9 @@ typedef struct GtDecoderFwd {
     /* attn_xbuf != NULL (with row_cnt, and gt_attn_step2_supported): energies + softmax + context of a step are ONE launch
      * with NO in-launch wait (gt_attn_step2_fwd): B * ceil(Ti / 32) rows of gt_attn_step2_xstride(d) floats. */
     float* attn_xbuf;
+    /* 1 (fp32 mode only, bf16 = 0): W1c is a gt_pack_rec_cell_weight_x3 image and the attention LSTM's fused product + cell
+     * runs as gt_rec_cell_fwd_x3 -- the exact fp32 product from three bf16 planes, on the bf16 matrix pipe */
+    int32_t rec_x3;
 } GtDecoderFwd;
 
 typedef struct GtDecoderBwd {
@@ -457,6 +461,9 @@ typedef struct GtDecoderBwd {
     float* pl_xbuf;
     uint32_t* pl_counters;
     int32_t* pl_timeout;
+    /* 1 (fp32 mode only, bf16 = 0): W1Tp is a gt_pack_rec_weight_x3 image and the attention LSTM's backward product runs as
+     * gt_rec_gemm_x3 */
+    int32_t rec_x3;
 } GtDecoderBwd;
 
 typedef struct GtBiLstm {
@@ -637,6 +644,30 @@ int gt_log_clamp(const float* x, int64_t n, float clip, float* out, void* stream
  * Everything below was built, is covered by kernel and parity tests, was MEASURED on MI355X and is NOT on the default path
  * ("measured and not adopted"; the switches are listed in gantron_amd/switches.py under
  * GANTRON_EXPERIMENTAL).  A binding that only wants the training step's path can ignore this section. */
+
+/* The same two kernels as an EXACT fp32 product on the bf16 matrix pipe ("x3"): the weights are packed as three bf16 planes
+ * w = w0 + w1 + w2 (all 24 significand bits; gt_rec_weight_x3_elems 16-bit elements, plane p of fragment block (nb, kb) at
+ * ((nb KB + kb) 3 + p) 64 lanes x 8), the fp32 activations are split the same way on their way through LDS and
+ * a . b = a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0) is accumulated in fp32, smallest terms first: every product
+ * exact, dropped terms <= 2^-24 |a||b| (the arithmetic of gt_sgemm's three-plane mode).  K-slices of at most 512:
+ * splits >= gt_rec_x3_min_splits(K).
+ * Measured (MI355X, round 3) and NOT adopted: the attention LSTM's fused step 31.1 us against 26.7 on the fp32 pipe, its backward
+ * product 25.6 against 19.6 (pair 141 ms against 128): these launches are bound by their weight stream (6 bytes per weight
+ * here instead of 4), not by the matrix pipe.  GANTRON_EXPERIMENTAL=rec_x3=<1 forward | 2 backward>. */
+int64_t gt_rec_weight_x3_elems(int32_t N, int32_t K);
+int32_t gt_rec_x3_min_splits(int32_t K);
+int gt_pack_rec_weight_x3(const float* W, int64_t ldw, int32_t transposed, int32_t N, int32_t n_valid,
+                          int32_t K, void* Wp, void* stream);
+int gt_rec_gemm_x3(const float* X, int64_t ldx, const void* Wp, float* part, int32_t mtiles, int32_t N,
+                   int32_t K, int32_t splits, int64_t part_sstride, int32_t nz, int64_t x_zstride,
+                   int64_t w_zstride, int64_t part_zstride, void* stream);
+int gt_pack_rec_cell_weight_x3(const float* W, int64_t ldw, int32_t H, int32_t K, void* Wp, void* stream);
+int gt_rec_cell_fwd_x3(const float* X, int64_t ldx, const void* Wp, float* part, uint32_t* counters, int32_t Bp,
+                         int32_t B, int32_t H, int32_t K, int32_t splits, const float* pre, int64_t ld_pre,
+                         const float* c_prev, const uint8_t* keep, float p_drop, float* gates, float* c_out,
+                         float* h_raw, float* h0, int64_t ld0, float* h1, int64_t ld1, float* h2, int64_t ld2,
+                         const float* Wq, int64_t ldwq, float* qpart, int64_t q_sstride, int32_t A, int32_t Apad,
+                         int32_t prio, void* stream);
 
 /* x[0..n) -> three bf16 planes, plane i at planes + i * plane_stride (16-bit elements): x0 = bf16(x), x1 = bf16(x - x0),
  * x2 = bf16(x - x0 - x1); x0 + x1 + x2 == x exactly (3 x 8 significand bits).  n, plane_stride multiples of 8. */

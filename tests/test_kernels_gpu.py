@@ -346,9 +346,46 @@ def test_cell_query_fused(dev, Bsz, H, A, S):
     assert torch.isfinite(qpart).all()                   # every slab element was written
 
 
+@pytest.mark.parametrize('Bsz,N,K', [(64, 4096, 1536), (64, 1536, 4096), (5, 128, 40), (33, 192, 1100), (64, 4096, 2117)])
+def test_rec_gemm_x3(dev, Bsz, N, K):
+    """gt_rec_gemm_x3: the fp32 product from three bf16 planes per operand (six exact bf16 MFMA products, fp32 accumulation)
+    against float64 -- held to the accuracy of an fp32 product (a few 2^-24 of sum |a||b|), over operands that span five
+    decades inside one reduction; plain and transposed packing."""
+    from gantron_amd import ops
+    from gantron_amd._lib import lib
+    from gantron_amd.engine import pack_rec_x3, rec_splits_x3
+    Bp, ld = ops.roundup(Bsz, 16), ops.roundup(K, 16)
+    gen = torch.Generator().manual_seed(N + K)
+    W = g(N, K, scale=0.1) * torch.pow(10.0, torch.randint(-3, 2, (N, K), generator=gen).float())
+    X = torch.zeros(Bp, ld)
+    X[:Bsz, :K] = g(Bsz, K, seed=1) * torch.pow(10.0, torch.randint(-2, 3, (Bsz, K), generator=gen).float())
+    S = rec_splits_x3(N, K)
+    assert S >= int(lib().gt_rec_x3_min_splits(K))
+    Wp = pack_rec_x3(W.to(dev), N, N, K)
+    part = torch.full((S, Bp, N), float('nan'), device=dev)
+    ops.call('gt_rec_gemm_x3', X.to(dev), ld, Wp, part, Bp // 16, N, K, S, Bp * N, 1, 0, 0, 0)
+    ref = X[:Bsz, :K].double() @ W.double().t()
+    mag = X[:Bsz, :K].double().abs() @ W.double().abs().t()
+    err = ((part.sum(0)[:Bsz].cpu().double() - ref).abs() / mag).max()
+    assert float(err) < 4e-7, f'rec_gemm_x3: error {float(err):.3g} of sum |a||b|'
+    N2 = ops.roundup(K, 16)
+    WTp = pack_rec_x3(W.to(dev), N2, K, N, transposed=True)
+    X2 = torch.zeros(Bp, N)
+    X2[:Bsz] = g(Bsz, N, seed=2)
+    S2 = rec_splits_x3(N2, N)
+    part2 = torch.full((S2, Bp, N2), float('nan'), device=dev)
+    ops.call('gt_rec_gemm_x3', X2.to(dev), N, WTp, part2, Bp // 16, N2, N, S2, Bp * N2, 1, 0, 0, 0)
+    ref2 = X2[:Bsz].double() @ W.double()
+    mag2 = X2[:Bsz].double().abs() @ W.double().abs()
+    err2 = ((part2.sum(0)[:Bsz, :K].cpu().double() - ref2).abs() / mag2).max()
+    assert float(err2) < 4e-7, f'rec_gemm_x3 transposed: error {float(err2):.3g} of sum |a||b|'
+    if N2 > K:
+        assert float(part2.sum(0)[:, K:].abs().max()) == 0.0          # padded columns meet zero weights
+
+
 @pytest.mark.parametrize('Bsz,H,K,S,A', [(64, 1024, 2048, 4, 128), (5, 32, 100, 2, 8), (70, 64, 333, 3, 40), (64, 1024, 1024, 4, 0),
                                          (33, 48, 50, 1, 24), (64, 1024, 3072, 6, 0)])
-@pytest.mark.parametrize('bf16', [False, True])
+@pytest.mark.parametrize('bf16', [False, True, 3])
 def test_rec_cell_fused(dev, Bsz, H, K, S, A, bf16):
     """gt_rec_cell_fwd = gt_rec_gemm + gt_lstm_cell_fwd (+ the query projection) in ONE launch: the K-splits of a
     column group meet through write-through slabs and a ticket, the last one runs the cell.  Three launches in a
@@ -362,14 +399,17 @@ def test_rec_cell_fused(dev, Bsz, H, K, S, A, bf16):
     Apad = ops.roundup(max(A, 1), 16)
     ld = ops.roundup(K, 16) + 16
     W = g(4 * H, K, scale=0.1)
-    if bf16:
+    if bf16 is True:
         kb = -(-K // 32)
         S = next(s for s in range(max(S, int(lib().gt_rec_bf16_min_splits(K))), 17) if -(-kb // -(-kb // s)) == s)
         W = W.bfloat16().float()
+    elif bf16 == 3:           # gt_rec_cell_fwd_x3: the exact fp32 product from three bf16 planes, K-slices of at most 512
+        kb = -(-K // 32)
+        S = next(s for s in range(max(S, int(lib().gt_rec_x3_min_splits(K))), 17) if -(-kb // -(-kb // s)) == s)
     else:
         S = ops.pick_splits(K, S)
     Wp = pack_rec_cell(W.to(dev), H, K, bf16)
-    fn = 'gt_rec_cell_fwd_bf16' if bf16 else 'gt_rec_cell_fwd'
+    fn = 'gt_rec_cell_fwd_bf16' if bf16 is True else 'gt_rec_cell_fwd_x3' if bf16 == 3 else 'gt_rec_cell_fwd'
     Wq = g(max(A, 1), H, seed=4, scale=0.1)
     part = torch.full((S, Bp, 4 * H), float('nan'), device=dev)
     counters = torch.zeros((Bp // 64 if Bp > 64 else 1) * (H // 16), dtype=torch.int32, device=dev)
@@ -379,7 +419,7 @@ def test_rec_cell_fused(dev, Bsz, H, K, S, A, bf16):
         pre = g(Bp, 4 * H, seed=20 + rep, scale=0.5)
         c_prev = g(Bp, H, seed=30 + rep)
         keep = (torch.rand(Bp, H, generator=torch.Generator().manual_seed(40 + rep)) >= p)
-        Xr = X.bfloat16().float() if bf16 else X
+        Xr = X.bfloat16().float() if bf16 is True else X
         gates_in = (Xr[:Bsz, :K].double() @ W.double().t() + pre[:Bsz].double())
         i, f, gg, o = gates_in.chunk(4, dim=1)
         c = torch.sigmoid(f) * c_prev[:Bsz].double() + torch.sigmoid(i) * torch.tanh(gg)

@@ -216,6 +216,16 @@ def test_per_step_lstm_launches_against_oracle(dev, monkeypatch, case):
     _midsize_against_oracle(dev, case)
 
 
+@pytest.mark.parametrize('case', ['full_dims_b64', 'vesus_b64', 'full_dims_b20'])
+def test_rec_x3_products_against_oracle(dev, monkeypatch, case):
+    """The attention LSTM's per-step products as exact fp32 products on the bf16 matrix pipe (GANTRON_EXPERIMENTAL=rec_x3=3:
+    gt_rec_cell_fwd_x3 forward, gt_rec_gemm_x3 backward) through whole pairs at the reference's dimensions."""
+    from gantron_amd import engine
+    monkeypatch.setattr(engine, 'REC_X3', 3)
+    _midsize_against_oracle(dev, case)
+    engine.check_handoffs()
+
+
 def test_plane_gemms_against_oracle(dev, monkeypatch):
     """The opt-in pre-split operand path of the decoder's weight-gradient GEMMs (GANTRON_EXPERIMENTAL=plane_gemms: gt_split3 +
     pgemm_kernel) through a whole pair at the reference's dimensions, 64 rows, several backward chunks."""
