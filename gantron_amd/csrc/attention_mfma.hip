@@ -580,6 +580,8 @@ __global__ __launch_bounds__(256) void attn_step2_fwd_mfma(AttnStep2Fwd a) {
     float4 mem4[CT];
     {
         const float* mp = a.memory + ((long)b * d.Ti) * a.ld_mem + 4 * c4;
+        // (Measured and not adopted: non-temporal loads here and non-temporal stores of u_out, so that the tile would not displace
+        // the LSTM weights in L2 -- this kernel 19.9 us instead of 18.6 in the loop, the LSTM launch unchanged.)
 #pragma unroll
         for (int l = 0; l < CT; ++l)
             mem4[l] = (a.dbg & 1) ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(mp + (long)min(t0 + l, Tv - 1) * a.ld_mem);

@@ -22,7 +22,11 @@ struct RecCellEpi {
     // of direction 1 relative to direction 0
     int nzb;
     long dX, dW, dPart, dPre, dC, dGates, dHraw, dH0, dHprev;
+    // diagnostics (GANTRON_DEBUG=rec_stamps): 8 wall-clock stamps (10 ns ticks) per workgroup of the launch, or NULL
+    long long* stamps;
 };
+#define REC_STAMP(e, k) do { if ((e).stamps != nullptr && threadIdx.x == 0) \
+    (e).stamps[((long)blockIdx.x + (long)gridDim.x * blockIdx.y) * 8 + (k)] = wall_clock64(); } while (0)
 
 namespace {
 
@@ -79,6 +83,7 @@ __device__ __forceinline__ void rec_cell_epilogue(float* red, const RecCellEpi& 
         if (tid == 0)
             *lds_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
+        REC_STAMP(e, 3);                 // tile published, ticket drawn
         if ((*lds_ticket % (unsigned)e.S) != (unsigned)(e.S - 1)) return;       // not the last K-slice of this group
     }
     // ---- last arriver: inputs of the cell are requested together with the other K-slices' slabs
@@ -160,6 +165,7 @@ __device__ __forceinline__ void rec_cell_epilogue(float* red, const RecCellEpi& 
             }
         }
         __syncthreads();
+        REC_STAMP(e, 4);                 // the other K-slices' slabs are in
     }
     // ---- cell: thread = (row, 4 units); tile column 16*gate + unit
     float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);      // carried hidden state (what the next step and the query see)
@@ -200,6 +206,7 @@ __device__ __forceinline__ void rec_cell_epilogue(float* red, const RecCellEpi& 
         if (e.h1 != nullptr) *reinterpret_cast<float4*>(e.h1 + (long)m * e.ld1 + u) = hv;
         if (e.h2 != nullptr) *reinterpret_cast<float4*>(e.h2 + (long)m * e.ld2 + u) = hv;
     }
+    REC_STAMP(e, 5);                     // cell done, state stored
     if (ncb == 0) return;
     // ---- query slab of this column group: [ROWS x 16 units] . [16 x Apad]
     if (cell_thread) *reinterpret_cast<float4*>(&lds_h[crow * 20 + 4 * uq]) = hv;       // rows beyond the batch: zeros
@@ -223,6 +230,7 @@ __device__ __forceinline__ void rec_cell_epilogue(float* red, const RecCellEpi& 
                 qout[(long)(row0 + 16 * mt + 4 * (lane >> 4) + r) * e.Apad + cb * 16 + (lane & 15)] = acc[r];
         }
     }
+    REC_STAMP(e, 6);                     // query slab issued
 }
 
 }  // namespace

@@ -97,9 +97,13 @@ constexpr int EP_LD = 68;                 // epilogue tile row stride: 4 rows ap
 // Product of one workgroup: 64 columns starting at column group `cg`, K-slice [kb0, kb1).  Returns (after a barrier)
 // the folded [MT*16 rows][64 columns] tile in LDS, row stride EP_LD; the LDS array has MT*16*REC_LD floats, of which
 // the tile uses the first MT*16*EP_LD.
+// (Measured with the phase stamps of GANTRON_DEBUG=rec_stamps and not adopted, attention LSTM of the training step, 64 rows x
+// 64 columns x K-slice 688 per workgroup, in the loop: this form -- first operands in LDS after 1.6 us, 2.4 us per chunk
+// iteration (1.7 us of MFMAs), products done at 16.2 us; every weight fragment of the slice requested up front: first
+// operands after 5.2 us, 2.1 us per chunk, done at 17.7; weights three chunks ahead, activations two: 3.6 / 2.2 / 16.9.)
 template <int MT, int DBG>
 __device__ __forceinline__ float* rec_gemm_tile(const float* __restrict__ Xz, long ldx, const float* __restrict__ Wpz,
-                                                int N, int KB, int kb0, int kb1, int cg) {
+                                                int N, int KB, int kb0, int kb1, int cg, long long* stamps = nullptr) {
     static_assert(MT == 4 || MT == 2 || MT == 1 || MT == 3, "row tiles");
     __shared__ __attribute__((aligned(16))) float Xs[MT * 16 * REC_LD];
     if (DBG & 8) return Xs;               // diagnostics: pure launch + wave start-up cost
@@ -129,6 +133,10 @@ __device__ __forceinline__ float* rec_gemm_tile(const float* __restrict__ Xz, lo
     auto chunk = [&](const RecW& cur, RecW& nxt, int kb) __attribute__((always_inline)) {
         if (!(DBG & 4) || kb == kb0) xstore();
         __syncthreads();
+        if (stamps != nullptr && tid == 0) {
+            if (kb == kb0) stamps[1] = wall_clock64();                      // first activation chunk arrived
+            else if (kb == kb0 + REC_CK) stamps[7] = wall_clock64();        // second chunk published
+        }
         const int kn = kb + REC_CK;
         if (!(DBG & 4) && kn < kb1) xload(kn);
         if (!(DBG & 1)) nxt.load(wp + (long)REC_CK * 64, kn + REC_HK * half, kb1);
@@ -159,6 +167,7 @@ __device__ __forceinline__ float* rec_gemm_tile(const float* __restrict__ Xz, lo
         chunk(wa, wb, kb);
         if (kb + REC_CK < kb1) chunk(wb, wa, kb + REC_CK);
     }
+    if (stamps != nullptr && tid == 0) stamps[2] = wall_clock64();                          // MFMAs done
     // Epilogue through LDS (Xs is free after the last barrier): the two K-halves are folded into a row-major
     // [row][64 columns] tile so that the slab is written with full-line float4 stores by all 8 waves (the MFMA
     // C layout would give 16 scalar stores of 64-byte pieces per lane, by half of the waves only).
@@ -260,7 +269,9 @@ __global__ __launch_bounds__(REC_THREADS) void rec_cell_kernel(const float* __re
         X += e.dX; Wp += e.dW; part += e.dPart;
         rec_cell_dir1(e);
     }
-    float* red = rec_gemm_tile<MT, 0>(X + (long)rb * xz, ldx, Wp, N, KB, kb0, min(KB, kb0 + KBS), cg);
+    REC_STAMP(e, 0);
+    float* red = rec_gemm_tile<MT, 0>(X + (long)rb * xz, ldx, Wp, N, KB, kb0, min(KB, kb0 + KBS), cg,
+                                          e.stamps ? e.stamps + ((long)blockIdx.x + (long)gridDim.x * blockIdx.y) * 8 : nullptr);
     static_assert(MT * 16 * REC_EP_LD + MT * 16 * 20 + 4 <= MT * 16 * REC_LD, "epilogue scratch fits the staging buffer");
     rec_cell_epilogue<MT>(red, e, part + (long)rb * pz, ps, N, cg, s, rb, e.counters + (long)z * gridDim.x + cg);
 }
@@ -608,6 +619,17 @@ int gt_launch_rec_cell_bf16(const float* X, int64_t ldx, const void* Wp, float* 
                             int32_t splits, int32_t ndir, int prio, const RecCellEpi& e, hipEvent_t e0, hipEvent_t e1,
                             void* stream, int planes);      // recurrent_bf16.hip
 
+static long long* g_rec_stamps = nullptr;
+static int g_rec_stamp_wgs = 0;
+// diagnostics: copies the stamps of the last stamped launch (8 per workgroup) to `out` (HOST, room for 8 * 4096) and returns
+// the number of workgroups; synchronises the device
+extern "C" int gt_debug_rec_stamps(int64_t* out) {
+    if (g_rec_stamps == nullptr || out == nullptr) return 0;
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(out, g_rec_stamps, sizeof(long long) * 8 * (size_t)g_rec_stamp_wgs, hipMemcpyDeviceToHost);
+    return g_rec_stamp_wgs;
+}
+
 int gt_rec_cell_fwd_z(const float* X, int64_t ldx, const void* Wpv, int wbf16, float* part, uint32_t* counters, int32_t Bp, int32_t B,
                       int32_t H, int32_t K, int32_t splits, const float* pre, int64_t ld_pre, const float* c_prev,
                       const uint8_t* keep, float p_drop, float* gates, float* c_out, float* h_raw, float* h0, int64_t ld0,
@@ -642,6 +664,19 @@ int gt_rec_cell_fwd_z(const float* X, int64_t ldx, const void* Wpv, int wbf16, f
     e.B = B; e.H = H; e.A = A; e.Apad = Apad; e.S = splits;
     e.active = active; e.h_prev = h_prev; e.ld_hprev = ld_hprev; e.nzb = nzb;
     e.dX = e.dW = e.dPart = e.dPre = e.dC = e.dGates = e.dHraw = e.dH0 = e.dHprev = 0;
+    e.stamps = nullptr;
+    {   // diagnostics: GANTRON_DEBUG=rec_stamps keeps the phase stamps of the LAST attention-LSTM launch (gt_debug_rec_stamps)
+        static const int want = gt_env_item("GANTRON_DEBUG", "rec_stamps", 0);
+        if (want && Wq != nullptr && ndir == 1) {
+            if (g_rec_stamps == nullptr) {
+                (void)hipMalloc(&g_rec_stamps, sizeof(long long) * 8 * 4096);
+                fprintf(stderr, "[rec_stamps] N=%d K=%d KB=%d splits=%d Bp=%d\n", N, K, KB, splits, Bp);
+            }
+            e.stamps = g_rec_stamps;
+            g_rec_stamp_wgs = (N / 64) * splits;
+            (void)hipMemsetAsync(g_rec_stamps, 0, sizeof(long long) * 8 * (size_t)g_rec_stamp_wgs, (hipStream_t)stream);
+        }
+    }
     if (ndir == 2) {
         e.dX = dz[0]; e.dW = dz[1]; e.dPart = dz[2]; e.dPre = dz[3]; e.dC = dz[4]; e.dGates = dz[5]; e.dHraw = dz[6];
         e.dH0 = dz[7]; e.dHprev = dz[8];

@@ -16,7 +16,7 @@
 // (a0 b2 + a1 b1 + a2 b0) runs as six v_mfma_f32_16x16x32_bf16 with fp32 accumulation, smallest terms first -- every
 // product exact, dropped terms <= 2^-24 |a||b|, the arithmetic of xgemm_kernel (gemm.hip).  At M = 64 rows the fp32 pipe
 // needs 6.8 us for a workgroup's 64 columns x 512 k (v_mfma_f32_16x16x4_f32: 256 flop per clock and CU); the six bf16
-// products take 2.6 us.  K-slices of at most 2 chunks (the three weight planes of a slice live in registers).
+// products take 2.6 us.  The three weight planes are held two chunks at a time and refilled two chunks ahead.
 #include <stdint.h>
 #include "common.h"
 #include "rec_cell.h"
@@ -100,10 +100,14 @@ __device__ __forceinline__ void rb_setprio(int prio) {
 // folded over the two K-halves in LDS (row stride REC_EP_LD floats, at the start of the staging array Xs), after a barrier.
 template <int MT, int NCH, int NP>
 __device__ __forceinline__ float* rec_bf16_tile(unsigned short* Xs, const float* __restrict__ Xz, long ldx, int kvalid,
-                                                const uint4* __restrict__ Wz, int N, int KB, int kb0, int kb1, int cg) {
+                                                const uint4* __restrict__ Wz, int N, int KB, int kb0, int kb1, int cg,
+                                                long long* stamps = nullptr) {
     constexpr int PL = MT * 16 * RB_LD;      // bf16 elements per activation plane in LDS
     constexpr int XV = MT * 2;         // float4 per thread per chunk (MT*16 rows x 64 float4 / 512 threads)
-    constexpr int XR = NCH < RB_XR ? NCH : RB_XR;
+    constexpr int XR = NP == 3 ? (NCH < 2 ? NCH : 2) : (NCH < RB_XR ? NCH : RB_XR);
+    // weight chunks held in registers: all of the slice (NP = 1), or two at a time, refilled two chunks ahead (NP = 3:
+    // three planes of a chunk are 48 registers)
+    constexpr int WR = NP == 3 ? (NCH < 2 ? NCH : 2) : NCH;
     constexpr int EP_LD = REC_EP_LD;
     static_assert(MT * 16 * RB_LD * 2 >= (MT * 16 * (EP_LD + 20) + 4) * 4, "epilogue tile + scratch fit the staging buffer");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -115,8 +119,19 @@ __device__ __forceinline__ float* rec_bf16_tile(unsigned short* Xs, const float*
 
     // ---- every load of the slice, issued together.  Out-of-range blocks are clamped to a valid address and
     // zeroed by a select (a predicated load would put s_waitcnt vmcnt(0) in front of everything behind it).
-    uint4 w[NCH][RB_HB][NP];
+    uint4 w[WR][RB_HB][NP];
     float4 x[XR][XV];
+    auto wload = [&](uint4 (&dst)[RB_HB][NP], int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < RB_HB; ++u) {
+            const int kb = kb0 + c * RB_CB + half * RB_HB + u;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const uint4 t = wp[((long)min(kb, kb1 - 1) * NP + p) * 64];
+                dst[u][p] = kb < kb1 ? t : make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    };
     auto xload = [&](float4 (&dst)[XV], int c) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
@@ -127,15 +142,7 @@ __device__ __forceinline__ float* rec_bf16_tile(unsigned short* Xs, const float*
     };
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-#pragma unroll
-        for (int u = 0; u < RB_HB; ++u) {
-            const int kb = kb0 + c * RB_CB + half * RB_HB + u;
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                const uint4 t = wp[((long)min(kb, kb1 - 1) * NP + p) * 64];
-                w[c][u][p] = kb < kb1 ? t : make_uint4(0u, 0u, 0u, 0u);
-            }
-        }
+        if (c < WR) wload(w[c], c);
         if (c < XR) xload(x[c], c);
     }
     f32x4 acc[MT];
@@ -156,6 +163,7 @@ __device__ __forceinline__ float* rec_bf16_tile(unsigned short* Xs, const float*
             }
             if (c + XR < NCH) xload(x[c % XR], c + XR);      // registers of this chunk are free again
             __syncthreads();
+            if (stamps != nullptr && tid == 0) { if (c == 0) stamps[1] = wall_clock64(); else if (c == 1) stamps[7] = wall_clock64(); }
 #pragma unroll
             for (int u = 0; u < RB_HB; ++u) {
                 bf16x8 a[NP][MT];
@@ -169,14 +177,16 @@ __device__ __forceinline__ float* rec_bf16_tile(unsigned short* Xs, const float*
                 for (int ord = NP - 1; ord >= 0; --ord)
 #pragma unroll
                     for (int pa = 0; pa <= ord; ++pa) {
-                        const bf16x8 b = __builtin_bit_cast(bf16x8, w[c][u][ord - pa]);
+                        const bf16x8 b = __builtin_bit_cast(bf16x8, w[c % WR][u][ord - pa]);
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[pa][mt], b, acc[mt], 0, 0, 0);
                     }
             }
+            if (c + WR < NCH) wload(w[c % WR], c + WR);      // registers of this chunk's weights are free again
             __syncthreads();
         }
     }
+    if (stamps != nullptr && tid == 0) stamps[2] = wall_clock64();
     // ---- epilogue through LDS: fold the two K-halves, write the slab with full-line float4 stores
     float* red = reinterpret_cast<float*>(Xs);
     const int ecol = (wave & 3) * 16 + (lane & 15), erow = 4 * (lane >> 4);
@@ -235,7 +245,9 @@ __global__ __launch_bounds__(RB_THREADS) void rec_cell_bf16_kernel(const float* 
         X += e.dX; Wp += e.dW / 8; part += e.dPart;          // dW counts bf16 elements
         rec_cell_dir1(e);
     }
-    float* red = rec_bf16_tile<MT, NCH, NP>(Xs, X + (long)rb * xz, ldx, kvalid, Wp, N, KB, kb0, min(KB, kb0 + KBS), cg);
+    REC_STAMP(e, 0);
+    float* red = rec_bf16_tile<MT, NCH, NP>(Xs, X + (long)rb * xz, ldx, kvalid, Wp, N, KB, kb0, min(KB, kb0 + KBS), cg,
+                                            e.stamps ? e.stamps + ((long)blockIdx.x + (long)gridDim.x * blockIdx.y) * 8 : nullptr);
     rec_cell_epilogue<MT>(red, e, part + (long)rb * pz, ps, N, cg, s, rb, e.counters + (long)z * gridDim.x + cg);
 }
 
@@ -247,7 +259,7 @@ extern "C" int64_t gt_rec_weight_bf16_elems(int32_t N, int32_t K) {
 extern "C" int64_t gt_rec_weight_x3_elems(int32_t N, int32_t K) { return 3 * gt_rec_weight_bf16_elems(N, K); }
 
 extern "C" int32_t gt_rec_bf16_min_splits(int32_t K) { return cdiv(cdiv(K, 32), RB_NCH * RB_CB); }
-constexpr int RB_NCH_X3 = 2;           // chunks per K-slice with three weight planes in registers
+constexpr int RB_NCH_X3 = 4;           // chunks per K-slice (the three weight planes are held two chunks at a time)
 extern "C" int32_t gt_rec_x3_min_splits(int32_t K) { return cdiv(cdiv(K, 32), RB_NCH_X3 * RB_CB); }
 
 static int pack_rec_planes(const char* what, const float* W, int64_t ldw, int32_t transposed, int32_t N, int32_t n_valid,
@@ -314,9 +326,11 @@ int gt_rec_gemm_bf16_prio(const float* X, int64_t ldx, const void* Wp, float* pa
                           kvalid, wp, part, N, KB, KBS, (long)x_zstride, (long)(w_zstride / 8), (long)part_zstride,        \
                           (long)part_sstride, prio)
 #define GT_RECB_M(MT)                                  \
-    if (planes == 3) {                                 \
-        if (nch == 1) GT_RECB(MT, 1, 3);               \
-        else GT_RECB(MT, 2, 3);                        \
+    if (planes == 3) switch (nch) {                    \
+        case 1: GT_RECB(MT, 1, 3); break;              \
+        case 2: GT_RECB(MT, 2, 3); break;              \
+        case 3: GT_RECB(MT, 3, 3); break;              \
+        default: GT_RECB(MT, 4, 3); break;             \
     } else switch (nch) {                              \
         case 1: GT_RECB(MT, 1, 1); break;              \
         case 2: GT_RECB(MT, 2, 1); break;              \
@@ -369,9 +383,11 @@ int gt_launch_rec_cell_bf16(const float* X, int64_t ldx, const void* Wp, float* 
     hipExtLaunchKernelGGL((rec_cell_bf16_kernel<MT, NCH, NP>), grid, dim3(RB_THREADS), 0, st, e0, e1, 0, X, (long)ldx, kvalid, wp, \
                           part, N, KB, KBS, (long)(64 * ldx), (long)64 * N, ps, prio, e)
 #define GT_RCB_M(MT)                                   \
-    if (planes == 3) {                                 \
-        if (nch == 1) GT_RCB(MT, 1, 3);                \
-        else GT_RCB(MT, 2, 3);                         \
+    if (planes == 3) switch (nch) {                    \
+        case 1: GT_RCB(MT, 1, 3); break;               \
+        case 2: GT_RCB(MT, 2, 3); break;               \
+        case 3: GT_RCB(MT, 3, 3); break;               \
+        default: GT_RCB(MT, 4, 3); break;              \
     } else switch (nch) {                              \
         case 1: GT_RCB(MT, 1, 1); break;               \
         case 2: GT_RCB(MT, 2, 1); break;               \

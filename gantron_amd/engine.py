@@ -299,8 +299,8 @@ def pack_rec_x3(W2d, N, n_valid, K, transposed=False):
 
 
 def rec_splits_x3(N, K, cus=256):
-    """K-splits of the three-plane products (K-slices of at most 512, gt_rec_x3_min_splits): the fewest splits whose
-    workgroups (64 columns x one slice, one per CU: 101 KB of LDS) fill `cus` CUs once; at least the minimum."""
+    """K-splits of the three-plane products (K-slices of at most 1024, gt_rec_x3_min_splits): the most splits whose
+    workgroups (64 columns x one slice, one per CU: 101 KB of LDS) still fit `cus` CUs in one round; at least the minimum."""
     kb = -(-K // 32)
     groups = -(-N // 64)
     lo = int(lib().gt_rec_x3_min_splits(K))

@@ -649,7 +649,7 @@ int gt_log_clamp(const float* x, int64_t n, float clip, float* out, void* stream
  * w = w0 + w1 + w2 (all 24 significand bits; gt_rec_weight_x3_elems 16-bit elements, plane p of fragment block (nb, kb) at
  * ((nb KB + kb) 3 + p) 64 lanes x 8), the fp32 activations are split the same way on their way through LDS and
  * a . b = a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0) is accumulated in fp32, smallest terms first: every product
- * exact, dropped terms <= 2^-24 |a||b| (the arithmetic of gt_sgemm's three-plane mode).  K-slices of at most 512:
+ * exact, dropped terms <= 2^-24 |a||b| (the arithmetic of gt_sgemm's three-plane mode).  K-slices of at most 1024:
  * splits >= gt_rec_x3_min_splits(K).
  * Measured (MI355X, round 3) and NOT adopted: the attention LSTM's fused step 31.1 us against 26.7 on the fp32 pipe, its backward
  * product 25.6 against 19.6 (pair 141 ms against 128): these launches are bound by their weight stream (6 bytes per weight
@@ -668,6 +668,11 @@ int gt_rec_cell_fwd_x3(const float* X, int64_t ldx, const void* Wp, float* part,
                          float* h_raw, float* h0, int64_t ld0, float* h1, int64_t ld1, float* h2, int64_t ld2,
                          const float* Wq, int64_t ldwq, float* qpart, int64_t q_sstride, int32_t A, int32_t Apad,
                          int32_t prio, void* stream);
+
+/* diagnostics (GANTRON_DEBUG=rec_stamps): wall-clock stamps (10 ns ticks) of the phases of the last attention-LSTM
+ * gt_rec_cell_fwd launch, 8 per workgroup (0 start, 1 first operands in LDS, 2 MFMAs done, 3 tile published, 4 other slabs
+ * added, 5 cell done, 6 query slab issued; 0 = not reached), into a HOST array of 8 * 4096; returns the workgroup count. */
+int gt_debug_rec_stamps(int64_t* out);
 
 /* x[0..n) -> three bf16 planes, plane i at planes + i * plane_stride (16-bit elements): x0 = bf16(x), x1 = bf16(x - x0),
  * x2 = bf16(x - x0 - x1); x0 + x1 + x2 == x exactly (3 x 8 significand bits).  n, plane_stride multiples of 8. */
