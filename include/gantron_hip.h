@@ -517,6 +517,68 @@ typedef struct GtDecoderInfer {
     int32_t t_lo, t_hi;
 } GtDecoderInfer;
 
+/* Persistent, weight-resident LSTM recurrence: ONE launch walks steps [s_lo, s_hi) of
+ *   G_s = pre_s + h_{s-1} . W_hh^T,  cell,  h_s = dropout(o tanh c_s)
+ * for ndir independent problems, each on H / 16 workgroups that keep W_hh in registers and exchange h through `hx`
+ * (csrc/plstm.hip).  Used for the encoder BiLSTM (ndir = 2, packed-sequence semantics through `active`: model.py:202-210)
+ * and for the decoder LSTM's h_dec recurrence inside a block of steps (ndir = 1, hx = the HC history itself: model.py:406-409);
+ * both are what the default schedule runs at 64 rows (GANTRON_SCHEDULE=no_plstm: the per-step launches).
+ * Bp must be 64 and H 256 or 1024 (gt_plstm_supported).  Direction d of every per-direction buffer lies *_dstride
+ * elements behind direction 0. */
+typedef struct GtPlstm {
+    int32_t B, Bp, H, T, ndir, s_lo, s_hi, hx_ring;
+    float p_drop;              /* dropout probability of `keep` (0: none) */
+    const float* Whh;          /* (4H, H) PyTorch layout, gate order i f g o */
+    int64_t w_dstride;
+    const float* pre;          /* (T, Bp, 4H) input projections + both biases */
+    int64_t pre_dstride;
+    float* gates;              /* (T, Bp, 4H) gate values kept for the backward pass; may alias pre */
+    int64_t gates_dstride;
+    float* c;                  /* (T + 1, Bp, H); slice s_lo is read, slices s_lo + 1 .. s_hi are written */
+    int64_t c_dstride;
+    float* hs;                 /* (T, Bp, H) emitted h (zero for inactive rows), or NULL */
+    int64_t hs_dstride;
+    float* hx;                 /* exchange: h_s is published at slot (hx_ring ? s % hx_ring : s) * hx_step, rows of hx_ld;
+                                  h_{s_lo - 1} is read from there when s_lo > 0.  hx_ring = 0 or >= 2 */
+    int64_t hx_dstride, hx_step, hx_ld;
+    const uint8_t* keep;       /* (T, Bp, H) keep mask of the dropout on h, or NULL */
+    const int32_t* active;     /* (T, Bp): rows with 0 pass their state through and emit zeros, or NULL */
+    uint32_t* counters;        /* ndir words (zeroed by the call) */
+    int32_t* timeout_flag;     /* raised when a bounded wait gives up (results invalid) */
+} GtPlstm;
+int32_t gt_plstm_supported(int32_t Bp, int32_t H);
+int gt_plstm_fwd(const GtPlstm* a, void* stream);
+
+/* Backward counterpart: ONE launch walks steps s_hi - 1 .. s_lo of  dh_s = dh_direct_s + dG_{s+1} . W_hh,  cell backward ->
+ * dG_s, dc carried on (csrc/plstm.hip).  The recurrent term travels between the H / 16 workgroups of a problem as a
+ * reduce-scatter of (64 x 16) tiles through `xbuf` (gt_plstm_bwd_xbuf_elems(H) floats per direction, two step slots);
+ * recurrent_in = 1: the tiles of step s_hi were published by an earlier call (a loop issued in blocks, highest steps
+ * first).  dc (Bp, H) is read at the start and holds the carried gradient at the end. */
+typedef struct GtPlstmBwd {
+    int32_t B, Bp, H, T, ndir, s_lo, s_hi, recurrent_in;
+    float p_drop;
+    const float* Whh;          /* (4H, H) PyTorch layout */
+    int64_t w_dstride;
+    const float* gates;        /* (T, Bp, 4H) gate values of the forward pass */
+    int64_t gates_dstride;
+    const float* c;            /* (T + 1, Bp, H) */
+    int64_t c_dstride;
+    const float* dh_direct;    /* gradient of the h emitted by step s at dh_direct + s * dd_step, rows of dd_ld */
+    int64_t dd_dstride, dd_step, dd_ld;
+    float* dG;                 /* (T, Bp, 4H) gate pre-activation gradients (out) */
+    int64_t dG_dstride;
+    float* dc;                 /* (Bp, H) */
+    int64_t dc_dstride;
+    float* xbuf;
+    int64_t x_dstride;
+    const uint8_t* keep;       /* (T, Bp, H) dropout keep mask of the forward pass, or NULL */
+    const int32_t* active;     /* (T, Bp), or NULL */
+    uint32_t* counters;        /* ndir words (zeroed by the call) */
+    int32_t* timeout_flag;
+} GtPlstmBwd;
+int64_t gt_plstm_bwd_xbuf_elems(int32_t H);
+int gt_plstm_bwd(const GtPlstmBwd* a, void* stream);
+
 int gt_decoder_fwd(const GtDecoderFwd* a, void* stream);
 int gt_decoder_bwd(const GtDecoderBwd* a, void* stream);
 int gt_bilstm_run(const GtBiLstm* a, void* stream);
@@ -763,67 +825,6 @@ int gt_attn_step_fwd(GtAttnDims d, GtSlabs qpart, const float* w_prev, const flo
                      int32_t* timeout_flag, const float* memory, int64_t ld_mem, float* w_out, const float* cum_in,
                      float* cum_out, float* c0, int64_t ld0, float* c1, int64_t ld1, float* c2, int64_t ld2,
                      void* stream);
-
-/* Persistent, weight-resident LSTM recurrence: ONE launch walks steps [s_lo, s_hi) of
- *   G_s = pre_s + h_{s-1} . W_hh^T,  cell,  h_s = dropout(o tanh c_s)
- * for ndir independent problems, each on H / 16 workgroups that keep W_hh in registers and exchange h through `hx`
- * (csrc/plstm.hip).  Used for the encoder BiLSTM (ndir = 2, packed-sequence semantics through `active`: model.py:202-210)
- * and for the decoder LSTM's h_dec recurrence inside a block of steps (ndir = 1, hx = the HC history itself: model.py:406-409).
- * Bp must be 64 and H 256 or 1024 (gt_plstm_supported).  Direction d of every per-direction buffer lies *_dstride
- * elements behind direction 0. */
-typedef struct GtPlstm {
-    int32_t B, Bp, H, T, ndir, s_lo, s_hi, hx_ring;
-    float p_drop;              /* dropout probability of `keep` (0: none) */
-    const float* Whh;          /* (4H, H) PyTorch layout, gate order i f g o */
-    int64_t w_dstride;
-    const float* pre;          /* (T, Bp, 4H) input projections + both biases */
-    int64_t pre_dstride;
-    float* gates;              /* (T, Bp, 4H) gate values kept for the backward pass; may alias pre */
-    int64_t gates_dstride;
-    float* c;                  /* (T + 1, Bp, H); slice s_lo is read, slices s_lo + 1 .. s_hi are written */
-    int64_t c_dstride;
-    float* hs;                 /* (T, Bp, H) emitted h (zero for inactive rows), or NULL */
-    int64_t hs_dstride;
-    float* hx;                 /* exchange: h_s is published at slot (hx_ring ? s % hx_ring : s) * hx_step, rows of hx_ld;
-                                  h_{s_lo - 1} is read from there when s_lo > 0.  hx_ring = 0 or >= 2 */
-    int64_t hx_dstride, hx_step, hx_ld;
-    const uint8_t* keep;       /* (T, Bp, H) keep mask of the dropout on h, or NULL */
-    const int32_t* active;     /* (T, Bp): rows with 0 pass their state through and emit zeros, or NULL */
-    uint32_t* counters;        /* ndir words (zeroed by the call) */
-    int32_t* timeout_flag;     /* raised when a bounded wait gives up (results invalid) */
-} GtPlstm;
-int32_t gt_plstm_supported(int32_t Bp, int32_t H);
-int gt_plstm_fwd(const GtPlstm* a, void* stream);
-
-/* Backward counterpart: ONE launch walks steps s_hi - 1 .. s_lo of  dh_s = dh_direct_s + dG_{s+1} . W_hh,  cell backward ->
- * dG_s, dc carried on (csrc/plstm.hip).  The recurrent term travels between the H / 16 workgroups of a problem as a
- * reduce-scatter of (64 x 16) tiles through `xbuf` (gt_plstm_bwd_xbuf_elems(H) floats per direction, two step slots);
- * recurrent_in = 1: the tiles of step s_hi were published by an earlier call (a loop issued in blocks, highest steps
- * first).  dc (Bp, H) is read at the start and holds the carried gradient at the end. */
-typedef struct GtPlstmBwd {
-    int32_t B, Bp, H, T, ndir, s_lo, s_hi, recurrent_in;
-    float p_drop;
-    const float* Whh;          /* (4H, H) PyTorch layout */
-    int64_t w_dstride;
-    const float* gates;        /* (T, Bp, 4H) gate values of the forward pass */
-    int64_t gates_dstride;
-    const float* c;            /* (T + 1, Bp, H) */
-    int64_t c_dstride;
-    const float* dh_direct;    /* gradient of the h emitted by step s at dh_direct + s * dd_step, rows of dd_ld */
-    int64_t dd_dstride, dd_step, dd_ld;
-    float* dG;                 /* (T, Bp, 4H) gate pre-activation gradients (out) */
-    int64_t dG_dstride;
-    float* dc;                 /* (Bp, H) */
-    int64_t dc_dstride;
-    float* xbuf;
-    int64_t x_dstride;
-    const uint8_t* keep;       /* (T, Bp, H) dropout keep mask of the forward pass, or NULL */
-    const int32_t* active;     /* (T, Bp), or NULL */
-    uint32_t* counters;        /* ndir words (zeroed by the call) */
-    int32_t* timeout_flag;
-} GtPlstmBwd;
-int64_t gt_plstm_bwd_xbuf_elems(int32_t H);
-int gt_plstm_bwd(const GtPlstmBwd* a, void* stream);
 
 #ifdef __cplusplus
 }
