@@ -44,7 +44,7 @@ FAMILIES = ['rec_gemm', 'sgemm', 'attn_energies_fwd', 'attn_context_fwd', 'attn_
             'lstm_cell_fwd', 'lstm_cell_bwd', 'rec_cell', 'plstm']
 NF = len(FAMILIES)                 # GT_PROF_FAMILIES of include/gantron_hip.h
 # kernel symbol of each family as rocprofv3 / profiles/rNN_pmc_traffic.json name it
-KERNEL_OF = {'rec_gemm': 'rec_gemm_kernel', 'sgemm': 'sgemm_kernel', 'attn_energies_fwd': 'attn_energies_fwd',
+KERNEL_OF = {'rec_gemm': 'rec_gemm_kernel', 'sgemm': 'sgemm_kernel', 'attn_energies_fwd': 'attn_step2_fwd',
              'attn_context_fwd': 'attn_context_fwd_kernel', 'attn_context_bwd': 'attn_context_bwd_kernel',
              'attn_energies_bwd': 'attn_energies_bwd', 'lstm_cell_fwd': 'lstm_cell_fwd_kernel',
              'lstm_cell_bwd': 'lstm_cell_bwd_kernel', 'rec_cell': 'rec_cell_kernel', 'plstm': 'plstm_fwd_kernel'}
