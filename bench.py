@@ -430,7 +430,7 @@ def main():
         pair(args.warmup + i)
     sync()
     elapsed = time.perf_counter() - t0
-    prof_out = (ctypes.c_double * (6 * NF + 2))()          # GT_PROF_DOUBLES
+    prof_out = (ctypes.c_double * (7 * NF + 2))()          # GT_PROF_DOUBLES
     _lib.check(lib.gt_prof_end(prof_out), 'gt_prof_end')
     log(f'timed region: {elapsed:.3f} s for {args.steps} pairs')
     from gantron_amd import engine as _engine
@@ -544,7 +544,7 @@ def main():
         # ceiling of 2500 / 6 TFLOP/s of fp32 work), the recurrent / attention products on the fp32 pipe: the pair is bound
         # by the SUM of the two pipes' times, not by all of its flops on the fp32 peak
         sg = next(r for r in fam if r['name'] == 'sgemm')
-        gemm_flops_pair = (sg['flops'] / max(sg['launches'], 1)) * sg['seen'] / args.steps if sg['launches'] else 0.0
+        gemm_flops_pair = out[6 * NF + 2 + FAMILIES.index('sgemm')] / args.steps          # every launch counted, not the sample
         gemm_peak = (BF16_MFMA_PEAK_TFLOPS if args.bf16 else
                      {0: FP32_MFMA_PEAK_TFLOPS, 3: BF16_MFMA_PEAK_TFLOPS / 6, 2: BF16_MFMA_PEAK_TFLOPS / 3}[_ops.FP32_SPLIT])
         if roof['families']['plstm']['launches']:

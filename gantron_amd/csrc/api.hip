@@ -106,6 +106,8 @@ void gt_prof_exact(int family, double flops, double bytes, hipEvent_t* e0, hipEv
 
 static int g_prof_stride = 1;
 static long g_prof_count[GT_FAM_COUNT];
+static double g_prof_flops_all[GT_FAM_COUNT];
+void gt_prof_count_flops(int family, double flops) { g_prof_flops_all[family] += flops; }
 
 bool g_gt_capturing = false;          // a decoder loop is being captured into a hipGraph: no timing brackets inside it
 
@@ -130,7 +132,7 @@ extern "C" int gt_prof_begin_sampled(int32_t stride) {
     g_prof_stride = stride;
     g_prof_null_every = stride > 1 ? 4 : 0;        // every 4th bracketed launch is followed by a bracketed empty kernel
     g_prof_null_ctr = 0;
-    for (int i = 0; i < GT_FAM_COUNT; ++i) g_prof_count[i] = 0;
+    for (int i = 0; i < GT_FAM_COUNT; ++i) { g_prof_count[i] = 0; g_prof_flops_all[i] = 0.0; }
     g_gt_prof_on = true;
     return 0;
 }
@@ -138,7 +140,8 @@ extern "C" int gt_prof_begin_sampled(int32_t stride) {
 // Stops recording, waits for the recorded events and fills per-family totals:
 // out[f*4+0] = bracketed launches, +1 = total ms, +2 = total flops, +3 = total bytes  (f < GT_FAM_COUNT);
 // out[4*GT_FAM_COUNT + f] = all launches of the family seen while profiling; then the empty-kernel brackets (count, ms);
-// out[5*GT_FAM_COUNT + 2 + f] = how many of the family's timed launches carry their own dispatch stamps (no event latency)
+// out[5*GT_FAM_COUNT + 2 + f] = how many of the family's timed launches carry their own dispatch stamps (no event latency);
+// out[6*GT_FAM_COUNT + 2 + f] = algorithmic flops of ALL launches of the family (bracketed or not)
 extern "C" int gt_prof_end(double* out) {
     g_gt_prof_on = false;
     GT_REQUIRE(out != nullptr, GT_E_ARG, "gt_prof_end: NULL");
@@ -146,6 +149,7 @@ extern "C" int gt_prof_end(double* out) {
     for (int i = 0; i < GT_FAM_COUNT; ++i) out[GT_FAM_COUNT * 4 + i] = (double)g_prof_count[i];
     out[GT_FAM_COUNT * 5] = out[GT_FAM_COUNT * 5 + 1] = 0.0;       // in-situ empty-kernel brackets: count, total ms
     for (int i = 0; i < GT_FAM_COUNT; ++i) out[GT_FAM_COUNT * 5 + 2 + i] = 0.0;     // launches timed by their own dispatch stamps
+    for (int i = 0; i < GT_FAM_COUNT; ++i) out[GT_FAM_COUNT * 6 + 2 + i] = g_prof_flops_all[i];       // flops of ALL launches
     for (auto& r : g_recs) {
         hipError_t e = hipEventSynchronize(r.e1);
         GT_REQUIRE(e == hipSuccess, (int)e, "gt_prof_end: event sync failed");

@@ -42,6 +42,7 @@ extern bool g_gt_prof_on;
 extern bool g_gt_capturing;          // loops.hip: stream capture in progress (GANTRON_EXPERIMENTAL=graph)
 extern double g_gt_prof_ctx_rows;   // valid attention-memory rows of the current batch (0: unknown, charge B*Ti)
 bool gt_prof_sample(int family);      // true for every `stride`-th launch of the family while profiling
+void gt_prof_count_flops(int family, double flops);      // algorithmic flops of EVERY launch of the family while profiling
 void gt_prof_mark(int family, double flops, double bytes, hipStream_t st, bool begin);
 void gt_prof_exact(int family, double flops, double bytes, hipEvent_t* e0, hipEvent_t* e1);
 // internal (not part of the C ABI): recurrent products with raised wave priority for the loops' critical chain
@@ -61,6 +62,7 @@ struct GtProfScope {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     GtProfScope(int family, double flops, double bytes, hipStream_t s, bool exact_ = false)
         : fam(family), st(s), on(g_gt_prof_on && gt_prof_sample(family)), exact(exact_) {
+        if (g_gt_prof_on) gt_prof_count_flops(family, flops);
         if (!on) return;
         if (exact) gt_prof_exact(fam, flops, bytes, &e0, &e1);
         else gt_prof_mark(fam, flops, bytes, st, true);

@@ -47,14 +47,15 @@ int64_t gt_abi_sizeof(int32_t which);
  * out[4*GT_PROF_FAMILIES + f] ALL launches of the family issued while profiling (bracketed or not); with sampling,
  * every 4th bracket is followed by the same bracket around an EMPTY kernel on the same stream:
  * out[5*GT_PROF_FAMILIES] their count, out[5*GT_PROF_FAMILIES + 1] their total ms.  `out` is a HOST array of
- * GT_PROF_DOUBLES = 62 doubles.  Not thread-safe.  A bracket = kernel duration (dispatch begin to end) + event latency
+ * GT_PROF_DOUBLES = 72 doubles.  Not thread-safe.  A bracket = kernel duration (dispatch begin to end) + event latency
  * (+ what the dispatch waited for), so the duration of a sampled kernel is bracket - (empty-kernel bracket -
  * empty-kernel duration), the latter from gt_prof_calibrate.  The two recurrent-product families (0 and 8) are not
  * bracketed: their sampled launches carry their own start / stop events (hipExtLaunchKernelGGL), stamped with the
  * dispatch's begin and end -- the duration a profiler reports; out[5*GT_PROF_FAMILIES + 2 + f] counts, per family, the
- * timed launches of that kind (no latency to subtract for them). */
+ * timed launches of that kind (no latency to subtract for them); out[6*GT_PROF_FAMILIES + 2 + f] the algorithmic flops of ALL
+ * launches of the family. */
 #define GT_PROF_FAMILIES 10
-#define GT_PROF_DOUBLES (6 * GT_PROF_FAMILIES + 2)
+#define GT_PROF_DOUBLES (7 * GT_PROF_FAMILIES + 2)
 int gt_prof_begin(void);
 /* the attention context kernels skip padded memory rows: tell the profiler how many rows of the current batch are valid
  * (sum of the memory lengths) so that their algorithmic bytes are charged for what they read; 0 = charge B*Ti */
