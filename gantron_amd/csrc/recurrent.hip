@@ -51,7 +51,8 @@ __global__ __launch_bounds__(256) void pack_rec_weight_kernel(const float* W, lo
 // wave per SIMD reached only ~60 % of the MFMA rate) and 64 KiB of weight loads are in flight per CU.
 // The two K-halves are folded through LDS at the end.  The wave's weight fragments (1 KiB per 16-wide
 // k-block, lane-linear) stream straight into VGPRs, one chunk ahead.
-constexpr int REC_CK = 8;                 // k-blocks (of 16) per LDS chunk
+constexpr int REC_CK = 8;                 // k-blocks (of 16) per LDS chunk (16: the fused step 29.3 us instead of 26.6, the
+                                          // backward products 28 instead of 20 -- round 3)
 constexpr int REC_HK = REC_CK / 2;        // k-blocks per wave per chunk
 constexpr int REC_LD = REC_CK * 16 + 4;   // padded LDS row: conflict-free ds_read_b128 / ds_write_b128
 constexpr int REC_THREADS = 512;
@@ -142,6 +143,7 @@ __device__ __forceinline__ float* rec_gemm_tile(const float* __restrict__ Xz, lo
         if (!(DBG & 1)) nxt.load(wp + (long)REC_CK * 64, kn + REC_HK * half, kb1);
 #pragma unroll
         for (int u = 0; u < REC_HK; ++u) {
+            if (kb + REC_HK * half + u >= kb1) break;       // (wave-uniform) k-blocks beyond the slice: zero weights, nothing to add
             float4 a[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float4*>(xs + mt * 16 * REC_LD + u * 16);
@@ -208,6 +210,8 @@ __device__ __forceinline__ void rec_gemm_body(const float* __restrict__ Xz, long
     }
 }
 
+// (Measured and not adopted, round 3: capped at 96 registers (amdgpu_waves_per_eu(5, 5), 52 bytes of scratch) so that a workgroup
+// fits beside TWO weight-gradient GEMM workgroups on a CU instead of one: 25 us per backward product instead of 20.)
 template <int MT, int DBG = 0>
 __global__ __launch_bounds__(REC_THREADS) void rec_gemm_kernel(const float* __restrict__ X, long ldx,
                                                                const float* __restrict__ Wp,
