@@ -796,6 +796,11 @@ extern "C" int gt_attn_energies_bwd_rec(GtAttnDims d, const float* dw, const flo
     return 0;
 }
 
+// the one-launch backward attention step (gt_attn_bwd_wterms + gt_attn_bwd_step + gt_attn_bwd_fixup) exists for these shapes
+extern "C" int32_t gt_attn_bwd_step_supported(GtAttnDims d) {
+    return (use_mfma(d) && d.Ti <= 512 && (size_t)d.E * 4 <= 32 * 1024 && d.E % 4 == 0) ? 1 : 0;
+}
+
 extern "C" int gt_attn_bwd_wterms(GtAttnDims d, int32_t nsteps, const float* w, int64_t w_step_stride, const float* u,
                                   const float* Wc, const float* Wd, const float* v, const int32_t* lengths, float* dq2,
                                   int64_t dq2_step_stride, int64_t ld_dq2, float* dwcat2, float* p_hist, const float* wpack,

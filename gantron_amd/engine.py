@@ -46,7 +46,10 @@ DEC_RING = 16     # ring of hand-off buffers between the two decoder chains;
 # is one tiled GEMM, only h_dec . W2hh stays in the per-step loops
 HOIST2 = sw.schedule_on('hoist2')
 # one launch per backward attention step (gt_attn_bwd_step) instead of context + energies backward; needs ATTN_HOIST, HOIST2
-ATTN_BWD_FUSED = bool(sw.experimental('attn_bwd_fused'))     # measured slower: off
+# context + energies backward of a step as ONE launch (gt_attn_bwd_step: the softmax row sums are applied by the consumers).
+# Round 2: neutral (132.3 against 132.5 ms per pair); round 3, with the rest of the loop shorter: 127.3-127.8 against
+# 128.1-128.4 in three alternating runs.  On (GANTRON_SCHEDULE=no_attn_bwd_fused: the two launches).
+ATTN_BWD_FUSED = sw.schedule_on('attn_bwd_fused')
 # fused product + cell (+ query) launches of the forward loops (gt_rec_cell_fwd): bit 0 = attention LSTM, bit 1 = decoder LSTM,
 # bit 2 = encoder BiLSTM; bits 3 / 4 = attention / decoder LSTM in bf16 mode (gt_rec_cell_fwd_bf16); bit 5 = the decoder
 # LSTM's backward product + cell backward (gt_rec_cellbwd; measured 0.3 ms slower per pair than two launches: off)
@@ -1064,7 +1067,8 @@ class GeneratorEngine:
             wpack_p = _f32(n_wpack, device=dev, zero=False)
             call('gt_attn_pack_weights', dims, Wc, Wd, wpack_p)
             BT = B * Ti
-        fused_attn = hoist and hoist2 and ATTN_BWD_FUSED
+        fused_attn = hoist and hoist2 and ATTN_BWD_FUSED and CELL_QUERY and Ha % 16 == 0 and N1pad % 4 == 0 and \
+            bool(lib().gt_attn_bwd_step_supported(dims))
         if fused_attn:
             # the terms of the energies backward that are linear in the step's own weights, for every step at once
             # (gt_attn_bwd_wterms): what the per-step launch subtracts s times from, see attention_mfma.hip

@@ -6,19 +6,22 @@ GANTRON_POISON=1       tests: buffers that are not zero-initialised start as NaN
 GANTRON_EXPERIMENTAL   comma list `name[=int]` of paths that were built, are parity-tested and measured SLOWER or no faster
                        than the default ("measured and not adopted"); nothing here is needed for
                        correctness and the default path never runs them:
-                         fused_cell, attn_step, attn_bwd_fused, leaf_defer, rec_cellbwd (the decoder LSTM's fused backward
-                         step), plane_gemms (pre-split GEMM operands), plstm=<bits> (persistent LSTM recurrences, default 3: 1
-                         encoder, 2 decoder; 0 = per-step launches), graph[=2] (hipGraph replay of the decoder loops; 2 also reports capture / replay),
+                         fused_cell, attn_step, leaf_defer, rec_cellbwd (the decoder LSTM's fused backward step), plane_gemms
+                         (pre-split GEMM operands), plstm=<bits> (persistent LSTM recurrences, default 7: 1 encoder forward, 2
+                         decoder forward blocks, 4 encoder backward, 8 decoder backward blocks; 0 = per-step launches),
+                         rec_x3=<bits> (attention-LSTM products from three bf16 planes: 1 forward, 2 backward), graph[=2] (hipGraph replay of the decoder loops; 2 also reports capture / replay),
                          no_pgemm2 (keep the plane GEMMs on 128 x 128 tiles).
 GANTRON_SCHEDULE       comma list switching OFF parts of the default schedule (what the schedule-invariance test toggles
                        through the module attributes instead): no_cell_query, no_attn_hoist, no_hoist2, no_leaf_stream,
                        no_fwd_splitk, no_rec_cell (per-step product + cell launches instead of the fused ones), no_attn_step2 (energies
                        and softmax + context of a forward step as two launches instead of gt_attn_step2_fwd), no_plstm (per-step
-                       launches instead of the persistent LSTM recurrences),
+                       launches instead of the persistent LSTM recurrences), no_attn_bwd_fused (context and energies backward
+                       of a step as two launches),
                        no_dist_overlap.
 GANTRON_DEBUG          comma list of diagnostics: phase_timing, host_timing, block_timing, dist_timing, attn_valu,
                        rec=<bits> / fused=<bits> / pgemm=<bits> (kernel knock-outs), rec_splits=<n>, s1_fwd=<n>, s2_fwd=<n>,
-                       s2_bwd=<n>, enc_splits=<n>, sync_every=<n>, rec_lds_pad=<n>.
+                       s2_bwd=<n>, s1_bwd=<n>, enc_splits=<n>, sync_every=<n>, rec_lds_pad=<n>, rec_stamps (phase stamps of the
+                       attention LSTM's launch: tools/rec_stamps.py).
 (The C side parses the same variables: csrc/api.hip, gt_env_item.)  bench.py / the tests additionally use
 GANTRON_FORCE_DIST, GANTRON_BENCH_DEVICE and GANTRON_BENCH_BACKEND for the one-GPU rehearsals of the multi-rank paths.
 Tuned constants (block sizes, split-K targets, ring depth ...) are plain module attributes of engine.py / ops.py."""

@@ -800,6 +800,7 @@ int gt_cell_bwd_query_c(GtSlabs dh_a, GtSlabs dh_c, const float* dq, int64_t ld_
  *                       dwcat2 -- the carried planes are read as dwcat_in - s_prev dwcat2_prev.
  *  gt_attn_bwd_fixup  : de[t] = e1[t] - s_t w_t and dq[t] -= s_t dq2[t] for `nsteps` steps (sum: (nsteps, B, chunks)).
  * The attention cell backward takes the correction on the fly (gt_cell_bwd_query_c). */
+int32_t gt_attn_bwd_step_supported(GtAttnDims d);
 int gt_attn_bwd_wterms(GtAttnDims d, int32_t nsteps, const float* w, int64_t w_step_stride, const float* u,
                        const float* Wc, const float* Wd, const float* v, const int32_t* lengths, float* dq2,
                        int64_t dq2_step_stride, int64_t ld_dq2, float* dwcat2, float* p_hist, const float* wpack,

@@ -179,14 +179,15 @@ def test_midsize_against_oracle(dev, case, monkeypatch):
         return _midsize_against_oracle(dev, case)
 
 
-def test_fused_attention_backward_step_against_oracle(dev, monkeypatch):
-    """The opt-in one-launch backward attention step (GANTRON_EXPERIMENTAL=attn_bwd_fused: gt_attn_bwd_wterms + gt_attn_bwd_step +
-    gt_cell_bwd_query_c + gt_attn_bwd_fixup) through a whole generator + discriminator pair at the reference's attention
-    dimensions, against the oracle."""
+@pytest.mark.parametrize('fused,case', [(True, 'full_dims_b20'), (False, 'full_dims_b20'), (False, 'full_dims_b64')])
+def test_attention_backward_step_forms_against_oracle(dev, monkeypatch, fused, case):
+    """The backward attention step as ONE launch (the default: gt_attn_bwd_wterms + gt_attn_bwd_step + gt_cell_bwd_query_c +
+    gt_attn_bwd_fixup) and as two (GANTRON_SCHEDULE=no_attn_bwd_fused: gt_attn_context_bwd + gt_attn_energies_bwd_rec) through
+    whole generator + discriminator pairs at the reference's attention dimensions, against the oracle."""
     from gantron_amd import engine
-    monkeypatch.setattr(engine, 'ATTN_BWD_FUSED', True)
+    monkeypatch.setattr(engine, 'ATTN_BWD_FUSED', fused)
     assert engine.ATTN_HOIST and engine.HOIST2
-    _midsize_against_oracle(dev, 'full_dims_b20')
+    _midsize_against_oracle(dev, case)
 
 
 @pytest.mark.parametrize('case,bits', [('full_dims_b64', 15), ('full_dims_b64_poison', 15), ('vesus_b64', 15), ('full_dims_b64', 3),
@@ -635,7 +636,8 @@ def test_full_size_training_step_is_schedule_invariant(dev, monkeypatch):
     out0, g0 = run()
     monkeypatch.undo()
     monkeypatch.setattr(ops, 'FWD_SPLITK', False)
-    assert engine.DEC_RING > 1 and engine.BWD_CHUNKS > 1 and engine.ATTN_HOIST and engine.LEAF.enabled and engine.HOIST2 and engine.PLSTM == 7
+    assert engine.DEC_RING > 1 and engine.BWD_CHUNKS > 1 and engine.ATTN_HOIST and engine.LEAF.enabled and engine.HOIST2 and engine.PLSTM == 7 and \
+        engine.ATTN_BWD_FUSED
     out1, g1 = run()
     for name, a, b in zip(('mel', 'mel_post', 'gate', 'align'), out1, out0):
         close(a, b, rtol=1e-4, atol=1e-6, what=f'out.{name}')
