@@ -518,6 +518,42 @@ typedef struct GtDecoderInfer {
     int32_t t_lo, t_hi;
 } GtDecoderInfer;
 
+/* gt_cell_bwd_query with a corrected query gradient dq - s dq2, s[m] = sum of row m's n_sum entries of dq_sum (B, n_sum): the
+ * consumer side of the fused backward attention step (gt_attn_bwd_step); dq2 laid out like dq.  dq_sum = dq2 = NULL:
+ * gt_cell_bwd_query. */
+int gt_cell_bwd_query_c(GtSlabs dh_a, GtSlabs dh_c, const float* dq, int64_t ld_dq, const float* dq_sum, int32_t n_sum,
+                        const float* dq2, const float* Wq, int64_t ldwq, const float* dc_next, const float* gates,
+                        const float* c_new, const float* c_prev, const uint8_t* keep, float p_drop, float* dgates,
+                        float* dc_prev, int32_t B, int32_t Bp, int32_t H, int32_t A, void* stream);
+
+/* Backward attention step as ONE launch (the default where gt_attn_bwd_step_supported: (128, 32, 31) dimensions, Ti <= 512;
+ * model.py:70-91 through autograd).  The softmax backward needs one scalar per batch
+ * row, s = sum_t w dw, but everything after it is linear in de = w dw - s w.  With M[t][d] = v[d] (1 - u[t][d]^2) and
+ * P = (M . Wd) . Wc (62 columns per position, stored 64 wide), functions of forward quantities only:
+ *     dq[d] = sum_t de[t] M[t][d],   d[w_prev; w_cum][c][t0 + p - 15] = sum_k de[p - k] P[p - k][(c, k)].
+ *  gt_attn_bwd_wterms : for `nsteps` steps in ONE launch: p_hist[t] = P ((B, Ti, 64) per step), dq2[t] = Lq(w_t) (step
+ *                       stride dq2_step_stride, rows ld_dq2 apart) and dwcat2[t] = Lw(w_t) ((2, B, Ti) per step); dq2 /
+ *                       dwcat2 zero-initialised by the caller; w advances by w_step_stride per step, u by B*Ti*A.
+ *  gt_attn_bwd_step   : gt_attn_context_bwd's inputs (dctx sources, memory, carried planes dwcat_in / dcum_acc, dw_extern,
+ *                       dctx_out) + the step's w, u and P rows.  Writes e1 = w dw to e1_out (B, Ti), the tile sums of e1 to
+ *                       sum_out (B, gt_attn_chunks(Ti)), and ADDS Lq(e1) to dq (zeroed by the caller) and Lw(e1) to
+ *                       dwcat_out.  sum_prev / dwcat2_prev (both or neither): the previous call's sum_out and that step's
+ *                       dwcat2 -- the carried planes are read as dwcat_in - s_prev dwcat2_prev.
+ *  gt_attn_bwd_fixup  : de[t] = e1[t] - s_t w_t and dq[t] -= s_t dq2[t] for `nsteps` steps (sum: (nsteps, B, chunks)).
+ * The attention cell backward takes the correction on the fly (gt_cell_bwd_query_c). */
+int32_t gt_attn_bwd_step_supported(GtAttnDims d);
+int gt_attn_bwd_wterms(GtAttnDims d, int32_t nsteps, const float* w, int64_t w_step_stride, const float* u,
+                       const float* Wc, const float* Wd, const float* v, const int32_t* lengths, float* dq2,
+                       int64_t dq2_step_stride, int64_t ld_dq2, float* dwcat2, float* p_hist, const float* wpack,
+                       void* stream);
+int gt_attn_bwd_step(GtAttnDims d, GtSlabs dctx_a, GtSlabs dctx_b, const float* dctx_direct, int64_t ld_direct,
+                     const float* memory, int64_t ld_mem, const int32_t* lengths, float* dwcat_in, float* dcum_acc,
+                     const float* dw_extern, float* dctx_out, int64_t ld_dctx_out, const float* w, const float* u,
+                     const float* v, const float* p, const float* sum_prev, const float* dwcat2_prev, float* sum_out,
+                     float* dq, int64_t ld_dq, float* dwcat_out, float* e1_out, void* stream);
+int gt_attn_bwd_fixup(GtAttnDims d, int32_t nsteps, const float* sum, const float* w, int64_t w_step_stride,
+                      float* de, float* dq, int64_t dq_step_stride, int64_t ld_dq, const float* dq2, void* stream);
+
 /* Persistent, weight-resident LSTM recurrence: ONE launch walks steps [s_lo, s_hi) of
  *   G_s = pre_s + h_{s-1} . W_hh^T,  cell,  h_s = dropout(o tanh c_s)
  * for ndir independent problems, each on H / 16 workgroups that keep W_hh in registers and exchange h through `hx`
@@ -777,41 +813,6 @@ int gt_lstm_step_fused(const float* X, int64_t ldx, const float* Wg, int32_t K, 
                        int64_t ld_pre, const float* c_prev, const uint8_t* keep, float p_drop, float* gates,
                        float* c_out, float* h_raw, float* h0, int64_t ld0, float* h1, int64_t ld1, float* h2,
                        int64_t ld2, int32_t B, int32_t Bp, int32_t H, void* stream);
-
-/* the same with a corrected query gradient dq - s dq2, s[m] = sum of row m's n_sum entries of dq_sum (B, n_sum): the
- * consumer side of the fused backward attention step (gt_attn_bwd_step); dq2 laid out like dq.  dq_sum = dq2 = NULL:
- * gt_cell_bwd_query. */
-int gt_cell_bwd_query_c(GtSlabs dh_a, GtSlabs dh_c, const float* dq, int64_t ld_dq, const float* dq_sum, int32_t n_sum,
-                        const float* dq2, const float* Wq, int64_t ldwq, const float* dc_next, const float* gates,
-                        const float* c_new, const float* c_prev, const uint8_t* keep, float p_drop, float* dgates,
-                        float* dc_prev, int32_t B, int32_t Bp, int32_t H, int32_t A, void* stream);
-
-/* Fused backward attention step ((128, 32, 31) dimensions, Ti <= 512).  The softmax backward needs one scalar per batch
- * row, s = sum_t w dw, but everything after it is linear in de = w dw - s w.  With M[t][d] = v[d] (1 - u[t][d]^2) and
- * P = (M . Wd) . Wc (62 columns per position, stored 64 wide), functions of forward quantities only:
- *     dq[d] = sum_t de[t] M[t][d],   d[w_prev; w_cum][c][t0 + p - 15] = sum_k de[p - k] P[p - k][(c, k)].
- *  gt_attn_bwd_wterms : for `nsteps` steps in ONE launch: p_hist[t] = P ((B, Ti, 64) per step), dq2[t] = Lq(w_t) (step
- *                       stride dq2_step_stride, rows ld_dq2 apart) and dwcat2[t] = Lw(w_t) ((2, B, Ti) per step); dq2 /
- *                       dwcat2 zero-initialised by the caller; w advances by w_step_stride per step, u by B*Ti*A.
- *  gt_attn_bwd_step   : gt_attn_context_bwd's inputs (dctx sources, memory, carried planes dwcat_in / dcum_acc, dw_extern,
- *                       dctx_out) + the step's w, u and P rows.  Writes e1 = w dw to e1_out (B, Ti), the tile sums of e1 to
- *                       sum_out (B, gt_attn_chunks(Ti)), and ADDS Lq(e1) to dq (zeroed by the caller) and Lw(e1) to
- *                       dwcat_out.  sum_prev / dwcat2_prev (both or neither): the previous call's sum_out and that step's
- *                       dwcat2 -- the carried planes are read as dwcat_in - s_prev dwcat2_prev.
- *  gt_attn_bwd_fixup  : de[t] = e1[t] - s_t w_t and dq[t] -= s_t dq2[t] for `nsteps` steps (sum: (nsteps, B, chunks)).
- * The attention cell backward takes the correction on the fly (gt_cell_bwd_query_c). */
-int32_t gt_attn_bwd_step_supported(GtAttnDims d);
-int gt_attn_bwd_wterms(GtAttnDims d, int32_t nsteps, const float* w, int64_t w_step_stride, const float* u,
-                       const float* Wc, const float* Wd, const float* v, const int32_t* lengths, float* dq2,
-                       int64_t dq2_step_stride, int64_t ld_dq2, float* dwcat2, float* p_hist, const float* wpack,
-                       void* stream);
-int gt_attn_bwd_step(GtAttnDims d, GtSlabs dctx_a, GtSlabs dctx_b, const float* dctx_direct, int64_t ld_direct,
-                     const float* memory, int64_t ld_mem, const int32_t* lengths, float* dwcat_in, float* dcum_acc,
-                     const float* dw_extern, float* dctx_out, int64_t ld_dctx_out, const float* w, const float* u,
-                     const float* v, const float* p, const float* sum_prev, const float* dwcat2_prev, float* sum_out,
-                     float* dq, int64_t ld_dq, float* dwcat_out, float* e1_out, void* stream);
-int gt_attn_bwd_fixup(GtAttnDims d, int32_t nsteps, const float* sum, const float* w, int64_t w_step_stride,
-                      float* de, float* dq, int64_t dq_step_stride, int64_t ld_dq, const float* dq2, void* stream);
 
 /* One launch for a whole forward attention step = gt_attn_energies_fwd_u + gt_attn_context_fwd (model.py:70-91), for the
  * dimensions gt_attn_step_supported() accepts ((128, 32, 31), Ti <= 256, E % 4 == 0).  The workgroups of a batch row
