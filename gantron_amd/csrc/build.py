@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
-SOURCES = ['api.hip', 'gemm.hip', 'recurrent.hip', 'recurrent_bf16.hip', 'recurrent_fused.hip', 'cell_query.hip', 'attention.hip', 'attention_mfma.hip', 'elementwise.hip', 'loss_optim.hip', 'loops.hip', 'plstm.hip']
+SOURCES = ['api.hip', 'gemm.hip', 'recurrent.hip', 'recurrent_bf16.hip', 'recurrent_fused.hip', 'cell_query.hip', 'attention.hip', 'attention_mfma.hip', 'elementwise.hip', 'loss_optim.hip', 'loops.hip', 'plstm.hip', 'collective.hip']
 LIB = os.path.join(PKG, 'libgantron_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
          '-fno-gpu-rdc', '-DNDEBUG']
@@ -57,7 +57,7 @@ def build(force=False, verbose=True):
         list(ex.map(run, jobs))
     objs = [os.path.join(objdir, s.replace('.hip', '.o')) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
-        run([hipcc, '-shared', '-fPIC', '--offload-arch=gfx950', '-o', LIB] + objs)
+        run([hipcc, '-shared', '-fPIC', '--offload-arch=gfx950', '-o', LIB] + objs + ['-ldl'])
     return LIB
 
 

@@ -621,6 +621,14 @@ int gt_decoder_bwd(const GtDecoderBwd* a, void* stream);
 int gt_bilstm_run(const GtBiLstm* a, void* stream);
 int gt_decoder_infer(const GtDecoderInfer* a, void* stream);
 
+/* ------------------------------------------------------------------------------------ collective
+ * The data-parallel gradient average (distributed.py:137-161: ONE flat all-reduce(SUM) per backward, then / world size) for a
+ * host that binds this library without PyTorch: buf[0..n) <- (sum over the ranks of `comm`) / ranks, in place, enqueued on
+ * `stream`.  `comm` is the caller's RCCL communicator (ncclComm_t); RCCL is resolved at the first call from the librccl
+ * already in the process (else loaded by name), never linked.  Returns the RCCL error code (> 0) if RCCL fails.  The Python
+ * package averages through torch.distributed (backend "nccl" = RCCL) instead: gantron_amd/distributed.py. */
+int gt_allreduce_avg(void* comm, float* buf, int64_t n, void* stream);
+
 /* -------------------------------------------------------------------- elementwise / reductions */
 /* per-column sums over rows: BatchNorm1d batch statistics incl. padding (model.py:123,176) and
  * bias gradients.  out[0..C) = sum x, out[C..2C) = sum x*y (sum x*x if y is NULL).  Passing

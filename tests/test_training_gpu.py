@@ -459,6 +459,63 @@ def test_data_parallel_step_rccl_two_gpus(tmp_path):
           what='averaged generator gradient')
 
 
+_CABI_ALLREDUCE = r'''
+import ctypes, os, sys
+root, rank, world, idfile = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+sys.path.insert(0, root)
+import torch
+from gantron_amd._lib import check, lib
+rccl = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so'))
+class UniqueId(ctypes.Structure):
+    _fields_ = [('internal', ctypes.c_char * 128)]
+torch.cuda.set_device(rank % torch.cuda.device_count())
+uid = UniqueId()
+if rank == 0:
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    open(idfile + '.tmp', 'wb').write(ctypes.string_at(ctypes.byref(uid), 128))
+    os.replace(idfile + '.tmp', idfile)
+else:
+    import time
+    while not os.path.exists(idfile):
+        time.sleep(0.05)
+    ctypes.memmove(ctypes.byref(uid), open(idfile, 'rb').read(), 128)
+comm = ctypes.c_void_p()
+rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+assert rccl.ncclCommInitRank(ctypes.byref(comm), world, uid, rank) == 0
+n = 1000003                                       # not a multiple of 4: the scalar tail of the scaling pass
+buf = torch.arange(n, device='cuda', dtype=torch.float32) * (rank + 1) * 1e-3
+want = torch.arange(n, dtype=torch.float64) * 1e-3 * sum(r + 1 for r in range(world)) / world
+st = torch.cuda.current_stream().cuda_stream
+check(lib().gt_allreduce_avg(comm, buf.data_ptr(), n, st), 'gt_allreduce_avg')
+torch.cuda.synchronize()
+err = float((buf.cpu().double() - want).abs().max() / want.abs().max())
+assert err < 1e-6, err
+rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+rccl.ncclCommDestroy(comm)
+print('OK', rank, err)
+'''
+
+
+@pytest.mark.parametrize('world', [1, 2])
+def test_c_abi_gradient_average_over_rccl(tmp_path, world):
+    """gt_allreduce_avg (SURVEY 8b: the collective behind the C ABI, distributed.py:137-161): a communicator made with RCCL's
+    own C API, no torch.distributed -- one rank on the one-GPU box (sum over one rank, no scaling), two ranks with one GPU
+    each wherever two are visible (sum, then / 2; n is not a multiple of 4)."""
+    import subprocess
+    import sys
+    if world > torch.cuda.device_count():
+        pytest.skip('needs two GPUs (one RCCL rank per GPU)')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'cabi_allreduce.py'
+    script.write_text(_CABI_ALLREDUCE)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    procs = [subprocess.Popen([sys.executable, str(script), root, str(r), str(world), str(tmp_path / 'nccl_id')], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    for p in procs:
+        out, _ = p.communicate(timeout=300)
+        assert p.returncode == 0 and 'OK' in out, out[-2000:]
+
+
 def test_steps_with_linear_discriminator(dev):
     """hparams.discriminator_type = 'linear': the generator step (adversarial gradient into the spectrogram) and the
     discriminator step run through the same step bodies and produce finite losses and non-zero gradients."""
