@@ -217,7 +217,9 @@ __device__ __forceinline__ void rec_gemm_body(const float* __restrict__ Xz, long
 }
 
 // (Measured and not adopted, round 3: capped at 96 registers (amdgpu_waves_per_eu(5, 5), 52 bytes of scratch) so that a workgroup
-// fits beside TWO weight-gradient GEMM workgroups on a CU instead of one: 25 us per backward product instead of 20.)
+// fits beside TWO weight-gradient GEMM workgroups on a CU instead of one: 25 us per backward product instead of 20.  Restructured
+// by hand to 95 registers without scratch -- one weight buffer, each fragment refilled with the next chunk's as soon as its
+// value is copied out: 20.5-21.1 us against 21.0-21.1, pair 127.7 against 128.0-128.3.  Registers are not what it waits for.)
 template <int MT, int DBG = 0>
 __global__ __launch_bounds__(REC_THREADS) void rec_gemm_kernel(const float* __restrict__ X, long ldx,
                                                                const float* __restrict__ Wp,
