@@ -43,24 +43,25 @@ __global__ __launch_bounds__(256) void pack_rec_weight_kernel(const float* W, lo
     }
 }
 
-// Activation chunks (MT*16 rows x 128 k) are staged through LDS once per workgroup with fully
-// coalesced 512-byte row segments and shared by all waves; the next chunk's global loads are issued
+// Activation chunks (MT*16 rows x 64 k) are staged through LDS once per workgroup with fully
+// coalesced 256-byte row segments and shared by all waves; the next chunk's global loads are issued
 // into registers before the current chunk's MFMAs.  A workgroup has 8 waves = 2 per SIMD: wave w owns
 // gate columns [16*(w&3), +16) of the workgroup's 64 and the k-blocks of half (w>>2) of every chunk, so
 // two waves interleave on each matrix pipe (one's LDS/VMEM waits hide under the other's MFMAs; a single
-// wave per SIMD reached only ~60 % of the MFMA rate) and 64 KiB of weight loads are in flight per CU.
+// wave per SIMD reached only ~60 % of the MFMA rate).
 // The two K-halves are folded through LDS at the end.  The wave's weight fragments (1 KiB per 16-wide
-// k-block, lane-linear) stream straight into VGPRs, one chunk ahead.
-constexpr int REC_CK = 8;                 // k-blocks (of 16) per LDS chunk (16: the fused step 29.3 us instead of 26.6, the
-                                          // backward products 28 instead of 20 -- round 3)
+// k-block, lane-linear) stream straight into VGPRs, one chunk ahead (two chunks ahead through three rotating buffers, round 3:
+// 126.9-127.2 ms per pair against 125.3-126.1).
+constexpr int REC_CK = 4;                 // k-blocks (of 16) per LDS chunk.  Round 3, pair time / fused forward step / backward
+                                          // product in the loop: 16 blocks 140 ms / 29.3 us / 28 us; 8 (rounds 1-3) 127.4-128.0 /
+                                          // 26.2 / 20.5-21; 4: 125.3-126.1 / 25.3 / 19.7-20.4; 2: 136.4-137.0 / 34 / 23.5
 constexpr int REC_HK = REC_CK / 2;        // k-blocks per wave per chunk
 constexpr int REC_LD = REC_CK * 16 + 4;   // padded LDS row: conflict-free ds_read_b128 / ds_write_b128
 constexpr int REC_THREADS = 512;
 
 template <int MT>
 struct RecChunk {                         // per-thread registers of one activation chunk
-    static constexpr int NV = MT * 16 * REC_CK * 16 / 4 / REC_THREADS;   // float4 per thread (= MT)
-    static_assert(NV >= 1, "every thread stages at least one float4 per chunk");
+    static constexpr int NV = (MT * 16 * REC_CK * 16 / 4 + REC_THREADS - 1) / REC_THREADS;   // float4 per thread
     float4 v[NV];
     __device__ __forceinline__ void load(const float* X, long ldx, int kb, int kb1, int tid) {
 #pragma unroll
@@ -68,8 +69,8 @@ struct RecChunk {                         // per-thread registers of one activat
             const int f = tid + REC_THREADS * i;
             const int row = f / (REC_CK * 4), c4 = f % (REC_CK * 4);
             const int kblk = kb + (c4 >> 2);
-            v[i] = (kblk < kb1) ? *reinterpret_cast<const float4*>(X + (long)row * ldx + (long)kb * 16 + 4 * c4)
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[i] = (kblk < kb1 && row < MT * 16) ? *reinterpret_cast<const float4*>(X + (long)row * ldx + (long)kb * 16 + 4 * c4)
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     __device__ __forceinline__ void store(float* S, int tid) const {
@@ -77,7 +78,7 @@ struct RecChunk {                         // per-thread registers of one activat
         for (int i = 0; i < NV; ++i) {
             const int f = tid + REC_THREADS * i;
             const int row = f / (REC_CK * 4), c4 = f % (REC_CK * 4);
-            *reinterpret_cast<float4*>(&S[row * REC_LD + 4 * c4]) = v[i];
+            if (row < MT * 16) *reinterpret_cast<float4*>(&S[row * REC_LD + 4 * c4]) = v[i];
         }
     }
 };
@@ -110,8 +111,10 @@ template <int MT, int DBG, int NBUF = 1>
 __device__ __forceinline__ float* rec_gemm_tile(const float* __restrict__ Xz, long ldx, const float* __restrict__ Wpz,
                                                 int N, int KB, int kb0, int kb1, int cg, long long* stamps = nullptr) {
     static_assert(MT == 4 || MT == 2 || MT == 1 || MT == 3, "row tiles");
-    __shared__ __attribute__((aligned(16))) float Xs2[NBUF][MT * 16 * REC_LD];
-    float* Xs = Xs2[0];
+    // the staging buffer(s); at least as large as what the callers' epilogues use of it afterwards
+    constexpr int SLOT = MT * 16 * REC_LD;
+    constexpr int EPI = MT * 16 * (REC_EP_LD + 20) + 4;
+    __shared__ __attribute__((aligned(16))) float Xs[NBUF * SLOT > EPI ? NBUF * SLOT : EPI];
     if (DBG & 8) return Xs;               // diagnostics: pure launch + wave start-up cost
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = wave >> 2;
@@ -128,7 +131,7 @@ __device__ __forceinline__ float* rec_gemm_tile(const float* __restrict__ Xz, lo
     RecChunk<MT> xc;                      // MT float4 per thread: MT*16 rows x 32 float4 over 512 threads
     RecW wa, wb;
     auto xload = [&](int kb) __attribute__((always_inline)) { xc.load(Xz, ldx, kb, kb1, tid); };
-    auto xstore = [&](int slot) __attribute__((always_inline)) { xc.store(Xs2[slot % NBUF], tid); };
+    auto xstore = [&](int slot) __attribute__((always_inline)) { xc.store(Xs + (slot % NBUF) * SLOT, tid); };
     xload(kb0);
     wa.load(wp, kb0 + REC_HK * half, kb1);
     if (DBG & 1) wb = wa;
@@ -138,7 +141,7 @@ __device__ __forceinline__ float* rec_gemm_tile(const float* __restrict__ Xz, lo
     auto chunk = [&](const RecW& cur, RecW& nxt, int kb, int slot) __attribute__((always_inline)) {
         if (!(DBG & 4) || kb == kb0) xstore(slot);
         __syncthreads();                  // also: every wave is done with the chunk before last, which lived in this slot
-        const float* xs = Xs2[slot % NBUF] + (lane & 15) * REC_LD + 4 * (lane >> 4) + REC_HK * half * 16;
+        const float* xs = Xs + (slot % NBUF) * SLOT + (lane & 15) * REC_LD + 4 * (lane >> 4) + REC_HK * half * 16;
         if (stamps != nullptr && tid == 0) {
             if (kb == kb0) stamps[1] = wall_clock64();                      // first activation chunk arrived
             else if (kb == kb0 + REC_CK) stamps[7] = wall_clock64();        // second chunk published
@@ -179,7 +182,6 @@ __device__ __forceinline__ float* rec_gemm_tile(const float* __restrict__ Xz, lo
     // Epilogue through LDS (Xs is free after the last barrier): the two K-halves are folded into a row-major
     // [row][64 columns] tile so that the slab is written with full-line float4 stores by all 8 waves (the MFMA
     // C layout would give 16 scalar stores of 64-byte pieces per lane, by half of the waves only).
-    static_assert(MT * 16 * EP_LD <= MT * 16 * REC_LD, "epilogue tile fits the staging buffer");
     float* red = Xs;
     const int ecol = (wave & 3) * 16 + (lane & 15), erow = 4 * (lane >> 4);
     if (half == 1) {
@@ -284,7 +286,6 @@ __global__ __launch_bounds__(REC_THREADS) void rec_cell_kernel(const float* __re
     REC_STAMP(e, 0);
     float* red = rec_gemm_tile<MT, 0, 2>(X + (long)rb * xz, ldx, Wp, N, KB, kb0, min(KB, kb0 + KBS), cg,
                                           e.stamps ? e.stamps + ((long)blockIdx.x + (long)gridDim.x * blockIdx.y) * 8 : nullptr);
-    static_assert(MT * 16 * REC_EP_LD + MT * 16 * 20 + 4 <= MT * 16 * REC_LD, "epilogue scratch fits the staging buffer");
     rec_cell_epilogue<MT>(red, e, part + (long)rb * pz, ps, N, cg, s, rb, e.counters + (long)z * gridDim.x + cg);
 }
 
@@ -299,8 +300,7 @@ __global__ __launch_bounds__(REC_THREADS) void rec_cellbwd_kernel(const float* _
     else if (prio == 1) __builtin_amdgcn_s_setprio(1);
     const int cg = blockIdx.x, s = blockIdx.y, rb = blockIdx.z;
     const int kb0 = s * KBS;
-    float* red = rec_gemm_tile<MT, 0>(X + (long)rb * xz, ldx, Wp, N, KB, kb0, min(KB, kb0 + KBS), cg);
-    static_assert(MT * 16 * REC_EP_LD + 4 <= MT * 16 * REC_LD, "epilogue scratch fits the staging buffer");
+    float* red = rec_gemm_tile<MT, 0, 2>(X + (long)rb * xz, ldx, Wp, N, KB, kb0, min(KB, kb0 + KBS), cg);
     rec_cellbwd_epilogue<MT>(red, e, part + (long)rb * pz, ps, N, cg, s, rb, e.counters + (long)rb * gridDim.x + cg);
 }
 
