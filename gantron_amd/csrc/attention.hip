@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void attn_energies_fwd_kernel(GtAttnDims dims,
         const int tn = t0 + tl + G;
         pm_next = (i + 1 < NIT && tn < d.Ti) ? pm_b[(long)tn * d.A] : 0.f;
         const float sarg = qd + pm_cur + dense_dot(S, tl, wrow);
-        S.buf[tl * LDS_A + dd] = (t0 + tl < d.Ti) ? vd * tanhf(sarg) : 0.f;
+        S.buf[tl * LDS_A + dd] = (t0 + tl < d.Ti) ? vd * tanhf_(sarg) : 0.f;
     }
     __syncthreads();
     // reduce over the attention channels: 8 lanes per position
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void attn_energies_bwd_kernel(GtAttnDims dims,
         }
         float ds = 0.f;
         if (t0 + tl < d.Ti) {
-            const float u = tanhf(qd + pm_cur + s0 + s1);
+            const float u = tanhf_(qd + pm_cur + s0 + s1);
             const float de = S.de[tl];
             ds = de * vd * (1.f - u * u);
             dv_acc += de * u;
@@ -670,8 +670,8 @@ extern "C" int gt_attn_step2_fwd(GtAttnDims d, GtSlabs qpart, const float* w_pre
     int rc = check_dims(d, "gt_attn_step2_fwd");
     if (rc) return rc;
     GT_REQUIRE(gt_attn_step2_supported(d), GT_E_LIMIT, "gt_attn_step2_fwd: needs attention dims (128, 32, 31), Ti <= 256, E %% 4 == 0 and E <= 1024");
-    GT_REQUIRE(qpart.p && w_prev && w_cum && pm && Wc && Wd && v && xbuf && row_cnt && memory && w_out && step1 >= 1, GT_E_ARG,
-               "gt_attn_step2_fwd: NULL pointer");
+    GT_REQUIRE(qpart.p && w_prev && w_cum && pm && Wc && Wd && v && xbuf && row_cnt && memory && w_out && wpack && step1 >= 1, GT_E_ARG,
+               "gt_attn_step2_fwd: NULL pointer (wpack, the gt_attn_pack_weights image, is required)");
     GT_REQUIRE(cum_out == nullptr || cum_in != nullptr, GT_E_ARG, "gt_attn_step2_fwd: cum_in missing");
     auto ok4 = [](const void* p, int64_t ld) { return p == nullptr || (aligned16(p) && ld % 4 == 0); };
     GT_REQUIRE(ok4(memory, ld_mem) && ld_mem >= d.E && ok4(c0, ld0) && ok4(c1, ld1) && ok4(c2, ld2) && aligned16(xbuf), GT_E_ALIGN,

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void attn_energies_fwd_mfma(GtAttnDims d, GtSl
 #pragma unroll
             for (int nl = 0; nl < 2; ++nl) {
                 const int dd = 32 * wave + 16 * nl + r;
-                const float u = tanhf(acc[mt][nl][e] + S.q[dd] + S.ds[(16 * mt + 4 * kq + e) * LDS_ + dd]);
+                const float u = tanhf_(acc[mt][nl][e] + S.q[dd] + S.ds[(16 * mt + 4 * kq + e) * LDS_ + dd]);
                 sum += S.v[dd] * u;
                 // hoisted backward (gt_attn_param_grads): keep tanh(.) of every step instead of recomputing it
                 if (u_out != nullptr && t0 + 16 * mt + 4 * kq + e < d.Ti)
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void attn_step_fwd_mfma(AttnStepFwd a) {
 #pragma unroll
             for (int nl = 0; nl < 2; ++nl) {
                 const int dd = 32 * wave + 16 * nl + r;
-                const float u = tanhf(acc[mt][nl][e] + S.q[dd] + S.ds[(16 * mt + 4 * kq + e) * LDS_ + dd]);
+                const float u = tanhf_(acc[mt][nl][e] + S.q[dd] + S.ds[(16 * mt + 4 * kq + e) * LDS_ + dd]);
                 sum += S.v[dd] * u;
                 if (a.u_out != nullptr && t0 + 16 * mt + 4 * kq + e < d.Ti)
                     a.u_out[((long)b * d.Ti + t0 + 16 * mt + 4 * kq + e) * A + dd] = u;
@@ -503,13 +503,17 @@ struct AttnStep2Fwd {
     int NC;
     int dbg;       // GANTRON_DEBUG=attn2=<bits> (timing knock-outs, results wrong): 1 no memory tile, 2 stop after the energies,
                    // 4 stop after the ticket (no combine)
+    long long* stamps;     // diagnostics (GANTRON_DEBUG=attn_stamps): 8 wall-clock stamps per workgroup, or NULL
 };
+// (a separate instantiation, stamps kept in registers until the end)
+#define AT_STAMP(k) do { if constexpr (STAMPS) { tstamp[k] = (long long)__builtin_amdgcn_s_memrealtime(); if ((k) >= 6 && threadIdx.x == 0) { for (int q_ = 0; q_ <= (k); ++q_) a.stamps[(long)blockIdx.x * 8 + q_] = tstamp[q_]; } } } while (0)
 
 typedef unsigned au32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t at_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
 }
 
+template <bool STAMPS>
 __global__ __launch_bounds__(256) void attn_step2_fwd_mfma(AttnStep2Fwd a) {
     __builtin_amdgcn_s_setprio(3);
     __shared__ SharedM S;
@@ -523,11 +527,30 @@ __global__ __launch_bounds__(256) void attn_step2_fwd_mfma(AttnStep2Fwd a) {
     const int Tv = a.lengths != nullptr ? min(a.lengths[b], d.Ti) : d.Ti;      // valid positions of this row
     if (t0 >= Tv) return;                                                    // chunk entirely in the padding: not a member
     const int NCv = (Tv + CT - 1) / CT;
+    long long tstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)tstamp;
+    AT_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, kq = lane >> 4;
     const int E4 = d.E >> 2;
     const int c4 = min(tid, E4 - 1);
-    // ---- 1. energies of positions [t0, t0 + 32)  (as attn_energies_fwd_mfma)
+    // ---- 1. energies of positions [t0, t0 + 32)  (as attn_energies_fwd_mfma).  Every input of the phase is REQUESTED before the
+    // first one is waited for (one memory round trip instead of two: the query slabs of the LSTM launch that has just ended
+    // come from farthest away and are requested last, loads return in order)
+    constexpr int NWP = (WPACK_F4 + 255) / 256;
+    float4 wp4[NWP];
+    float v_in = 0.f, win_in = 0.f;
+    {       // (the packed [Wc | Wd] image is required: gt_attn_step2_fwd checks it)
+        const float4* src = reinterpret_cast<const float4*>(a.wpack);
+#pragma unroll
+        for (int i2 = 0; i2 < NWP; ++i2) wp4[i2] = src[min(tid + 256 * i2, WPACK_F4 - 1)];
+        v_in = a.v[min(tid, A - 1)];
+        const int tw2 = min(tid, 2 * WL - 1);
+        const int c = tw2 / WL, p = tw2 - c * WL;
+        const int t = t0 + p - (KC - 1) / 2;
+        const float wv = (c == 0 ? a.w_prev : a.w_cum)[(long)b * d.Ti + min(max(t, 0), d.Ti - 1)];
+        win_in = (p < CT + KC - 1 && t >= 0 && t < d.Ti) ? wv : 0.f;
+    }
     float4 pm4[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -556,7 +579,15 @@ __global__ __launch_bounds__(256) void attn_step2_fwd_mfma(AttnStep2Fwd a) {
 #pragma unroll 8
         for (int s2 = 0; s2 < a.qpart.n; ++s2) qv += qp[(long)s2 * a.qpart.slab_stride];
     }
-    stage_common(S, d, a.Wc, a.Wd, a.v, a.w_prev, a.w_cum, b, t0, a.wpack);
+    // (no stamp here: one between the slab sums and the staging makes the compiler move a register array into LDS, 80 KB
+    // instead of 64, and the kernel then runs one workgroup per CU)
+    {
+        float4* dst = reinterpret_cast<float4*>(&S.wc[0]);
+#pragma unroll
+        for (int i2 = 0; i2 < NWP; ++i2) dst[min(tid + 256 * i2, WPACK_F4 - 1)] = wp4[i2];
+        if (tid < A) S.v[tid] = v_in;
+        if (tid < 2 * WL) S.win[tid / WL][tid % WL] = win_in;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int f = tid + 256 * i, tl = f >> 5, cc = f & 31;
@@ -587,8 +618,10 @@ __global__ __launch_bounds__(256) void attn_step2_fwd_mfma(AttnStep2Fwd a) {
             mem4[l] = (a.dbg & 1) ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(mp + (long)min(t0 + l, Tv - 1) * a.ld_mem);
     }
     __syncthreads();
+    AT_STAMP(2);                     // inputs staged, memory tile requested
     conv_tile(S, wave, lane);
     __syncthreads();
+    AT_STAMP(3);                     // location convolution done
     f32x4 acc[2][2];
     dense_tiles(S, wave, lane, acc);
     float ep[2][4];
@@ -600,7 +633,7 @@ __global__ __launch_bounds__(256) void attn_step2_fwd_mfma(AttnStep2Fwd a) {
 #pragma unroll
             for (int nl = 0; nl < 2; ++nl) {
                 const int dd = 32 * wave + 16 * nl + r;
-                const float u = tanhf(acc[mt][nl][e] + S.q[dd] + S.ds[(16 * mt + 4 * kq + e) * LDS_ + dd]);
+                const float u = tanhf_(acc[mt][nl][e] + S.q[dd] + S.ds[(16 * mt + 4 * kq + e) * LDS_ + dd]);
                 sum += S.v[dd] * u;
                 if (a.u_out != nullptr && t0 + 16 * mt + 4 * kq + e < d.Ti)
                     a.u_out[((long)b * d.Ti + t0 + 16 * mt + 4 * kq + e) * A + dd] = u;
@@ -619,6 +652,7 @@ __global__ __launch_bounds__(256) void attn_step2_fwd_mfma(AttnStep2Fwd a) {
     }
     __syncthreads();
     if (a.dbg & 2) return;
+    AT_STAMP(4);                     // energies done
     // ---- 2. softmax numerators relative to the chunk's own maximum (wave 0), then the partial context
     float* pl = S.de;                                   // CT numerators
     if (wave == 0) {
@@ -637,6 +671,7 @@ __global__ __launch_bounds__(256) void attn_step2_fwd_mfma(AttnStep2Fwd a) {
         const float pv = pl[l];
         part.x += pv * mem4[l].x; part.y += pv * mem4[l].y; part.z += pv * mem4[l].z; part.w += pv * mem4[l].w;
     }
+    AT_STAMP(5);                     // partial context done (the memory tile has arrived)
     // ---- 3. publish (write-through), drain, ticket
     float* xrow = a.xbuf + ((long)b * a.NC + chunk) * a.xs;      // [E partial context | 32 numerators | m | s | pad]
     {
@@ -654,6 +689,7 @@ __global__ __launch_bounds__(256) void attn_step2_fwd_mfma(AttnStep2Fwd a) {
         S.red[2] = ticket == (unsigned)NCv * a.step1 - 1u ? 1.f : 0.f;
     }
     __syncthreads();
+    AT_STAMP(6);                     // published, ticket drawn
     if (S.red[2] == 0.f || (a.dbg & 4)) return;                    // not the row's last arriver
     // ---- 4. last arriver: everything the other members published is requested at once (one round trip): their
     // statistics, their partial contexts, their numerators
@@ -707,6 +743,7 @@ __global__ __launch_bounds__(256) void attn_step2_fwd_mfma(AttnStep2Fwd a) {
         a.w_out[(long)b * d.Ti + tid] = wt;
         if (a.cum_out != nullptr) a.cum_out[(long)b * d.Ti + tid] = a.cum_in[(long)b * d.Ti + tid] + wt;
     }
+    AT_STAMP(7);                     // last arriver: context, weights, cumulative weights written
 }
 
 __global__ __launch_bounds__(256) void attn_energies_bwd_mfma(GtAttnDims d, const float* dw, const float* w,
@@ -790,7 +827,7 @@ __global__ __launch_bounds__(256) void attn_energies_bwd_mfma(GtAttnDims d, cons
                 const int tl = 16 * mt + 4 * kq + e;
                 float dsv = 0.f;
                 if (t0 + tl < d.Ti) {
-                    const float u = tanhf(acc[mt][nl][e] + qd + S.ds[tl * LDS_ + dd]);      // pm parked here
+                    const float u = tanhf_(acc[mt][nl][e] + qd + S.ds[tl * LDS_ + dd]);      // pm parked here
                     const float de = S.de[tl];
                     dsv = de * vd * (1.f - u * u);
                     dvs[nl] += de * u;
@@ -1456,6 +1493,17 @@ void gt_launch_attn_step_fwd_mfma(GtAttnDims d, GtSlabs qpart, const float* w_pr
     hipLaunchKernelGGL(attn_step_fwd_mfma, dim3(groups * 8 * a.NC), dim3(256), 0, st, a);
 }
 
+static long long* g_attn_stamps = nullptr;
+static int g_attn_stamp_wgs = 0;
+// diagnostics: the stamps of the last stamped gt_attn_step2_fwd launch (8 per workgroup) into a HOST array of 8 * 4096;
+// returns the number of workgroups; synchronises the device
+extern "C" int gt_debug_attn_stamps(int64_t* out) {
+    if (g_attn_stamps == nullptr || out == nullptr) return 0;
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(out, g_attn_stamps, sizeof(long long) * 8 * (size_t)g_attn_stamp_wgs, hipMemcpyDeviceToHost);
+    return g_attn_stamp_wgs;
+}
+
 void gt_launch_attn_step2_fwd_mfma(GtAttnDims d, GtSlabs qpart, const float* w_prev, const float* w_cum, const float* pm,
                                    const float* Wc, const float* Wd, const float* v, const int* lengths, float* q_out,
                                    const float* wpack, float* u_out, float* xbuf, long xs, unsigned* row_cnt, unsigned step1,
@@ -1470,7 +1518,16 @@ void gt_launch_attn_step2_fwd_mfma(GtAttnDims d, GtSlabs qpart, const float* w_p
     static const int dbg = gt_env_item("GANTRON_DEBUG", "attn2", 0);
     a.dbg = dbg;
     const int groups = cdiv(d.B, 8);
-    hipLaunchKernelGGL(attn_step2_fwd_mfma, dim3(groups * 8 * a.NC), dim3(256), 0, st, a);
+    a.stamps = nullptr;
+    static const int want_stamps = gt_env_item("GANTRON_DEBUG", "attn_stamps", 0);
+    if (want_stamps && groups * 8 * a.NC <= 4096) {
+        if (g_attn_stamps == nullptr) (void)hipMalloc(&g_attn_stamps, sizeof(long long) * 8 * 4096);
+        a.stamps = g_attn_stamps;
+        g_attn_stamp_wgs = groups * 8 * a.NC;
+        (void)hipMemsetAsync(g_attn_stamps, 0, sizeof(long long) * 8 * (size_t)g_attn_stamp_wgs, st);
+    }
+    if (a.stamps != nullptr) hipLaunchKernelGGL(attn_step2_fwd_mfma<true>, dim3(groups * 8 * a.NC), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(attn_step2_fwd_mfma<false>, dim3(groups * 8 * a.NC), dim3(256), 0, st, a);
 }
 
 void gt_launch_attn_energies_bwd_rec_mfma(GtAttnDims d, const float* dw, const float* w, const float* u, const float* Wc,

@@ -12,7 +12,7 @@ struct RecCellEpi {
     float* gates;                         // (rows, 4H) gate values saved for the backward pass (may alias `pre`)
     float* h_raw; float* h0; long ld0; float* h1; long ld1; float* h2; long ld2;     // h destinations (NULL = skip)
     const float* Wq; long ldwq;           // query_layer weight (A, H) or NULL
-    float* qpart; long q_sstride;         // query slab of column group cg at qpart + cg * q_sstride, rows of Apad
+    float* qpart; long q_sstride; long q_ld;      // query slab of column group cg at qpart + cg * q_sstride, rows q_ld apart
     unsigned* counters;                   // (row blocks, N/64) tickets, zero-initialised ONCE by the caller
     int B, H, A, Apad, S;
     // packed-sequence semantics (encoder BiLSTM): rows with active[m] == 0 pass their state through (c' = c, the emitted
@@ -227,7 +227,7 @@ __device__ __forceinline__ void rec_cell_epilogue(float* red, const RecCellEpi& 
             // C layout: column n = lane & 15, rows 4*(lane>>4) + r
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                qout[(long)(row0 + 16 * mt + 4 * (lane >> 4) + r) * e.Apad + cb * 16 + (lane & 15)] = acc[r];
+                qout[(long)(row0 + 16 * mt + 4 * (lane >> 4) + r) * e.q_ld + cb * 16 + (lane & 15)] = acc[r];
         }
     }
     REC_STAMP(e, 6);                     // query slab issued

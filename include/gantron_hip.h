@@ -780,6 +780,9 @@ int gt_rec_cell_fwd_x3(const float* X, int64_t ldx, const void* Wp, float* part,
  * gt_rec_cell_fwd launch, 8 per workgroup (0 start, 1 first operands in LDS, 2 MFMAs done, 3 tile published, 4 other slabs
  * added, 5 cell done, 6 query slab issued; 0 = not reached), into a HOST array of 8 * 4096; returns the workgroup count. */
 int gt_debug_rec_stamps(int64_t* out);
+/* the same for the last gt_attn_step2_fwd launch (GANTRON_DEBUG=attn_stamps): 0 start, 2 inputs staged, 3 location
+ * convolution done, 4 energies done, 5 partial context done, 6 published, 7 last arriver done */
+int gt_debug_attn_stamps(int64_t* out);
 
 /* x[0..n) -> three bf16 planes, plane i at planes + i * plane_stride (16-bit elements): x0 = bf16(x), x1 = bf16(x - x0),
  * x2 = bf16(x - x0 - x1); x0 + x1 + x2 == x exactly (3 x 8 significand bits).  n, plane_stride multiples of 8. */

@@ -2,7 +2,7 @@
 GANTRON_DEBUG=rec_stamps python tools/rec_stamps.py : runs two pairs, then prints the phase stamps of the last
 gt_rec_cell_fwd launch of the attention LSTM (decoder step To - 1 of the last forward), per phase: mean / max over workgroups."""
 import ctypes, os, sys
-os.environ['GANTRON_DEBUG'] = (os.environ.get('GANTRON_DEBUG', '') + ',rec_stamps').lstrip(',')
+os.environ['GANTRON_DEBUG'] = (os.environ.get('GANTRON_DEBUG', '') + ',rec_stamps,attn_stamps').lstrip(',')
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
@@ -38,3 +38,15 @@ print('last arrivers: publish -> slabs added', np.mean(last[:, 4] - last[:, 3]).
       ' cell -> query', np.mean(last[:, 6] - last[:, 5]).round(2))
 print('per workgroup: start -> first operands', np.mean(st[:, 1] - st[:, 0]).round(2), ' -> MFMAs done', np.mean(st[:, 2] - st[:, 1]).round(2),
       ' -> published', np.mean(st[:, 3] - st[:, 2]).round(2))
+
+n = lib().gt_debug_attn_stamps(buf)
+if n:
+    st = np.array(buf[:8 * n], dtype=np.int64).reshape(n, 8).astype(np.float64) * 0.01
+    st = st[st[:, 0] > 0]                                   # workgroups of chunks beyond a row's length leave at once
+    t0 = st[:, 0].min()
+    print(f'\nattention step (gt_attn_step2_fwd): {len(st)} member workgroups of {n}')
+    for k, name in enumerate(['start', '(unused)', 'inputs staged', 'location conv done', 'energies done',
+                              'partial context done', 'published + ticket', 'last arriver done']):
+        v = st[:, k][st[:, k] > 0] - t0
+        if len(v):
+            print(f'{name:24s} n={len(v):4d}  min {v.min():6.2f}  mean {v.mean():6.2f}  max {v.max():6.2f}')
