@@ -83,11 +83,11 @@ __global__ __launch_bounds__(128) void cell_query_kernel(CellQuery a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float i = sigmoidf_(gif[0 * 4 + e]), f = sigmoidf_(gif[1 * 4 + e]);
-            const float gg = tanhf(gif[2 * 4 + e]), o = sigmoidf_(gif[3 * 4 + e]);
+            const float gg = tanhf_(gif[2 * 4 + e]), o = sigmoidf_(gif[3 * 4 + e]);
             gvf[0 * 4 + e] = i; gvf[1 * 4 + e] = f; gvf[2 * 4 + e] = gg; gvf[3 * 4 + e] = o;
             const float c = f * cpf[e] + i * gg;
             cnf[e] = c;
-            float h = o * tanhf(c);
+            float h = o * tanhf_(c);
             if (a.keep != nullptr) h *= kpf[e] ? a.scale : 0.f;
             hvf[e] = h;
         }
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(64) void cell_bwd_query_kernel(CellBwdQuery a) {
     for (int e = 0; e < 4; ++e) {
         float d = dhv[e];
         if (a.keep != nullptr) d *= (kpv[e] ? a.scale : 0.f);
-        const float tc = tanhf(cnv[e]);
+        const float tc = tanhf_(cnv[e]);
         const float dcell = dcv[e] + d * gov[e] * (1.f - tc * tc);
         dgi[e] = dcell * ggv[e] * giv[e] * (1.f - giv[e]);
         dgf[e] = dcell * cpv[e] * gfv[e] * (1.f - gfv[e]);

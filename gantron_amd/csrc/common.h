@@ -72,10 +72,11 @@ struct GtProfScope {
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
-// tanh as 1 - 2 / (e^{2x} + 1) on the exp / rcp units (|error| < 1e-6 absolute, exact limits at +-inf): the attention
-// energies take 4096 of these per workgroup and step, where the library tanhf (a few dozen instructions) was 3 us of the
-// kernel's 18 (phase stamps, round 3)
+__device__ __forceinline__ float sigmoidf_(float x) { return __fdividef(1.0f, 1.0f + __expf(-x)); }      // v_exp + v_rcp (1 ulp each)
+// tanh as 1 - 2 / (e^{2x} + 1) on the exp / rcp units (|error| < 1e-6 absolute, exact limits at +-inf), used by the loop
+// kernels: the attention energies take 4096 of these per workgroup and step, where the library tanhf (a few dozen
+// instructions) was 1.2 us of the kernel's 18, the LSTM cells 8 per thread (the fused step 25.5 -> 24.9 us); forward and
+// backward kernels use the same function (the backward recomputes tanh(c)).  PostNet / discriminator activations keep tanhf.
 __device__ __forceinline__ float tanhf_(float x) { return 1.0f - __fdividef(2.0f, __expf(2.0f * x) + 1.0f); }
 
 // sum of `n` partial slabs (16 per trip) at element index idx (slab s lives at p + s*stride).  The loads are

@@ -183,9 +183,9 @@ __global__ __launch_bounds__(256) void plstm_fwd_kernel(PlstmDev a) {
         float hraw[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float ig = sigmoidf_(G[0][r]), fg = sigmoidf_(G[1][r]), gg = tanhf(G[2][r]), og = sigmoidf_(G[3][r]);
+            const float ig = sigmoidf_(G[0][r]), fg = sigmoidf_(G[1][r]), gg = tanhf_(G[2][r]), og = sigmoidf_(G[3][r]);
             const float cn = fg * cst[r] + ig * gg;
-            const float h = og * tanhf(cn) * kp[r];
+            const float h = og * tanhf_(cn) * kp[r];
             const long m = row_base + r;
             if (m < a.B) {
                 float* gp = gates + ((long)s * PL_ROWS + m) * N + u0 + ln;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void plstm_bwd_kernel(PlstmBwdDev a) {
             for (int e = 0; e < 4; ++e) {
                 float d = dhv[e];
                 if (a.keep != nullptr) d *= kpv[e] ? a.scale : 0.f;
-                const float tc = tanhf(cnv[e]);
+                const float tc = tanhf_(cnv[e]);
                 const float dcell = dcn[e] + d * gov[e] * (1.f - tc * tc);
                 o[0][e] = dcell * ggv[e] * giv[e] * (1.f - giv[e]);
                 o[1][e] = dcell * cpv[e] * gfv[e] * (1.f - gfv[e]);

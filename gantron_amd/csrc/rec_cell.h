@@ -186,11 +186,11 @@ __device__ __forceinline__ void rec_cell_epilogue(float* red, const RecCellEpi& 
 #pragma unroll
         for (int el = 0; el < 4; ++el) {
             const float ig = sigmoidf_(gi[0 * 4 + el]), fg = sigmoidf_(gi[1 * 4 + el]);
-            const float gg = tanhf(gi[2 * 4 + el]), og = sigmoidf_(gi[3 * 4 + el]);
+            const float gg = tanhf_(gi[2 * 4 + el]), og = sigmoidf_(gi[3 * 4 + el]);
             gvf[0 * 4 + el] = ig; gvf[1 * 4 + el] = fg; gvf[2 * 4 + el] = gg; gvf[3 * 4 + el] = og;
             const float c = fg * cpf[el] + ig * gg;
             cnf[el] = c;
-            float h = og * tanhf(c);
+            float h = og * tanhf_(c);
             if (e.keep != nullptr) h *= kpf[el] ? e.scale : 0.f;
             hvf[el] = h;
         }
@@ -351,7 +351,7 @@ __device__ __forceinline__ void rec_cellbwd_epilogue(float* red, const RecCellBw
         for (int q = 0; q < 4; ++q) {
             float dh = dhv[q];
             if (e.keep != nullptr) dh *= (kpv[q] ? e.scale : 0.f);
-            const float tc = tanhf(cnv[q]);
+            const float tc = tanhf_(cnv[q]);
             const float dcell = dcv[q] + dh * gov[q] * (1.f - tc * tc);
             dgi[q] = dcell * ggv[q] * giv[q] * (1.f - giv[q]);
             dgf[q] = dcell * cpv[q] * gfv[q] * (1.f - gfv[q]);

@@ -378,10 +378,10 @@ __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(CellFwd a) {
     }
 #pragma unroll
     for (int e = 0; e < V; ++e) {
-        const float i = sigmoidf_(gi[0][e]), f = sigmoidf_(gi[1][e]), g = tanhf(gi[2][e]), o = sigmoidf_(gi[3][e]);
+        const float i = sigmoidf_(gi[0][e]), f = sigmoidf_(gi[1][e]), g = tanhf_(gi[2][e]), o = sigmoidf_(gi[3][e]);
         gv[0][e] = i; gv[1][e] = f; gv[2][e] = g; gv[3][e] = o;
         float c = f * cp[e] + i * g;
-        const float h = o * tanhf(c);
+        const float h = o * tanhf_(c);
         if (act) {
             hout[e] = (a.keep != nullptr) ? h * (kp[e] ? a.scale : 0.f) : h;
             hcarry[e] = hout[e];
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(CellBwd a) {
         for (int e = 0; e < V; ++e) {
             float dh = dh_carry[e] + dh_out[e];
             if (a.keep != nullptr) dh *= (kp[e] ? a.scale : 0.f);
-            const float tc = tanhf(cn[e]);
+            const float tc = tanhf_(cn[e]);
             const float dcell = dcn[e] + dh * go[e] * (1.f - tc * tc);
             dgi[e] = dcell * gg[e] * gi[e] * (1.f - gi[e]);
             dgf[e] = dcell * cp[e] * gf[e] * (1.f - gf[e]);

@@ -179,9 +179,9 @@ __global__ __launch_bounds__(FC_THREADS) void rec_gemm_cell_kernel(FusedCell a) 
         const float4 t = red[(sw * MT + wave) * 64 + lane];
         g[0] += t.x; g[1] += t.y; g[2] += t.z; g[3] += t.w;
     }
-    const float gi = sigmoidf_(g[0]), gf = sigmoidf_(g[1]), gg = tanhf(g[2]), go = sigmoidf_(g[3]);
+    const float gi = sigmoidf_(g[0]), gf = sigmoidf_(g[1]), gg = tanhf_(g[2]), go = sigmoidf_(g[3]);
     const float c = gf * cp + gi * gg;
-    float h = go * tanhf(c);
+    float h = go * tanhf_(c);
     if (a.keep != nullptr) h *= kept ? a.scale : 0.f;
     if (a.gates != nullptr) {
         float* gp = a.gates + (long)m * 4 * H + u;
