@@ -212,6 +212,8 @@ __device__ __forceinline__ void rec_cell_epilogue(float* red, const RecCellEpi& 
     if (cell_thread) *reinterpret_cast<float4*>(&lds_h[crow * 20 + 4 * uq]) = hv;       // rows beyond the batch: zeros
     __syncthreads();
     float* qout = e.qpart + (long)cg * e.q_sstride;
+    const __amdgpu_buffer_rsrc_t qr = rc_rsrc(qout);      // (uniform descriptor; the row goes into the per-lane offset)
+    constexpr int QAUX = 16;
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl) {
         const int cb = wave + 8 * sl;
@@ -219,15 +221,16 @@ __device__ __forceinline__ void rec_cell_epilogue(float* red, const RecCellEpi& 
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const float4 x = *reinterpret_cast<const float4*>(&lds_h[(16 * mt + (lane & 15)) * 20 + 4 * (lane >> 4)]);
+            // TRANSPOSED (Wq as the A operand): C^T[query column 4 (lane >> 4) + r][row lane & 15] leaves four consecutive
+            // query columns of one batch row in a lane -- one 16-byte write-through store instead of four scattered dwords
+            // (the slab reaches the fabric while the launch still runs, not in its end-of-kernel write-back)
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, wq[sl].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, wq[sl].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, wq[sl].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, wq[sl].w, acc, 0, 0, 0);
-            // C layout: column n = lane & 15, rows 4*(lane>>4) + r
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                qout[(long)(row0 + 16 * mt + 4 * (lane >> 4) + r) * e.q_ld + cb * 16 + (lane & 15)] = acc[r];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[sl].x, x.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[sl].y, x.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[sl].z, x.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[sl].w, x.w, acc, 0, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), qr,
+                                                   (int)(((long)(row0 + 16 * mt + (lane & 15)) * e.q_ld + cb * 16 + 4 * (lane >> 4)) * 4), 0, QAUX);
         }
     }
     REC_STAMP(e, 6);                     // query slab issued
