@@ -12,7 +12,7 @@ struct RecCellEpi {
     float* gates;                         // (rows, 4H) gate values saved for the backward pass (may alias `pre`)
     float* h_raw; float* h0; long ld0; float* h1; long ld1; float* h2; long ld2;     // h destinations (NULL = skip)
     const float* Wq; long ldwq;           // query_layer weight (A, H) or NULL
-    float* qpart; long q_sstride; long q_ld;      // query slab of column group cg at qpart + cg * q_sstride, rows q_ld apart
+    float* qpart; long q_sstride;         // query slab of column group cg at qpart + cg * q_sstride, rows of Apad
     unsigned* counters;                   // (row blocks, N/64) tickets, zero-initialised ONCE by the caller
     int B, H, A, Apad, S;
     // packed-sequence semantics (encoder BiLSTM): rows with active[m] == 0 pass their state through (c' = c, the emitted
@@ -22,15 +22,18 @@ struct RecCellEpi {
     // of direction 1 relative to direction 0
     int nzb;
     long dX, dW, dPart, dPre, dC, dGates, dHraw, dH0, dHprev;
-    // diagnostics (GANTRON_DEBUG=rec_stamps): 8 wall-clock stamps (10 ns ticks) per workgroup of the launch, or NULL
-    long long* stamps;
+    // diagnostics (GANTRON_DEBUG=rec_stamps): phase stamps go to stamps[8 * workgroup + k] when the struct's `stamp_on` is set; the
+    // buffer's address travels in a __device__ variable, not here (the struct is a by-value kernel argument: with 16 more
+    // bytes in it rocprofv3's counter collection crashed in its copy of the kernel arguments)
+    int stamp_on;
 };
-#define REC_STAMP(e, k) do { if ((e).stamps != nullptr && threadIdx.x == 0) \
-    (e).stamps[((long)blockIdx.x + (long)gridDim.x * blockIdx.y) * 8 + (k)] = wall_clock64(); } while (0)
+#define REC_STAMP(e, k) do { if ((e).stamp_on && threadIdx.x == 0) \
+    g_rec_stamps_dev[((long)blockIdx.x + (long)gridDim.x * blockIdx.y) * 8 + (k)] = wall_clock64(); } while (0)
 
 namespace {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ long long* g_rec_stamps_dev = nullptr;      // (one per translation unit that includes this header)
 
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rc_rsrc(const void* p) {
@@ -230,7 +233,7 @@ __device__ __forceinline__ void rec_cell_epilogue(float* red, const RecCellEpi& 
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[sl].z, x.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[sl].w, x.w, acc, 0, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), qr,
-                                                   (int)(((long)(row0 + 16 * mt + (lane & 15)) * e.q_ld + cb * 16 + 4 * (lane >> 4)) * 4), 0, QAUX);
+                                                   (int)(((long)(row0 + 16 * mt + (lane & 15)) * e.Apad + cb * 16 + 4 * (lane >> 4)) * 4), 0, QAUX);
         }
     }
     REC_STAMP(e, 6);                     // query slab issued

@@ -285,7 +285,7 @@ __global__ __launch_bounds__(REC_THREADS) void rec_cell_kernel(const float* __re
     }
     REC_STAMP(e, 0);
     float* red = rec_gemm_tile<MT, 0, 2>(X + (long)rb * xz, ldx, Wp, N, KB, kb0, min(KB, kb0 + KBS), cg,
-                                          e.stamps ? e.stamps + ((long)blockIdx.x + (long)gridDim.x * blockIdx.y) * 8 : nullptr);
+                                          e.stamp_on ? g_rec_stamps_dev + ((long)blockIdx.x + (long)gridDim.x * blockIdx.y) * 8 : nullptr);
     rec_cell_epilogue<MT>(red, e, part + (long)rb * pz, ps, N, cg, s, rb, e.counters + (long)z * gridDim.x + cg);
 }
 
@@ -633,6 +633,7 @@ int gt_launch_rec_cell_bf16(const float* X, int64_t ldx, const void* Wp, float* 
 
 static long long* g_rec_stamps = nullptr;
 static int g_rec_stamp_wgs = 0;
+static bool g_rec_stamps_set = false;
 // diagnostics: copies the stamps of the last stamped launch (8 per workgroup) to `out` (HOST, room for 8 * 4096) and returns
 // the number of workgroups; synchronises the device
 extern "C" int gt_debug_rec_stamps(int64_t* out) {
@@ -674,11 +675,11 @@ int gt_rec_cell_fwd_z(const float* X, int64_t ldx, const void* Wpv, int wbf16, f
     e.gates = gates; e.h_raw = h_raw; e.h0 = h0; e.ld0 = ld0; e.h1 = h1; e.ld1 = ld1; e.h2 = h2; e.ld2 = ld2;
     // (query slabs laid out [row][column group][Apad] instead, so that a row's 64 slabs are one contiguous 32 KB for the attention
     // step that sums them: no difference, 126.5-127.6 against 127.0 ms per pair, round 3)
-    e.Wq = Wq; e.ldwq = ldwq; e.qpart = qpart; e.q_sstride = q_sstride; e.q_ld = Apad; e.counters = counters;
+    e.Wq = Wq; e.ldwq = ldwq; e.qpart = qpart; e.q_sstride = q_sstride; e.counters = counters;
     e.B = B; e.H = H; e.A = A; e.Apad = Apad; e.S = splits;
     e.active = active; e.h_prev = h_prev; e.ld_hprev = ld_hprev; e.nzb = nzb;
     e.dX = e.dW = e.dPart = e.dPre = e.dC = e.dGates = e.dHraw = e.dH0 = e.dHprev = 0;
-    e.stamps = nullptr;
+    e.stamp_on = 0;
     {   // diagnostics: GANTRON_DEBUG=rec_stamps keeps the phase stamps of the LAST attention-LSTM launch (gt_debug_rec_stamps)
         static const int want = gt_env_item("GANTRON_DEBUG", "rec_stamps", 0);
         if (want && Wq != nullptr && ndir == 1) {
@@ -686,7 +687,11 @@ int gt_rec_cell_fwd_z(const float* X, int64_t ldx, const void* Wpv, int wbf16, f
                 (void)hipMalloc(&g_rec_stamps, sizeof(long long) * 8 * 4096);
                 fprintf(stderr, "[rec_stamps] N=%d K=%d KB=%d splits=%d Bp=%d\n", N, K, KB, splits, Bp);
             }
-            e.stamps = g_rec_stamps;
+            if (!g_rec_stamps_set) {
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rec_stamps_dev), &g_rec_stamps, sizeof(g_rec_stamps));
+                g_rec_stamps_set = true;
+            }
+            e.stamp_on = wbf16 ? 0 : 1;         // (the fp32 kernel of this translation unit)
             g_rec_stamp_wgs = (N / 64) * splits;
             (void)hipMemsetAsync(g_rec_stamps, 0, sizeof(long long) * 8 * (size_t)g_rec_stamp_wgs, (hipStream_t)stream);
         }

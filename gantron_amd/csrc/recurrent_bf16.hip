@@ -247,7 +247,7 @@ __global__ __launch_bounds__(RB_THREADS) void rec_cell_bf16_kernel(const float* 
     }
     REC_STAMP(e, 0);
     float* red = rec_bf16_tile<MT, NCH, NP>(Xs, X + (long)rb * xz, ldx, kvalid, Wp, N, KB, kb0, min(KB, kb0 + KBS), cg,
-                                            e.stamps ? e.stamps + ((long)blockIdx.x + (long)gridDim.x * blockIdx.y) * 8 : nullptr);
+                                            e.stamp_on ? g_rec_stamps_dev + ((long)blockIdx.x + (long)gridDim.x * blockIdx.y) * 8 : nullptr);
     rec_cell_epilogue<MT>(red, e, part + (long)rb * pz, ps, N, cg, s, rb, e.counters + (long)z * gridDim.x + cg);
 }
 
