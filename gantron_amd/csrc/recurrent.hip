@@ -143,8 +143,7 @@ __device__ __forceinline__ float* rec_gemm_tile(const float* __restrict__ Xz, lo
         __syncthreads();                  // also: every wave is done with the chunk before last, which lived in this slot
         const float* xs = Xs + (slot % NBUF) * SLOT + (lane & 15) * REC_LD + 4 * (lane >> 4) + REC_HK * half * 16;
         if (stamps != nullptr && tid == 0) {
-            if (kb == kb0) stamps[1] = wall_clock64();                      // first activation chunk arrived
-            else if (kb == kb0 + REC_CK) stamps[7] = wall_clock64();        // second chunk published
+            if (kb == kb0) { stamps[1] = wall_clock64(); stamps[7] = clock64(); }       // first activation chunk arrived
         }
         const int kn = kb + REC_CK;
         if (!(DBG & 4) && kn < kb1) xload(kn);
@@ -178,7 +177,7 @@ __device__ __forceinline__ float* rec_gemm_tile(const float* __restrict__ Xz, lo
         if (kb + REC_CK < kb1) chunk(wb, wa, kb + REC_CK, 1);
     }
     if (NBUF > 1) __syncthreads();        // the staging buffers are free: the epilogue reuses the first one
-    if (stamps != nullptr && tid == 0) stamps[2] = wall_clock64();                          // MFMAs done
+    if (stamps != nullptr && tid == 0) { stamps[2] = wall_clock64(); stamps[7] = clock64() - stamps[7]; }      // MFMAs done; [7] = shader clocks of the loop
     // Epilogue through LDS (Xs is free after the last barrier): the two K-halves are folded into a row-major
     // [row][64 columns] tile so that the slab is written with full-line float4 stores by all 8 waves (the MFMA
     // C layout would give 16 scalar stores of 64-byte pieces per lane, by half of the waves only).

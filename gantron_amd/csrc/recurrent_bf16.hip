@@ -163,7 +163,7 @@ __device__ __forceinline__ float* rec_bf16_tile(unsigned short* Xs, const float*
             }
             if (c + XR < NCH) xload(x[c % XR], c + XR);      // registers of this chunk are free again
             __syncthreads();
-            if (stamps != nullptr && tid == 0) { if (c == 0) stamps[1] = wall_clock64(); else if (c == 1) stamps[7] = wall_clock64(); }
+            if (stamps != nullptr && tid == 0) { if (c == 0) { stamps[1] = wall_clock64(); stamps[7] = clock64(); } }
 #pragma unroll
             for (int u = 0; u < RB_HB; ++u) {
                 bf16x8 a[NP][MT];
@@ -186,7 +186,7 @@ __device__ __forceinline__ float* rec_bf16_tile(unsigned short* Xs, const float*
             __syncthreads();
         }
     }
-    if (stamps != nullptr && tid == 0) stamps[2] = wall_clock64();
+    if (stamps != nullptr && tid == 0) { stamps[2] = wall_clock64(); stamps[7] = clock64() - stamps[7]; }
     // ---- epilogue through LDS: fold the two K-halves, write the slab with full-line float4 stores
     float* red = reinterpret_cast<float*>(Xs);
     const int ecol = (wave & 3) * 16 + (lane & 15), erow = 4 * (lane >> 4);

@@ -778,7 +778,7 @@ int gt_rec_cell_fwd_x3(const float* X, int64_t ldx, const void* Wp, float* part,
 
 /* diagnostics (GANTRON_DEBUG=rec_stamps): wall-clock stamps (10 ns ticks) of the phases of the last attention-LSTM
  * gt_rec_cell_fwd launch, 8 per workgroup (0 start, 1 first operands in LDS, 2 MFMAs done, 3 tile published, 4 other slabs
- * added, 5 cell done, 6 query slab issued; 0 = not reached), into a HOST array of 8 * 4096; returns the workgroup count. */
+ * added, 5 cell done, 6 query slab issued, 7 shader clocks (clock64) between stamps 1 and 2; 0 = not reached), into a HOST array of 8 * 4096; returns the workgroup count. */
 int gt_debug_rec_stamps(int64_t* out);
 /* the same for the last gt_attn_step2_fwd launch (GANTRON_DEBUG=attn_stamps): 0 start, 2 inputs staged, 3 location
  * convolution done, 4 energies done, 5 partial context done, 6 published, 7 last arriver done */

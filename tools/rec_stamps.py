@@ -27,7 +27,7 @@ buf = (ctypes.c_int64 * (8 * 4096))()
 n = lib().gt_debug_rec_stamps(buf)
 st = np.array(buf[:8 * n], dtype=np.int64).reshape(n, 8).astype(np.float64) * 0.01      # us
 t0 = st[:, 0].min()
-names = ['start', 'first operands in LDS', 'MFMAs done', 'tile published', 'other slabs added', 'cell done', 'query issued', 'second chunk in LDS']
+names = ['start', 'first operands in LDS', 'MFMAs done', 'tile published', 'other slabs added', 'cell done', 'query issued']
 print(f'{n} workgroups; times in us relative to the first workgroup start')
 for k, name in enumerate(names):
     v = st[:, k][st[:, k] > 0] - t0
@@ -36,6 +36,7 @@ for k, name in enumerate(names):
 last = st[st[:, 5] > 0]
 print('last arrivers: publish -> slabs added', np.mean(last[:, 4] - last[:, 3]).round(2), ' slabs -> cell done', np.mean(last[:, 5] - last[:, 4]).round(2),
       ' cell -> query', np.mean(last[:, 6] - last[:, 5]).round(2))
+print('shader clock during the product loop: %.2f GHz (clock64 ticks / wall-clock time, mean over workgroups)' % float(np.mean(st[:, 7] / 0.01 / np.maximum(st[:, 2] - st[:, 1], 1e-9)) / 1e3))
 print('per workgroup: start -> first operands', np.mean(st[:, 1] - st[:, 0]).round(2), ' -> MFMAs done', np.mean(st[:, 2] - st[:, 1]).round(2),
       ' -> published', np.mean(st[:, 3] - st[:, 2]).round(2))
 
