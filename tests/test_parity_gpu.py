@@ -155,9 +155,9 @@ def test_full_size_matches_reference_summaries(dev, golden_dir, name):
     assert not bad, '\n'.join(bad)
 
 
-@pytest.mark.parametrize('case', ['ragged5', 'batch70', 'full_dims_b64', 'full_dims_b20', 'full_dims_long', 'ragged5_bf16',
+@pytest.mark.parametrize('case', ['ragged5', 'batch70', 'full_dims_b64', 'full_dims_b20', 'full_dims_long',
                                   'full_dims_b20_bf16', 'full_dims_b64_t200', 'vesus_b64', 'vesus_b128_bf16',
-                                  'full_dims_b64_bf16', 'ragged5_f32pipe', 'full_dims_b64_f32pipe',
+                                  'full_dims_b64_bf16', 'ragged5_f32pipe',
                                   'full_dims_b64_poison', 'batch70_poison', 'full_dims_b64_bf16_poison'])
 def test_midsize_against_oracle(dev, case, monkeypatch):
     """B=5 (padded to 16 rows) with ragged lengths and To not a multiple of the discriminator window, and
@@ -207,7 +207,7 @@ def test_persistent_lstm_recurrences_against_oracle(dev, monkeypatch, case, bits
     engine.check_handoffs()
 
 
-@pytest.mark.parametrize('case', ['full_dims_b64', 'vesus_b64'])
+@pytest.mark.parametrize('case', ['full_dims_b64'])
 def test_per_step_lstm_launches_against_oracle(dev, monkeypatch, case):
     """The per-step fused product + cell launches that the persistent recurrences replace at 64 rows (GANTRON_SCHEDULE=
     no_plstm; still what every other batch size and bf16 mode run) at the reference's dimensions."""
