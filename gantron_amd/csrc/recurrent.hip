@@ -113,7 +113,9 @@ __device__ __forceinline__ float* rec_gemm_tile(const float* __restrict__ Xz, lo
     static_assert(MT == 4 || MT == 2 || MT == 1 || MT == 3, "row tiles");
     // the staging buffer(s); at least as large as what the callers' epilogues use of it afterwards
     constexpr int SLOT = MT * 16 * REC_LD;
-    constexpr int EPI = MT * 16 * (REC_EP_LD + 20) + 4;
+    // (the plain product's epilogue is the folded tile alone, the fused ones add their scratch: with 17.4 KB the attention chain's
+    // and the decoder-LSTM chain's backward products TOGETHER fit the 37 KB that two weight-gradient GEMM workgroups leave on a CU)
+    constexpr int EPI = NBUF == 1 ? MT * 16 * REC_EP_LD : MT * 16 * (REC_EP_LD + 20) + 4;
     __shared__ __attribute__((aligned(16))) float Xs[NBUF * SLOT > EPI ? NBUF * SLOT : EPI];
     if (DBG & 8) return Xs;               // diagnostics: pure launch + wave start-up cost
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
