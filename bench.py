@@ -529,6 +529,27 @@ def main():
             roof['algorithmic_bytes_per_launch'] = dom['bytes'] / max(dom['launches'], 1)
         except (IndexError, KeyError, OSError, ValueError):
             pass
+        # the same kernel in the committed rocprofv3 --kernel-trace --stats summary of this command (profiles/): under the profiler
+        # the weight-gradient GEMMs do not run beside the loops, so that average is the kernel's UNCONTENDED duration
+        try:
+            import csv
+            import glob
+            stats_path = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_kernel_stats.csv')))[-1]
+            calls, total_ns = 0, 0.0
+            for row in csv.DictReader(open(stats_path)):
+                if KERNEL_OF[dom['name']] in row['Name'] and 'bf16' not in row['Name']:
+                    calls += int(row['Calls'])
+                    total_ns += float(row['TotalDurationNs'])
+            if calls:
+                prof_us = total_ns / calls / 1e3
+                roof['rocprofv3'] = dict(avg_launch_us=prof_us, calls=calls, source=os.path.relpath(stats_path, ROOT),
+                                         frac_at_that_duration=(dom['flops'] / max(dom['launches'], 1)) / (prof_us * 1e-6) / 1e12 / roof['peak']
+                                         if dom['name'] in MFMA_BOUND else None,
+                                         note='committed kernel-trace summary of this command; under the profiler the weight-gradient GEMMs do '
+                                              'not overlap the decoder loops, so this is the uncontended duration -- avg_launch_us above is '
+                                              'measured live, inside the timed region, beside them')
+        except (IndexError, KeyError, OSError, ValueError):
+            pass
         roof.update(kernel=KERNEL_OF[dom['name']] + ('' if not args.bf16 else ' (bf16-operand instantiation)'), sampled_launches=dom['launches'], sample_stride=PROF_STRIDE,
                     avg_launch_us=avg_ms * 1e3,
                     timing=('start / stop events of the sampled launches themselves (hipExtLaunchKernelGGL: dispatch begin to end)'
