@@ -52,7 +52,9 @@ __global__ __launch_bounds__(256) void pack_rec_weight_kernel(const float* W, lo
 // The two K-halves are folded through LDS at the end.  The wave's weight fragments (1 KiB per 16-wide
 // k-block, lane-linear) stream straight into VGPRs, one chunk ahead (two chunks ahead through three rotating buffers, round 3:
 // 126.9-127.2 ms per pair against 125.3-126.1; the ACTIVATION chunks two ahead instead: the fused step 27.2 us against 24.9 --
-// more requests in flight have made this kernel slower every time).
+// more requests in flight have made this kernel slower every time.  The chunks of a slice visited in an order rotated by the
+// column group, so that the 64 workgroups sharing a K-slice do not ask for the same activation lines at the same moment: 25.9-26.3
+// us against 24.9, the backward product 21.6-22.0 against 20 -- running in lockstep is what makes those lines cheap).
 constexpr int REC_CK = 4;                 // k-blocks (of 16) per LDS chunk.  Round 3, pair time / fused forward step / backward
                                           // product in the loop: 16 blocks 140 ms / 29.3 us / 28 us; 8 (rounds 1-3) 127.4-128.0 /
                                           // 26.2 / 20.5-21; 4: 125.3-126.1 / 25.3 / 19.7-20.4; 2: 136.4-137.0 / 34 / 23.5
