@@ -61,6 +61,7 @@ static const int kPrioA = 3, kPrioB = 2;
 struct LoopCtx {
     std::mutex mu;
     hipStream_t aux = nullptr;
+    hipStream_t aux2 = nullptr;       // the forward loop's block GEMMs, beside the decoder-LSTM chain they feed
     std::vector<hipEvent_t> events;
 };
 static std::mutex g_ctx_mu;
@@ -99,6 +100,14 @@ static int aux_stream(LoopCtx* c, hipStream_t* out) {
         GT_REQUIRE(e == hipSuccess, (int)e, "decoder loop: cannot create the auxiliary stream");
     }
     *out = c->aux;
+    return 0;
+}
+static int aux2_stream(LoopCtx* c, hipStream_t* out) {
+    if (c->aux2 == nullptr) {
+        hipError_t e = hipStreamCreateWithFlags(&c->aux2, hipStreamNonBlocking);
+        GT_REQUIRE(e == hipSuccess, (int)e, "decoder loop: cannot create the second auxiliary stream");
+    }
+    *out = c->aux2;
     return 0;
 }
 static int loop_event(LoopCtx* c, size_t i, hipEvent_t* out) {
@@ -299,14 +308,24 @@ static int decoder_fwd_hoisted(const GtDecoderFwd* a, void* stream) {
                                        a->cum_hist + (int64_t)t * BT, a->cum_hist + (int64_t)(t + 1) * BT, X1n, a->ld1,
                                        XAt + a->Ha, a->ld2, hc_t + a->Hd, hc_ld, sA));
         }
+        // ---- decoder LSTM (stream B): input pre-activations of the block, then its recurrence.  With the persistent recurrence
+        // the block GEMM goes to a stream of its own (C): the GEMM of block n + 1 then runs beside the recurrence of block n
+        // instead of in front of it -- 530 us per block on stream B instead of 700, which the attention chain (620) had overtaken
+        hipStream_t sG = sB;
+        static const int gemm_aside = gt_env_item("GANTRON_SCHEDULE", "no_blk_gemm_aside", 0) == 0;
+        if (two && persistB && gemm_aside && !g_gt_capturing) GT_TRY(aux2_stream(ctx, &sG));
         if (two) {
             GT_TRY(loop_event(ctx, 1 + (size_t)(nblock % 32), &ev));
             GT_HIP(hipEventRecord(ev, sA));
+            GT_HIP(hipStreamWaitEvent(sG, ev, 0));
+        }
+        GT_TRY(block_gemm(op_kc(a->X2 + (int64_t)t0 * xa_step, a->ld2), op_kc(a->W2ih, a->ldw2), a->bias2,
+                          a->pre2 + (int64_t)t0 * a->Bp * N2, N2, (t1 - t0) * a->Bp, N2, a->Ha + a->E, 0, a->bf16, sG));
+        if (sG != sB) {
+            GT_TRY(loop_event(ctx, 40 + (size_t)(nblock % 32), &ev));
+            GT_HIP(hipEventRecord(ev, sG));
             GT_HIP(hipStreamWaitEvent(sB, ev, 0));
         }
-        // ---- decoder LSTM (stream B): input pre-activations of the block, then its recurrence
-        GT_TRY(block_gemm(op_kc(a->X2 + (int64_t)t0 * xa_step, a->ld2), op_kc(a->W2ih, a->ldw2), a->bias2,
-                          a->pre2 + (int64_t)t0 * a->Bp * N2, N2, (t1 - t0) * a->Bp, N2, a->Ha + a->E, 0, a->bf16, sB));
         if (persistB) {
             // the block's recurrence as ONE persistent launch: h_dec_t is published into HC[t] and read from there
             GtPlstm q = {};

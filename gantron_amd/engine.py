@@ -932,6 +932,33 @@ class GeneratorEngine:
         hc, nout = Hd + Ep, n_mel + 1          # [h_dec | ctx] rows are Ep wide in their ctx part (engine.Ep)
 
         PHASES.mark(None)
+        # ---- the one-launch backward attention step's per-position terms of ALL steps (gt_attn_bwd_wterms: 2.7 GB at the benchmark
+        # batch, ~3.5 ms) need forward quantities only: issued FIRST, on the leaf stream, they run beside the PostNet backward;
+        # the loop later waits for their own event, not for the whole leaf stream (the PostNet's weight gradients stay under the loop)
+        early = None
+        if ATTN_BWD_FUSED and 'u_hist' in hist and HOIST2 and not FUSED_CELL and CELL_QUERY and Ha % 16 == 0:
+            dims_e = ops.attn_dims(B, Ti, Ep, A, self.F, self.Kc)
+            if lib().gt_attn_bwd_step_supported(dims_e):
+                al_e = 'decoder.attention_layer.'
+                Wc_e, Wd_e, v_e = (P[al_e + 'location_layer.location_conv.conv.weight'],
+                                   P[al_e + 'location_layer.location_dense.linear_layer.weight'], P[al_e + 'v.linear_layer.weight'])
+                Apad_e, nch_e, BT_e = roundup(A, 16), int(lib().gt_attn_chunks(Ti)), B * Ti
+                wpack_e = _f32(int(lib().gt_attn_wpack_elems(dims_e)), device=dev, zero=False)
+                fz_e = dict(sum_hist=_f32(To, B, nch_e, device=dev, zero=False), dq2_hist=_f32(To, Bp, Apad_e, device=dev),
+                            dwcat2_hist=_f32(To, 2, B, Ti, device=dev), p_hist=_f32(To, B, Ti, 64, device=dev, zero=False))
+
+                def wterms():
+                    call('gt_attn_pack_weights', dims_e, Wc_e, Wd_e, wpack_e)
+                    check(lib().gt_attn_bwd_wterms(
+                        dims_e, To, ptr(hist['w_hist'], BT_e), BT_e, ptr(hist['u_hist']), ptr(Wc_e), ptr(Wd_e), ptr(v_e),
+                        ptr(sv['lens32']), ptr(fz_e['dq2_hist']), Bp * Apad_e, Apad_e, ptr(fz_e['dwcat2_hist']), ptr(fz_e['p_hist']),
+                        ptr(wpack_e), ops._stream()), 'gt_attn_bwd_wterms')
+                LEAF.run(wterms, wpack_e)
+                if LEAF.defer:
+                    LEAF.flush()
+                ready = torch.cuda.Event()
+                ready.record(LEAF.stream if (LEAF.enabled and LEAF.stream is not None and not LEAF.defer) else torch.cuda.current_stream())
+                early = dict(fz=fz_e, wpack=wpack_e, ready=ready)
         # ---- PostNet backward (channels-last)
         dmel_cl = _f32(B * To, n_mel, device=dev)
         if dmel is not None:
@@ -1064,26 +1091,19 @@ class GeneratorEngine:
             # summed on the leaf stream by gt_attn_param_grads (needs the packed [Wc | Wd] image: made here, once)
             de_hist = _f32(To, B, Ti, device=dev, zero=False)
             b.u_hist, b.de_hist = ptr(hist['u_hist']), ptr(de_hist)
-            wpack_p = _f32(n_wpack, device=dev, zero=False)
-            call('gt_attn_pack_weights', dims, Wc, Wd, wpack_p)
+            if early is not None:
+                wpack_p = early['wpack']
+            else:
+                wpack_p = _f32(n_wpack, device=dev, zero=False)
+                call('gt_attn_pack_weights', dims, Wc, Wd, wpack_p)
             BT = B * Ti
-        fused_attn = hoist and hoist2 and ATTN_BWD_FUSED and CELL_QUERY and Ha % 16 == 0 and N1pad % 4 == 0 and \
-            bool(lib().gt_attn_bwd_step_supported(dims))
+        fused_attn = early is not None and hoist and hoist2 and N1pad % 4 == 0
         if fused_attn:
             # the terms of the energies backward that are linear in the step's own weights, for every step at once
-            # (gt_attn_bwd_wterms): what the per-step launch subtracts s times from, see attention_mfma.hip
+            # (gt_attn_bwd_wterms, issued at the top of this function): what the per-step launch subtracts s times from
             nch = int(lib().gt_attn_chunks(Ti))
-            fz = dict(sum_hist=_f32(To, B, nch, device=dev, zero=False), dq2_hist=_f32(To, Bp, Apad, device=dev),
-                      dwcat2_hist=_f32(To, 2, B, Ti, device=dev), p_hist=_f32(To, B, Ti, 64, device=dev, zero=False))
-            # on the leaf stream: it needs forward quantities only and overlaps the PostNet / projection backward
-            LEAF.run(lambda: check(lib().gt_attn_bwd_wterms(
-                dims, To, ptr(hist['w_hist'], BT), BT, ptr(hist['u_hist']), ptr(Wc), ptr(Wd), ptr(v), ptr(sv['lens32']),
-                ptr(fz['dq2_hist']), Bp * Apad, Apad, ptr(fz['dwcat2_hist']), ptr(fz['p_hist']), ptr(wpack_p), ops._stream()),
-                'gt_attn_bwd_wterms'), wpack_p)
-            if LEAF.defer:
-                LEAF.flush()
-            if LEAF.enabled and LEAF.stream is not None and not LEAF.defer:
-                torch.cuda.current_stream().wait_stream(LEAF.stream)
+            fz = early['fz']
+            torch.cuda.current_stream().wait_event(early['ready'])
             b.sum_hist, b.dq2_hist, b.dwcat2_hist, b.p_hist = (ptr(fz['sum_hist']), ptr(fz['dq2_hist']), ptr(fz['dwcat2_hist']),
                                                                ptr(fz['p_hist']))
         dG1, dG2 = buf['dG1'], buf['dG2']

@@ -16,7 +16,8 @@ GANTRON_SCHEDULE       comma list switching OFF parts of the default schedule (w
                        no_fwd_splitk, no_rec_cell (per-step product + cell launches instead of the fused ones), no_attn_step2 (energies
                        and softmax + context of a forward step as two launches instead of gt_attn_step2_fwd), no_plstm (per-step
                        launches instead of the persistent LSTM recurrences), no_attn_bwd_fused (context and energies backward
-                       of a step as two launches),
+                       of a step as two launches), no_blk_gemm_aside (the forward loop's block GEMMs on the decoder-LSTM
+                       chain's own stream instead of a third one),
                        no_dist_overlap.
 GANTRON_DEBUG          comma list of diagnostics: phase_timing, host_timing, block_timing, dist_timing, attn_valu,
                        rec=<bits> / fused=<bits> / pgemm=<bits> (kernel knock-outs), rec_splits=<n>, s1_fwd=<n>, s2_fwd=<n>,

@@ -8,7 +8,7 @@ anchor, nth = sys.argv[2], int(sys.argv[3])
 n = int(sys.argv[4]) if len(sys.argv) > 4 else 40
 for r in rows:
     r['s'], r['e'] = int(r['Start_Timestamp']), int(r['End_Timestamp'])
-    r['n'] = re.sub(r'\(.*', '', re.sub(r'^void ', '', r['Kernel_Name'])).replace('(anonymous namespace)::', '')[:44]
+    r['n'] = re.sub(r'\(.*', '', re.sub(r'^void ', '', r['Kernel_Name'].replace('(anonymous namespace)::', '')))[:44]
 rows.sort(key=lambda r: r['s'])
 idx = [i for i, r in enumerate(rows) if anchor in r['Kernel_Name']]
 print(f'{len(idx)} launches match {anchor!r}')
