@@ -63,6 +63,7 @@ def _parse_header(path):
 
 
 STRUCTS, PROTOS = _parse_header(HEADER)
+ABI_VERSION = int(re.search(r'#define\s+GT_ABI_VERSION\s+(\d+)', open(HEADER).read()).group(1))
 globals().update(STRUCTS)
 
 
@@ -87,8 +88,11 @@ def lib():
         for name, (restype, argtypes) in PROTOS.items():
             fn = getattr(handle, name)        # AttributeError here = header/library drift
             fn.restype, fn.argtypes = restype, argtypes
+        if handle.gt_version() != ABI_VERSION:
+            raise GantronHipError(f'ABI mismatch: {LIB_PATH} was built as version {handle.gt_version()}, {HEADER} declares '
+                                  f'GT_ABI_VERSION {ABI_VERSION}: rebuild it (python -m gantron_amd.csrc.build)')
         for which, sname in enumerate(('GtOperand', 'GtGemm', 'GtSlabs', 'GtAttnDims', 'GtDecoderFwd',
-                                       'GtDecoderBwd', 'GtBiLstm', 'GtDecoderInfer', 'GtPlstm', 'GtPlstmBwd')):
+                                       'GtDecoderBwd', 'GtBiLstm', 'GtDecoderInfer', 'GtPlstm', 'GtPlstmBwd', 'GtRecTail')):
             want, got = handle.gt_abi_sizeof(which), ctypes.sizeof(STRUCTS[sname])
             if want != got:
                 raise GantronHipError(f'ABI mismatch: sizeof({sname}) is {want} in the library, {got} in the binding')

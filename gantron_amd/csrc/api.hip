@@ -14,23 +14,34 @@ void gt_set_error(const char* fmt, ...) {
 
 extern "C" const char* gt_last_error_string(void) { return g_err; }
 
+// `name[=int]` items separated by ',' or ';'; blanks around the name, the '=' and the value are ignored -- the same rules as
+// gantron_amd/switches.py:_parse, which also rejects unknown names when the package is imported
 int gt_env_item(const char* var, const char* key, int dflt) {
     const char* e = getenv(var);
     if (e == nullptr) return dflt;
     const size_t n = strlen(key);
+    auto blank = [](char c) { return c == ' ' || c == '\t'; };
     for (const char* p = e; *p;) {
-        while (*p == ',' || *p == ';' || *p == ' ') ++p;
+        while (*p == ',' || *p == ';' || blank(*p)) ++p;
         const char* q = p;
         while (*q && *q != ',' && *q != ';') ++q;
-        if ((size_t)(q - p) >= n && strncmp(p, key, n) == 0) {
-            if (p + n == q) return 1;
-            if (p[n] == '=') return atoi(p + n + 1);
+        const char* ne = p;                                      // end of the name
+        while (ne < q && *ne != '=' && !blank(*ne)) ++ne;
+        if ((size_t)(ne - p) == n && strncmp(p, key, n) == 0) {
+            const char* r = ne;
+            while (r < q && blank(*r)) ++r;
+            if (r == q) return 1;
+            if (*r == '=') {
+                ++r;
+                while (r < q && blank(*r)) ++r;
+                return atoi(r);
+            }
         }
         p = q;
     }
     return dflt;
 }
-extern "C" int gt_version(void) { return 100; }
+extern "C" int gt_version(void) { return GT_ABI_VERSION; }
 
 // sizeof of every struct that crosses the ABI, so a binding can verify its layout at load time
 extern "C" int64_t gt_abi_sizeof(int32_t which) {
@@ -45,6 +56,7 @@ extern "C" int64_t gt_abi_sizeof(int32_t which) {
         case 7: return sizeof(GtDecoderInfer);
         case 8: return sizeof(GtPlstm);
         case 9: return sizeof(GtPlstmBwd);
+        case 10: return sizeof(GtRecTail);
         default: return -1;
     }
 }

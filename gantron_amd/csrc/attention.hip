@@ -9,6 +9,7 @@
 // gradients in per-workgroup slabs (no atomics) that gt_attn_acc_reduce folds after the loop.
 #include <stdlib.h>
 #include "common.h"
+#include "rec_tail.h"
 #include "attn_ctx_bwd.h"
 
 // matrix-core versions for the reference's default dimensions (attention_mfma.hip)
@@ -37,7 +38,8 @@ void gt_launch_attn_step2_fwd_mfma(GtAttnDims d, GtSlabs qpart, const float* w_p
                                    const float* Wc, const float* Wd, const float* v, const int* lengths, float* q_out,
                                    const float* wpack, float* u_out, float* xbuf, long xs, unsigned* row_cnt, unsigned step1,
                                    const float* memory, long ld_mem, float* w_out, const float* cum_in, float* cum_out,
-                                   float* c0, long ld0, float* c1, long ld1, float* c2, long ld2, hipStream_t st);
+                                   float* c0, long ld0, float* c1, long ld1, float* c2, long ld2, const GtRecTail* tail,
+                                   hipStream_t st);
 void gt_launch_attn_bwd_wterms_mfma(GtAttnDims d, int nsteps, const float* w, long w_step, const float* u, const float* Wc,
                                      const float* Wd, const float* v, const int* lengths, float* dq2, long dq2_step,
                                      long ld_dq2, float* dwcat2, float* p_hist, const float* wpack, hipStream_t st);
@@ -667,8 +669,19 @@ extern "C" int gt_attn_step2_fwd(GtAttnDims d, GtSlabs qpart, const float* w_pre
                                  const float* wpack, float* u_out, float* xbuf, uint32_t* row_cnt, uint32_t step1,
                                  const float* memory, int64_t ld_mem, float* w_out, const float* cum_in, float* cum_out,
                                  float* c0, int64_t ld0, float* c1, int64_t ld1, float* c2, int64_t ld2, void* stream) {
+    return gt_attn_step2_fwd_tail(d, qpart, w_prev, w_cum, pm, Wc, Wd, v, lengths, q_out, wpack, u_out, xbuf, row_cnt, step1, memory,
+                                  ld_mem, w_out, cum_in, cum_out, c0, ld0, c1, ld1, c2, ld2, nullptr, stream);
+}
+
+extern "C" int gt_attn_step2_fwd_tail(GtAttnDims d, GtSlabs qpart, const float* w_prev, const float* w_cum, const float* pm,
+                                      const float* Wc, const float* Wd, const float* v, const int32_t* lengths, float* q_out,
+                                      const float* wpack, float* u_out, float* xbuf, uint32_t* row_cnt, uint32_t step1,
+                                      const float* memory, int64_t ld_mem, float* w_out, const float* cum_in, float* cum_out,
+                                      float* c0, int64_t ld0, float* c1, int64_t ld1, float* c2, int64_t ld2, const GtRecTail* tail,
+                                      void* stream) {
     int rc = check_dims(d, "gt_attn_step2_fwd");
     if (rc) return rc;
+    if ((rc = gt_rec_tail_check(tail, "gt_attn_step2_fwd_tail")) != 0) return rc;
     GT_REQUIRE(gt_attn_step2_supported(d), GT_E_LIMIT, "gt_attn_step2_fwd: needs attention dims (128, 32, 31), Ti <= 256, E %% 4 == 0 and E <= 1024");
     GT_REQUIRE(qpart.p && w_prev && w_cum && pm && Wc && Wd && v && xbuf && row_cnt && memory && w_out && wpack && step1 >= 1, GT_E_ARG,
                "gt_attn_step2_fwd: NULL pointer (wpack, the gt_attn_pack_weights image, is required)");
@@ -677,11 +690,17 @@ extern "C" int gt_attn_step2_fwd(GtAttnDims d, GtSlabs qpart, const float* w_pre
     GT_REQUIRE(ok4(memory, ld_mem) && ld_mem >= d.E && ok4(c0, ld0) && ok4(c1, ld1) && ok4(c2, ld2) && aligned16(xbuf), GT_E_ALIGN,
                "gt_attn_step2_fwd: memory, the context destinations and xbuf must be 16-byte aligned with leading dimensions %% 4 == 0");
     const double ctx_rows = g_gt_prof_ctx_rows > 0.0 ? g_gt_prof_ctx_rows : (double)d.B * d.Ti;
-    GtProfScope prof(GT_FAM_ATTN_E_FWD, 2.0 * d.B * d.Ti * (double)(d.F * 2 * d.Kc + d.A * d.F + 2 * d.A) + 2.0 * ctx_rows * d.E,
-                     4.0 * (d.B * d.Ti * (d.A + 3.0) + ctx_rows * d.E + d.B * (3.0 * d.E + 4.0 * d.Ti)), (hipStream_t)stream);
+    // the tail's product is charged to this launch: flops, packed weights + activations read once per column group + slabs
+    const bool has_tail = tail != nullptr && tail->work != nullptr;
+    const double tk = has_tail ? 16.0 * (tail->kb1 - tail->kb0) : 0.0, tn = has_tail ? 64.0 * tail->groups : 0.0;
+    const double trows = has_tail ? 16.0 * tail->mtiles : 0.0, tsl = has_tail ? (double)cdiv(tail->kb1 - tail->kb0, tail->kbs) : 0.0;
+    GtProfScope prof(GT_FAM_ATTN_E_FWD, 2.0 * d.B * d.Ti * (double)(d.F * 2 * d.Kc + d.A * d.F + 2 * d.A) + 2.0 * ctx_rows * d.E +
+                                            2.0 * trows * tn * tk,
+                     4.0 * (d.B * d.Ti * (d.A + 3.0) + ctx_rows * d.E + d.B * (3.0 * d.E + 4.0 * d.Ti) + tn * tk + trows * tk +
+                            trows * tn * tsl), (hipStream_t)stream);
     gt_launch_attn_step2_fwd_mfma(d, qpart, w_prev, w_cum, pm, Wc, Wd, v, lengths, q_out, wpack, u_out, xbuf,
                                   (long)gt_attn_step2_xstride(d), row_cnt, step1, memory, (long)ld_mem, w_out, cum_in, cum_out,
-                                  c0, (long)ld0, c1, (long)ld1, c2, (long)ld2, (hipStream_t)stream);
+                                  c0, (long)ld0, c1, (long)ld1, c2, (long)ld2, tail, (hipStream_t)stream);
     GT_LAUNCH_CHECK();
     return 0;
 }

@@ -17,6 +17,7 @@
 #include <stddef.h>
 #include "common.h"
 #include "attn_ctx_bwd.h"
+#include "rec_tail.h"
 
 namespace {
 
@@ -287,6 +288,7 @@ struct AttnStepFwd {
     float* c0; long ld0; float* c1; long ld1; float* c2; long ld2;
     int NC;
 };
+static_assert(sizeof(AttnStepFwd) <= 1024, "AttnStepFwd is a by-value kernel argument: keep it well below the 4 KB kernel-argument segment");
 
 __global__ __launch_bounds__(256) void attn_step_fwd_mfma(AttnStepFwd a) {
     __builtin_amdgcn_s_setprio(3);
@@ -504,7 +506,11 @@ struct AttnStep2Fwd {
     int dbg;       // GANTRON_DEBUG=attn2=<bits> (timing knock-outs, results wrong): 1 no memory tile, 2 stop after the energies,
                    // 4 stop after the ticket (no combine)
     long long* stamps;     // diagnostics (GANTRON_DEBUG=attn_stamps): 8 wall-clock stamps per workgroup, or NULL
+    long long* tstamps;    // ... and 4 per workgroup for the tail (gt_debug_attn_tail_stamps)
+    GtRecTail tail;        // recurrent-product items for workgroups with nothing (more) to do (rec_tail.h); work == NULL: none
 };
+// (by-value kernel argument: far below the 4 KB the runtime copies per launch)
+static_assert(sizeof(AttnStep2Fwd) <= 512, "AttnStep2Fwd grew: check the kernel-argument segment");
 // (a separate instantiation, stamps kept in registers until the end)
 #define AT_STAMP(k) do { if constexpr (STAMPS) { tstamp[k] = (long long)__builtin_amdgcn_s_memrealtime(); if ((k) >= 6 && threadIdx.x == 0) { for (int q_ = 0; q_ <= (k); ++q_) a.stamps[(long)blockIdx.x * 8 + q_] = tstamp[q_]; } } } while (0)
 
@@ -514,9 +520,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t at_rsrc(const void* p) {
 }
 
 template <bool STAMPS>
-__global__ __launch_bounds__(256) void attn_step2_fwd_mfma(AttnStep2Fwd a) {
-    __builtin_amdgcn_s_setprio(3);
-    __shared__ SharedM S;
+__device__ __forceinline__ void attn_step2_fwd_body(const AttnStep2Fwd& a, SharedM& S) {
     const GtAttnDims& d = a.d;
     // workgroup id -> (row, chunk): groups of 8 rows; inside a group id = chunk * 8 + (row % 8): a row's chunks share an XCD
     const int L = blockIdx.x;
@@ -748,6 +752,23 @@ __global__ __launch_bounds__(256) void attn_step2_fwd_mfma(AttnStep2Fwd a) {
         if (a.cum_out != nullptr) a.cum_out[(long)b * d.Ti + tid] = a.cum_in[(long)b * d.Ti + tid] + wt;
     }
     AT_STAMP(7);                     // last arriver: context, weights, cumulative weights written
+}
+
+template <bool STAMPS>
+__global__ __launch_bounds__(256) void attn_step2_fwd_mfma(AttnStep2Fwd a) {
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ SharedM S;
+    static_assert(sizeof(SharedM) >= sizeof(float) * RT_LDS_FLOATS, "the tail's staging buffers live in the step's LDS");
+    if constexpr (STAMPS) {
+        if (threadIdx.x == 0 && a.tstamps != nullptr) a.tstamps[(long)blockIdx.x * 4] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
+    attn_step2_fwd_body<STAMPS>(a, S);
+    // this workgroup's share of the step is done (or it never had one: its chunk lies in the row's padding): the next LSTM
+    // step's early half, at the default issue priority -- the step's own waves on this CU come first
+    if (a.tail.work != nullptr) {
+        if (!(a.dbg & 8)) __builtin_amdgcn_s_setprio(0);       // (GANTRON_DEBUG=attn2=8: the tail keeps the step's priority)
+        rec_tail_run(a.tail, reinterpret_cast<float*>(&S), STAMPS && a.tstamps != nullptr ? a.tstamps + (long)blockIdx.x * 4 : nullptr);
+    }
 }
 
 __global__ __launch_bounds__(256) void attn_energies_bwd_mfma(GtAttnDims d, const float* dw, const float* w,
@@ -1212,6 +1233,7 @@ struct AttnBwdStep {
     float* sum_out;                                       // (B, chunks) this step's partial row sums
     float* dq; long ld_dq; float* dwcat_out; float* e1_out;
 };
+static_assert(sizeof(AttnBwdStep) <= 1024, "AttnBwdStep is a by-value kernel argument: keep it well below the 4 KB kernel-argument segment");
 
 struct SharedStep {
     alignas(16) float M[CT * LDS_];
@@ -1508,12 +1530,22 @@ extern "C" int gt_debug_attn_stamps(int64_t* out) {
     return g_attn_stamp_wgs;
 }
 
+extern "C" int gt_debug_attn_tail_stamps(int64_t* out) {
+    if (g_attn_stamps == nullptr || out == nullptr) return 0;
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(out, g_attn_stamps + 8 * 4096, sizeof(long long) * 4 * (size_t)g_attn_stamp_wgs, hipMemcpyDeviceToHost);
+    return g_attn_stamp_wgs;
+}
+
 void gt_launch_attn_step2_fwd_mfma(GtAttnDims d, GtSlabs qpart, const float* w_prev, const float* w_cum, const float* pm,
                                    const float* Wc, const float* Wd, const float* v, const int* lengths, float* q_out,
                                    const float* wpack, float* u_out, float* xbuf, long xs, unsigned* row_cnt, unsigned step1,
                                    const float* memory, long ld_mem, float* w_out, const float* cum_in, float* cum_out,
-                                   float* c0, long ld0, float* c1, long ld1, float* c2, long ld2, hipStream_t st) {
+                                   float* c0, long ld0, float* c1, long ld1, float* c2, long ld2, const GtRecTail* tail,
+                                   hipStream_t st) {
     AttnStep2Fwd a;
+    memset(&a.tail, 0, sizeof(a.tail));
+    if (tail != nullptr && tail->work != nullptr) a.tail = *tail;
     a.d = d; a.qpart = qpart; a.w_prev = w_prev; a.w_cum = w_cum; a.pm = pm; a.Wc = Wc; a.Wd = Wd; a.v = v; a.lengths = lengths;
     a.q_out = q_out; a.wpack = wpack; a.u_out = u_out; a.xbuf = xbuf; a.xs = xs; a.row_cnt = row_cnt; a.step1 = step1;
     a.memory = memory; a.ld_mem = ld_mem; a.w_out = w_out; a.cum_in = cum_in; a.cum_out = cum_out;
@@ -1522,13 +1554,17 @@ void gt_launch_attn_step2_fwd_mfma(GtAttnDims d, GtSlabs qpart, const float* w_p
     static const int dbg = gt_env_item("GANTRON_DEBUG", "attn2", 0);
     a.dbg = dbg;
     const int groups = cdiv(d.B, 8);
-    a.stamps = nullptr;
+    a.stamps = nullptr; a.tstamps = nullptr;
     static const int want_stamps = gt_env_item("GANTRON_DEBUG", "attn_stamps", 0);
     if (want_stamps && groups * 8 * a.NC <= 4096) {
-        if (g_attn_stamps == nullptr) (void)hipMalloc(&g_attn_stamps, sizeof(long long) * 8 * 4096);
+        if (g_attn_stamps == nullptr) (void)hipMalloc(&g_attn_stamps, sizeof(long long) * 12 * 4096);
         a.stamps = g_attn_stamps;
         g_attn_stamp_wgs = groups * 8 * a.NC;
         (void)hipMemsetAsync(g_attn_stamps, 0, sizeof(long long) * 8 * (size_t)g_attn_stamp_wgs, st);
+        if (a.tail.work != nullptr) {       // (the last step of a loop carries no tail: the stamps of the one before it stay)
+            a.tstamps = g_attn_stamps + 8 * 4096;
+            (void)hipMemsetAsync(a.tstamps, 0, sizeof(long long) * 4 * (size_t)g_attn_stamp_wgs, st);
+        }
     }
     if (a.stamps != nullptr) hipLaunchKernelGGL(attn_step2_fwd_mfma<true>, dim3(groups * 8 * a.NC), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(attn_step2_fwd_mfma<false>, dim3(groups * 8 * a.NC), dim3(256), 0, st, a);

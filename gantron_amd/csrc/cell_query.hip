@@ -27,6 +27,7 @@ struct CellQuery {
     float* qpart; long q_sstride;     // slab g at qpart + g*q_sstride, rows of Apad
     int B, H, A, Apad, mtiles;
 };
+static_assert(sizeof(CellQuery) <= 1024, "CellQuery is a by-value kernel argument: keep it well below the 4 KB kernel-argument segment");
 
 __global__ __launch_bounds__(128) void cell_query_kernel(CellQuery a) {
     __builtin_amdgcn_s_setprio(3);      // the attention chain is the serial critical path of the decoder loops: its waves
@@ -180,6 +181,7 @@ struct CellBwdQuery {
     float* dgates; float* dc_prev;
     int B, H, A, mtiles;
 };
+static_assert(sizeof(CellBwdQuery) <= 1024, "CellBwdQuery is a by-value kernel argument: keep it well below the 4 KB kernel-argument segment");
 
 __global__ __launch_bounds__(64) void cell_bwd_query_kernel(CellBwdQuery a) {
     __builtin_amdgcn_s_setprio(3);      // the attention chain is the serial critical path of the decoder loops: its waves

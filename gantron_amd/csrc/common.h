@@ -70,6 +70,17 @@ struct GtProfScope {
     ~GtProfScope() { if (on && !exact) gt_prof_mark(fam, 0, 0, st, false); }
 };
 
+// A launch that carries its own begin / end events when it is one of the profiler's samples (GtProfScope exact = true) and is a
+// PLAIN launch otherwise.  (Round 3 launched every recurrent product through hipExtLaunchKernelGGL, events or not; under
+// `rocprofv3 --pmc` that path segfaulted now and then inside the tool's copy of the dispatch's kernel arguments -- a read
+// running off the end of a mapping, page-aligned fault address, only for the launches with the 288-byte RecCellEpi
+// argument and only after several thousand dispatches; the events were NULL in the faulting launches.)
+#define GT_LAUNCH_TIMED(kernel, grid, block, lds, st, e0, e1, ...)                                          \
+    do {                                                                                                    \
+        if ((e0) != nullptr) hipExtLaunchKernelGGL(kernel, grid, block, lds, st, e0, e1, 0, __VA_ARGS__);   \
+        else hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                 \
+    } while (0)
+
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return __fdividef(1.0f, 1.0f + __expf(-x)); }      // v_exp + v_rcp (1 ulp each)
@@ -161,4 +172,4 @@ int gt_rec_cell_fwd_z(const float* X, int64_t ldx, const void* Wp, int wbf16, fl
                       const uint8_t* keep, float p_drop, float* gates, float* c_out, float* h_raw, float* h0, int64_t ld0,
                       float* h1, int64_t ld1, float* h2, int64_t ld2, const float* Wq, int64_t ldwq, float* qpart,
                       int64_t q_sstride, int32_t A, int32_t Apad, const int32_t* active, const float* h_prev, int64_t ld_hprev,
-                      int32_t ndir, const int64_t* dz, int32_t prio, void* stream);
+                      int32_t ndir, const int64_t* dz, int32_t prio, void* stream, int32_t k_own = 0, int32_t extra_slabs = 0);

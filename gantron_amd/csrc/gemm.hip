@@ -37,6 +37,7 @@ struct GemmDev {
                             // re-reads the first one's addresses (cache-hot sources), 4 = no MFMAs
     float alpha;
 };
+static_assert(sizeof(GemmDev) <= 1024, "GemmDev is a by-value kernel argument: keep it well below the 4 KB kernel-argument segment");
 
 constexpr int BK = 16;
 

@@ -245,6 +245,13 @@ static int decoder_fwd_hoisted(const GtDecoderFwd* a, void* stream) {
                             a->ld1 % 4 == 0 && a->ld2 % 4 == 0 && a->ldE % 4 == 0 && (a->Hd % 4 == 0) && a->To < (1 << 24);
     const int64_t x1_slot = fusedA ? (int64_t)a->Bp * a->ld1 : 0;      // operand ping-pong (see GtDecoderFwd::W1c)
     const int64_t xh_slot = fusedB ? (int64_t)a->Bp * a->ldh : 0;
+    // the h_att half of the attention LSTM's product rides in the attention step in front of it (GtDecoderFwd::tail_work)
+    const bool tailA = a->tail_work != nullptr && a->Sx1 >= 1 && fusedA && attn_step2 && !a->bf16 && !a->rec_x3 && a->Bp <= 64 &&
+                       a->E % 16 == 0 && a->S1 + a->Sx1 <= 16 && a->Sx1 <= a->Ha / 16;
+    GT_REQUIRE(a->tail_work == nullptr || tailA, GT_E_ARG,
+               "gt_decoder_fwd: tail_work needs W1c + attn_xbuf, fp32, Bp <= 64, E %% 16 == 0, 1 <= Sx1 <= Ha / 16, S1 + Sx1 <= 16");
+    const int tail_kb = (a->tail_kb >= 1 && a->tail_kb <= a->Ha / 16) ? a->tail_kb : a->Ha / 16;      // k-blocks of the tail
+    const int k_own = K1 - 16 * tail_kb;                                                                 // what the LSTM launch keeps
     int nblock = 0;
     for (int t0 = 0; t0 < a->To;) {
         // the last `blk` steps go in quarter blocks: what stream B still has to do after A's last step is exposed
@@ -263,7 +270,7 @@ static int decoder_fwd_hoisted(const GtDecoderFwd* a, void* stream) {
                                        a->gates1 + (int64_t)t * a->Bp * N1, a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha,
                                        a->hatt + (int64_t)t * a->Bp * a->Ha, X1n + a->E, a->ld1, XAt, a->ld2, nullptr, 0, a->Wq,
                                        a->Ha, a->partq, (int64_t)a->Bp * a->Apad, a->A, a->Apad, nullptr, nullptr, 0, 1, nullptr,
-                                       two ? kPrioA : 0, sA));
+                                       two ? kPrioA : 0, sA, (tailA && t > 0) ? k_own : 0, (tailA && t > 0) ? a->Sx1 : 0));
             } else {
                 GT_TRY(rec_rows(X1c, a->ld1, a->W1p, a->part, a->Bp, N1, K1, a->S1, sA, a->bf16, two ? kPrioA : 0));
                 if (cq)      // cell + query projection in one launch
@@ -284,12 +291,19 @@ static int decoder_fwd_hoisted(const GtDecoderFwd* a, void* stream) {
             const GtSlabs qs = cq ? slabs(a->partq, a->Ha / (fusedA ? 16 : 32), (int64_t)a->Bp * a->Apad, a->Apad)
                                   : slabs(a->part, a->Sq, (int64_t)a->Bp * a->Apad, a->Apad);
             if (attn_step2) {       // energies + softmax + context: one launch, partial contexts, the row's last arriver combines
-                GT_TRY(gt_attn_step2_fwd(d, qs, a->w_hist + (int64_t)t * BT, a->cum_hist + (int64_t)t * BT, a->pm, a->Wc, a->Wd,
-                                         a->v, a->lengths, a->q_hist + (int64_t)t * a->B * a->A, wpack,
-                                         a->u_hist ? a->u_hist + (int64_t)t * BT * a->A : nullptr, a->attn_xbuf, a->row_cnt,
-                                         (uint32_t)(t + 1), a->memory, a->ldE, a->w_hist + (int64_t)(t + 1) * BT,
-                                         a->cum_hist + (int64_t)t * BT, a->cum_hist + (int64_t)(t + 1) * BT, X1n, a->ld1,
-                                         XAt + a->Ha, a->ld2, hc_t + a->Hd, hc_ld, sA));
+                GtRecTail tl = {};
+                if (tailA && t + 1 < a->To) {       // h_att_t . W1[:, E:]^T for LSTM step t + 1: h_att_t is in X1n already
+                    tl.X = X1n; tl.ldx = a->ld1; tl.Wp = a->W1c;
+                    tl.out = a->part + (int64_t)a->S1 * a->Bp * N1; tl.out_sstride = (int64_t)a->Bp * N1;
+                    tl.N = N1; tl.KB = cdiv(K1, 16); tl.kb0 = k_own / 16; tl.kb1 = tl.KB; tl.kbs = cdiv(tl.kb1 - tl.kb0, a->Sx1);
+                    tl.cg0 = 0; tl.groups = N1 / 64; tl.mtiles = a->Bp / 16; tl.work = a->tail_work + t;
+                }
+                GT_TRY(gt_attn_step2_fwd_tail(d, qs, a->w_hist + (int64_t)t * BT, a->cum_hist + (int64_t)t * BT, a->pm, a->Wc, a->Wd,
+                                              a->v, a->lengths, a->q_hist + (int64_t)t * a->B * a->A, wpack,
+                                              a->u_hist ? a->u_hist + (int64_t)t * BT * a->A : nullptr, a->attn_xbuf, a->row_cnt,
+                                              (uint32_t)(t + 1), a->memory, a->ldE, a->w_hist + (int64_t)(t + 1) * BT,
+                                              a->cum_hist + (int64_t)t * BT, a->cum_hist + (int64_t)(t + 1) * BT, X1n, a->ld1,
+                                              XAt + a->Ha, a->ld2, hc_t + a->Hd, hc_ld, &tl, sA));
                 continue;
             }
             if (attn_step) {        // energies + softmax + context: one launch, the row's workgroups meet inside it

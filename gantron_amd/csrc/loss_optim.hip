@@ -77,7 +77,11 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* x, long n, floa
 
 __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, long n, float lr,
                                                    float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
-                                                   const float* sumsq, float max_norm) {
+                                                   const float* sumsq, float max_norm, const int* skip_flag) {
+    // skip_flag (or NULL): a word that kernels with a bounded in-launch wait raise when a wait gives up (the gradients of that
+    // step are then undefined): the step is not applied -- parameters and moments stay as they were -- without the host
+    // having to look (it finds the flag at its next synchronisation point and stops)
+    if (skip_flag != nullptr && __hip_atomic_load(skip_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     float coef = 1.f;
     if (sumsq != nullptr) coef = fminf(max_norm / (sqrtf(*sumsq) + 1e-6f), 1.f);
     const float step = lr / bc1;
@@ -132,12 +136,18 @@ extern "C" int gt_sumsq(const float* x, int64_t n, float* out, void* stream) {
 extern "C" int gt_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
                             float beta2, float eps, float weight_decay, int32_t step, const float* sumsq,
                             float max_norm, void* stream) {
+    return gt_adam_step_guarded(param, grad, m, v, n, lr, beta1, beta2, eps, weight_decay, step, sumsq, max_norm, nullptr, stream);
+}
+
+extern "C" int gt_adam_step_guarded(float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
+                                    float beta2, float eps, float weight_decay, int32_t step, const float* sumsq,
+                                    float max_norm, const int32_t* skip_flag, void* stream) {
     GT_REQUIRE(param && grad && m && v && n > 0 && step >= 1, GT_E_ARG, "gt_adam_step: bad argument");
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
     const unsigned blocks = (unsigned)std::min<long>(std::max<long>(cdiv64(n, 1024), 1), 4096);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, ST, param, grad, m, v, (long)n, lr, beta1, beta2, eps,
-                       weight_decay, bc1, bc2s, sumsq, max_norm);
+                       weight_decay, bc1, bc2s, sumsq, max_norm, skip_flag);
     GT_LAUNCH_CHECK();
     return 0;
 }

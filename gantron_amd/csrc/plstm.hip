@@ -46,6 +46,7 @@ struct PlstmDev {
     int* timeout_flag;
     int B, H, s_lo, s_hi, NW;
 };
+static_assert(sizeof(PlstmDev) <= 1024, "PlstmDev is a by-value kernel argument: keep it well below the 4 KB kernel-argument segment");
 
 constexpr int PL_ROWS = 64;                      // Bp (four 16-row MFMA tiles)
 constexpr int PL_RED = 4 * 4 * 4 * 64;           // float4 slots of the K-slice fold: [wave][gate][row tile][lane]
@@ -238,6 +239,7 @@ struct PlstmBwdDev {
     unsigned* cnt; int* timeout_flag;
     int B, H, s_lo, s_hi, NW, recurrent_in;
 };
+static_assert(sizeof(PlstmBwdDev) <= 1024, "PlstmBwdDev is a by-value kernel argument: keep it well below the 4 KB kernel-argument segment");
 
 template <int KW>       // KW = H / 4 output columns per wave
 __global__ __launch_bounds__(256) void plstm_bwd_kernel(PlstmBwdDev a) {
@@ -384,7 +386,28 @@ __global__ __launch_bounds__(256) void plstm_bwd_kernel(PlstmBwdDev a) {
 
 }  // namespace
 
-extern "C" int gt_plstm_supported(int32_t Bp, int32_t H) { return Bp == PL_ROWS && (H == 256 || H == 1024) ? 1 : 0; }
+// Every workgroup of a persistent recurrence spin-waits on its peers: all ndir * H / 16 of them (one per CU, the whole
+// register file) must be resident at once, beside the kernels of the attention chain that run meanwhile.  So the CURRENT
+// device must have at least twice as many CUs as the largest launch holds (H = 1024: 64 workgroups -> 128 CUs; H = 256, two
+// directions: 32 -> 64): a partitioned device (CPX: 32 CUs) or a small part gets the per-step launches instead.  (Streams
+// with CU masks are the caller's business: the loops never create any.)  A launch whose workgroups could not all become
+// resident does not hang -- the waits are bounded and raise the sticky time-out flag -- but its results are undefined.
+static int plstm_device_cus() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        cus[dev] = n > 0 ? n : -1;
+    }
+    return cus[dev] > 0 ? cus[dev] : 0;
+}
+extern "C" int gt_plstm_supported(int32_t Bp, int32_t H) {
+    if (Bp != PL_ROWS || !(H == 256 || H == 1024)) return 0;
+    const int need = 2 * (H == 1024 ? H / 16 : 2 * (H / 16));
+    return plstm_device_cus() >= need ? 1 : 0;
+}
 
 extern "C" int gt_plstm_fwd(const GtPlstm* q, void* stream) {
     GT_REQUIRE(q != nullptr, GT_E_ARG, "gt_plstm_fwd: NULL");

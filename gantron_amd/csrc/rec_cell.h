@@ -26,7 +26,11 @@ struct RecCellEpi {
     // buffer's address travels in a __device__ variable, not here (the struct is a by-value kernel argument: with 16 more
     // bytes in it rocprofv3's counter collection crashed in its copy of the kernel arguments)
     int stamp_on;
+    // Sx > 0: slabs S .. S + Sx - 1 of this column group were written by an EARLIER launch (the part of the product whose
+    // operands existed before this step's: GtRecTail, rec_tail.h); the last arriver adds them with the K-slices' own
+    int Sx;
 };
+static_assert(sizeof(RecCellEpi) == 288, "RecCellEpi is a by-value kernel argument (288 bytes: Sx sits in what was padding)");
 #define REC_STAMP(e, k) do { if ((e).stamp_on && threadIdx.x == 0) \
     g_rec_stamps_dev[((long)blockIdx.x + (long)gridDim.x * blockIdx.y) * 8 + (k)] = wall_clock64(); } while (0)
 
@@ -126,19 +130,22 @@ __device__ __forceinline__ void rec_cell_epilogue(float* red, const RecCellEpi& 
             if (cb * 16 + (lane & 15) < e.A) wq[sl] = t;
         }
     }
-    if (e.S > 1) {
+    const int nsl = e.S + e.Sx;                    // the K-slices' slabs, then the earlier launch's
+    if (nsl > 1) {
         const __amdgpu_buffer_rsrc_t rd = rc_rsrc(slab0);
         float4 acc[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int s0 = 0; s0 < e.S; s0 += 4) {       // four slabs in flight per pass
+        for (int s0 = 0; s0 < nsl; s0 += 4) {       // four slabs in flight per pass
             float4 t[4][NV];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                // slabs beyond S and this workgroup's own (still in LDS) are replaced by a re-read of slab 0 and masked
+                // slabs beyond the last and this workgroup's own (still in LDS) are replaced by a re-read of slab 0 and masked
                 const int sj = s0 + j;
-                const bool use = sj < e.S && sj != s;
-                const long base = (long)(use ? sj : 0) * ps;
+                const bool use = sj < nsl && sj != s;
+                // (the re-read must hit written memory: slab 0 is published before any ticket when S > 1; with S == 1 this
+                // workgroup's own tile never leaves LDS and the first earlier slab stands in)
+                const long base = (long)(use ? sj : (e.Sx > 0 ? e.S : 0)) * ps;
 #pragma unroll
                 for (int i = 0; i < NV; ++i) {
                     const int f = min(tid + REC_THREADS * i, ROWS * 16 - 1);
@@ -149,7 +156,7 @@ __device__ __forceinline__ void rec_cell_epilogue(float* red, const RecCellEpi& 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int sj = s0 + j;
-                const float w = (sj < e.S && sj != s) ? 1.f : 0.f;
+                const float w = (sj < nsl && sj != s) ? 1.f : 0.f;
 #pragma unroll
                 for (int i = 0; i < NV; ++i) {
                     acc[i].x += w * t[j][i].x; acc[i].y += w * t[j][i].y; acc[i].z += w * t[j][i].z; acc[i].w += w * t[j][i].w;

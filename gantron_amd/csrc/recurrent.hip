@@ -250,6 +250,7 @@ struct RecProblem {
     float* part; long ps;
     int N, KB, KBS, groups, splits;
 };
+static_assert(sizeof(RecProblem) <= 1024, "RecProblem is a by-value kernel argument: keep it well below the 4 KB kernel-argument segment");
 
 template <int MT>
 __global__ __launch_bounds__(REC_THREADS) void rec_gemm2_kernel(RecProblem p0, RecProblem p1) {
@@ -276,7 +277,8 @@ __global__ __launch_bounds__(REC_THREADS) void rec_gemm2_kernel(RecProblem p0, R
 template <int MT>
 __global__ __launch_bounds__(REC_THREADS) void rec_cell_kernel(const float* __restrict__ X, long ldx,
                                                                const float* __restrict__ Wp, float* part, int N, int KB,
-                                                               int KBS, long xz, long pz, long ps, int prio, RecCellEpi e) {
+                                                               int KBS, int KBlim, long xz, long pz, long ps, int prio, RecCellEpi e) {
+    // KBlim <= KB: the k-blocks beyond it are not this launch's (e.Sx: an earlier launch has left their products as slabs)
     if (prio == 3) __builtin_amdgcn_s_setprio(3);
     else if (prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (prio == 1) __builtin_amdgcn_s_setprio(1);
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(REC_THREADS) void rec_cell_kernel(const float* __re
         rec_cell_dir1(e);
     }
     REC_STAMP(e, 0);
-    float* red = rec_gemm_tile<MT, 0, 2>(X + (long)rb * xz, ldx, Wp, N, KB, kb0, min(KB, kb0 + KBS), cg,
+    float* red = rec_gemm_tile<MT, 0, 2>(X + (long)rb * xz, ldx, Wp, N, KB, kb0, min(KBlim, kb0 + KBS), cg,
                                           e.stamp_on ? g_rec_stamps_dev + ((long)blockIdx.x + (long)gridDim.x * blockIdx.y) * 8 : nullptr);
     rec_cell_epilogue<MT>(red, e, part + (long)rb * pz, ps, N, cg, s, rb, e.counters + (long)z * gridDim.x + cg);
 }
@@ -321,6 +323,7 @@ struct CellFwd {
     // blockIdx.y = 1 (second BiLSTM direction): element offsets added to the pointers above
     long z_part, z_pre, z_c, z_hprev, z_gates, z_hraw, z_h0;
 };
+static_assert(sizeof(CellFwd) <= 1024, "CellFwd is a by-value kernel argument: keep it well below the 4 KB kernel-argument segment");
 
 // V = hidden units per thread (4: float4 accesses when every pointer / leading dimension allows it)
 template <int V>
@@ -423,6 +426,7 @@ struct CellBwd {
     int B, H;
     long z_da, z_direct, z_dc, z_gates, z_c, z_dgates;     // blockIdx.y = 1: second BiLSTM direction
 };
+static_assert(sizeof(CellBwd) <= 1024, "CellBwd is a by-value kernel argument: keep it well below the 4 KB kernel-argument segment");
 
 template <int V>
 __device__ __forceinline__ void vload(const float* p, float (&o)[V]) {
@@ -586,12 +590,12 @@ int gt_rec_gemm_prio(const float* X, int64_t ldx, const float* Wp, float* part, 
     // two co-resident workgroups would serialise on one CU's matrix pipes while another CU idles
     static const int lds_pad = gt_env_item("GANTRON_DEBUG", "rec_lds_pad", 0);
 #define GT_REC(MT)                                                                                    \
-    hipExtLaunchKernelGGL((rec_gemm_kernel<MT>), grid, dim3(REC_THREADS), lds_pad, st, prof.e0, prof.e1, 0, X, (long)ldx, \
+    GT_LAUNCH_TIMED((rec_gemm_kernel<MT>), grid, dim3(REC_THREADS), lds_pad, st, prof.e0, prof.e1, X, (long)ldx, \
                           Wp, part, N, KB, KBS, (long)x_zstride, (long)w_zstride, (long)part_zstride, (long)part_sstride, prio)
     static const int dbg = gt_env_item("GANTRON_DEBUG", "rec", 0);
     if (dbg && mtiles == 4) {   // diagnostic variants (wrong results by construction)
 #define GT_RECD(D)                                                                                       \
-    hipExtLaunchKernelGGL((rec_gemm_kernel<4, D>), grid, dim3(REC_THREADS), lds_pad, st, prof.e0, prof.e1, 0, X, (long)ldx, \
+    GT_LAUNCH_TIMED((rec_gemm_kernel<4, D>), grid, dim3(REC_THREADS), lds_pad, st, prof.e0, prof.e1, X, (long)ldx, \
                           Wp, part, N, KB, KBS, (long)x_zstride, (long)w_zstride, (long)part_zstride, (long)part_sstride, prio)
         switch (dbg) {
             case 1: GT_RECD(1); break;
@@ -652,8 +656,14 @@ int gt_rec_cell_fwd_z(const float* X, int64_t ldx, const void* Wpv, int wbf16, f
                       const uint8_t* keep, float p_drop, float* gates, float* c_out, float* h_raw, float* h0, int64_t ld0,
                       float* h1, int64_t ld1, float* h2, int64_t ld2, const float* Wq, int64_t ldwq, float* qpart,
                       int64_t q_sstride, int32_t A, int32_t Apad, const int32_t* active, const float* h_prev, int64_t ld_hprev,
-                      int32_t ndir, const int64_t* dz, int32_t prio, void* stream) {
+                      int32_t ndir, const int64_t* dz, int32_t prio, void* stream, int32_t k_own, int32_t extra_slabs) {
     const float* Wp = static_cast<const float*>(Wpv);
+    // k_own > 0: only the first k_own (a multiple of 16) of the K reduction columns are this launch's; the products of the
+    // rest lie in `extra_slabs` slabs behind the K-slices' own (part + (splits + j) * Bp * 4H), written by an earlier launch
+    GT_REQUIRE(k_own == 0 || (k_own > 0 && k_own % 16 == 0 && k_own <= K && wbf16 == 0 && ndir == 1), GT_E_ARG,
+               "gt_rec_cell_fwd: k_own=%d must be a multiple of 16 <= K (fp32, one direction)", k_own);
+    GT_REQUIRE(extra_slabs >= 0 && extra_slabs + splits <= 16 && (extra_slabs == 0 || wbf16 == 0), GT_E_ARG,
+               "gt_rec_cell_fwd: extra_slabs=%d (with %d splits: at most 16 slabs, fp32 only)", extra_slabs, splits);
     GT_REQUIRE(X && Wp && part && counters && c_prev && c_out, GT_E_ARG, "gt_rec_cell_fwd: NULL pointer");
     GT_REQUIRE(B > 0 && Bp >= B && ((Bp <= 64 && Bp % 16 == 0) || Bp % 64 == 0) && H > 0 && H % 16 == 0 && K > 0 && splits >= 1 &&
                    splits <= 16, GT_E_ARG, "gt_rec_cell_fwd: bad sizes B=%d Bp=%d H=%d K=%d splits=%d", B, Bp, H, K, splits);
@@ -671,10 +681,12 @@ int gt_rec_cell_fwd_z(const float* X, int64_t ldx, const void* Wpv, int wbf16, f
     if (Wq != nullptr)
         GT_REQUIRE(qpart && A > 0 && Apad >= A && Apad % 16 == 0 && Apad <= 256 && q_sstride >= (int64_t)Bp * Apad, GT_E_LIMIT,
                    "gt_rec_cell_fwd: attention_dim %d (padded %d) must fit 16 column blocks", A, Apad);
-    const int KBS = cdiv(KB, splits);
-    GT_REQUIRE(cdiv(KB, KBS) == splits, GT_E_ARG, "gt_rec_cell_fwd: splits=%d leaves empty slabs for K=%d", splits, K);
+    const int KBlim = k_own > 0 ? k_own / 16 : KB;
+    const int KBS = cdiv(KBlim, splits);
+    GT_REQUIRE(cdiv(KBlim, KBS) == splits, GT_E_ARG, "gt_rec_cell_fwd: splits=%d leaves empty slabs for K=%d", splits, 16 * KBlim);
     const int mt = Bp <= 64 ? Bp / 16 : 4, nzb = Bp <= 64 ? 1 : Bp / 64;
     RecCellEpi e;
+    e.Sx = extra_slabs;
     e.pre = pre; e.ld_pre = ld_pre; e.c_prev = c_prev; e.c_out = c_out; e.keep = keep; e.scale = 1.0f / (1.0f - p_drop);
     e.gates = gates; e.h_raw = h_raw; e.h0 = h0; e.ld0 = ld0; e.h1 = h1; e.ld1 = ld1; e.h2 = h2; e.ld2 = ld2;
     // (query slabs laid out [row][column group][Apad] instead, so that a row's 64 slabs are one contiguous 32 KB for the attention
@@ -707,14 +719,16 @@ int gt_rec_cell_fwd_z(const float* X, int64_t ldx, const void* Wpv, int wbf16, f
     }
     dim3 grid(N / 64, splits, nzb * ndir);
     hipStream_t st = (hipStream_t)stream;
-    GtProfScope prof(GT_FAM_REC_CELL, ndir * (2.0 * Bp * (double)N * K + (Wq ? 2.0 * Bp * (double)H * A : 0.0)),
-                     ndir * ((wbf16 == 3 ? 6.0 : wbf16 ? 2.0 : 4.0) * (double)N * K +
-                             4.0 * ((double)Bp * K + (double)Bp * N * (splits > 1 ? 2 * splits - 1 : 0) + (double)B * H * 12)), st, true);
+    const double Kown = 16.0 * KBlim < K ? 16.0 * KBlim : (double)K;        // the reduction columns this launch multiplies
+    GtProfScope prof(GT_FAM_REC_CELL, ndir * (2.0 * Bp * (double)N * Kown + (Wq ? 2.0 * Bp * (double)H * A : 0.0)),
+                     ndir * ((wbf16 == 3 ? 6.0 : wbf16 ? 2.0 : 4.0) * (double)N * Kown +
+                             4.0 * ((double)Bp * Kown + (double)Bp * N * ((splits > 1 ? 2 * splits - 1 : 0) + extra_slabs) +
+                                    (double)B * H * 12)), st, true);
     if (wbf16) return gt_launch_rec_cell_bf16(X, ldx, Wpv, part, Bp, N, K, splits, ndir, prio, e, prof.e0, prof.e1, stream, wbf16 == 3 ? 3 : 1);
     const long ps = (long)Bp * N;
 #define GT_RC(MT)                                                                                                      \
-    hipExtLaunchKernelGGL((rec_cell_kernel<MT>), grid, dim3(REC_THREADS), 0, st, prof.e0, prof.e1, 0, X, (long)ldx, Wp, part,  \
-                          N, KB, KBS, (long)(64 * ldx), (long)64 * N, ps, prio, e)
+    GT_LAUNCH_TIMED((rec_cell_kernel<MT>), grid, dim3(REC_THREADS), 0, st, prof.e0, prof.e1, X, (long)ldx, Wp, part,  \
+                          N, KB, KBS, KBlim, (long)(64 * ldx), (long)64 * N, ps, prio, e)
     switch (mt) {
         case 1: GT_RC(1); break;
         case 2: GT_RC(2); break;
@@ -735,6 +749,17 @@ extern "C" int gt_rec_cell_fwd(const float* X, int64_t ldx, const float* Wp, flo
     return gt_rec_cell_fwd_z(X, ldx, Wp, 0, part, counters, Bp, B, H, K, splits, pre, ld_pre, c_prev, keep, p_drop, gates, c_out,
                              h_raw, h0, ld0, h1, ld1, h2, ld2, Wq, ldwq, qpart, q_sstride, A, Apad, nullptr, nullptr, 0, 1,
                              nullptr, prio, stream);
+}
+
+extern "C" int gt_rec_cell_fwd_part(const float* X, int64_t ldx, const float* Wp, float* part, uint32_t* counters, int32_t Bp,
+                                    int32_t B, int32_t H, int32_t K, int32_t splits, const float* pre, int64_t ld_pre,
+                                    const float* c_prev, const uint8_t* keep, float p_drop, float* gates, float* c_out,
+                                    float* h_raw, float* h0, int64_t ld0, float* h1, int64_t ld1, float* h2, int64_t ld2,
+                                    const float* Wq, int64_t ldwq, float* qpart, int64_t q_sstride, int32_t A, int32_t Apad,
+                                    int32_t k_own, int32_t extra_slabs, int32_t prio, void* stream) {
+    return gt_rec_cell_fwd_z(X, ldx, Wp, 0, part, counters, Bp, B, H, K, splits, pre, ld_pre, c_prev, keep, p_drop, gates, c_out,
+                             h_raw, h0, ld0, h1, ld1, h2, ld2, Wq, ldwq, qpart, q_sstride, A, Apad, nullptr, nullptr, 0, 1,
+                             nullptr, prio, stream, k_own, extra_slabs);
 }
 
 extern "C" int gt_rec_cell_fwd_bf16(const float* X, int64_t ldx, const void* Wp, float* part, uint32_t* counters, int32_t Bp,
@@ -787,7 +812,7 @@ extern "C" int gt_rec_cellbwd(const float* X, int64_t ldx, const float* Wp, floa
                      true);
     const long ps = (long)Bp * N;
 #define GT_RCB(MT)                                                                                                     \
-    hipExtLaunchKernelGGL((rec_cellbwd_kernel<MT>), grid, dim3(REC_THREADS), 0, st, prof.e0, prof.e1, 0, X, (long)ldx, Wp, part,  \
+    GT_LAUNCH_TIMED((rec_cellbwd_kernel<MT>), grid, dim3(REC_THREADS), 0, st, prof.e0, prof.e1, X, (long)ldx, Wp, part,  \
                           N, KB, KBS, (long)(64 * ldx), (long)64 * N, ps, prio, e)
     switch (mt) {
         case 1: GT_RCB(1); break;

@@ -322,7 +322,7 @@ int gt_rec_gemm_bf16_prio(const float* X, int64_t ldx, const void* Wp, float* pa
     const uint4* wp = reinterpret_cast<const uint4*>(Wp);
     const int nch = cdiv(KBS, RB_CB);           // chunks of a slice: one instantiation each (all loads issued up front)
 #define GT_RECB(MT, NCH, NP)                                                                                          \
-    hipExtLaunchKernelGGL((rec_gemm_bf16_kernel<MT, NCH, NP>), grid, dim3(RB_THREADS), 0, st, prof.e0, prof.e1, 0, X, (long)ldx, \
+    GT_LAUNCH_TIMED((rec_gemm_bf16_kernel<MT, NCH, NP>), grid, dim3(RB_THREADS), 0, st, prof.e0, prof.e1, X, (long)ldx, \
                           kvalid, wp, part, N, KB, KBS, (long)x_zstride, (long)(w_zstride / 8), (long)part_zstride,        \
                           (long)part_sstride, prio)
 #define GT_RECB_M(MT)                                  \
@@ -380,7 +380,7 @@ int gt_launch_rec_cell_bf16(const float* X, int64_t ldx, const void* Wp, float* 
     const long ps = (long)Bp * N;
     const int nch = cdiv(KBS, RB_CB);
 #define GT_RCB(MT, NCH, NP)                                                                                              \
-    hipExtLaunchKernelGGL((rec_cell_bf16_kernel<MT, NCH, NP>), grid, dim3(RB_THREADS), 0, st, e0, e1, 0, X, (long)ldx, kvalid, wp, \
+    GT_LAUNCH_TIMED((rec_cell_bf16_kernel<MT, NCH, NP>), grid, dim3(RB_THREADS), 0, st, e0, e1, X, (long)ldx, kvalid, wp, \
                           part, N, KB, KBS, (long)(64 * ldx), (long)64 * N, ps, prio, e)
 #define GT_RCB_M(MT)                                   \
     if (planes == 3) switch (nch) {                    \

@@ -38,6 +38,7 @@ struct FusedCell {
     float* h0; long ld0; float* h1; long ld1; float* h2; long ld2;
     int B;                                // valid rows (rows >= B are not written)
 };
+static_assert(sizeof(FusedCell) <= 1024, "FusedCell is a by-value kernel argument: keep it well below the 4 KB kernel-argument segment");
 
 // DBG (diagnostics, GANTRON_DEBUG=fused=<bits>): bit 0 = no weight loads, bit 1 = no MFMAs, bit 2 = no activation staging,
 // bit 3 = no chunk rotation

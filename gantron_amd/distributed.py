@@ -61,6 +61,11 @@ def _average_flat(module):
     for _, _, work in early:
         work.wait()                # the current stream waits for the side-stream collective
     _scale(flat, dist.get_world_size())
+    if flat.is_cuda:
+        # one rank whose in-launch hand-offs gave up (engine.handoff_flag) has just poisoned the average: every rank must
+        # skip this optimizer step (gt_adam_step_guarded reads the flag), or the replicas drift apart
+        from .engine import handoff_flag
+        dist.all_reduce(handoff_flag(flat.device), op=dist.ReduceOp.MAX)
 
 
 def apply_gradient_allreduce(module):

@@ -90,6 +90,17 @@ DEC_BLK = 16       # steps per block in that mode (measured: 8: 160.6 ms per pai
 ATTN_STEP = bool(sw.experimental('attn_step'))
 # the same step as one launch WITHOUT a wait: per-chunk partial contexts, the row's last arriver combines (gt_attn_step2_fwd)
 ATTN_STEP2 = sw.schedule_on('attn_step2')
+# The h_att half of the attention LSTM's forward product rides in the attention step in front of it (GtRecTail, csrc/rec_tail.h):
+# the step's workgroups that have nothing (more) to do pick up (column group, K-slice) items of h_att_t . W1[:, E:]^T, and LSTM
+# step t + 1 multiplies the ctx half only.  REC_TAIL_FWD = K-slices of that half (GANTRON_EXPERIMENTAL=rec_tail[=slices], 0: off),
+# REC_TAIL_KB = how many of its 16-wide k-blocks ride (GANTRON_DEBUG=rec_tail_kb=<n>, 0: all).  Measured (round 4, DESIGN.md
+# section 3) and NOT adopted: the LSTM launch gets 5-6 us shorter and the attention step 5.6-6.6 us longer, whatever the item
+# size (2 / 3 / 4 / 6 / 8 slices), the prefetch depth of the tail's product, its issue priority and the share of the half
+# that rides (24 / 36 / 44 / 64 k-blocks: the two launches always sum to 41.6-42.3 us) -- pair 123.8-125.4 against
+# 123.4-123.8 ms.  The bytes cost the same wherever they are moved.
+REC_TAIL_FWD = sw.experimental('rec_tail', 0)
+REC_TAIL_FWD = 3 if REC_TAIL_FWD == 1 else REC_TAIL_FWD
+REC_TAIL_KB = sw.debug('rec_tail_kb', 0)
 _HANDOFF_FLAGS = {}
 
 
@@ -707,9 +718,20 @@ class GeneratorEngine:
         # loop kernels for every row < B; they only have to start as zeros where the loops leave something unwritten that a
         # later GEMM reads: padded rows (Bp > B), padded context columns (Ep > E), padded leading dimensions.
         zh = not (Bp == B and Ep == E)
+        dims_f = ops.attn_dims(B, Ti, Ep, A, self.F, self.Kc)
+        # the h_att half of the attention LSTM's product as a tail of the attention step (REC_TAIL_FWD K-slices): fp32, <= 64 rows
+        tail1 = REC_TAIL_FWD if (hoist2 and use_c1 and not self.bf16 and not x3 and Bp <= 64 and Ep % 16 == 0 and ATTN_STEP2 and
+                                 lib().gt_attn_step2_supported(dims_f) and REC_TAIL_FWD <= Ha // 16) else 0
+        if tail1:
+            # K-slices of what stays in the LSTM launch (step 0 multiplies all of K with the same count)
+            tkb = REC_TAIL_KB if 1 <= REC_TAIL_KB <= Ha // 16 else Ha // 16
+            d.S1 = next(s_ for s_ in range(S1_FWD or d.S1, 0, -1)
+                        if ops.pick_splits(K1 - 16 * tkb, s_) == s_ and ops.pick_splits(K1, s_) == s_)
+            tail1 = ops.pick_splits(16 * tkb, min(tail1, 16 - d.S1))
+            d.tail_kb = tkb
         ws = dict(X1=_f32(2, Bp, ld1, device=dev),
                   X2=_f32(To if hoist2 else DEC_RING, Bp, ld2, device=dev, zero=zh or not hoist2 or ld2 != Ha + Ep),
-                  part=_f32(max(d.S1 * Bp * 4 * Ha, d.S2 * Bp * 4 * Hd, d.Sq * Bp * Apad), device=dev, zero=False),
+                  part=_f32(max((d.S1 + tail1) * Bp * 4 * Ha, d.S2 * Bp * 4 * Hd, d.Sq * Bp * Apad), device=dev, zero=False),
                   part2=_f32(d.S2 * Bp * 4 * Hd, device=dev, zero=False),
                   energies=_f32(B, Ti, device=dev, zero=False))
         hist = dict(gates1=_f32(To, Bp, 4 * Ha, device=dev, zero=zh), c1=_state(To + 1, Bp, Ha, dev, zh),
@@ -756,7 +778,9 @@ class GeneratorEngine:
             keep_t['W2hh_raw'] = W2hh.contiguous()
             ws['pl_counters'] = torch.zeros(1, dtype=torch.int32, device=dev)
             d.W2hh, d.pl_counters, d.pl_timeout = ptr(keep_t['W2hh_raw']), ptr(ws['pl_counters']), ptr(handoff_flag(dev))
-        dims_f = ops.attn_dims(B, Ti, Ep, A, self.F, self.Kc)
+        if tail1:
+            ws['tail_work'] = torch.zeros(To, dtype=torch.int32, device=dev)
+            d.tail_work, d.Sx1 = ptr(ws['tail_work']), tail1
         if hoist2 and ATTN_STEP2 and lib().gt_attn_step2_supported(dims_f):
             nch = int(lib().gt_attn_chunks(Ti))
             ws['row_cnt'] = torch.zeros(B, dtype=torch.int32, device=dev)

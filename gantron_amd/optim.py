@@ -109,9 +109,13 @@ class FlatAdam:
         sumsq = None
         if max_norm is not None:
             sumsq = self.grad_norm()
-        ops.call('gt_adam_step', self.flat, self.grad, self.m, self.v, self.flat.numel(), float(g['lr']),
+        # the device's hand-off flag guards the update: a step whose in-launch waits gave up (engine.handoff_flag) leaves
+        # parameters and moments untouched, with no host synchronisation here; engine.check_handoffs() raises at the
+        # caller's next synchronisation point
+        from .engine import handoff_flag
+        ops.call('gt_adam_step_guarded', self.flat, self.grad, self.m, self.v, self.flat.numel(), float(g['lr']),
                  float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), float(g['weight_decay']), self.step_count,
-                 sumsq, float(max_norm) if max_norm is not None else 0.0)
+                 sumsq, float(max_norm) if max_norm is not None else 0.0, handoff_flag(self.flat.device))
         return sumsq
 
     # ---- torch.optim.Adam-compatible checkpoint format

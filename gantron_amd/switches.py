@@ -10,7 +10,8 @@ GANTRON_EXPERIMENTAL   comma list `name[=int]` of paths that were built, are par
                          (pre-split GEMM operands), plstm=<bits> (persistent LSTM recurrences, default 7: 1 encoder forward, 2
                          decoder forward blocks, 4 encoder backward, 8 decoder backward blocks; 0 = per-step launches),
                          rec_x3=<bits> (attention-LSTM products from three bf16 planes: 1 forward, 2 backward), graph[=2] (hipGraph replay of the decoder loops; 2 also reports capture / replay),
-                         no_pgemm2 (keep the plane GEMMs on 128 x 128 tiles).
+                         no_pgemm2 (keep the plane GEMMs on 128 x 128 tiles), rec_tail[=slices] (the h_att half of the
+                         attention LSTM's forward product rides in the attention step in front of it: csrc/rec_tail.h).
 GANTRON_SCHEDULE       comma list switching OFF parts of the default schedule (what the schedule-invariance test toggles
                        through the module attributes instead): no_cell_query, no_attn_hoist, no_hoist2, no_leaf_stream,
                        no_fwd_splitk, no_rec_cell (per-step product + cell launches instead of the fused ones), no_attn_step2 (energies
@@ -21,21 +22,43 @@ GANTRON_SCHEDULE       comma list switching OFF parts of the default schedule (w
                        no_dist_overlap.
 GANTRON_DEBUG          comma list of diagnostics: phase_timing, host_timing, block_timing, dist_timing, attn_valu,
                        rec=<bits> / fused=<bits> / pgemm=<bits> (kernel knock-outs), rec_splits=<n>, s1_fwd=<n>, s2_fwd=<n>,
-                       s2_bwd=<n>, s1_bwd=<n>, enc_splits=<n>, sync_every=<n>, rec_lds_pad=<n>, rec_stamps (phase stamps of the
-                       attention LSTM's launch: tools/rec_stamps.py).
-(The C side parses the same variables: csrc/api.hip, gt_env_item.)  bench.py / the tests additionally use
+                       s2_bwd=<n>, s1_bwd=<n>, enc_splits=<n>, sync_every=<n>, rec_lds_pad=<n>, rec_stamps / attn_stamps (phase
+                       stamps of the attention LSTM's launch and of the attention step: tools/rec_stamps.py), attn2=<bits>
+                       (knock-outs of the attention step), rec_tail_kb=<n>.
+An unknown name in any of the three lists raises at import with the valid names (a mistyped switch would otherwise run
+the default schedule silently); values are decimal integers.  (The C side parses the same variables with the same
+trimming rules: csrc/api.hip, gt_env_item.)  bench.py / the tests additionally use
 GANTRON_FORCE_DIST, GANTRON_BENCH_DEVICE and GANTRON_BENCH_BACKEND for the one-GPU rehearsals of the multi-rank paths.
 Tuned constants (block sizes, split-K targets, ring depth ...) are plain module attributes of engine.py / ops.py."""
 import os as _os
 
+# every name the package (Python or C side) looks up; keep in step with the docstring above
+_KNOWN = {
+    'GANTRON_EXPERIMENTAL': {'fused_cell', 'attn_step', 'leaf_defer', 'rec_cellbwd', 'plane_gemms', 'plstm', 'rec_x3', 'graph',
+                             'no_pgemm2', 'rec_tail'},
+    'GANTRON_SCHEDULE': {'no_cell_query', 'no_attn_hoist', 'no_hoist2', 'no_leaf_stream', 'no_fwd_splitk', 'no_rec_cell',
+                         'no_attn_step2', 'no_plstm', 'no_attn_bwd_fused', 'no_blk_gemm_aside', 'no_dist_overlap'},
+    'GANTRON_DEBUG': {'phase_timing', 'host_timing', 'block_timing', 'dist_timing', 'attn_valu', 'rec', 'fused', 'pgemm',
+                      'rec_splits', 's1_fwd', 's2_fwd', 's2_bwd', 's1_bwd', 'enc_splits', 'sync_every', 'rec_lds_pad',
+                      'rec_stamps', 'attn_stamps', 'attn2', 'rec_tail_kb'},
+}
 
-def _parse(var):
+
+def _parse(var, text=None):
+    """`name[=int]` items separated by ',' or ';', blanks around names, '=' and values ignored (the C parser's rules)."""
     out = {}
-    for item in _os.environ.get(var, '').replace(';', ',').split(','):
+    text = _os.environ.get(var, '') if text is None else text
+    for item in text.replace(';', ',').split(','):
         item = item.strip()
-        if item:
-            k, _, v = item.partition('=')
-            out[k.strip()] = int(v) if v.strip() else 1
+        if not item:
+            continue
+        k, eq, v = item.partition('=')
+        k, v = k.strip(), v.strip()
+        if k not in _KNOWN[var]:
+            raise ValueError(f'{var}: unknown switch {k!r}; valid names: {", ".join(sorted(_KNOWN[var]))}')
+        if eq and not v.lstrip('+-').isdigit():
+            raise ValueError(f'{var}: {k}={v!r} is not a decimal integer')
+        out[k] = int(v) if eq else 1
     return out
 
 
@@ -43,13 +66,16 @@ EXPERIMENTAL, SCHEDULE, DEBUG = _parse('GANTRON_EXPERIMENTAL'), _parse('GANTRON_
 
 
 def experimental(name, default=0):
+    assert name in _KNOWN['GANTRON_EXPERIMENTAL'], name
     return EXPERIMENTAL.get(name, default)
 
 
 def schedule_on(name):
     """True unless GANTRON_SCHEDULE lists no_<name>."""
+    assert 'no_' + name in _KNOWN['GANTRON_SCHEDULE'], name
     return not SCHEDULE.get('no_' + name, 0)
 
 
 def debug(name, default=0):
+    assert name in _KNOWN['GANTRON_DEBUG'], name
     return DEBUG.get(name, default)

@@ -202,6 +202,13 @@ def train(output_directory, checkpoint_path, warm_start, n_gpus, rank, group_nam
                 gen_times += 1
                 if gen_times > hparams.g_freq and hparams.d_freq > 0:
                     gen_times, disc_times = 0, 1
+            if rank == 0:
+                # the logger has just read this step's losses (a synchronisation): the cheapest place to find out that an
+                # in-launch hand-off gave up.  The optimizer step of such an iteration was not applied on ANY rank
+                # (gt_adam_step_guarded; the flag is MAX-reduced with the gradients); the other ranks find out at the next
+                # checkpoint at the latest.
+                from .engine import check_handoffs
+                check_handoffs()
             iteration += 1
             if iteration % hparams.iters_per_checkpoint == 0:
                 checkpoint_and_validate()

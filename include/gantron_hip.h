@@ -31,7 +31,8 @@ extern "C" {
 #define GT_E_ALIGN (-2)   /* pointer or leading dimension violates an alignment requirement */
 #define GT_E_LIMIT (-3)   /* size exceeds a compiled-in limit */
 
-int gt_version(void);
+#define GT_ABI_VERSION 400      /* bumped whenever a declared signature, struct layout or buffer size changes */
+int gt_version(void);           /* GT_ABI_VERSION of the library that was built: compare it with the header's at load */
 const char* gt_last_error_string(void);
 /* sizeof of ABI structs: 0 GtOperand, 1 GtGemm, 2 GtSlabs, 3 GtAttnDims, 4 GtDecoderFwd,
  * 5 GtDecoderBwd, 6 GtBiLstm (lets a binding verify its layout at load time) */
@@ -173,6 +174,16 @@ int gt_pack_rec_weight_bf16(const float* W, int64_t ldw, int32_t transposed, int
 int gt_rec_gemm_bf16(const float* X, int64_t ldx, const void* Wp, float* part, int32_t mtiles, int32_t N,
                      int32_t K, int32_t splits, int64_t part_sstride, int32_t nz, int64_t x_zstride,
                      int64_t w_zstride, int64_t part_zstride, void* stream);
+/* gt_rec_cell_fwd for a product whose tail was multiplied by an EARLIER launch (GtRecTail): only the first k_own (a
+ * multiple of 16, <= K) reduction columns are this launch's, cut into `splits` K-slices; the last arriver of a column group
+ * also adds `extra_slabs` slabs behind the K-slices' own (part + (splits + j) * Bp * 4H, j < extra_slabs; splits +
+ * extra_slabs <= 16).  k_own = 0: all of K. */
+int gt_rec_cell_fwd_part(const float* X, int64_t ldx, const float* Wp, float* part, uint32_t* counters, int32_t Bp,
+                         int32_t B, int32_t H, int32_t K, int32_t splits, const float* pre, int64_t ld_pre,
+                         const float* c_prev, const uint8_t* keep, float p_drop, float* gates, float* c_out,
+                         float* h_raw, float* h0, int64_t ld0, float* h1, int64_t ld1, float* h2, int64_t ld2,
+                         const float* Wq, int64_t ldwq, float* qpart, int64_t q_sstride, int32_t A, int32_t Apad,
+                         int32_t k_own, int32_t extra_slabs, int32_t prio, void* stream);
 /* gt_rec_cell_fwd with bf16-packed weights (gt_pack_rec_cell_weight_bf16: gt_rec_weight_bf16_elems(4H, K) 16-bit
  * elements, gate-grouped columns): bf16 MFMA product with fp32 accumulation, the cell, dropout and the query slabs in
  * fp32 exactly as in gt_rec_cell_fwd.  splits >= gt_rec_bf16_min_splits(K), <= 16. */
@@ -260,6 +271,31 @@ int gt_attn_step2_fwd(GtAttnDims d, GtSlabs qpart, const float* w_prev, const fl
                       const float* wpack, float* u_out, float* xbuf, uint32_t* row_cnt, uint32_t step1,
                       const float* memory, int64_t ld_mem, float* w_out, const float* cum_in, float* cum_out,
                       float* c0, int64_t ld0, float* c1, int64_t ld1, float* c2, int64_t ld2, void* stream);
+/* Recurrent-product work that rides in another launch (csrc/rec_tail.h).  Half of what an LSTM step of the decoder's
+ * attention chain multiplies exists one launch earlier than the launch that consumes it (forward: the h_att half of
+ * [ctx | h_att] . W1; backward: the d h_att columns of dG1 . W1^T); that half is cut into (64-column group, K-slice) items
+ * which the workgroups of the attention step in between pick up from a work counter when they have nothing (more) of their
+ * own to do.  Every workgroup drains the counter before it exits: all items are done when the launch ends.
+ * Item (g, s), g < groups, s < ceil((kb1 - kb0) / kbs): out[s * out_sstride + row * N + 64 (cg0 + g) + c] =
+ * sum over the k-blocks [kb0 + s kbs, min(kb1, kb0 + (s + 1) kbs)) of X[row][k] Wp(column 64 (cg0 + g) + c, k), rows
+ * 0 .. 16 mtiles - 1.  work == NULL: no tail. */
+typedef struct GtRecTail {
+    const float* X; int64_t ldx;      /* (16 mtiles rows, ldx >= 16 kb1) activations, 16-byte aligned, ldx % 4 == 0 */
+    const float* Wp;                  /* gt_pack_rec_weight / gt_pack_rec_cell_weight image: [N/16][KB][64][4] */
+    float* out; int64_t out_sstride;  /* slab of K-slice s at out + s * out_sstride, rows of N floats */
+    int32_t N, KB;                    /* columns (N % 64 == 0) and 16-wide k-blocks of the packed image */
+    int32_t kb0, kb1, kbs;            /* the items' K range [kb0, kb1) in k-blocks, kbs k-blocks per K-slice */
+    int32_t cg0, groups;              /* 64-column groups [cg0, cg0 + groups) */
+    int32_t mtiles;                   /* row tiles of 16 (1..4) */
+    uint32_t* work;                   /* ONE word, zero before the launch: the launch's work counter */
+} GtRecTail;
+/* gt_attn_step2_fwd carrying a tail (NULL or tail->work == NULL: exactly gt_attn_step2_fwd) */
+int gt_attn_step2_fwd_tail(GtAttnDims d, GtSlabs qpart, const float* w_prev, const float* w_cum, const float* pm,
+                           const float* Wc, const float* Wd, const float* v, const int32_t* lengths, float* q_out,
+                           const float* wpack, float* u_out, float* xbuf, uint32_t* row_cnt, uint32_t step1,
+                           const float* memory, int64_t ld_mem, float* w_out, const float* cum_in, float* cum_out,
+                           float* c0, int64_t ld0, float* c1, int64_t ld1, float* c2, int64_t ld2, const GtRecTail* tail,
+                           void* stream);
 int gt_attn_context_fwd(GtAttnDims d, const float* energies, const float* memory, int64_t ld_mem,
                         const int32_t* lengths, float* w_out, const float* cum_in, float* cum_out,
                         float* c0, int64_t ld0, float* c1, int64_t ld1, float* c2, int64_t ld2,
@@ -394,6 +430,14 @@ typedef struct GtDecoderFwd {
     /* 1 (fp32 mode only, bf16 = 0): W1c is a gt_pack_rec_cell_weight_x3 image and the attention LSTM's fused product + cell
      * runs as gt_rec_cell_fwd_x3 -- the exact fp32 product from three bf16 planes, on the bf16 matrix pipe */
     int32_t rec_x3;
+    /* tail_work != NULL (with W1c, attn_xbuf, fp32, Bp <= 64, E % 16 == 0, Sx1 >= 1): the h_att half of the attention LSTM's
+     * product leaves its launch (GtRecTail): the workgroups of attention step t that have nothing (more) to do compute
+     * h_att_t . W1[:, E:]^T in Sx1 K-slices into slabs S1 .. S1 + Sx1 - 1 of `part` (which then holds S1 + Sx1 slabs), and
+     * LSTM step t + 1 multiplies the ctx half only (S1 K-slices of E) and adds those slabs.  tail_work: To words, zeroed. */
+    uint32_t* tail_work;
+    int32_t Sx1;
+    int32_t tail_kb;           /* 16-wide k-blocks of the h_att half that ride in the attention step, counted from the END of
+                                  K (1 .. Ha / 16; 0 = all of them): the LSTM step keeps [ctx | first h_att columns] */
 } GtDecoderFwd;
 
 typedef struct GtDecoderBwd {
@@ -560,8 +604,11 @@ int gt_attn_bwd_fixup(GtAttnDims d, int32_t nsteps, const float* sum, const floa
  * (csrc/plstm.hip).  Used for the encoder BiLSTM (ndir = 2, packed-sequence semantics through `active`: model.py:202-210)
  * and for the decoder LSTM's h_dec recurrence inside a block of steps (ndir = 1, hx = the HC history itself: model.py:406-409);
  * both are what the default schedule runs at 64 rows (GANTRON_SCHEDULE=no_plstm: the per-step launches).
- * Bp must be 64 and H 256 or 1024 (gt_plstm_supported).  Direction d of every per-direction buffer lies *_dstride
- * elements behind direction 0. */
+ * Bp must be 64 and H 256 or 1024, and the CURRENT device must have at least twice as many CUs as the launch's workgroups
+ * hold -- every workgroup waits for its peers, so all of them must be resident at once beside the rest of the step
+ * (gt_plstm_supported: 128 CUs for H = 1024, 64 for H = 256; a CPX partition gets the per-step launches).  The waits are
+ * bounded: a launch that could not become resident raises timeout_flag instead of hanging; gt_adam_step_guarded then
+ * skips the optimizer step.  Direction d of every per-direction buffer lies *_dstride elements behind direction 0. */
 typedef struct GtPlstm {
     int32_t B, Bp, H, T, ndir, s_lo, s_hi, hx_ring;
     float p_drop;              /* dropout probability of `keep` (0: none) */
@@ -624,10 +671,16 @@ int gt_decoder_infer(const GtDecoderInfer* a, void* stream);
 /* ------------------------------------------------------------------------------------ collective
  * The data-parallel gradient average (distributed.py:137-161: ONE flat all-reduce(SUM) per backward, then / world size) for a
  * host that binds this library without PyTorch: buf[0..n) <- (sum over the ranks of `comm`) / ranks, in place, enqueued on
- * `stream`.  `comm` is the caller's RCCL communicator (ncclComm_t); RCCL is resolved at the first call from the librccl
- * already in the process (else loaded by name), never linked.  Returns the RCCL error code (> 0) if RCCL fails.  The Python
- * package averages through torch.distributed (backend "nccl" = RCCL) instead: gantron_amd/distributed.py. */
+ * `stream`.  `comm` is the caller's RCCL communicator (ncclComm_t).  RCCL is never linked and never loaded here: its entry
+ * points are taken at the first call from the RCCL the process ALREADY has -- global symbols, or librccl.so.1 / librccl.so
+ * (RTLD_NOLOAD) -- because only the library that created `comm` may be handed it, and its ncclGetVersion must report an
+ * NCCL 2.x API (the ncclFloat32 / ncclSum values used).  Nothing found: GT_E_ARG.  Returns the RCCL error code (> 0) if RCCL
+ * fails.  The Python package averages through torch.distributed (backend "nccl" = RCCL) instead: gantron_amd/distributed.py.
+ * Exercised on one rank on the test pool (one GPU per box); the two-rank test skips itself there. */
 int gt_allreduce_avg(void* comm, float* buf, int64_t n, void* stream);
+/* the same for a host whose RCCL is not visible that way (a framework's private copy): it passes that library's
+ * ncclAllReduce and ncclCommCount itself */
+int gt_allreduce_avg_with(void* comm, float* buf, int64_t n, void* nccl_all_reduce, void* nccl_comm_count, void* stream);
 
 /* -------------------------------------------------------------------- elementwise / reductions */
 /* per-column sums over rows: BatchNorm1d batch statistics incl. padding (model.py:123,176) and
@@ -730,6 +783,12 @@ int gt_sumsq(const float* x, int64_t n, float* out /* += */, void* stream);
 int gt_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, float lr,
                  float beta1, float beta2, float eps, float weight_decay, int32_t step,
                  const float* sumsq /* NULL: no clipping */, float max_norm, void* stream);
+/* the same, NOT applied when *skip_flag != 0 at the time the kernel runs (skip_flag = the word that the loop kernels with a
+ * bounded in-launch wait -- gt_plstm_fwd / gt_plstm_bwd, gt_attn_step_fwd -- raise when a wait gives up: that step's
+ * gradients are undefined); parameters and moments are left as they were.  skip_flag = NULL: gt_adam_step. */
+int gt_adam_step_guarded(float* param, const float* grad, float* m, float* v, int64_t n, float lr,
+                         float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                         const float* sumsq, float max_norm, const int32_t* skip_flag, void* stream);
 
 /* -------------------------------------------------------------------------------------- STFT
  * TacotronSTFT.mel_spectrogram (layers.py:97-114, stft.py:77-105, audio_processing.py:78-84) */
@@ -783,6 +842,9 @@ int gt_debug_rec_stamps(int64_t* out);
 /* the same for the last gt_attn_step2_fwd launch (GANTRON_DEBUG=attn_stamps): 0 start, 2 inputs staged, 3 location
  * convolution done, 4 energies done, 5 partial context done, 6 published, 7 last arriver done */
 int gt_debug_attn_stamps(int64_t* out);
+/* and for the tail that launch carried (GtRecTail), 4 per workgroup of the whole grid: 0 workgroup start, 1 first item
+ * drawn, 2 counter ran dry, 3 items this workgroup computed; HOST array of 4 * 4096 */
+int gt_debug_attn_tail_stamps(int64_t* out);
 
 /* x[0..n) -> three bf16 planes, plane i at planes + i * plane_stride (16-bit elements): x0 = bf16(x), x1 = bf16(x - x0),
  * x2 = bf16(x - x0 - x1); x0 + x1 + x2 == x exactly (3 x 8 significand bits).  n, plane_stride multiples of 8. */

@@ -304,3 +304,29 @@ def test_load_wav_resamples_other_rates(tmp_path):
         assert abs(len(y) - 22050) <= 1 and y.dtype == np.float32
         ref = 0.5 * np.sin(2 * np.pi * 440.0 * np.arange(len(y)) / 22050)
         assert np.abs(y[2000:-2000] - ref[2000:-2000]).max() < 2e-3, sr
+
+
+def test_switch_lists_reject_unknown_names_and_trim_like_the_c_parser(monkeypatch):
+    """gantron_amd/switches.py: a mistyped switch raises with the list of valid names instead of silently running the default
+    schedule; blanks around names, '=' and values are ignored (csrc/api.hip:gt_env_item follows the same rules -- checked
+    here through the library, which needs no GPU for it)."""
+    import ctypes
+    import pytest
+    from gantron_amd import switches as sw
+    assert sw._parse('GANTRON_EXPERIMENTAL', ' plstm = 5 ; rec_tail ,graph=2') == {'plstm': 5, 'rec_tail': 1, 'graph': 2}
+    with pytest.raises(ValueError, match='no_plstm'):
+        sw._parse('GANTRON_SCHEDULE', 'no_pltsm')
+    with pytest.raises(ValueError, match='decimal'):
+        sw._parse('GANTRON_EXPERIMENTAL', 'plstm=0xf')
+    with pytest.raises(AssertionError):
+        sw.debug('no_such_diagnostic')
+    from gantron_amd._lib import LIB_PATH
+    h = ctypes.CDLL(LIB_PATH)
+    fn = h._Z11gt_env_itemPKcS0_i if hasattr(h, '_Z11gt_env_itemPKcS0_i') else None
+    if fn is None:
+        pytest.skip('gt_env_item is not exported under its mangled name')
+    fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int]
+    monkeypatch.setenv('GT_TEST_LIST', ' plstm = 5 ; rec_tail ,graph=2, no_blk_gemm_aside ,x')
+    assert fn(b'GT_TEST_LIST', b'plstm', 0) == 5 and fn(b'GT_TEST_LIST', b'rec_tail', 0) == 1
+    assert fn(b'GT_TEST_LIST', b'graph', 0) == 2 and fn(b'GT_TEST_LIST', b'no_blk_gemm_aside', 0) == 1
+    assert fn(b'GT_TEST_LIST', b'rec', 7) == 7 and fn(b'GT_TEST_LIST', b'pl', 9) == 9        # prefixes are not matches

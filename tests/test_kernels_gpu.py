@@ -798,6 +798,102 @@ def test_attention_step2_partial_contexts(dev, B, Ti, E, nslabs):
     assert torch.equal(cnt.cpu(), want)          # every member workgroup of every step drew exactly one ticket
 
 
+@pytest.mark.parametrize('Bsz,H,E,S,Sx,B,Ti', [(64, 1024, 1024, 3, 3, 64, 187), (64, 1024, 1024, 2, 2, 3, 40), (5, 32, 64, 2, 2, 5, 77),
+                                               (33, 64, 48, 1, 1, 33, 150), (48, 128, 512, 3, 4, 9, 256)])
+def test_rec_tail_rides_in_the_attention_step(dev, Bsz, H, E, S, Sx, B, Ti):
+    """GtRecTail: the h half of [ctx | h] . W^T is cut into (column group, K-slice) items that the workgroups of an attention
+    step pick up when they have nothing (more) of their own to do (gt_attn_step2_fwd_tail), and the LSTM step behind it
+    multiplies the ctx half only and adds those slabs (gt_rec_cell_fwd_part).  Three rounds on the same workspaces: the
+    attention step's own results equal those of the launch without a tail, every item is computed exactly once (the
+    slabs start as NaN, the work counter ends at items + workgroups), and cell state / h / gates equal the float64 LSTM
+    step over ALL of K.  (B, Ti): the attention batch -- few rows = few workgroups for many items; ragged lengths = chunk
+    workgroups that lie in the padding and start on the items at once.)"""
+    from gantron_amd import ops
+    from gantron_amd._lib import GtRecTail, lib
+    from gantron_amd.engine import pack_rec_cell
+    A, Fn, Kc = 128, 32, 31
+    d = ops.attn_dims(B, Ti, 1024, A, Fn, Kc)
+    gen = torch.Generator().manual_seed(B * 1000 + Ti + H)
+    lens = torch.randint(1, Ti + 1, (B,), generator=gen)
+    lens[0] = Ti
+    f32 = lambda t: t.detach().float().contiguous().to(dev)
+    Wc, Wd, v = f32(g(Fn, 2, Kc, seed=1, scale=0.3)), f32(g(A, Fn, seed=2, scale=0.3)), f32(g(1, A, seed=3, scale=0.5))
+    wpack = torch.empty(int(lib().gt_attn_wpack_elems(d)), device=dev)
+    ops.call('gt_attn_pack_weights', d, Wc, Wd, wpack)
+    lens32 = lens.to(torch.int32).to(dev)
+    mem_d, pm_d = f32(g(B, Ti, 1024, seed=4)), f32(g(B, Ti, A, seed=5, scale=0.5))
+    nch = int(lib().gt_attn_chunks(Ti))
+    xs = int(lib().gt_attn_step2_xstride(d))
+    n_wg = -(-B // 8) * 8 * nch
+    # the LSTM step
+    K = E + H
+    Bp = ops.roundup(Bsz, 16)
+    ld = ops.roundup(K, 16) + 16
+    N = 4 * H
+    W = g(N, K, scale=0.1)
+    Wp = pack_rec_cell(W.to(dev), H, K, False)
+    S = ops.pick_splits(E, S)
+    Sx = ops.pick_splits(H, Sx)
+    kbs = -(-(H // 16) // Sx)
+    items = (N // 64) * Sx
+    part = torch.full((S + Sx, Bp, N), float('nan'), device=dev)
+    counters = torch.zeros(H // 16, dtype=torch.int32, device=dev)
+    p = 0.1
+    for rep in range(3):
+        X = torch.zeros(Bp, ld)
+        X[:Bsz, :K] = g(Bsz, K, seed=10 + rep)
+        Xd = X.to(dev)
+        outs = []
+        work = torch.zeros(1, dtype=torch.int32, device=dev)
+        part[S:] = float('nan')
+        for with_tail in (False, True):
+            tl = GtRecTail()
+            if with_tail:
+                tl.X, tl.ldx, tl.Wp, tl.out, tl.out_sstride = ops.ptr(Xd), ld, ops.ptr(Wp), ops.ptr(part, S * Bp * N), Bp * N
+                tl.N, tl.KB, tl.kb0, tl.kb1, tl.kbs, tl.cg0, tl.groups, tl.mtiles = N, -(-K // 16), E // 16, -(-K // 16), kbs, 0, N // 64, Bp // 16
+                tl.work = ops.ptr(work)
+            xbuf = torch.full((B * nch * xs,), float('nan'), device=dev)
+            cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+            qd = f32(g(2, B, A, seed=60 + rep, scale=0.1))
+            w_prev, w_cum = f32(torch.softmax(g(B, Ti, seed=70 + rep), 1)), f32(torch.softmax(g(B, Ti, seed=80 + rep), 1) * 3)
+            q_out = torch.empty(B, A, device=dev); u_out = torch.zeros(B, Ti, A, device=dev)
+            w_out = torch.zeros(B, Ti, device=dev); cum_out = torch.zeros(B, Ti, device=dev)
+            c0 = torch.zeros(B, 1024, device=dev)
+            ops.call('gt_attn_step2_fwd_tail', d, ops.slabs(qd, 2, B * A, A), w_prev, w_cum, pm_d, Wc, Wd, v, lens32, q_out, wpack,
+                     u_out, xbuf, cnt, 1, mem_d, 1024, w_out, w_cum, cum_out, c0, 1024, None, 0, None, 0, tl)
+            outs.append((w_out, cum_out, c0, q_out, u_out))
+        for a_, b_, what in zip(outs[0], outs[1], ('weights', 'cumulative weights', 'context', 'query', 'tanh history')):
+            if what == 'context':       # summed in the order the row's LAST arriver sees its partials: not the same in every launch
+                close(a_, b_, rtol=1e-5, atol=1e-6, what='context with / without a tail')
+                continue
+            assert torch.equal(a_, b_), f'the attention step changed its {what} when it carried a tail'
+        assert int(work.item()) == items + n_wg, (int(work.item()), items, n_wg)      # every workgroup drew until the counter ran dry
+        # slab columns are in the packed order of gt_pack_rec_cell_weight: column 64 cg + 16 gate + u = gate `gate` of unit 16 cg + u
+        n_p = torch.arange(N)
+        nat = ((n_p // 16) % 4) * H + 16 * (n_p // 64) + n_p % 16
+        tail_ref = (X[:Bsz, E:K].double() @ W[:, E:].double().t())[:, nat]
+        assert torch.isfinite(part[S:, :Bsz]).all()
+        close(part[S:].sum(0)[:Bsz], tail_ref, rtol=1e-5, atol=2e-5, what=f'tail slabs (round {rep})')
+        if Bsz < Bp:
+            assert float(part[S:, Bsz:].abs().max()) == 0.0           # zero operand rows give zero slab rows
+        # the LSTM step over the ctx half + the slabs
+        pre = g(Bp, N, seed=20 + rep, scale=0.5)
+        c_prev = g(Bp, H, seed=30 + rep)
+        keep = (torch.rand(Bp, H, generator=torch.Generator().manual_seed(40 + rep)) >= p)
+        gates_in = X[:Bsz, :K].double() @ W.double().t() + pre[:Bsz].double()
+        i, f, gg, o = gates_in.chunk(4, dim=1)
+        c = torch.sigmoid(f) * c_prev[:Bsz].double() + torch.sigmoid(i) * torch.tanh(gg)
+        h = torch.sigmoid(o) * torch.tanh(c) * keep[:Bsz].double() / (1 - p)
+        gates = pre.clone().to(dev)
+        c_out = torch.zeros(Bp, H, device=dev); h_raw = torch.zeros(Bp, H, device=dev)
+        ops.call('gt_rec_cell_fwd_part', Xd, ld, Wp, part, counters, Bp, Bsz, H, K, S, gates, N, c_prev.to(dev),
+                 keep.to(torch.uint8).to(dev), p, gates, c_out, h_raw, None, 0, None, 0, None, 0, None, 0, None, 0, 0, 16, E, Sx, 3)
+        close(c_out[:Bsz], c, rtol=1e-5, atol=2e-5, what=f'c (round {rep})')
+        close(h_raw[:Bsz], h, rtol=1e-5, atol=2e-5, what=f'h (round {rep})')
+        close(gates[:Bsz], torch.cat((torch.sigmoid(i), torch.sigmoid(f), torch.tanh(gg), torch.sigmoid(o)), 1), rtol=1e-5,
+              atol=2e-5, what='gates')
+
+
 @pytest.mark.parametrize('B,Ti', [(3, 150), (5, 77), (2, 33)])
 def test_attention_hoisted_backward_equals_in_loop(dev, B, Ti):
     """gt_attn_energies_fwd_u + gt_attn_energies_bwd_rec per step + ONE gt_attn_param_grads over the steps == the
@@ -1082,6 +1178,30 @@ def test_adam_and_clip(dev):
         ops.call('gt_sumsq', gd, n, ss)
         ops.call('gt_adam_step', pd, gd, m, v, n, 1e-3, 0.9, 0.999, 1e-8, 1e-6, step, ss, 1.0)
     close(pd, P['w'], rtol=1e-5, atol=1e-6, what='adam')
+
+
+def test_adam_step_is_skipped_when_the_handoff_flag_is_up(dev):
+    """gt_adam_step_guarded: with the flag at 0 it is gt_adam_step bit for bit; with the flag raised (an in-launch hand-off of
+    the step gave up: its gradients are undefined) parameters and both moments stay untouched."""
+    from gantron_amd import ops
+    n = 100003
+    p0, g0 = g(n, seed=1).to(dev), g(n, seed=2).to(dev)
+    m0, v0 = g(n, seed=3, scale=0.1).to(dev), g(n, seed=4).abs().to(dev)
+    ss = (g0.double() ** 2).sum().float().reshape(1).to(dev)
+    outs = []
+    for flag_val in (None, 0, 1):
+        p, m, v = p0.clone(), m0.clone(), v0.clone()
+        if flag_val is None:
+            ops.call('gt_adam_step', p, g0, m, v, n, 1e-3, 0.9, 0.999, 1e-8, 1e-6, 3, ss, 1.0)
+        else:
+            flag = torch.full((1,), flag_val, dtype=torch.int32, device=dev)
+            ops.call('gt_adam_step_guarded', p, g0, m, v, n, 1e-3, 0.9, 0.999, 1e-8, 1e-6, 3, ss, 1.0, flag)
+        outs.append((p, m, v))
+    for a_, b_ in zip(outs[0], outs[1]):
+        assert torch.equal(a_, b_)
+    assert not torch.equal(outs[0][0], p0)
+    for a_, b_ in zip(outs[2], (p0, m0, v0)):
+        assert torch.equal(a_, b_)
 
 
 def test_stft_mel(dev, golden_dir):

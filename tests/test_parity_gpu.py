@@ -226,6 +226,22 @@ def test_rec_x3_products_against_oracle(dev, monkeypatch, case):
     engine.check_handoffs()
 
 
+@pytest.mark.parametrize('case,slices,kb', [('full_dims_b64', 3, 0), ('full_dims_b64_poison', 6, 40), ('full_dims_b20', 2, 0)])
+def test_rec_tail_against_oracle(dev, monkeypatch, case, slices, kb):
+    """GANTRON_EXPERIMENTAL=rec_tail: the h_att half of the attention LSTM's forward product (or its last `kb` k-blocks) rides in
+    the attention step in front of it (GtRecTail, gt_attn_step2_fwd_tail) and the LSTM step adds its slabs
+    (gt_rec_cell_fwd_part), through whole pairs at the reference's dimensions: 64 rows, 20 rows (two row tiles), and with
+    NaN-poisoned slabs."""
+    from gantron_amd import engine
+    monkeypatch.setattr(engine, 'REC_TAIL_FWD', slices)
+    monkeypatch.setattr(engine, 'REC_TAIL_KB', kb)
+    if case.endswith('_poison'):
+        monkeypatch.setattr(engine, 'POISON', True)
+        case = case[:-len('_poison')]
+    _midsize_against_oracle(dev, case)
+    engine.check_handoffs()
+
+
 def test_plane_gemms_against_oracle(dev, monkeypatch):
     """The opt-in pre-split operand path of the decoder's weight-gradient GEMMs (GANTRON_EXPERIMENTAL=plane_gemms: gt_split3 +
     pgemm_kernel) through a whole pair at the reference's dimensions, 64 rows."""

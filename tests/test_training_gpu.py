@@ -490,6 +490,12 @@ check(lib().gt_allreduce_avg(comm, buf.data_ptr(), n, st), 'gt_allreduce_avg')
 torch.cuda.synchronize()
 err = float((buf.cpu().double() - want).abs().max() / want.abs().max())
 assert err < 1e-6, err
+# the same through the caller's own entry points (a host whose RCCL the library cannot see)
+buf2 = torch.arange(n, device='cuda', dtype=torch.float32) * (rank + 1) * 1e-3
+fn = lambda f: ctypes.cast(f, ctypes.c_void_p)
+check(lib().gt_allreduce_avg_with(comm, buf2.data_ptr(), n, fn(rccl.ncclAllReduce), fn(rccl.ncclCommCount), st), 'gt_allreduce_avg_with')
+torch.cuda.synchronize()
+assert torch.equal(buf, buf2)
 rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
 rccl.ncclCommDestroy(comm)
 print('OK', rank, err)

@@ -51,3 +51,20 @@ if n:
         v = st[:, k][st[:, k] > 0] - t0
         if len(v):
             print(f'{name:24s} n={len(v):4d}  min {v.min():6.2f}  mean {v.mean():6.2f}  max {v.max():6.2f}')
+
+n = lib().gt_debug_attn_tail_stamps(buf)
+if n:
+    ts = np.array(buf[:4 * n], dtype=np.int64).reshape(n, 4).astype(np.float64)
+    ts[:, :3] *= 0.01
+    ran = ts[ts[:, 1] > 0]
+    if len(ran):
+        print(f'\ntail of the attention step (GtRecTail): {int(ts[:, 3].sum())} items over {int((ts[:, 3] > 0).sum())} of {n} workgroups')
+        t0 = ts[:, 0][ts[:, 0] > 0].min()
+        for k, name in enumerate(['workgroup start', 'first draw', 'counter dry']):
+            v = ran[:, k] - t0
+            print(f'{name:24s} n={len(v):4d}  min {v.min():6.2f}  mean {v.mean():6.2f}  max {v.max():6.2f}')
+        w = ran[ran[:, 3] > 0]
+        print('per working workgroup: items %.2f, us per item %.2f; early workers (first draw < 2 us): %d' % (
+            w[:, 3].mean(), np.mean((w[:, 2] - w[:, 1]) / w[:, 3]), int(((ran[:, 1] - t0) < 2.0).sum())))
+        order = np.argsort(ts[:, 0])
+        print('workgroup starts (us, every 32nd in start order):', np.round(ts[order[::32], 0] - t0, 2).tolist())
