@@ -304,7 +304,7 @@ def main():
     ap.add_argument('--bf16', action='store_true',
                     help='BASELINE config 3 (hparams.fp16_run): bf16 operands in the decoder LSTM products and the layer '
                          'GEMMs, fp32 accumulation and master weights; NOT the headline metric, the default line is fp32')
-    ap.add_argument('--fp32-split', type=int, choices=(0, 2, 3), default=None,
+    ap.add_argument('--fp32-split', type=int, choices=(0, 2, 3, 4), default=None,
                     help='how the tiled fp32 GEMMs are computed (gt_sgemm_set_fp32_split): 3 = three bf16 planes per operand, six '
                          'exact products, fp32 accumulation (default, GANTRON_FP32_SPLIT); 0 = the fp32 matrix pipe; 2 = two '
                          'planes, 2^-16 accuracy class')
@@ -355,7 +355,12 @@ def main():
                      'fp32 accumulation: dropped terms <= 2^-24 |a||b|, measured error vs fp64 <= the fp32 MFMA\'s in every operand '
                      'mode (tests/test_kernels_gpu.py::test_sgemm_split_planes_accuracy, tools/split_accuracy.py)',
                   2: 'fp32 operands split into two bf16 planes, three bf16 MFMA products, fp32 accumulation: dropped terms '
-                     '<= 2^-16 |a||b|'}[_ops.FP32_SPLIT]
+                     '<= 2^-16 |a||b|',
+                  4: 'fp32 operands scaled by a power of two per operand tensor (max |x| -> [2^14, 2^15), found by one pass in front '
+                     'of the product) and split into two fp16 planes in the tile loader (22 of the 24 significand bits; exact '
+                     'residuals), three fp16 MFMA products (each exact), fp32 accumulation, scales taken out exactly in the epilogue: '
+                     'dropped terms <= 2^-22 |a||b| per product, measured error vs fp64 <= the fp32 MFMA\'s in every operand mode '
+                     '(tests/test_kernels_gpu.py::test_sgemm_split_planes_accuracy, tools/split_accuracy.py)'}[_ops.FP32_SPLIT]
     # GANTRON_FORCE_DIST=1 exercises the RCCL gradient-averaging path on a single rank (1-GPU boxes)
     use_dist = world > 1 or os.environ.get('GANTRON_FORCE_DIST') == '1'
     if use_dist:
@@ -567,7 +572,8 @@ def main():
         sg = next(r for r in fam if r['name'] == 'sgemm')
         gemm_flops_pair = out[6 * NF + 2 + FAMILIES.index('sgemm')] / args.steps          # every launch counted, not the sample
         gemm_peak = (BF16_MFMA_PEAK_TFLOPS if args.bf16 else
-                     {0: FP32_MFMA_PEAK_TFLOPS, 3: BF16_MFMA_PEAK_TFLOPS / 6, 2: BF16_MFMA_PEAK_TFLOPS / 3}[_ops.FP32_SPLIT])
+                     {0: FP32_MFMA_PEAK_TFLOPS, 3: BF16_MFMA_PEAK_TFLOPS / 6, 2: BF16_MFMA_PEAK_TFLOPS / 3,
+                      4: BF16_MFMA_PEAK_TFLOPS / 3}[_ops.FP32_SPLIT])
         if roof['families']['plstm']['launches']:
             pl_peak = FP32_MFMA_PEAK_TFLOPS * CHIP_SHARE['plstm']
             roof['families']['plstm'].update(peak=round(pl_peak, 1), frac=round(roof['families']['plstm']['tflops'] / pl_peak, 3),
@@ -575,7 +581,7 @@ def main():
                                              note='persistent recurrences: 64 of the 256 CUs (32 for the encoder BiLSTM) for a whole block '
                                                   'of steps, beside the attention chain; peak = the fp32 matrix pipe of the CUs held')
         roof['families']['sgemm'].update(peak=round(gemm_peak, 1), frac=round(roof['families']['sgemm']['tflops'] / gemm_peak, 3),
-                                         pipe='bf16 MFMA' if (args.bf16 or _ops.FP32_SPLIT) else 'fp32 MFMA',
+                                         pipe=('fp16 MFMA' if (_ops.FP32_SPLIT == 4 and not args.bf16) else 'bf16 MFMA') if (args.bf16 or _ops.FP32_SPLIT) else 'fp32 MFMA',
                                          est_tflop_per_pair=round(gemm_flops_pair / 1e12, 3))
     if use_dist:
         dist.barrier()

@@ -39,6 +39,7 @@ __host__ __device__ static inline int cdiv(int a, int b) { return (a + b - 1) / 
 enum { GT_FAM_REC_GEMM = 0, GT_FAM_SGEMM = 1, GT_FAM_ATTN_E_FWD = 2, GT_FAM_ATTN_C_FWD = 3, GT_FAM_ATTN_C_BWD = 4,
        GT_FAM_ATTN_E_BWD = 5, GT_FAM_CELL_FWD = 6, GT_FAM_CELL_BWD = 7, GT_FAM_REC_CELL = 8, GT_FAM_PLSTM = 9, GT_FAM_COUNT = 10 };
 extern bool g_gt_prof_on;
+int gt_absmax_ring(const float* x, long rows, long cols, long ld, const uint64_t** word, hipStream_t st);     // gemm.hip
 extern bool g_gt_capturing;          // loops.hip: stream capture in progress (GANTRON_EXPERIMENTAL=graph)
 extern double g_gt_prof_ctx_rows;   // valid attention-memory rows of the current batch (0: unknown, charge B*Ti)
 bool gt_prof_sample(int family);      // true for every `stride`-th launch of the family while profiling

@@ -13,7 +13,11 @@
 // MFMA operand fetch is one conflict-free ds_read_b32 per lane; the next tile's global loads are
 // issued into registers before the current tile's MFMAs (register prefetch).
 #include <algorithm>
+#include <atomic>
+#include <map>
+#include <mutex>
 #include <stdlib.h>
+#include <string.h>
 #include "common.h"
 
 namespace {
@@ -32,7 +36,10 @@ struct GemmDev {
     const float* bias;
     long ldc, a_bs, b_bs, c_bs;
     int M, N, K, accumulate, split_k, k_per_split;
-    int bf16;               // 0: fp32 MFMA, 1: operands rounded to bf16, 2 / 3: fp32 product from 2 / 3 bf16 planes (xgemm_kernel)
+    int bf16;               // 0: fp32 MFMA, 1: operands rounded to bf16, 2 / 3: fp32 product from 2 / 3 bf16 planes (xgemm_kernel),
+                            // 4: from two SCALED fp16 planes (xgemm_kernel, FMT = 1)
+    int amax_slot;          // mode 4: g_amax_ring[amax_slot], [amax_slot + 1] hold (epoch << 32 | bits of max |a|), ... max |b|
+    const unsigned long long* amax_a; const unsigned long long* amax_b;     // ... unless the caller brought the words (GtOperand.amax)
     int dbg;                // GANTRON_DEBUG=pgemm=<bits> (diagnostics, pgemm_kernel): 1 = no DMA after the first tile, 2 = every tile
                             // re-reads the first one's addresses (cache-hot sources), 4 = no MFMAs
     float alpha;
@@ -495,6 +502,53 @@ __device__ __forceinline__ void split_all(const float4 (&reg)[NV], unsigned (&lo
     }
 }
 
+// ---- two SCALED fp16 planes ("h2", gt_sgemm_set_fp32_split(4)) ------------------------------------------------------------
+// x s = h0 + h1 + r with h0 = f16(x s), h1 = f16(x s - h0) (both nearest even, the residual x s - h0 is exact in fp32):
+// |r| <= 2^-22 |x s|, i.e. 22 of the operand's 24 significand bits travel, and a . b = (a0 b0 + a0 b1 + a1 b0) / (sa sb) runs
+// as THREE v_mfma_f32_32x32x16_f16 with fp32 accumulation (every product exact; a1 b1 <= 2^-22 |a||b| is dropped with the
+// r terms).  fp16 has 5 exponent bits, so each operand is multiplied by a power of two s = 2^k that puts the operand
+// TENSOR's largest magnitude into [2^14, 2^15) (gt_sgemm finds it with one pass over the operand in front of the product:
+// absmax2_kernel): elements down to 2^-18 of that maximum keep all 22 bits (h1 >= 2^-14, fp16's smallest normal), smaller
+// ones lose them gradually -- absolute error <= 2^-25 / s = 2^-39 of the tensor's maximum -- and nothing overflows.  The
+// scaling is exact both ways (powers of two; the epilogue's v_ldexp_f32 takes sa sb out again).  Per PAIR of values the split
+// is five vector instructions, scale included: v_fma_mixlo_f16 / v_fma_mixhi_f16 (h0 = f16(s x), one rounding),
+// 2 x v_fma_mix_f32 (s x - h0, reading the fp16 halves in place), v_cvt_pk_f16_f32 -- against eleven for three bf16 planes;
+// two plane stores instead of three, three MFMAs instead of six.
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+template <int NV>
+__device__ __forceinline__ void split_h2(const float4 (&reg)[NV], float s, unsigned (&lo)[NV][2], unsigned (&hi)[NV][2]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float v[4] = {reg[i].x, reg[i].y, reg[i].z, reg[i].w};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            unsigned p0;
+            float ra, rb;
+            // (VALU only, operands in registers: nothing for the compiler to count or pad, cdna_hip_programming.md 5.7)
+            asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(p0) : "s"(s), "v"(v[2 * h]));
+            asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(p0) : "s"(s), "v"(v[2 * h + 1]));
+            asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(ra) : "s"(s), "v"(v[2 * h]), "v"(p0));
+            asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rb) : "s"(s), "v"(v[2 * h + 1]), "v"(p0));
+            const f16x2_t p1 = __builtin_convertvector((f32x2_t){ra, rb}, f16x2_t);
+            (h == 0 ? lo : hi)[i][0] = p0;
+            (h == 0 ? lo : hi)[i][1] = __builtin_bit_cast(unsigned, p1);
+        }
+    }
+}
+
+// operand scale of mode 4 from the bits of max |x|: s = 2^k with max |x| s in [2^14, 2^15); k is clamped to fp32's exponent
+// range (an all-zero or denormal tensor gets 2^127, an Inf / NaN one any power of two: the product is NaN either way)
+__device__ __forceinline__ int h2_scale_exp(unsigned maxbits) {
+    const int e = (int)((maxbits >> 23) & 0xffu);
+    return min(127, max(-126, 141 - e));
+}
+// (one 128-byte line per call: words of different calls -- different streams -- never share a cache line)
+constexpr int AMAX_SLOTS = 8192, AMAX_STRIDE = 16;
+__device__ __attribute__((aligned(128))) unsigned long long g_amax_ring[AMAX_SLOTS * AMAX_STRIDE];
+
 // FAST loads: the tile lies inside the matrix, the k-tile inside the reduction range and the operand is 16-byte
 // addressable, so nothing is checked per element; conv taps outside [0, T) read a clamped address and select zero
 // (the zeroing is a bitwise AND: with a select the compiler moves the load under a branch, and a branch around a load
@@ -519,7 +573,7 @@ __device__ __forceinline__ float4 fast_rvec(const OpDev& o, const float* base, i
     return mask4(*reinterpret_cast<const float4*>(base + ((long)b * o.T + (ok ? tt : t)) * o.C + c), ok);
 }
 
-template <int MODE, int BR, int NP>
+template <int MODE, int BR, int NP, int FMT = 0>
 struct TileLoaderX {
     static constexpr bool KT = is_ktype<MODE>();
     static constexpr int NK = BR / 32;            // k-type: float4 per thread (row f / 8, k-quad f % 8)
@@ -588,9 +642,10 @@ struct TileLoaderX {
             }
         }
     }
-    __device__ __forceinline__ void store(unsigned short* S, int tid) const {
+    __device__ __forceinline__ void store(unsigned short* S, int tid, float scale = 1.f) const {
         unsigned lo[NV][NP], hi[NV][NP];
-        split_all<NP, NV>(reg, lo, hi);
+        if constexpr (FMT == 1) split_h2<NV>(reg, scale, lo, hi);
+        else split_all<NP, NV>(reg, lo, hi);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             unsigned short* d;
@@ -621,11 +676,12 @@ struct TileLoaderX {
     }
 };
 
-template <int BM, int BN, int AMODE, int BMODE, int NP>
+template <int BM, int BN, int AMODE, int BMODE, int NP, int FMT = 0>
 __global__ __launch_bounds__(256) void xgemm_kernel(GemmDev g) {
+    static_assert(FMT == 0 || NP == 2, "the fp16 form has two planes");
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-    typedef TileLoaderX<AMODE, BM, NP> LA;
-    typedef TileLoaderX<BMODE, BN, NP> LB;
+    typedef TileLoaderX<AMODE, BM, NP, FMT> LA;
+    typedef TileLoaderX<BMODE, BN, NP, FMT> LB;
     __shared__ __attribute__((aligned(16))) unsigned short smem[NP * (LA::PLANE + LB::PLANE)];
     unsigned short* Ax = smem;
     unsigned short* Bx = smem + NP * LA::PLANE;
@@ -645,6 +701,19 @@ __global__ __launch_bounds__(256) void xgemm_kernel(GemmDev g) {
     LB lb;
     la.init(g.A, m0, kbeg, tid);
     lb.init(g.B, n0, kbeg, tid);
+    // mode 4: the operands' scales (wave-uniform: scalar loads of what absmax2_kernel left in front of this launch)
+    float sa = 1.f, sb = 1.f;
+    int kab = 0;
+    if constexpr (FMT == 1) {
+        // (agent-scope loads: served by L2, past this CU's vector / scalar caches)
+        const unsigned long long wa = __hip_atomic_load(g.amax_a != nullptr ? g.amax_a : &g_amax_ring[g.amax_slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long wb = __hip_atomic_load(g.amax_b != nullptr ? g.amax_b : &g_amax_ring[g.amax_slot + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int ka = h2_scale_exp(__builtin_amdgcn_readfirstlane((unsigned)wa));
+        const int kb = h2_scale_exp(__builtin_amdgcn_readfirstlane((unsigned)wb));
+        sa = __uint_as_float((unsigned)(127 + ka) << 23);
+        sb = __uint_as_float((unsigned)(127 + kb) << 23);
+        kab = ka + kb;
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -666,8 +735,8 @@ __global__ __launch_bounds__(256) void xgemm_kernel(GemmDev g) {
     }
     const int abase = LA::frag_base(wm0, lane), bbase = LB::frag_base(wn0, lane);
     for (int k0 = kbeg; k0 < kend; k0 += BKX) {
-        la.store(Ax, tid);
-        lb.store(Bx, tid);
+        la.store(Ax, tid, sa);
+        lb.store(Bx, tid, sb);
         __syncthreads();
         if (k0 + BKX < kend) {
             if (inside && k0 + 2 * BKX <= kend) {
@@ -696,12 +765,17 @@ __global__ __launch_bounds__(256) void xgemm_kernel(GemmDev g) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa][i], b[ord - pa][j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < TN; ++j) {
+                            if constexpr (FMT == 1)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a[pa][i]),
+                                                                                    __builtin_bit_cast(f16x8_t, b[ord - pa][j]), acc[i][j], 0, 0, 0);
+                            else
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa][i], b[ord - pa][j], acc[i][j], 0, 0, 0);
+                        }
         }
         __syncthreads();
     }
-    // epilogue: as sgemm_kernel
+    // epilogue: as sgemm_kernel (mode 4: the operand scales leave first, exactly)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -714,12 +788,62 @@ __global__ __launch_bounds__(256) void xgemm_kernel(GemmDev g) {
                 const int m = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m >= g.M) continue;
                 float* c = Cb + (long)m * g.ldc + n;
-                const float v = g.alpha * acc[i][j][r] + bias;
+                const float sum = FMT == 1 ? ldexpf(acc[i][j][r], -kab) : acc[i][j][r];
+                const float v = g.alpha * sum + bias;
                 if (g.split_k > 1) atomicAdd(c, v);
                 else if (g.accumulate) *c += v;
                 else *c = v;
             }
         }
+}
+
+// ---- mode 4's pass in front of the product: max |x| over the FINITE elements of both operands, as fp32 bit patterns (monotonic
+// in |x|; an Inf / NaN element does not take part: it makes its own row's products NaN, as in the other modes, instead of
+// ruining the scale of every row).  grid (blocks, 2): blockIdx.y = operand; an operand with rows == 0 is skipped.  The maxima meet in two 64-bit
+// words of g_amax_ring whose HIGH half is the call's epoch: a later call's values are always larger than an earlier call's,
+// so a slot is never reset (no memset in front of the launch, and a slot that comes round again after 8192 calls needs no
+// care beyond the earlier product having finished).
+struct AbsmaxOp { const float* p; long rows, cols, ld, batch_stride; int batch, vec; };
+__device__ __forceinline__ unsigned finite_abs_bits(float x) {
+    const unsigned u = __float_as_uint(x) & 0x7fffffffu;
+    return u < 0x7f800000u ? u : 0u;
+}
+
+__global__ __launch_bounds__(256) void absmax2_kernel(AbsmaxOp a, AbsmaxOp b, unsigned long long* out, unsigned epoch) {
+    const AbsmaxOp& o = blockIdx.y == 0 ? a : b;
+    if (o.rows == 0) return;
+    unsigned m = 0;
+    const long stride = (long)gridDim.x * 256, first = (long)blockIdx.x * 256 + threadIdx.x;
+    if (o.vec) {
+        const long c4 = o.cols >> 2, per = o.rows * c4, total = per * o.batch;
+        for (long f = first; f < total; f += 4 * stride) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long g = min(f + u * stride, total - 1);
+                const long bt = g / per, rem = g - bt * per, r = rem / c4, c = rem - r * c4;
+                v[u] = *reinterpret_cast<const float4*>(o.p + bt * o.batch_stride + r * o.ld + 4 * c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                m = max(max(m, finite_abs_bits(v[u].x)), max(max(finite_abs_bits(v[u].y), finite_abs_bits(v[u].z)), finite_abs_bits(v[u].w)));
+        }
+    } else {
+        const long per = o.rows * o.cols, total = per * o.batch;
+        for (long g = first; g < total; g += stride) {
+            const long bt = g / per, rem = g - bt * per, r = rem / o.cols, c = rem - r * o.cols;
+            m = max(m, finite_abs_bits(o.p[bt * o.batch_stride + r * o.ld + c]));
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+    __shared__ unsigned wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+        atomicMax(&out[blockIdx.y], ((unsigned long long)epoch << 32) | m);
+    }
 }
 
 // =====================================================================================================================
@@ -1115,6 +1239,7 @@ int launch_tile(const GemmDev& d, dim3 grid, hipStream_t st, int lds_pad) {
         else if (d.bf16 == 1) hipLaunchKernelGGL((hgemm_kernel<BM, BN, AM, BMD>), grid, dim3(256), lds_pad, st, d);      \
         else if (d.bf16 == 2) hipLaunchKernelGGL((xgemm_kernel<BM, BN, AM, BMD, 2>), grid, dim3(256), lds_pad, st, d);   \
         else if (d.bf16 == 3) hipLaunchKernelGGL((xgemm_kernel<BM, BN, AM, BMD, 3>), grid, dim3(256), lds_pad, st, d);   \
+        else if (d.bf16 == 4) hipLaunchKernelGGL((xgemm_kernel<BM, BN, AM, BMD, 2, 1>), grid, dim3(256), lds_pad, st, d); \
         else hipLaunchKernelGGL((sgemm_kernel<BM, BN, AM, BMD>), grid, dim3(256), lds_pad, st, d);                      \
         return 0;                                                                                           \
     }
@@ -1158,8 +1283,48 @@ int prep_operand(const GtOperand& s, OpDev& o, int rows, int K, const char* name
     return 0;
 }
 
-int g_fp32_planes = 3;       // gt_sgemm_set_fp32_split: how GtGemm.bf16 == 0 products are computed
-int g_last_kernel = -1;      // gt_sgemm_last_kernel (tests): 0 sgemm, 1 hgemm, 2 xgemm, 3 pgemm, 4 pgemm2
+// the memory an operand of `rows` x K addresses, as (rows of memory) x (contiguous columns) per batch entry
+AbsmaxOp absmax_extent(const GtOperand& s, const OpDev& o, int rows, int K, int batch) {
+    AbsmaxOp a;
+    a.p = s.p; a.batch = batch; a.batch_stride = s.batch_stride;
+    switch (s.mode) {
+        case GT_OP_KC: a.rows = rows; a.cols = K; a.ld = s.ld; break;
+        case GT_OP_RC: a.rows = K; a.cols = rows; a.ld = s.ld; break;
+        case GT_OP_IM2COL_K: a.rows = rows; a.cols = s.C; a.ld = s.C; break;           // rows = B * T positions of C channels
+        default: a.rows = K; a.cols = s.C; a.ld = s.C; break;                          // IM2COL_R: K = B * T positions
+    }
+    a.vec = o.vec && a.cols % 4 == 0;
+    if (a.ld == a.cols) { a.cols *= a.rows; a.ld = a.cols; a.rows = 1; }             // contiguous: one long row
+    return a;
+}
+
+#define GT_TRY_RC(call) do { int rc__ = (call); if (rc__ != 0) return rc__; } while (0)
+// next pair of words of the device's g_amax_ring + a fresh epoch (see absmax2_kernel)
+int amax_ring_slot(unsigned long long** ring, int* slot, unsigned* epoch) {
+    static std::atomic<unsigned> next_slot{0}, next_epoch{0};
+    static std::mutex mu;
+    static std::map<int, unsigned long long*> base;          // per device
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    GT_REQUIRE(e == hipSuccess, (int)e, "gt_sgemm: hipGetDevice failed");
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = base.find(dev);
+        if (it == base.end()) {
+            void* p = nullptr;
+            e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_amax_ring));
+            GT_REQUIRE(e == hipSuccess && p != nullptr, (int)e, "gt_sgemm: hipGetSymbolAddress(g_amax_ring) failed");
+            it = base.emplace(dev, (unsigned long long*)p).first;
+        }
+        *ring = it->second;
+    }
+    *slot = AMAX_STRIDE * (int)(next_slot.fetch_add(1u) % (unsigned)AMAX_SLOTS);
+    *epoch = next_epoch.fetch_add(1u) + 1u;
+    return 0;
+}
+
+int g_fp32_planes = 4;       // gt_sgemm_set_fp32_split: how GtGemm.bf16 == 0 products are computed
+int g_last_kernel = -1;      // gt_sgemm_last_kernel (tests): 0 sgemm, 1 hgemm, 2 xgemm, 3 pgemm, 4 pgemm2, 5 xgemm on fp16 planes
 
 // can pgemm_kernel address this operand's planes? (16-byte chunks of 8 bf16 that never straddle a row / tap / matrix end)
 bool planes_ok(const GtOperand& s, int rows) {
@@ -1176,7 +1341,8 @@ bool planes_ok(const GtOperand& s, int rows) {
 }  // namespace
 
 extern "C" int gt_sgemm_set_fp32_split(int32_t planes) {
-    GT_REQUIRE(planes == 0 || planes == 2 || planes == 3, GT_E_ARG, "gt_sgemm_set_fp32_split: planes must be 0, 2 or 3");
+    GT_REQUIRE(planes == 0 || planes == 2 || planes == 3 || planes == 4, GT_E_ARG,
+               "gt_sgemm_set_fp32_split: 0 (fp32 pipe), 2 / 3 (bf16 planes) or 4 (two scaled fp16 planes)");
     g_fp32_planes = planes;
     return 0;
 }
@@ -1196,6 +1362,39 @@ extern "C" int gt_split3(const float* x, int64_t n, void* planes, int64_t plane_
     return 0;
 }
 
+// internal (loops.hip): max |x| of a matrix that SEVERAL products of one loop call share (the decoder LSTM's input weights:
+// one tiled GEMM per block of steps), into the next ring word; *word stays valid for ~8000 later gt_sgemm calls
+int gt_absmax_ring(const float* x, long rows, long cols, long ld, const uint64_t** word, hipStream_t st) {
+    unsigned long long* ring = nullptr;
+    int slot = 0;
+    unsigned epoch = 0;
+    GT_TRY_RC(amax_ring_slot(&ring, &slot, &epoch));
+    AbsmaxOp a, none = {};
+    a.p = x; a.rows = rows; a.cols = cols; a.ld = ld; a.batch = 1; a.batch_stride = 0;
+    a.vec = aligned16(x) && cols % 4 == 0 && ld % 4 == 0;
+    if (a.ld == a.cols) { a.cols *= a.rows; a.ld = a.cols; a.rows = 1; }
+    const unsigned blocks = (unsigned)std::min<long>(256, std::max<long>(1, cdiv64(a.rows * a.cols, 256L * 16)));
+    hipLaunchKernelGGL(absmax2_kernel, dim3(blocks, 1), dim3(256), 0, st, a, none, ring + slot, epoch);
+    GT_LAUNCH_CHECK();
+    *word = (const uint64_t*)(ring + slot);
+    return 0;
+}
+
+extern "C" int gt_absmax(const float* x, int64_t rows, int64_t cols, int64_t ld, uint64_t* out, void* stream) {
+    GT_REQUIRE(x != nullptr && out != nullptr && rows > 0 && cols > 0 && ld >= cols, GT_E_ARG, "gt_absmax: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(uint64_t), st);
+    GT_REQUIRE(e == hipSuccess, (int)e, "gt_absmax: hipMemsetAsync failed");
+    AbsmaxOp a, none = {};
+    a.p = x; a.rows = rows; a.cols = cols; a.ld = ld; a.batch = 1; a.batch_stride = 0;
+    a.vec = aligned16(x) && cols % 4 == 0 && ld % 4 == 0;
+    if (a.ld == a.cols) { a.cols *= a.rows; a.ld = a.cols; a.rows = 1; }
+    const unsigned blocks = (unsigned)std::min<long>(256, std::max<long>(1, cdiv64(a.rows * a.cols, 256L * 16)));
+    hipLaunchKernelGGL(absmax2_kernel, dim3(blocks, 1), dim3(256), 0, st, a, none, (unsigned long long*)out, 1u);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int gt_sgemm(const GtGemm* g, void* stream) {
     GT_REQUIRE(g != nullptr && g->C != nullptr, GT_E_ARG, "gt_sgemm: NULL argument");
     GT_REQUIRE(g->M > 0 && g->N > 0 && g->K > 0 && g->batch >= 1 && g->split_k >= 1, GT_E_ARG,
@@ -1209,8 +1408,18 @@ extern "C" int gt_sgemm(const GtGemm* g, void* stream) {
     d.a_bs = g->A.batch_stride; d.b_bs = g->B.batch_stride; d.c_bs = g->c_batch_stride;
     d.M = g->M; d.N = g->N; d.K = g->K; d.accumulate = g->accumulate; d.alpha = g->alpha;
     d.split_k = g->split_k;
-    GT_REQUIRE(g->bf16 >= 0 && g->bf16 <= 3, GT_E_ARG, "gt_sgemm: bf16 = %d (0 fp32, 1 bf16 operands, 2 / 3 split planes)", g->bf16);
+    GT_REQUIRE(g->bf16 >= 0 && g->bf16 <= 4, GT_E_ARG, "gt_sgemm: bf16 = %d (0 fp32, 1 bf16 operands, 2 / 3 bf16 planes, 4 fp16 planes)", g->bf16);
     d.bf16 = g->bf16 != 0 ? g->bf16 : g_fp32_planes;
+    // (a captured launch would bake this call's slot and epoch into the graph: replays keep the three bf16 planes)
+    if (d.bf16 == 4 && (g_gt_capturing || g->A.p == nullptr || g->B.p == nullptr)) d.bf16 = 3;
+    static const int h2_skip = gt_env_item("GANTRON_DEBUG", "h2_skip", 0);      // diagnostics: classes of products kept on three bf16 planes
+    if (d.bf16 == 4 && h2_skip) {
+        if (((h2_skip & 1) && g->N < 128) || ((h2_skip & 2) && g->M <= 4096) || ((h2_skip & 4) && g->K < 512) ||
+            ((h2_skip & 8) && (g->A.mode >= GT_OP_IM2COL_K || g->B.mode >= GT_OP_IM2COL_K)) || ((h2_skip & 16) && (g->A.amax || g->B.amax)) ||
+            ((h2_skip & 32) && g->M > 4096 && g->N >= 128 && g->K >= 512 && g->A.mode < GT_OP_IM2COL_K && g->B.mode < GT_OP_IM2COL_K))
+            d.bf16 = 3;
+    }
+    d.amax_slot = 0; d.amax_a = d.amax_b = nullptr;
     static const int pgemm_dbg = gt_env_item("GANTRON_DEBUG", "pgemm", 0);
     d.dbg = pgemm_dbg;
     // operands that arrive as bf16 planes: the pure three-plane kernel, when the shapes allow whole 16-byte chunks and
@@ -1231,6 +1440,35 @@ extern "C" int gt_sgemm(const GtGemm* g, void* stream) {
 
     GtProfScope prof(GT_FAM_SGEMM, 2.0 * g->M * (double)g->N * g->K * g->batch,
                      4.0 * g->batch * ((double)g->M * g->K + (double)g->N * g->K + (double)g->M * g->N), st);
+    if (d.bf16 == 4) {
+        // max |a|, max |b| over everything the product addresses: one pass per operand that did not bring its word
+        // (GtOperand.amax), inside the family's timing bracket; blockIdx.y picks the operand
+        d.amax_a = (const unsigned long long*)g->A.amax; d.amax_b = (const unsigned long long*)g->B.amax;
+        if (h2_skip & 64) d.amax_a = d.amax_b = nullptr;        // diagnostics: ignore the words the caller brought
+        if (d.amax_a == nullptr || d.amax_b == nullptr) {
+            unsigned long long* ring = nullptr;
+            unsigned epoch = 0;
+            GT_TRY_RC(amax_ring_slot(&ring, &d.amax_slot, &epoch));
+            AbsmaxOp ao = absmax_extent(g->A, d.A, g->M, g->K, g->batch), bo = absmax_extent(g->B, d.B, g->N, g->K, g->batch);
+            if (d.amax_a != nullptr) ao.rows = 0;
+            if (d.amax_b != nullptr) bo.rows = 0;
+            const long work = std::max(ao.rows * ao.cols * ao.batch, bo.rows * bo.cols * bo.batch);
+            const unsigned blocks = (unsigned)std::min<long>(256, std::max<long>(1, cdiv64(work, 256L * 16)));
+            hipLaunchKernelGGL(absmax2_kernel, dim3(blocks, 2), dim3(256), 0, st, ao, bo, ring + d.amax_slot, epoch);
+            static const int amax_dbg = gt_env_item("GANTRON_DEBUG", "amax", 0);
+            if (amax_dbg) {         // diagnostics (synchronises): the two maxima this product is scaled by
+                unsigned long long w[2] = {0, 0};
+                (void)hipStreamSynchronize(st);
+                (void)hipMemcpy(w, ring + d.amax_slot, sizeof(w), hipMemcpyDeviceToHost);
+                float fa, fb; unsigned ua = (unsigned)w[0], ub = (unsigned)w[1];
+                memcpy(&fa, &ua, 4); memcpy(&fb, &ub, 4);
+                if (d.amax_a) { (void)hipMemcpy(w, d.amax_a, 8, hipMemcpyDeviceToHost); ua = (unsigned)w[0]; memcpy(&fa, &ua, 4); }
+                if (d.amax_b) { (void)hipMemcpy(w, d.amax_b, 8, hipMemcpyDeviceToHost); ub = (unsigned)w[0]; memcpy(&fb, &ub, 4); }
+                fprintf(stderr, "[amax] M=%d N=%d K=%d modes %d/%d batch %d split %d: max|a| %.4g (%s) max|b| %.4g (%s)\n", g->M, g->N, g->K,
+                        g->A.mode, g->B.mode, g->batch, g->split_k, fa, d.amax_a ? "given" : "pass", fb, d.amax_b ? "given" : "pass");
+            }
+        }
+    }
     const long tiles128 = (long)cdiv(g->M, 128) * cdiv(g->N, 128) * g->batch * d.split_k;
     // (Measured and not adopted, round 3: 64 x 64 tiles -- 31 KB of LDS instead of 61, so that the launch fits beside TWO workgroups
     // of the attention step on a CU -- for the forward loop's block GEMMs: attention 16.9 instead of 17.1 us, LSTM step 24.4 instead
@@ -1261,7 +1499,7 @@ extern "C" int gt_sgemm(const GtGemm* g, void* stream) {
         rc = launch_tile<64, 64>(d, grid, st, lds_pad);
     }
     GT_REQUIRE(rc == 0, rc, "gt_sgemm: unsupported operand mode pair (%d,%d)", g->A.mode, g->B.mode);
-    if (g_last_kernel != 4 || d.Ap == nullptr) g_last_kernel = d.Ap != nullptr ? 3 : d.bf16 >= 2 ? 2 : d.bf16;
+    if (g_last_kernel != 4 || d.Ap == nullptr) g_last_kernel = d.Ap != nullptr ? 3 : d.bf16 == 4 ? 5 : d.bf16 >= 2 ? 2 : d.bf16;
     GT_LAUNCH_CHECK();
     return 0;
 }

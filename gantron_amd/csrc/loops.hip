@@ -189,7 +189,8 @@ static GtOperand op_rc(const float* p, int64_t ld) {
 }
 // C[M,N] (=|+=) A[M,K] . B(n,k) (+ bias) through the tiled MFMA GEMM (bf16 operands when the loop runs in that mode)
 static int block_gemm(GtOperand A, GtOperand B, const float* bias, float* C, int64_t ldc, int M, int N, int K, int accumulate,
-                      int bf16, void* stream) {
+                      int bf16, void* stream, const uint64_t* b_amax = nullptr) {
+    B.amax = b_amax;          // fp16-plane products: the weights' maximum is found once per loop call, not once per block
     GtGemm g = {}; g.A = A; g.B = B; g.C = C; g.ldc = ldc; g.c_batch_stride = 0; g.bias = bias;
     g.M = M; g.N = N; g.K = K; g.batch = 1; g.accumulate = accumulate; g.split_k = 1; g.alpha = 1.f; g.bf16 = bf16;
     return gt_sgemm(&g, stream);
@@ -231,6 +232,9 @@ static int decoder_fwd_hoisted(const GtDecoderFwd* a, void* stream) {
         wpack = a->attn_wpack;
     }
     const int blk = block_steps(a->blk);
+    const uint64_t* w2_amax = nullptr;
+    if (!a->bf16 && gt_sgemm_get_fp32_split() == 4 && !g_gt_capturing)
+        GT_TRY(gt_absmax_ring(a->W2ih, N2, a->Ha + a->E, a->ldw2, &w2_amax, sA));
     const int64_t xa_step = (int64_t)a->Bp * a->ld2;
     // fused product + cell (+ query) launches: float4-friendly sizes (bf16 mode: the bf16 images of the same packing)
     const bool fusedA = a->W1c != nullptr && a->counters1 != nullptr && cq && a->Ha % 16 == 0;
@@ -334,7 +338,7 @@ static int decoder_fwd_hoisted(const GtDecoderFwd* a, void* stream) {
             GT_HIP(hipStreamWaitEvent(sG, ev, 0));
         }
         GT_TRY(block_gemm(op_kc(a->X2 + (int64_t)t0 * xa_step, a->ld2), op_kc(a->W2ih, a->ldw2), a->bias2,
-                          a->pre2 + (int64_t)t0 * a->Bp * N2, N2, (t1 - t0) * a->Bp, N2, a->Ha + a->E, 0, a->bf16, sG));
+                          a->pre2 + (int64_t)t0 * a->Bp * N2, N2, (t1 - t0) * a->Bp, N2, a->Ha + a->E, 0, a->bf16, sG, w2_amax));
         if (sG != sB) {
             GT_TRY(loop_event(ctx, 40 + (size_t)(nblock % 32), &ev));
             GT_HIP(hipEventRecord(ev, sG));
@@ -628,6 +632,9 @@ static int decoder_bwd_hoisted(const GtDecoderBwd* a, void* stream) {
         wpack = a->attn_wpack;
     }
     const int blk = block_steps(a->blk);
+    const uint64_t* w2_amax = nullptr;
+    if (!a->bf16 && gt_sgemm_get_fp32_split() == 4 && !g_gt_capturing)       // (stream B issues the block GEMMs)
+        GT_TRY(gt_absmax_ring(a->W2ih, N2, a->Ha + a->E, a->ldw2, &w2_amax, sB));
     int nblock = 0;
     // GANTRON_DEBUG=block_timing (diagnostic): events around the B-chain block, its block GEMM and the A-chain block; printed
     // at the end of the call (synchronises)
@@ -679,7 +686,7 @@ static int decoder_bwd_hoisted(const GtDecoderBwd* a, void* stream) {
         }
         mark(&bt.b1, sB);
         GT_TRY(block_gemm(op_kc(a->dG2 + (int64_t)b0 * a->Bp * N2, N2), op_rc(a->W2ih, a->ldw2), nullptr,
-                          a->dXA + (int64_t)b0 * a->Bp * a->ldxa, a->ldxa, (b1 - b0 + 1) * a->Bp, a->Ha + a->E, N2, 0, a->bf16, sB));
+                          a->dXA + (int64_t)b0 * a->Bp * a->ldxa, a->ldxa, (b1 - b0 + 1) * a->Bp, a->Ha + a->E, N2, 0, a->bf16, sB, w2_amax));
         mark(&bt.g1, sB);
         if (two) {
             GT_TRY(loop_event(ctx, 1 + (size_t)(nblock % 32), &ev));

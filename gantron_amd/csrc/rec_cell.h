@@ -132,10 +132,17 @@ __device__ __forceinline__ void rec_cell_epilogue(float* red, const RecCellEpi& 
     }
     const int nsl = e.S + e.Sx;                    // the K-slices' slabs, then the earlier launch's
     if (nsl > 1) {
+        // The slabs are summed in SLAB order whoever arrived last -- this workgroup's own tile (still in LDS) takes its place s
+        // in the sequence -- so the gate sums do not depend on the arrival order (round 4: `the others in order, then my own`
+        // made their rounding depend on which K-slice drew the last ticket; the recurrence amplified that over a sequence).
         const __amdgpu_buffer_rsrc_t rd = rc_rsrc(slab0);
-        float4 acc[NV];
+        float4 own[NV], acc[NV];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < NV; ++i) {
+            const int f = min(tid + REC_THREADS * i, ROWS * 16 - 1);
+            own[i] = *reinterpret_cast<const float4*>(&red[(f >> 4) * EP_LD + 4 * (f & 15)]);
+            acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         for (int s0 = 0; s0 < nsl; s0 += 4) {       // four slabs in flight per pass
             float4 t[4][NV];
 #pragma unroll
@@ -156,10 +163,13 @@ __device__ __forceinline__ void rec_cell_epilogue(float* red, const RecCellEpi& 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int sj = s0 + j;
+                const bool mine = sj == s && e.S > 1;          // (S == 1: the own tile is slab 0 of the sequence, s == 0)
                 const float w = (sj < nsl && sj != s) ? 1.f : 0.f;
 #pragma unroll
                 for (int i = 0; i < NV; ++i) {
-                    acc[i].x += w * t[j][i].x; acc[i].y += w * t[j][i].y; acc[i].z += w * t[j][i].z; acc[i].w += w * t[j][i].w;
+                    const float4 v = mine ? own[i] : t[j][i];
+                    const float wv = mine ? 1.f : w;
+                    acc[i].x += wv * v.x; acc[i].y += wv * v.y; acc[i].z += wv * v.z; acc[i].w += wv * v.w;
                 }
             }
         }
@@ -169,9 +179,8 @@ __device__ __forceinline__ void rec_cell_epilogue(float* red, const RecCellEpi& 
             const int row = f >> 4, c4 = f & 15;
             if (row < ROWS) {
                 float4* d = reinterpret_cast<float4*>(&red[row * EP_LD + 4 * c4]);
-                float4 v = *d;
-                v.x += acc[i].x; v.y += acc[i].y; v.z += acc[i].z; v.w += acc[i].w;
-                *d = v;
+                if (e.S > 1) *d = acc[i];
+                else { float4 v = *d; v.x += acc[i].x; v.y += acc[i].y; v.z += acc[i].z; v.w += acc[i].w; *d = v; }
             }
         }
         __syncthreads();

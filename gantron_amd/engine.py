@@ -50,6 +50,10 @@ HOIST2 = sw.schedule_on('hoist2')
 # Round 2: neutral (132.3 against 132.5 ms per pair); round 3, with the rest of the loop shorter: 127.3-127.8 against
 # 128.1-128.4 in three alternating runs.  On (GANTRON_SCHEDULE=no_attn_bwd_fused: the two launches).
 ATTN_BWD_FUSED = sw.schedule_on('attn_bwd_fused')
+# gt_attn_bwd_wterms (the per-position terms of that launch for ALL steps, forward quantities only) issued by the training
+# forward right behind the decoder loop instead of at the top of the backward pass (round 4: the launch took 7.6 ms beside the
+# PostNet backward's 5.5 ms and the backward loop waited 2.1 ms for it)
+WTERMS_IN_FORWARD = sw.schedule_on('wterms_in_forward')
 # fused product + cell (+ query) launches of the forward loops (gt_rec_cell_fwd): bit 0 = attention LSTM, bit 1 = decoder LSTM,
 # bit 2 = encoder BiLSTM; bits 3 / 4 = attention / decoder LSTM in bf16 mode (gt_rec_cell_fwd_bf16); bit 5 = the decoder
 # LSTM's backward product + cell backward (gt_rec_cellbwd; measured 0.3 ms slower per pair than two launches: off)
@@ -800,6 +804,10 @@ class GeneratorEngine:
         PHASES.mark('f.dec_loop')
         sv.update(hist=hist, pre1=pre1, lens32=lens32, att_keep=att_keep, dec_keep=dec_keep,
                   prenet_keep=pk)
+        if training and WTERMS_IN_FORWARD:
+            early = self._attn_wterms(P, sv, hist, in_forward=True)
+            if early is not None:
+                sv['attn_early'] = early
 
         # ---- mel / gate projection of all steps, output layouts
         hc = Hd + Ep
@@ -931,6 +939,56 @@ class GeneratorEngine:
 
     # ------------------------------------------------------------------------------ backward
     @_gemm_precision
+    def _attn_wterms(self, P, sv, hist, in_forward=False):
+        """gt_attn_bwd_wterms for every step of the decoder loop in one launch on the leaf stream (2.7 GB read, 2.7 GB written at
+        the benchmark batch): P rows and the s-terms of the one-launch backward attention step.  Returns the buffers + the
+        event the backward loop waits for, or None when that form of the backward step is not in use.
+        in_forward: issued by the training forward behind the decoder loop, so that the launch (7.6 ms beside the PostNet
+        backward's GEMMs, of which 2.1 ms used to be exposed in front of the backward loop: profiles/r04_trace_wterms.txt)
+        runs under the projection, the PostNet forward, the losses and the PostNet backward instead."""
+        B, Bp, Ti, To = sv['B'], sv['Bp'], sv['Ti'], sv['To']
+        A, Ha, Ep = self.A, self.Ha, self.Ep
+        if not (ATTN_BWD_FUSED and 'u_hist' in hist and HOIST2 and not FUSED_CELL and CELL_QUERY and Ha % 16 == 0):
+            return None
+        if in_forward and (not LEAF.enabled or LEAF.defer):
+            return None
+        dims_e = ops.attn_dims(B, Ti, Ep, A, self.F, self.Kc)
+        if not lib().gt_attn_bwd_step_supported(dims_e):
+            return None
+        dev = hist['u_hist'].device
+        al_e = 'decoder.attention_layer.'
+        Wc_e, Wd_e, v_e = (P[al_e + 'location_layer.location_conv.conv.weight'],
+                           P[al_e + 'location_layer.location_dense.linear_layer.weight'], P[al_e + 'v.linear_layer.weight'])
+        Apad_e, nch_e, BT_e = roundup(A, 16), int(lib().gt_attn_chunks(Ti)), B * Ti
+        wpack_e = _f32(int(lib().gt_attn_wpack_elems(dims_e)), device=dev, zero=False)
+        fz_e = dict(sum_hist=_f32(To, B, nch_e, device=dev, zero=False), dq2_hist=_f32(To, Bp, Apad_e, device=dev),
+                    dwcat2_hist=_f32(To, 2, B, Ti, device=dev), p_hist=_f32(To, B, Ti, 64, device=dev, zero=False))
+
+        def wterms():
+            call('gt_attn_pack_weights', dims_e, Wc_e, Wd_e, wpack_e)
+            check(lib().gt_attn_bwd_wterms(
+                dims_e, To, ptr(hist['w_hist'], BT_e), BT_e, ptr(hist['u_hist']), ptr(Wc_e), ptr(Wd_e), ptr(v_e),
+                ptr(sv['lens32']), ptr(fz_e['dq2_hist']), Bp * Apad_e, Apad_e, ptr(fz_e['dwcat2_hist']), ptr(fz_e['p_hist']),
+                ptr(wpack_e), ops._stream()), 'gt_attn_bwd_wterms')
+        if in_forward:
+            # not LEAF.run: nothing joins the leaf stream at the end of a forward, so the buffers are handed to the
+            # allocator's stream bookkeeping instead of LEAF.keep (a forward that is never followed by a backward frees them
+            # with `sv`)
+            if LEAF.stream is None:
+                LEAF.stream = torch.cuda.Stream(priority=torch.cuda.Stream.priority_range()[0])
+            LEAF.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(LEAF.stream):
+                wterms()
+            for t_ in (wpack_e, *fz_e.values(), hist['u_hist'], hist['w_hist']):
+                t_.record_stream(LEAF.stream)
+        else:
+            LEAF.run(wterms, wpack_e)
+            if LEAF.defer:
+                LEAF.flush()
+        ready = torch.cuda.Event()
+        ready.record(LEAF.stream if (LEAF.enabled and LEAF.stream is not None and not LEAF.defer) else torch.cuda.current_stream())
+        return dict(fz=fz_e, wpack=wpack_e, ready=ready)
+
     def backward(self, P, G, sv, dmel, dmel_post, dgate, dalign, on_ready=None):
         """Generator backward (see _backward).  Whatever happens inside -- a GantronHipError from a loop call included --
         the split-K target of the overlapped region is restored and the leaf stream is joined before the buffers it
@@ -956,33 +1014,13 @@ class GeneratorEngine:
         hc, nout = Hd + Ep, n_mel + 1          # [h_dec | ctx] rows are Ep wide in their ctx part (engine.Ep)
 
         PHASES.mark(None)
-        # ---- the one-launch backward attention step's per-position terms of ALL steps (gt_attn_bwd_wterms: 2.7 GB at the benchmark
-        # batch, ~3.5 ms) need forward quantities only: issued FIRST, on the leaf stream, they run beside the PostNet backward;
-        # the loop later waits for their own event, not for the whole leaf stream (the PostNet's weight gradients stay under the loop)
-        early = None
-        if ATTN_BWD_FUSED and 'u_hist' in hist and HOIST2 and not FUSED_CELL and CELL_QUERY and Ha % 16 == 0:
-            dims_e = ops.attn_dims(B, Ti, Ep, A, self.F, self.Kc)
-            if lib().gt_attn_bwd_step_supported(dims_e):
-                al_e = 'decoder.attention_layer.'
-                Wc_e, Wd_e, v_e = (P[al_e + 'location_layer.location_conv.conv.weight'],
-                                   P[al_e + 'location_layer.location_dense.linear_layer.weight'], P[al_e + 'v.linear_layer.weight'])
-                Apad_e, nch_e, BT_e = roundup(A, 16), int(lib().gt_attn_chunks(Ti)), B * Ti
-                wpack_e = _f32(int(lib().gt_attn_wpack_elems(dims_e)), device=dev, zero=False)
-                fz_e = dict(sum_hist=_f32(To, B, nch_e, device=dev, zero=False), dq2_hist=_f32(To, Bp, Apad_e, device=dev),
-                            dwcat2_hist=_f32(To, 2, B, Ti, device=dev), p_hist=_f32(To, B, Ti, 64, device=dev, zero=False))
-
-                def wterms():
-                    call('gt_attn_pack_weights', dims_e, Wc_e, Wd_e, wpack_e)
-                    check(lib().gt_attn_bwd_wterms(
-                        dims_e, To, ptr(hist['w_hist'], BT_e), BT_e, ptr(hist['u_hist']), ptr(Wc_e), ptr(Wd_e), ptr(v_e),
-                        ptr(sv['lens32']), ptr(fz_e['dq2_hist']), Bp * Apad_e, Apad_e, ptr(fz_e['dwcat2_hist']), ptr(fz_e['p_hist']),
-                        ptr(wpack_e), ops._stream()), 'gt_attn_bwd_wterms')
-                LEAF.run(wterms, wpack_e)
-                if LEAF.defer:
-                    LEAF.flush()
-                ready = torch.cuda.Event()
-                ready.record(LEAF.stream if (LEAF.enabled and LEAF.stream is not None and not LEAF.defer) else torch.cuda.current_stream())
-                early = dict(fz=fz_e, wpack=wpack_e, ready=ready)
+        # ---- the one-launch backward attention step's per-position terms of ALL steps (gt_attn_bwd_wterms) need forward
+        # quantities only.  Round 4: the training forward issues them itself, right behind the decoder loop (`_attn_wterms`,
+        # sv['attn_early']); a forward that did not (leaf stream off / deferred) gets them here, beside the PostNet backward.
+        # The loop later waits for their own event, not for the whole leaf stream.
+        early = sv.pop('attn_early', None)
+        if early is None:
+            early = self._attn_wterms(P, sv, hist)
         # ---- PostNet backward (channels-last)
         dmel_cl = _f32(B * To, n_mel, device=dev)
         if dmel is not None:

@@ -63,9 +63,11 @@ class bf16_gemms:
 
 
 # How fp32 GEMMs are computed (gt_sgemm_set_fp32_split): 0 = fp32 matrix pipe, 3 = three bf16 planes per operand and
-# six bf16 MFMAs (fp32-accurate, 16/6 of the fp32 pipe's rate), 2 = two planes / three MFMAs (2^-16 accuracy class).
+# six bf16 MFMAs (fp32-exact operands, 16/6 of the fp32 pipe's rate), 2 = two bf16 planes / three MFMAs (2^-16 accuracy
+# class), 4 = two SCALED fp16 planes per operand / three fp16 MFMAs (round 4, the default: 22 significand bits per operand,
+# measured error against float64 below the fp32 pipe's; include/gantron_hip.h).
 # GANTRON_FP32_SPLIT picks the process default, applied when the first GEMM is issued.
-FP32_SPLIT = int(_os.environ.get('GANTRON_FP32_SPLIT', '3'))
+FP32_SPLIT = int(_os.environ.get('GANTRON_FP32_SPLIT', '4'))
 _split_applied = None
 
 
@@ -83,7 +85,7 @@ def apply_fp32_split():
 
 
 class fp32_split:
-    """with ops.fp32_split(planes): ... -- fp32 GEMMs inside the block are computed with that many bf16 planes."""
+    """with ops.fp32_split(mode): ... -- fp32 GEMMs inside the block are computed in that mode (0 / 2 / 3 / 4, above)."""
 
     def __init__(self, planes):
         self.planes = int(planes)

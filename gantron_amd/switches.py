@@ -1,7 +1,8 @@
 """Every run-time switch of the package, in one place.  Five environment variables, read once at import:
 
-GANTRON_FP32_SPLIT     0 / 2 / 3 (default 3): how the tiled fp32 GEMMs are computed -- the fp32 matrix pipe, or two / three
-                       bf16 planes per operand on the bf16 pipe (3 = fp32-exact).
+GANTRON_FP32_SPLIT     0 / 2 / 3 / 4 (default 4): how the tiled fp32 GEMMs are computed -- the fp32 matrix pipe, two / three
+                       bf16 planes per operand on the bf16 pipe (3 = exact operands), or two scaled fp16 planes (4: 22 significand
+                       bits per operand, three MFMAs).
 GANTRON_POISON=1       tests: buffers that are not zero-initialised start as NaN.
 GANTRON_EXPERIMENTAL   comma list `name[=int]` of paths that were built, are parity-tested and measured SLOWER or no faster
                        than the default ("measured and not adopted"); nothing here is needed for
@@ -19,12 +20,14 @@ GANTRON_SCHEDULE       comma list switching OFF parts of the default schedule (w
                        launches instead of the persistent LSTM recurrences), no_attn_bwd_fused (context and energies backward
                        of a step as two launches), no_blk_gemm_aside (the forward loop's block GEMMs on the decoder-LSTM
                        chain's own stream instead of a third one),
-                       no_dist_overlap.
+                       no_wterms_in_forward (gt_attn_bwd_wterms at the top of the backward pass instead of behind the forward
+                       loop), no_dist_overlap.
 GANTRON_DEBUG          comma list of diagnostics: phase_timing, host_timing, block_timing, dist_timing, attn_valu,
                        rec=<bits> / fused=<bits> / pgemm=<bits> (kernel knock-outs), rec_splits=<n>, s1_fwd=<n>, s2_fwd=<n>,
                        s2_bwd=<n>, s1_bwd=<n>, enc_splits=<n>, sync_every=<n>, rec_lds_pad=<n>, rec_stamps / attn_stamps (phase
                        stamps of the attention LSTM's launch and of the attention step: tools/rec_stamps.py), attn2=<bits>
-                       (knock-outs of the attention step), rec_tail_kb=<n>.
+                       (knock-outs of the attention step), rec_tail_kb=<n>, amax (prints the operand maxima every fp16-plane product is
+                       scaled by; synchronises).
 An unknown name in any of the three lists raises at import with the valid names (a mistyped switch would otherwise run
 the default schedule silently); values are decimal integers.  (The C side parses the same variables with the same
 trimming rules: csrc/api.hip, gt_env_item.)  bench.py / the tests additionally use
@@ -37,10 +40,11 @@ _KNOWN = {
     'GANTRON_EXPERIMENTAL': {'fused_cell', 'attn_step', 'leaf_defer', 'rec_cellbwd', 'plane_gemms', 'plstm', 'rec_x3', 'graph',
                              'no_pgemm2', 'rec_tail'},
     'GANTRON_SCHEDULE': {'no_cell_query', 'no_attn_hoist', 'no_hoist2', 'no_leaf_stream', 'no_fwd_splitk', 'no_rec_cell',
-                         'no_attn_step2', 'no_plstm', 'no_attn_bwd_fused', 'no_blk_gemm_aside', 'no_dist_overlap'},
+                         'no_attn_step2', 'no_plstm', 'no_attn_bwd_fused', 'no_blk_gemm_aside', 'no_wterms_in_forward',
+                         'no_dist_overlap'},
     'GANTRON_DEBUG': {'phase_timing', 'host_timing', 'block_timing', 'dist_timing', 'attn_valu', 'rec', 'fused', 'pgemm',
                       'rec_splits', 's1_fwd', 's2_fwd', 's2_bwd', 's1_bwd', 'enc_splits', 'sync_every', 'rec_lds_pad',
-                      'rec_stamps', 'attn_stamps', 'attn2', 'rec_tail_kb'},
+                      'rec_stamps', 'attn_stamps', 'attn2', 'rec_tail_kb', 'amax', 'h2_skip'},
 }
 
 

@@ -31,7 +31,7 @@ extern "C" {
 #define GT_E_ALIGN (-2)   /* pointer or leading dimension violates an alignment requirement */
 #define GT_E_LIMIT (-3)   /* size exceeds a compiled-in limit */
 
-#define GT_ABI_VERSION 400      /* bumped whenever a declared signature, struct layout or buffer size changes */
+#define GT_ABI_VERSION 401      /* bumped whenever a declared signature, struct layout or buffer size changes */
 int gt_version(void);           /* GT_ABI_VERSION of the library that was built: compare it with the header's at load */
 const char* gt_last_error_string(void);
 /* sizeof of ABI structs: 0 GtOperand, 1 GtGemm, 2 GtSlabs, 3 GtAttnDims, 4 GtDecoderFwd,
@@ -93,6 +93,8 @@ typedef struct GtOperand {
                                    allow it (K % 32 == 0, ld % 8 == 0, im2col C % 32 / % 8 == 0), gt_sgemm runs the kernel
                                    that has no split left to do; otherwise it uses p (p may be NULL only if planes suffice) */
     int64_t plane_stride;
+    const uint64_t* amax;       /* optional (fp16-plane products, GtGemm.bf16 = 4 / gt_sgemm_set_fp32_split(4)): device word left by
+                                   gt_absmax over everything this operand addresses; NULL: gt_sgemm makes the pass itself */
 } GtOperand;
 
 typedef struct GtGemm {
@@ -108,20 +110,32 @@ typedef struct GtGemm {
     int32_t bf16;               /* 0: fp32 product (computed as gt_sgemm_set_fp32_split selects);
                                    1: operands rounded to bf16 (nearest even) in the tile loader, bf16 MFMA, fp32
                                    accumulation and output (hparams.fp16_run);
-                                   2 / 3: fp32 product from 2 / 3 bf16 planes per operand, regardless of the setting */
+                                   2 / 3: fp32 product from 2 / 3 bf16 planes per operand, regardless of the setting;
+                                   4: from two scaled fp16 planes per operand (below), regardless of the setting */
 } GtGemm;
 
 int gt_sgemm(const GtGemm* g, void* stream);
 
-/* How products with GtGemm.bf16 == 0 are computed (process-wide; default 3, the same as the Python package):
+/* How products with GtGemm.bf16 == 0 are computed (process-wide; default 4, the same as the Python package):
  *   0  v_mfma_f32_32x32x2_f32, the fp32 matrix pipe (157 TFLOP/s peak on MI355X);
  *   3  every fp32 operand x is staged as three bf16 planes x0 + x1 + x2 = x (exact: 3 x 8 significand bits) and
  *      a . b = a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0) runs as six bf16 MFMAs with fp32 accumulation: each
  *      product is exact, the dropped terms are <= 2^-24 |a||b| -- the rounding unit of the fp32 pipe itself -- and the
  *      bf16 pipe is 16x faster, so the product costs 6/16 of the fp32 MFMA time;
- *   2  two planes, three MFMAs: dropped terms <= 2^-16 |a||b| (the accuracy class of 3xTF32).
- * Inf / NaN operands produce NaN in modes 2 / 3. */
+ *   2  two planes, three MFMAs: dropped terms <= 2^-16 |a||b| (the accuracy class of 3xTF32);
+ *   4  (round 4) every fp32 operand TENSOR is multiplied by a power of two s that puts its largest finite magnitude into
+ *      [2^14, 2^15) -- found by one pass over the operand in front of the product, or taken from GtOperand.amax -- and each
+ *      element is staged as two fp16 planes h0 = f16(s x), h1 = f16(s x - h0) (nearest even; the residual is exact): 22 of the
+ *      24 significand bits for elements down to 2^-18 of the tensor's maximum, absolute error <= 2^-39 of that maximum below;
+ *      a . b = (a0 b0 + a0 b1 + a1 b0) / (sa sb) runs as three fp16 MFMAs with fp32 accumulation (every product exact, the
+ *      scales leave exactly: v_ldexp_f32).  Dropped terms <= 2^-22 |a||b| per product, one seventh of what the fp32 pipe's own
+ *      accumulation leaves at the reduction lengths of the training step: measured against float64 it errs less than mode 0 in
+ *      every operand mode (tests/test_kernels_gpu.py::test_sgemm_split_planes_accuracy).  3/16 of the fp32 MFMA time.
+ * Inf / NaN operands produce NaN in modes 2 / 3 / 4 (in the rows they belong to). */
 int gt_sgemm_set_fp32_split(int32_t planes);
+/* max |x| over the finite elements of a rows x cols matrix (row stride ld), as mode 4 wants it in GtOperand.amax: the word is
+ * reset and filled on `stream`; it stays valid for as long as the operand's contents do */
+int gt_absmax(const float* x, int64_t rows, int64_t cols, int64_t ld, uint64_t* out, void* stream);
 int32_t gt_sgemm_get_fp32_split(void);
 
 /* ------------------------------------------------------------------- recurrent (small-M) GEMM

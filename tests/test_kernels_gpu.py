@@ -31,8 +31,9 @@ def rb(t, bf16):
 
 
 # GtGemm.bf16: False = fp32 MFMA, True = operands rounded to bf16, 3 / 2 = fp32 product from three / two bf16 planes per
-# operand (xgemm_kernel).  Three planes hold to the fp32 tolerances; two planes drop terms of 2^-16 |a||b|.
-PRECISIONS = [False, True, 3, 2]
+# operand (xgemm_kernel), 4 = from two scaled fp16 planes (22 significand bits per operand).  Three bf16 planes and two fp16
+# planes hold to the fp32 tolerances; two bf16 planes drop terms of 2^-16 |a||b|.
+PRECISIONS = [False, True, 3, 2, 4]
 
 
 def native_if_false(bf16):
@@ -70,14 +71,16 @@ def test_sgemm_split_planes_accuracy(dev):
     ref = A.double() @ B.double().t()
     scale = (A.double().abs() @ B.double().abs().t())           # sum |a||b|: what a rounding error is relative to
     err = {}
-    for prec in (False, 3, 2):
+    for prec in (False, 3, 2, 4):
         C = torch.empty(M, N, device=dev)
         with native_if_false(prec):
             ops.sgemm(ops.Operand(A.to(dev), ops.KC, ld=K), ops.Operand(B.to(dev), ops.KC, ld=K), C, M, N, K, bf16=prec)
         err[prec] = float(((C.cpu().double() - ref).abs() / scale).max())
+    print('max |error| / sum |a||b| against float64:', err)
     # fp32 accumulation over K = 4096 terms leaves a few 1e-6 of sum |a||b| on either pipe
-    assert err[False] < 1e-5 and err[3] < 1e-5, err
+    assert err[False] < 1e-5 and err[3] < 1e-5 and err[4] < 1e-5, err
     assert err[3] < 1.5 * err[False], err
+    assert err[4] < 1.5 * err[False], err                       # two fp16 planes: the same bar as three bf16 planes
     assert err[2] < 4e-5, err                                   # 2^-16 per product
 
 

@@ -14,12 +14,12 @@ for (M, N, K) in ((384, 512, 4096), (96, 130, 2816)):
                          ('kc/rc', ops.Operand(A.to(dev), ops.KC, ld=K), ops.Operand(B.t().contiguous().to(dev), ops.RC, ld=N)),
                          ('rc/kc', ops.Operand(A.t().contiguous().to(dev), ops.RC, ld=M), ops.Operand(B.to(dev), ops.KC, ld=K))):
         out = []
-        for prec in (0, 3, 2):
+        for prec in (0, 3, 2, 4):
             with ops.fp32_split(prec):
                 C = torch.zeros(M, N, device=dev)
                 ops.sgemm(oa, ob, C, M, N, K)
             out.append(err(C, ref, scale))
-        print(f'{M}x{N}x{K} {name}: native {out[0]:.2e}  3 planes {out[1]:.2e}  2 planes {out[2]:.2e}', flush=True)
+        print(f'{M}x{N}x{K} {name}: native {out[0]:.2e}  3 planes {out[1]:.2e}  2 planes {out[2]:.2e}  2 fp16 planes {out[3]:.2e}', flush=True)
 # conv
 for (Bn, T, Cin, Cout, Kk) in ((4, 150, 80, 512, 5), (64, 44, 64, 128, 5)):
     x, W, dy = rnd(Bn, Cin, T), rnd(Cout, Cin, Kk) * 0.2, rnd(Bn, Cout, T)
@@ -32,11 +32,11 @@ for (Bn, T, Cin, Cout, Kk) in ((4, 150, 80, 512, 5), (64, 44, 64, 128, 5)):
     xcl = x.permute(0, 2, 1).contiguous().view(Bn * T, Cin).to(dev); Wd = W.to(dev)
     dycl = dy.permute(0, 2, 1).contiguous().view(Bn * T, Cout).to(dev)
     res = {}
-    for prec in (0, 3, 2):
+    for prec in (0, 3, 2, 4):
         with ops.fp32_split(prec):
             ycl = ops.conv1d_fwd(xcl, ops.conv_weight_fwd(Wd), None, Bn, T, Cin, Cout, Kk, 1)
             dx = ops.conv1d_dx(dycl, ops.conv_weight_bwd(Wd), Bn, T, Cin, Cout, Kk, 1)
             dW = torch.zeros(Cout, Cin, Kk, device=dev); ops.conv1d_dw(dycl, xcl, Bn, T, Cin, Cout, Kk, 1, dW)
         res[prec] = (err(ycl.view(Bn, T, Cout).permute(0, 2, 1), y.detach(), ya), err(dx.view(Bn, T, Cin).permute(0, 2, 1), gx, gxa), err(dW, gw, gwa))
     for i, nm in enumerate(('conv fwd', 'conv dx', 'conv dW')):
-        print(f'B{Bn} T{T} {Cin}->{Cout} {nm}: native {res[0][i]:.2e}  3 planes {res[3][i]:.2e}  2 planes {res[2][i]:.2e}', flush=True)
+        print(f'B{Bn} T{T} {Cin}->{Cout} {nm}: native {res[0][i]:.2e}  3 planes {res[3][i]:.2e}  2 planes {res[2][i]:.2e}  2 fp16 planes {res[4][i]:.2e}', flush=True)
