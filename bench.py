@@ -430,11 +430,16 @@ def main():
                'gt_prof_calibrate')
     sync()
     lib.gt_prof_begin_sampled(PROF_STRIDE)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]       # one event per pair: spread of the pairs
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         pair(args.warmup + i)
+        marks[i + 1].record()
     sync()
     elapsed = time.perf_counter() - t0
+    pair_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    log('pairs (ms, by their own events): ' + ' '.join(f'{x:.1f}' for x in pair_ms))
     prof_out = (ctypes.c_double * (7 * NF + 2))()          # GT_PROF_DOUBLES
     _lib.check(lib.gt_prof_end(prof_out), 'gt_prof_end')
     log(f'timed region: {elapsed:.3f} s for {args.steps} pairs')
@@ -615,6 +620,7 @@ def main():
                                 tiled_gemm_arithmetic='bf16 operands, fp32 accumulation' if args.bf16 else GEMM_ARITH,
                                 recurrent_product_arithmetic='bf16 operands, fp32 accumulation' if args.bf16 else 'fp32 MFMA (v_mfma_f32_16x16x4_f32)',
                                 padded_frames_per_s=args.batch * To * world * args.steps / elapsed,
+                                pair_ms_min_median_max=[round(pair_ms[0], 2), round(pair_ms[len(pair_ms) // 2], 2), round(pair_ms[-1], 2)],
                                 g_step_ms=g_s * 1e3, d_step_ms=d_s * 1e3,
                                 schedule_2g1d_frames_per_s=2 * total_frames / (2 * g_s + d_s),
                                 pair_mfma_frac=fl / (elapsed / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS,

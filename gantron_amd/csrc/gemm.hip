@@ -582,7 +582,6 @@ struct TileLoaderX {
     static constexpr int NV = KT ? NK : KPT;
     static constexpr int SR = BR + 32;            // r-type: bf16 elements per k-row of the LDS image
     static constexpr int PLANE = KT ? BR * LDX : BKX * SR;        // bf16 elements per plane
-    float4 reg[NV];
     int p0[KT ? NK : 1], p1[KT ? NK : 1];         // fixed decomposition of the row index
     int q0, q1;                                   // running decomposition of the first k
     long foff;                                    // KC / RC: element offset of this thread's first load of the next k-tile
@@ -608,8 +607,9 @@ struct TileLoaderX {
             q0 = k / o.T; q1 = k - q0 * o.T;                      // (b, t) of the first k
         }
     }
+    // (the k-tile's values go to / come from a register set of the CALLER: xgemm_kernel keeps PF of them in flight)
     template <bool FAST>
-    __device__ __forceinline__ void load(const OpDev& o, const float* base, int r0, int R, int k0, int K, int tid) {
+    __device__ __forceinline__ void load(float4 (&reg)[NV], const OpDev& o, const float* base, int r0, int R, int k0, int K, int tid) {
         if (KT) {
             const int k = k0 + 4 * (tid & 7);
 #pragma unroll
@@ -642,7 +642,7 @@ struct TileLoaderX {
             }
         }
     }
-    __device__ __forceinline__ void store(unsigned short* S, int tid, float scale = 1.f) const {
+    __device__ __forceinline__ void store(const float4 (&reg)[NV], unsigned short* S, int tid, float scale = 1.f) const {
         unsigned lo[NV][NP], hi[NV][NP];
         if constexpr (FMT == 1) split_h2<NV>(reg, scale, lo, hi);
         else split_all<NP, NV>(reg, lo, hi);
@@ -676,7 +676,8 @@ struct TileLoaderX {
     }
 };
 
-template <int BM, int BN, int AMODE, int BMODE, int NP, int FMT = 0>
+// PF = k-tiles of operand loads in flight per workgroup (register sets of the kernel; 1 everywhere: see the note below the kernel)
+template <int BM, int BN, int AMODE, int BMODE, int NP, int FMT = 0, int PF = 1>
 __global__ __launch_bounds__(256) void xgemm_kernel(GemmDev g) {
     static_assert(FMT == 0 || NP == 2, "the fp16 form has two planes");
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -724,57 +725,60 @@ __global__ __launch_bounds__(256) void xgemm_kernel(GemmDev g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
-    if (kbeg < kend) {
-        if (inside && kbeg + BKX <= kend) {
-            la.template load<true>(g.A, Ab, m0, g.M, kbeg, kend, tid);
-            lb.template load<true>(g.B, Bb, n0, g.N, kbeg, kend, tid);
-        } else {
-            la.template load<false>(g.A, Ab, m0, g.M, kbeg, kend, tid);
-            lb.template load<false>(g.B, Bb, n0, g.N, kbeg, kend, tid);
-        }
-    }
+    float4 ra[PF][LA::NV], rb[PF][LB::NV];
+#define XG_LOAD(U, KT_)                                                                     \
+    do {                                                                                    \
+        if (inside && (KT_) + BKX <= kend) {                                                \
+            la.template load<true>(ra[U], g.A, Ab, m0, g.M, (KT_), kend, tid);              \
+            lb.template load<true>(rb[U], g.B, Bb, n0, g.N, (KT_), kend, tid);              \
+        } else {                                                                            \
+            la.template load<false>(ra[U], g.A, Ab, m0, g.M, (KT_), kend, tid);             \
+            lb.template load<false>(rb[U], g.B, Bb, n0, g.N, (KT_), kend, tid);             \
+        }                                                                                   \
+    } while (0)
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+        if (kbeg + u * BKX < kend) XG_LOAD(u, kbeg + u * BKX);
     const int abase = LA::frag_base(wm0, lane), bbase = LB::frag_base(wn0, lane);
-    for (int k0 = kbeg; k0 < kend; k0 += BKX) {
-        la.store(Ax, tid, sa);
-        lb.store(Bx, tid, sb);
-        __syncthreads();
-        if (k0 + BKX < kend) {
-            if (inside && k0 + 2 * BKX <= kend) {
-                la.template load<true>(g.A, Ab, m0, g.M, k0 + BKX, kend, tid);
-                lb.template load<true>(g.B, Bb, n0, g.N, k0 + BKX, kend, tid);
-            } else {
-                la.template load<false>(g.A, Ab, m0, g.M, k0 + BKX, kend, tid);
-                lb.template load<false>(g.B, Bb, n0, g.N, k0 + BKX, kend, tid);
+    for (int k0 = kbeg; k0 < kend; k0 += PF * BKX) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int kt = k0 + u * BKX;
+            if (kt >= kend) break;               // (uniform)
+            la.store(ra[u], Ax, tid, sa);
+            lb.store(rb[u], Bx, tid, sb);
+            __syncthreads();
+            if (kt + PF * BKX < kend) XG_LOAD(u, kt + PF * BKX);
+#pragma unroll
+            for (int s = 0; s < BKX / 16; ++s) {
+                bf16x8_t a[NP][TM], b[NP][TN];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[p][i] = LA::frag(Ax, abase, p, i, s);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b[p][j] = LB::frag(Bx, bbase, p, j, s);
+                }
+                // smallest terms first; between two MFMAs on the same accumulator lie the other TM * TN - 1 tiles
+#pragma unroll
+                for (int ord = NP - 1; ord >= 0; --ord)
+#pragma unroll
+                    for (int pa = 0; pa <= ord; ++pa)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) {
+                                if constexpr (FMT == 1)
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a[pa][i]),
+                                                                                        __builtin_bit_cast(f16x8_t, b[ord - pa][j]), acc[i][j], 0, 0, 0);
+                                else
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa][i], b[ord - pa][j], acc[i][j], 0, 0, 0);
+                            }
             }
+            __syncthreads();
         }
-#pragma unroll
-        for (int s = 0; s < BKX / 16; ++s) {
-            bf16x8_t a[NP][TM], b[NP][TN];
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[p][i] = LA::frag(Ax, abase, p, i, s);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[p][j] = LB::frag(Bx, bbase, p, j, s);
-            }
-            // smallest terms first; between two MFMAs on the same accumulator lie the other TM * TN - 1 tiles
-#pragma unroll
-            for (int ord = NP - 1; ord >= 0; --ord)
-#pragma unroll
-                for (int pa = 0; pa <= ord; ++pa)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) {
-                            if constexpr (FMT == 1)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a[pa][i]),
-                                                                                    __builtin_bit_cast(f16x8_t, b[ord - pa][j]), acc[i][j], 0, 0, 0);
-                            else
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa][i], b[ord - pa][j], acc[i][j], 0, 0, 0);
-                        }
-        }
-        __syncthreads();
     }
+#undef XG_LOAD
     // epilogue: as sgemm_kernel (mode 4: the operand scales leave first, exactly)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -797,6 +801,17 @@ __global__ __launch_bounds__(256) void xgemm_kernel(GemmDev g) {
         }
 }
 
+// (Measured and not adopted, round 4 -- numbers in DESIGN.md section 3: (a) PF = 2 / 3 k-tiles of operand loads in flight per
+// workgroup: 245 / 155 against 274 TFLOP/s on the decoder weight gradients, the extra register sets cost occupancy 3 -> 2 -> 1;
+// (b) h2gemm_kernel: two LDS images per workgroup, the split of tile t + 1 and the MFMAs of tile t in ONE instruction stream with
+// no barrier between them, laid out by sched_group_barrier as {1 MFMA, 5 vector, 2 LDS, 1 load} x 24, loads three tiles ahead,
+// one barrier per k-tile, 80 KB of LDS and 254 registers = two workgroups per CU: +21 % stand-alone where both operands are
+// k-contiguous (PostNet convolutions 204 -> 247, 212 -> 256 TFLOP/s), -8 % where an operand is read through
+// ds_read_b64_tr_b16 (decoder weight gradients 276 -> 255), and in the step 116.6-116.8 against 115.2-115.5 ms per pair -- what
+// it gains alone it loses beside the loops' kernels; (c) s_setprio 1 around the MFMA block: +0.5-1.5 %.  The counters say why
+// the simple form is hard to beat: per wave and k-tile 768 cycles of MFMA, 600 of vector instructions (116 of them), 315 of
+// LDS instructions, and the SUM is what a k-tile takes (3086 cycles for the two waves of a SIMD, matrix pipe 39 % busy,
+// SQ_WAIT_INST_ANY 46 %): the two waves of a SIMD do not overlap one's vector work with the other's MFMAs.)
 // ---- mode 4's pass in front of the product: max |x| over the FINITE elements of both operands, as fp32 bit patterns (monotonic
 // in |x|; an Inf / NaN element does not take part: it makes its own row's products NaN, as in the other modes, instead of
 // ruining the scale of every row).  grid (blocks, 2): blockIdx.y = operand; an operand with rows == 0 is skipped.  The maxima meet in two 64-bit
@@ -813,27 +828,32 @@ __global__ __launch_bounds__(256) void absmax2_kernel(AbsmaxOp a, AbsmaxOp b, un
     const AbsmaxOp& o = blockIdx.y == 0 ? a : b;
     if (o.rows == 0) return;
     unsigned m = 0;
-    const long stride = (long)gridDim.x * 256, first = (long)blockIdx.x * 256 + threadIdx.x;
-    if (o.vec) {
-        const long c4 = o.cols >> 2, per = o.rows * c4, total = per * o.batch;
-        for (long f = first; f < total; f += 4 * stride) {
-            float4 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const long g = min(f + u * stride, total - 1);
-                const long bt = g / per, rem = g - bt * per, r = rem / c4, c = rem - r * c4;
-                v[u] = *reinterpret_cast<const float4*>(o.p + bt * o.batch_stride + r * o.ld + 4 * c);
+    // lines of `cols` contiguous floats (a contiguous operand is ONE line: absmax_extent folds it); workgroups take lines in
+    // turn when there are several, and share the one long line otherwise -- no per-element index arithmetic either way
+    const long nlines = o.rows * o.batch;
+    const bool one = nlines == 1;
+    for (long L = one ? 0 : blockIdx.x; L < nlines; L += gridDim.x) {
+        const float* p = o.p + (L / o.rows) * o.batch_stride + (L % o.rows) * o.ld;
+        const long stride = one ? (long)gridDim.x * 256 : 256, first = one ? (long)blockIdx.x * 256 + threadIdx.x : threadIdx.x;
+        if (o.vec) {
+            const float4* p4 = reinterpret_cast<const float4*>(p);
+            const long n4 = o.cols >> 2;
+            long i = first;
+            for (; i + 3 * stride < n4; i += 4 * stride) {
+                const float4 v0 = p4[i], v1 = p4[i + stride], v2 = p4[i + 2 * stride], v3 = p4[i + 3 * stride];
+                m = max(max(max(m, finite_abs_bits(v0.x)), max(finite_abs_bits(v0.y), finite_abs_bits(v0.z))), finite_abs_bits(v0.w));
+                m = max(max(max(m, finite_abs_bits(v1.x)), max(finite_abs_bits(v1.y), finite_abs_bits(v1.z))), finite_abs_bits(v1.w));
+                m = max(max(max(m, finite_abs_bits(v2.x)), max(finite_abs_bits(v2.y), finite_abs_bits(v2.z))), finite_abs_bits(v2.w));
+                m = max(max(max(m, finite_abs_bits(v3.x)), max(finite_abs_bits(v3.y), finite_abs_bits(v3.z))), finite_abs_bits(v3.w));
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                m = max(max(m, finite_abs_bits(v[u].x)), max(max(finite_abs_bits(v[u].y), finite_abs_bits(v[u].z)), finite_abs_bits(v[u].w)));
+            for (; i < n4; i += stride) {
+                const float4 v0 = p4[i];
+                m = max(max(max(m, finite_abs_bits(v0.x)), max(finite_abs_bits(v0.y), finite_abs_bits(v0.z))), finite_abs_bits(v0.w));
+            }
+        } else {
+            for (long i = first; i < o.cols; i += stride) m = max(m, finite_abs_bits(p[i]));
         }
-    } else {
-        const long per = o.rows * o.cols, total = per * o.batch;
-        for (long g = first; g < total; g += stride) {
-            const long bt = g / per, rem = g - bt * per, r = rem / o.cols, c = rem - r * o.cols;
-            m = max(m, finite_abs_bits(o.p[bt * o.batch_stride + r * o.ld + c]));
-        }
+        if (one) break;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
@@ -1453,7 +1473,7 @@ extern "C" int gt_sgemm(const GtGemm* g, void* stream) {
             if (d.amax_a != nullptr) ao.rows = 0;
             if (d.amax_b != nullptr) bo.rows = 0;
             const long work = std::max(ao.rows * ao.cols * ao.batch, bo.rows * bo.cols * bo.batch);
-            const unsigned blocks = (unsigned)std::min<long>(256, std::max<long>(1, cdiv64(work, 256L * 16)));
+            const unsigned blocks = (unsigned)std::min<long>(512, std::max<long>(1, cdiv64(work, 256L * 32)));
             hipLaunchKernelGGL(absmax2_kernel, dim3(blocks, 2), dim3(256), 0, st, ao, bo, ring + d.amax_slot, epoch);
             static const int amax_dbg = gt_env_item("GANTRON_DEBUG", "amax", 0);
             if (amax_dbg) {         // diagnostics (synchronises): the two maxima this product is scaled by

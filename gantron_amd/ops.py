@@ -162,10 +162,11 @@ PLANE_GEMMS = bool(sw.experimental('plane_gemms'))
 class Operand:
     """Addressing of one GEMM operand (see GtOperand).  planes: a Planes of the tensor `t` is a view of (same offsets)."""
 
-    def __init__(self, t, mode, ld=0, T=0, C=0, dil=1, pad=0, offset=0, batch_stride=0, planes=None):
+    def __init__(self, t, mode, ld=0, T=0, C=0, dil=1, pad=0, offset=0, batch_stride=0, planes=None, amax=None):
         self.t, self.mode, self.ld, self.T, self.C = t, mode, ld, T, C
         self.dil, self.pad, self.offset, self.batch_stride = dil, pad, offset, batch_stride
         self.planes = planes
+        self.amax = amax          # int64[1] from absmax(): the fp16-plane product then skips its own pass over this operand
 
     def c(self):
         o = GtOperand()
@@ -174,7 +175,20 @@ class Operand:
         o.ld, o.batch_stride = self.ld, self.batch_stride
         if self.planes is not None:
             o.planes, o.plane_stride = ptr(self.planes.t, self.offset), self.planes.n
+        if self.amax is not None:
+            assert self.amax.is_cuda and self.amax.dtype == torch.int64 and self.amax.numel() == 1
+            o.amax = self.amax.data_ptr()
         return o
+
+
+def absmax(t, rows=None, cols=None, ld=None):
+    """gt_absmax: max |x| over the finite elements of a (rows, cols) matrix with row stride ld inside the fp32 tensor t (default:
+    all of t), as the device word GtOperand.amax takes -- for an operand that several fp16-plane products share."""
+    _require(t)
+    rows, cols = (1, t.numel()) if rows is None else (rows, cols)
+    out = torch.empty(1, dtype=torch.int64, device=t.device)
+    check(lib().gt_absmax(ptr(t), rows, cols, cols if ld is None else ld, ptr(out), _stream()), 'gt_absmax')
+    return out
 
 
 def default_split_k(M, N, K, batch=1):

@@ -84,6 +84,36 @@ def test_sgemm_split_planes_accuracy(dev):
     assert err[2] < 4e-5, err                                   # 2^-16 per product
 
 
+def test_sgemm_fp16_planes_scales_and_given_maxima(dev):
+    """Mode 4 (two scaled fp16 planes): operands far outside fp16's range in both directions (gradient-sized 1e-9 against
+    activations of 1e+3, the scales leave exactly), the caller-supplied maxima (gt_absmax -> GtOperand.amax: same result as the
+    product's own pass), an all-zero operand, and a NaN that poisons its own output row only."""
+    from gantron_amd import ops
+    M, N, K = 200, 300, 1000
+    for sa, sb in ((1e-9, 1e3), (3e5, 2e-7), (1.0, 1.0)):
+        A, B = g(M, K) * sa, g(N, K, seed=1) * sb
+        ref = A.double() @ B.double().t()
+        Ad, Bd = A.to(dev), B.to(dev)
+        C = torch.empty(M, N, device=dev)
+        ops.sgemm(ops.Operand(Ad, ops.KC, ld=K), ops.Operand(Bd, ops.KC, ld=K), C, M, N, K, bf16=4)
+        assert int(ops.lib().gt_sgemm_last_kernel()) == 5
+        close(C, ref, rtol=1e-5, atol=0.0, what=f'scaled operands {sa:g} x {sb:g}')
+        C2 = torch.empty(M, N, device=dev)
+        ops.sgemm(ops.Operand(Ad, ops.KC, ld=K, amax=ops.absmax(Ad)), ops.Operand(Bd, ops.KC, ld=K, amax=ops.absmax(Bd, N, K, K)),
+                  C2, M, N, K, bf16=4)
+        assert torch.equal(C, C2), 'given maxima must reproduce the product\'s own pass bit for bit'
+    Z = torch.zeros(M, K, device=dev)
+    C = torch.full((M, N), 7.0, device=dev)
+    ops.sgemm(ops.Operand(Z, ops.KC, ld=K), ops.Operand(Bd, ops.KC, ld=K), C, M, N, K, bf16=4)
+    assert float(C.abs().max()) == 0.0
+    An = A.clone()
+    An[5, 17] = float('nan')
+    C = torch.empty(M, N, device=dev)
+    ops.sgemm(ops.Operand(An.to(dev), ops.KC, ld=K), ops.Operand(Bd, ops.KC, ld=K), C, M, N, K, bf16=4)
+    assert bool(torch.isnan(C[5]).all()) and bool(torch.isfinite(C[torch.arange(M) != 5]).all())
+    close(C[torch.arange(M) != 5], ref[torch.arange(M) != 5], rtol=1e-5, atol=0.0, what='rows beside the NaN row')
+
+
 @pytest.mark.parametrize('bf16', PRECISIONS)
 def test_sgemm_modes_accumulate_splitk_batch(dev, bf16):
     with native_if_false(bf16):

@@ -7,10 +7,12 @@ OUT=${1:-gpurun_out/prof}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline"
-# (one pair, no warm-up: with more dispatches rocprofv3 7.2 segfaults in its counter collection once the step went below ~9 000
-# launches per pair -- `--steps 2` or `--steps 1 --warmup 1` crash after the timed region, `--steps 1 --warmup 0` does not)
-ARGS1="bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-data-path"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o r03k -- python3 $ARGS > "$OUT/stats.log" 2>&1 && echo "stats pass done" &&
+# (round 3 ran the counter passes on ONE un-warmed pair: with more dispatches rocprofv3 7.2 segfaulted in its copy of a dispatch's
+# kernel arguments, only for launches that went through hipExtLaunchKernelGGL with NULL events.  Since round 4 those launches are
+# plain hipLaunchKernelGGL unless they are one of the profiler's samples (GT_LAUNCH_TIMED, csrc/common.h) and the passes run with
+# the normal warm-up; PMC_ARGS overrides)
+ARGS1="${PMC_ARGS:-bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-data-path}"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o r04k -- python3 $ARGS > "$OUT/stats.log" 2>&1 && echo "stats pass done" &&
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -o fetch -- python3 $ARGS1 > "$OUT/fetch.log" 2>&1 && echo "fetch pass done" &&
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -o write -- python3 $ARGS1 > "$OUT/write.log" 2>&1 && echo "write pass done" &&
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d "$OUT/mfma" -o mfma -- python3 $ARGS1 > "$OUT/mfma.log" 2>&1 && echo "mfma pass done" &&
