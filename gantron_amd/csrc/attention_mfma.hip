@@ -930,79 +930,92 @@ __device__ __forceinline__ void apply_e(const float* e, const float* M, const fl
     }
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_wterms_mfma(GtAttnDims d, const float* w, long w_step, const float* u,
+// (round 4: a workgroup walks WT_STEPS steps of its (row, chunk) instead of one -- the packed weights, 24 KB, are staged once
+// per workgroup, not once per 16 KB tile of tanh outputs: 8.3 -> see DESIGN.md section 5 -- and the next step's tile is
+// requested under the current step's two small GEMMs)
+constexpr int WT_STEPS = 8;
+__global__ __launch_bounds__(256) void attn_bwd_wterms_mfma(GtAttnDims d, int nsteps, const float* w, long w_step, const float* u,
                                                             const float* Wc, const float* Wd, const float* v,
                                                             const int* lengths, float* dq2, long dq2_step, long ld_dq2,
                                                             float* dwcat2, float* p_hist, const float* wpack) {
     __shared__ SharedM S;
-    const int b = blockIdx.x, t0 = blockIdx.y * CT, step = blockIdx.z;       // grid (B, chunks, steps)
+    const int b = blockIdx.x, t0 = blockIdx.y * CT, step0 = blockIdx.z * WT_STEPS;       // grid (B, chunks, ceil(steps / WT_STEPS))
     if (lengths != nullptr && t0 >= lengths[b]) return;                      // dq2 / dwcat2 are zero-initialised; P unread
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, kq = lane >> 4;
     const long BTi = (long)d.B * d.Ti;
-    u += (long)step * BTi * A;
-    w += (long)step * w_step;
-    dq2 += (long)step * dq2_step;
-    dwcat2 += (long)step * 2 * BTi;
-    p_hist += (long)step * BTi * PW;
-    float4 u4[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int f = threadIdx.x + 256 * i, tl = f >> 5, c4 = f & 31;
-        u4[i] = *reinterpret_cast<const float4*>(u + ((long)b * d.Ti + min(t0 + tl, d.Ti - 1)) * A + 4 * c4);
-    }
-    const float w_c = w[(long)b * d.Ti + min(t0 + (int)(threadIdx.x & (CT - 1)), d.Ti - 1)];
+    const int step1 = min(nsteps, step0 + WT_STEPS);
     stage_common(S, d, Wc, Wd, v, nullptr, nullptr, b, t0, wpack, false);
-    __syncthreads();                                   // S.v
+    float4 u4[4];
+    float w_c;
+#define WT_LOAD(ST_)                                                                                                         \
+    do {                                                                                                                     \
+        const float* u_ = u + (long)(ST_) * BTi * A;                                                                         \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                      \
+            const int f = threadIdx.x + 256 * i, tl = f >> 5, c4 = f & 31;                                                   \
+            u4[i] = *reinterpret_cast<const float4*>(u_ + ((long)b * d.Ti + min(t0 + tl, d.Ti - 1)) * A + 4 * c4);          \
+        }                                                                                                                    \
+        w_c = (w + (long)(ST_) * w_step)[(long)b * d.Ti + min(t0 + (int)(threadIdx.x & (CT - 1)), d.Ti - 1)];                \
+    } while (0)
+    WT_LOAD(step0);
+    __syncthreads();                                   // S.v, S.wc, S.wd
+    for (int step = step0; step < step1; ++step) {
+        float* dq2_s = dq2 + (long)step * dq2_step;
+        float* dwcat2_s = dwcat2 + (long)step * 2 * BTi;
+        float* p_s = p_hist + (long)step * BTi * PW;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {                      // M = v (1 - u^2), zero beyond Ti
-        const int f = threadIdx.x + 256 * i, tl = f >> 5, c4 = f & 31;
-        const float4 vv = *reinterpret_cast<const float4*>(&S.v[4 * c4]);
-        const float m = (t0 + tl < d.Ti) ? 1.f : 0.f;
-        *reinterpret_cast<float4*>(&S.ds[tl * LDS_ + 4 * c4]) =
-            make_float4(m * vv.x * (1.f - u4[i].x * u4[i].x), m * vv.y * (1.f - u4[i].y * u4[i].y),
-                        m * vv.z * (1.f - u4[i].z * u4[i].z), m * vv.w * (1.f - u4[i].w * u4[i].w));
-    }
-    if (threadIdx.x < CT) S.de[threadIdx.x] = (t0 + (int)threadIdx.x < d.Ti) ? w_c : 0.f;
-    __syncthreads();
-    {   // M . Wd
-        const int mt = wave >> 1, nt = wave & 1;
-        f32x4 c3 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s4 = 0; s4 < 8; ++s4) {
-            const int k0 = 16 * s4 + 4 * kq;
-            c3 = mfma4(ld4(&S.ds[(16 * mt + r) * LDS_ + k0]), ld4s(&S.wd[k0 * LDD + 16 * nt + r], LDD), c3);
+        for (int i = 0; i < 4; ++i) {                      // M = v (1 - u^2), zero beyond Ti
+            const int f = threadIdx.x + 256 * i, tl = f >> 5, c4 = f & 31;
+            const float4 vv = *reinterpret_cast<const float4*>(&S.v[4 * c4]);
+            const float m = (t0 + tl < d.Ti) ? 1.f : 0.f;
+            *reinterpret_cast<float4*>(&S.ds[tl * LDS_ + 4 * c4]) =
+                make_float4(m * vv.x * (1.f - u4[i].x * u4[i].x), m * vv.y * (1.f - u4[i].y * u4[i].y),
+                            m * vv.z * (1.f - u4[i].z * u4[i].z), m * vv.w * (1.f - u4[i].w * u4[i].w));
         }
+        if (threadIdx.x < CT) S.de[threadIdx.x] = (t0 + (int)threadIdx.x < d.Ti) ? w_c : 0.f;
+        if (step + 1 < step1) WT_LOAD(step + 1);           // the next step's tile travels under this step's products
+        __syncthreads();
+        {   // M . Wd
+            const int mt = wave >> 1, nt = wave & 1;
+            f32x4 c3 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) S.dlocf[(16 * mt + 4 * kq + e) * LDL + 16 * nt + r] = c3[e];
-    }
-    __syncthreads();
-    {   // P = (M . Wd) . Wc
-        const int mt = wave >> 1;
-        f32x4 c6[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            for (int s4 = 0; s4 < 8; ++s4) {
+                const int k0 = 16 * s4 + 4 * kq;
+                c3 = mfma4(ld4(&S.ds[(16 * mt + r) * LDS_ + k0]), ld4s(&S.wd[k0 * LDD + 16 * nt + r], LDD), c3);
+            }
 #pragma unroll
-        for (int s4 = 0; s4 < 2; ++s4) {
-            const int k0 = 16 * s4 + 4 * kq;
-            const float4 a6 = ld4(&S.dlocf[(16 * mt + r) * LDL + k0]);
+            for (int e = 0; e < 4; ++e) S.dlocf[(16 * mt + 4 * kq + e) * LDL + 16 * nt + r] = c3[e];
+        }
+        __syncthreads();
+        {   // P = (M . Wd) . Wc
+            const int mt = wave >> 1;
+            f32x4 c6[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int s4 = 0; s4 < 2; ++s4) {
+                const int k0 = 16 * s4 + 4 * kq;
+                const float4 a6 = ld4(&S.dlocf[(16 * mt + r) * LDL + k0]);
+#pragma unroll
+                for (int nl = 0; nl < 2; ++nl) {
+                    const int kk = 16 * (2 * (wave & 1) + nl) + r;
+                    c6[nl] = mfma4(a6, ld4s(&S.wc[k0 * LDC + kk], LDC), c6[nl]);
+                }
+            }
 #pragma unroll
             for (int nl = 0; nl < 2; ++nl) {
                 const int kk = 16 * (2 * (wave & 1) + nl) + r;
-                c6[nl] = mfma4(a6, ld4s(&S.wc[k0 * LDC + kk], LDC), c6[nl]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) S.g[(16 * mt + 4 * kq + e) * LDG + kk] = c6[nl][e];
             }
         }
-#pragma unroll
-        for (int nl = 0; nl < 2; ++nl) {
-            const int kk = 16 * (2 * (wave & 1) + nl) + r;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) S.g[(16 * mt + 4 * kq + e) * LDG + kk] = c6[nl][e];
+        __syncthreads();
+        for (int i = threadIdx.x; i < CT * PW; i += 256) {               // P rows of the tile's valid positions
+            const int tl = i / PW, kk = i - tl * PW;
+            if (t0 + tl < d.Ti) p_s[((long)b * d.Ti + t0 + tl) * PW + kk] = S.g[tl * LDG + kk];
         }
+        apply_e(S.de, S.ds, S.g, d, b, t0, dq2_s, ld_dq2, dwcat2_s);
+        __syncthreads();                                   // S.ds / S.de / S.g are rewritten by the next step
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < CT * PW; i += 256) {               // P rows of the tile's valid positions
-        const int tl = i / PW, kk = i - tl * PW;
-        if (t0 + tl < d.Ti) p_hist[((long)b * d.Ti + t0 + tl) * PW + kk] = S.g[tl * LDG + kk];
-    }
-    apply_e(S.de, S.ds, S.g, d, b, t0, dq2, ld_dq2, dwcat2);
+#undef WT_LOAD
 }
 
 struct AttnBwdStep {
@@ -1372,8 +1385,8 @@ void gt_launch_attn_energies_bwd_rec_mfma(GtAttnDims d, const float* dw, const f
 void gt_launch_attn_bwd_wterms_mfma(GtAttnDims d, int nsteps, const float* w, long w_step, const float* u, const float* Wc,
                                      const float* Wd, const float* v, const int* lengths, float* dq2, long dq2_step,
                                      long ld_dq2, float* dwcat2, float* p_hist, const float* wpack, hipStream_t st) {
-    dim3 grid(d.B, cdiv(d.Ti, CT), nsteps);
-    hipLaunchKernelGGL(attn_bwd_wterms_mfma, grid, dim3(256), 0, st, d, w, w_step, u, Wc, Wd, v, lengths, dq2, dq2_step,
+    dim3 grid(d.B, cdiv(d.Ti, CT), cdiv(nsteps, WT_STEPS));
+    hipLaunchKernelGGL(attn_bwd_wterms_mfma, grid, dim3(256), 0, st, d, nsteps, w, w_step, u, Wc, Wd, v, lengths, dq2, dq2_step,
                        ld_dq2, dwcat2, p_hist, wpack);
 }
 
