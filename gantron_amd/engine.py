@@ -1183,6 +1183,8 @@ class GeneratorEngine:
             LEAF.run(split_histories, sv['p2'], hist['hatt'], hist['HC'])
             pl['dG1'], pl['dG2'] = ops.Planes(dG1), ops.Planes(dG2)
 
+        dG1_words = []                # ops.absmax words of the chunks of dG1 (fp16-plane products): the prenet's backward reads all of it
+
         def leaf_decoder(lo, hi):
             """Weight gradients contributed by decoder steps lo..hi (dW = dGates^T . inputs, K = rows)."""
             n, o = (hi - lo + 1) * Bp, lo * Bp
@@ -1190,21 +1192,32 @@ class GeneratorEngine:
                 pl['dG1'].split(o * 4 * Ha, (o + n) * 4 * Ha)
                 pl['dG2'].split(o * 4 * Hd, (o + n) * 4 * Hd)
             g1p, g2p, p2p, hap, hcp = (pl.get(k) for k in ('dG1', 'dG2', 'p2', 'hatt', 'HC'))
+            # fp16-plane products: the chunk's gate gradients enter three products each, its [h_dec | ctx] and h_att rows up
+            # to three -- one pass over each for the maximum instead of one per product (rows of the step in front of the
+            # chunk included: the recurrent inputs' products read those; a superset's maximum bounds the operand as well)
+            a1 = a2 = ahc = aha = None
+            if ops.h2_active():
+                lo_ = max(lo - 1, 0)
+                a1 = ops.absmax(dG1, n, 4 * Ha, 4 * Ha, offset=o * 4 * Ha)
+                a2 = ops.absmax(dG2, n, 4 * Hd, 4 * Hd, offset=o * 4 * Hd)
+                ahc = ops.absmax(hist['HC'], (hi - lo_ + 1) * Bp, hc, hc, offset=lo_ * Bp * hc)
+                aha = ops.absmax(hist['hatt'], (hi - lo_ + 1) * Bp, Ha, Ha, offset=lo_ * Bp * Ha)
+                dG1_words.append(a1)
             ops.linear_dw(dG1, sv['p2'], n, 4 * Ha, Pd, g1ih, dy_offset=o * 4 * Ha, x_offset=o * Pd, ldc=Pd + E,
-                          dy_planes=g1p, x_planes=p2p)
+                          dy_planes=g1p, x_planes=p2p, dy_amax=a1)
             ops.linear_dw(dG2, hist['hatt'], n, 4 * Hd, Ha, g2ih, dy_offset=o * 4 * Hd, x_offset=o * Ha, ldc=Ha + E,
-                          dy_planes=g2p, x_planes=hap)
+                          dy_planes=g2p, x_planes=hap, dy_amax=a2, x_amax=aha)
             ops.linear_dw(dG2, hist['HC'], n, 4 * Hd, E, g2ih, dy_offset=o * 4 * Hd, ldx=hc, x_offset=o * hc + Hd,
-                          ldc=Ha + E, c_offset=Ha, dy_planes=g2p, x_planes=hcp)
+                          ldc=Ha + E, c_offset=Ha, dy_planes=g2p, x_planes=hcp, dy_amax=a2, x_amax=ahc)
             l1 = max(lo, 1)                      # pairs (t, t-1): gradients of the recurrent inputs
             if hi >= l1:
                 n1, o1, p1_ = (hi - l1 + 1) * Bp, l1 * Bp, (l1 - 1) * Bp
                 ops.linear_dw(dG1, hist['HC'], n1, 4 * Ha, E, g1ih, dy_offset=o1 * 4 * Ha, ldx=hc,
-                              x_offset=p1_ * hc + Hd, ldc=Pd + E, c_offset=Pd, dy_planes=g1p, x_planes=hcp)
+                              x_offset=p1_ * hc + Hd, ldc=Pd + E, c_offset=Pd, dy_planes=g1p, x_planes=hcp, dy_amax=a1, x_amax=ahc)
                 ops.linear_dw(dG1, hist['hatt'], n1, 4 * Ha, Ha, g1hh, dy_offset=o1 * 4 * Ha, x_offset=p1_ * Ha,
-                              dy_planes=g1p, x_planes=hap)
+                              dy_planes=g1p, x_planes=hap, dy_amax=a1, x_amax=aha)
                 ops.linear_dw(dG2, hist['HC'], n1, 4 * Hd, Hd, g2hh, dy_offset=o1 * 4 * Hd, ldx=hc, x_offset=p1_ * hc,
-                              dy_planes=g2p, x_planes=hcp)
+                              dy_planes=g2p, x_planes=hcp, dy_amax=a2, x_amax=ahc)
             s1 = ops.col_sums(dG1[lo:hi + 1], n, 4 * Ha)
             acc_add(G['decoder.attention_rnn.bias_ih'], s1)
             acc_add(G['decoder.attention_rnn.bias_hh'], s1)
@@ -1254,7 +1267,10 @@ class GeneratorEngine:
         # ---- prenet backward: a leaf of the graph as a whole (nothing below depends on it) -- it runs on the leaf stream
         # beside d(memory), the BiLSTM backward and the encoder convolutions, which are latency-bound launch chains
         def leaf_prenet():
-            dp2 = ops.linear_dx(dG1, W1ih, rows, 4 * Ha, Pd, ldw=Pd + E)
+            # (the maximum of ALL gate gradients = the largest of the chunks' words: they carry the same tag, so the integer
+            # maximum of the words is the word of the maximum -- no second pass over 912 MB at the tail of the step)
+            a_all = torch.stack(dG1_words).max().reshape(1) if dG1_words and ops.h2_active() else None
+            dp2 = ops.linear_dx(dG1, W1ih, rows, 4 * Ha, Pd, ldw=Pd + E, dy_amax=a_all)
             pk = sv['prenet_keep']
             call('gt_bias_act_drop_bwd', dp2, sv['p2'], rows, Pd, ACT_RELU, 0, pk[1], 0.5, dp2)
             ops.linear_dw(dp2, sv['p1'], rows, Pd, Pd, G['decoder.prenet.layers.1.linear_layer.weight'])

@@ -181,14 +181,21 @@ class Operand:
         return o
 
 
-def absmax(t, rows=None, cols=None, ld=None):
-    """gt_absmax: max |x| over the finite elements of a (rows, cols) matrix with row stride ld inside the fp32 tensor t (default:
-    all of t), as the device word GtOperand.amax takes -- for an operand that several fp16-plane products share."""
+def absmax(t, rows=None, cols=None, ld=None, offset=0):
+    """gt_absmax: max |x| over the finite elements of a (rows, cols) matrix with row stride ld that starts at element `offset`
+    of the fp32 tensor t (default: all of t), as the device word GtOperand.amax takes -- for an operand that several fp16-plane
+    products share (the word of a superset of what a product addresses is as good: the scale only has to bound the operand)."""
     _require(t)
     rows, cols = (1, t.numel()) if rows is None else (rows, cols)
     out = torch.empty(1, dtype=torch.int64, device=t.device)
-    check(lib().gt_absmax(ptr(t), rows, cols, cols if ld is None else ld, ptr(out), _stream()), 'gt_absmax')
+    check(lib().gt_absmax(ptr(t, offset), rows, cols, cols if ld is None else ld, ptr(out), _stream()), 'gt_absmax')
     return out
+
+
+def h2_active():
+    """True when the tiled fp32 GEMMs issued now run from scaled fp16 planes (mode 4), i.e. when a shared operand's maximum is
+    worth computing once (absmax) instead of once per product."""
+    return FP32_SPLIT == 4 and not BF16_GEMMS
 
 
 def default_split_k(M, N, K, batch=1):
@@ -271,21 +278,22 @@ def linear(x, W, M, K, N, bias=None, out=None, ldw=None, w_offset=0, ldx=None, x
     return out
 
 
-def linear_dx(dy, W, M, N, K, out=None, ldw=None, w_offset=0, lddy=None, dy_offset=0, dy_planes=None, w_planes=None):
+def linear_dx(dy, W, M, N, K, out=None, ldw=None, w_offset=0, lddy=None, dy_offset=0, dy_planes=None, w_planes=None, dy_amax=None):
     """out[M,K] = dy[M,N] @ W[N,K]."""
     if out is None:
         out = torch.empty(M, K, device=dy.device, dtype=torch.float32)
-    sgemm(Operand(dy, KC, ld=lddy or N, offset=dy_offset, planes=dy_planes),
+    sgemm(Operand(dy, KC, ld=lddy or N, offset=dy_offset, planes=dy_planes, amax=dy_amax),
           Operand(W, RC, ld=ldw or K, offset=w_offset, planes=w_planes), out, M, K, N, bf16=BF16_GEMMS)
     return out
 
 
 def linear_dw(dy, x, rows, N, K, dW, lddy=None, dy_offset=0, ldx=None, x_offset=0, ldc=None, c_offset=0, dy_planes=None,
-              x_planes=None):
-    """dW[N,K] += dy[rows,N]^T @ x[rows,K]  (split-K over rows when the output grid is small)."""
+              x_planes=None, dy_amax=None, x_amax=None):
+    """dW[N,K] += dy[rows,N]^T @ x[rows,K]  (split-K over rows when the output grid is small).  *_amax: ops.absmax words of
+    (a superset of) the operands, when several products share them."""
     sk = default_split_k(N, K, rows)
-    sgemm(Operand(dy, RC, ld=lddy or N, offset=dy_offset, planes=dy_planes),
-          Operand(x, RC, ld=ldx or K, offset=x_offset, planes=x_planes), dW, N, K, rows,
+    sgemm(Operand(dy, RC, ld=lddy or N, offset=dy_offset, planes=dy_planes, amax=dy_amax),
+          Operand(x, RC, ld=ldx or K, offset=x_offset, planes=x_planes, amax=x_amax), dW, N, K, rows,
           ldc=ldc, accumulate=True, split_k=sk, c_offset=c_offset, bf16=BF16_GEMMS)
 
 
