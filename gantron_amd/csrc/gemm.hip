@@ -678,7 +678,7 @@ struct TileLoaderX {
 
 // PF = k-tiles of operand loads in flight per workgroup (register sets of the kernel; 1 everywhere: see the note below the kernel)
 template <int BM, int BN, int AMODE, int BMODE, int NP, int FMT = 0, int PF = 1>
-__global__ __launch_bounds__(256) void xgemm_kernel(GemmDev g) {
+__global__ __launch_bounds__(256, (BM * BN > 128 * 128 ? 2 : 1)) void xgemm_kernel(GemmDev g) {
     static_assert(FMT == 0 || NP == 2, "the fp16 form has two planes");
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     typedef TileLoaderX<AMODE, BM, NP, FMT> LA;
@@ -1273,6 +1273,22 @@ int launch_tile(const GemmDev& d, dim3 grid, hipStream_t st, int lds_pad) {
     return GT_E_ARG;
 }
 
+// fp16-plane form only, other tile shapes: 128 x 256 (wave tiles 64 x 128) for large products of k-contiguous operands (gt_sgemm);
+// GANTRON_DEBUG=h2_wide=1 / 2 (diagnostics): 128 x 256 / 256 x 128 tiles for every large product, 0: never
+template <int BM, int BN>
+int launch_tile_h2(const GemmDev& d, dim3 grid, hipStream_t st) {
+    const int am = d.A.mode, bm = d.B.mode;
+#define GT_CASEH(AM, BMD) if (am == AM && bm == BMD) { hipLaunchKernelGGL((xgemm_kernel<BM, BN, AM, BMD, 2, 1>), grid, dim3(256), 0, st, d); return 0; }
+    GT_CASEH(GT_OP_KC, GT_OP_KC)
+    GT_CASEH(GT_OP_KC, GT_OP_RC)
+    GT_CASEH(GT_OP_RC, GT_OP_RC)
+    GT_CASEH(GT_OP_RC, GT_OP_KC)
+    GT_CASEH(GT_OP_IM2COL_K, GT_OP_KC)
+    GT_CASEH(GT_OP_RC, GT_OP_IM2COL_R)
+#undef GT_CASEH
+    return GT_E_ARG;
+}
+
 int prep_operand(const GtOperand& s, OpDev& o, int rows, int K, const char* name) {
     GT_REQUIRE(s.p != nullptr || s.planes != nullptr, GT_E_ARG, "gt_sgemm: operand %s is NULL", name);
     o.p = s.p; o.mode = s.mode; o.T = s.T; o.C = s.C; o.dil = s.dil; o.pad = s.pad; o.ld = s.ld;
@@ -1502,6 +1518,7 @@ extern "C" int gt_sgemm(const GtGemm* g, void* stream) {
     // CU's register file) capped at one workgroup per CU while the loops run: 146.9 vs 134.0 ms -- the GEMMs slow down by
     // more than the loop kernels gain.)
     const int lds_pad = 0;
+    static const int h2_wide = gt_env_item("GANTRON_DEBUG", "h2_wide", 3);
     static const int pgemm2_on = !gt_env_item("GANTRON_EXPERIMENTAL", "no_pgemm2", 0);
     const long tiles256 = (long)cdiv(g->M, 256) * cdiv(g->N, 128) * gz;
     if (d.Ap != nullptr && pgemm2_on && g->M >= 256 && g->N >= 128 && tiles256 >= 128) {
@@ -1509,6 +1526,20 @@ extern "C" int gt_sgemm(const GtGemm* g, void* stream) {
         GT_REQUIRE(grid.y <= 65535, GT_E_LIMIT, "gt_sgemm: M too large for grid.y");
         rc = launch_pgemm2(d, grid, st);
         g_last_kernel = 4;
+    } else if (big && d.bf16 == 4 && g->N >= 256 && ((h2_wide == 1 && tiles128 >= 384) ||
+               (h2_wide == 3 && d.A.mode != GT_OP_RC && d.B.mode == GT_OP_KC && g->M >= 8192 && tiles128 >= 176))) {
+        // 128 x 256 tiles (wave tiles 64 x 128: three quarters of the vector and LDS work per MFMA, 234 registers = two workgroups
+        // per CU) where BOTH operands are k-contiguous and the product is large: the convolutions' forward and input-gradient
+        // passes and the prenet -> attention-LSTM projection, which run outside the decoder loops.  Stand-alone +20-25 % there
+        // (PostNet convolution forward 206 -> 257, input gradient 216 -> 269 TFLOP/s), -10 % where ds_read_b64_tr_b16 feeds an
+        // operand (weight gradients: they keep 128 x 128); pair 113.0-113.3 against 114.9-115.1 ms.  GANTRON_DEBUG=h2_wide=0: off.
+        dim3 grid(cdiv(g->N, 256), cdiv(g->M, 128), (unsigned)gz);
+        GT_REQUIRE(grid.y <= 65535, GT_E_LIMIT, "gt_sgemm: M too large for grid.y");
+        rc = launch_tile_h2<128, 256>(d, grid, st);
+    } else if (big && d.bf16 == 4 && h2_wide == 2 && g->M >= 256 && tiles128 >= 384) {
+        dim3 grid(cdiv(g->N, 128), cdiv(g->M, 256), (unsigned)gz);
+        GT_REQUIRE(grid.y <= 65535, GT_E_LIMIT, "gt_sgemm: M too large for grid.y");
+        rc = launch_tile_h2<256, 128>(d, grid, st);
     } else if (big) {
         dim3 grid(cdiv(g->N, 128), cdiv(g->M, 128), (unsigned)gz);
         GT_REQUIRE(grid.y <= 65535, GT_E_LIMIT, "gt_sgemm: M too large for grid.y");

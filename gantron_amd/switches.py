@@ -44,7 +44,7 @@ _KNOWN = {
                          'no_dist_overlap'},
     'GANTRON_DEBUG': {'phase_timing', 'host_timing', 'block_timing', 'dist_timing', 'attn_valu', 'rec', 'fused', 'pgemm',
                       'rec_splits', 's1_fwd', 's2_fwd', 's2_bwd', 's1_bwd', 'enc_splits', 'sync_every', 'rec_lds_pad',
-                      'rec_stamps', 'attn_stamps', 'attn2', 'rec_tail_kb', 'amax', 'h2_skip'},
+                      'rec_stamps', 'attn_stamps', 'attn2', 'rec_tail_kb', 'amax', 'h2_skip', 'h2_wide'},
 }
 
 
