@@ -1532,7 +1532,9 @@ extern "C" int gt_sgemm(const GtGemm* g, void* stream) {
         // per CU) where BOTH operands are k-contiguous and the product is large: the convolutions' forward and input-gradient
         // passes and the prenet -> attention-LSTM projection, which run outside the decoder loops.  Stand-alone +20-25 % there
         // (PostNet convolution forward 206 -> 257, input gradient 216 -> 269 TFLOP/s), -10 % where ds_read_b64_tr_b16 feeds an
-        // operand (weight gradients: they keep 128 x 128); pair 113.0-113.3 against 114.9-115.1 ms.  GANTRON_DEBUG=h2_wide=0: off.
+        // operand (weight gradients: they keep 128 x 128); pair 113.8-114.0 against 114.9-115.1 ms (the forward loop's block GEMMs
+        // too, M = 1024: 114.8-114.9 against 114.4-114.5 -- they stay on 128 x 128; the discriminator's M = 2816 convolutions lose
+        // 0.2-0.3 ms of the D step on the wide tile).  GANTRON_DEBUG=h2_wide=0: off.
         dim3 grid(cdiv(g->N, 256), cdiv(g->M, 128), (unsigned)gz);
         GT_REQUIRE(grid.y <= 65535, GT_E_LIMIT, "gt_sgemm: M too large for grid.y");
         rc = launch_tile_h2<128, 256>(d, grid, st);
