@@ -1274,7 +1274,8 @@ int launch_tile(const GemmDev& d, dim3 grid, hipStream_t st, int lds_pad) {
 }
 
 // fp16-plane form only, other tile shapes: 128 x 256 (wave tiles 64 x 128) for large products of k-contiguous operands (gt_sgemm);
-// GANTRON_DEBUG=h2_wide=1 / 2 (diagnostics): 128 x 256 / 256 x 128 tiles for every large product, 0: never
+// GANTRON_DEBUG=h2_wide=1 / 2 (diagnostics): 128 x 256 / 256 x 128 tiles for every large product, 4: the default rule plus
+// the weight gradients (reduction-major operands) with M >= 1024, N >= 512, 0: never
 template <int BM, int BN>
 int launch_tile_h2(const GemmDev& d, dim3 grid, hipStream_t st) {
     const int am = d.A.mode, bm = d.B.mode;
@@ -1527,14 +1528,20 @@ extern "C" int gt_sgemm(const GtGemm* g, void* stream) {
         rc = launch_pgemm2(d, grid, st);
         g_last_kernel = 4;
     } else if (big && d.bf16 == 4 && g->N >= 256 && ((h2_wide == 1 && tiles128 >= 384) ||
-               (h2_wide == 3 && d.A.mode != GT_OP_RC && d.B.mode == GT_OP_KC && g->M >= 8192 && tiles128 >= 176))) {
+               ((h2_wide == 3 || h2_wide == 4) && d.A.mode != GT_OP_RC && d.B.mode == GT_OP_KC && g->M >= 8192 && tiles128 >= 176) ||
+               (h2_wide == 4 && d.A.mode == GT_OP_RC && d.B.mode != GT_OP_KC && g->M >= 1024 && g->N >= 512))) {
         // 128 x 256 tiles (wave tiles 64 x 128: three quarters of the vector and LDS work per MFMA, 234 registers = two workgroups
         // per CU) where BOTH operands are k-contiguous and the product is large: the convolutions' forward and input-gradient
         // passes and the prenet -> attention-LSTM projection, which run outside the decoder loops.  Stand-alone +20-25 % there
         // (PostNet convolution forward 206 -> 257, input gradient 216 -> 269 TFLOP/s), -10 % where ds_read_b64_tr_b16 feeds an
         // operand (weight gradients: they keep 128 x 128); pair 113.8-114.0 against 114.9-115.1 ms (the forward loop's block GEMMs
         // too, M = 1024: 114.8-114.9 against 114.4-114.5 -- they stay on 128 x 128; the discriminator's M = 2816 convolutions lose
-        // 0.2-0.3 ms of the D step on the wide tile).  GANTRON_DEBUG=h2_wide=0: off.
+        // 0.2-0.3 ms of the D step on the wide tile).  GANTRON_DEBUG=h2_wide=0: off.  The -10 % of the weight gradients is the
+        // grid, not the transposed reads: M = 4096, N = 2048 is 256 wide tiles, one workgroup per CU; with split_k = 2 (512
+        // workgroups) the same product runs at 326 instead of 283 TFLOP/s stand-alone (profiles/r04_gbench_wide.txt).  In the
+        // step the decoder's weight gradients are M = 4096, N <= 1024 products per backward chunk that run UNDER the loop with
+        // few workgroups on purpose (ops.SPLITK_OVERLAPPED); h2_wide=4 gives those the wide tile as well: 113.9-114.4 against
+        // 113.7-114.0 ms per pair at split-K targets 64 / 128 / 256 -- the pair no longer follows the speed of these GEMMs.
         dim3 grid(cdiv(g->N, 256), cdiv(g->M, 128), (unsigned)gz);
         GT_REQUIRE(grid.y <= 65535, GT_E_LIMIT, "gt_sgemm: M too large for grid.y");
         rc = launch_tile_h2<128, 256>(d, grid, st);

@@ -27,7 +27,8 @@ GANTRON_DEBUG          comma list of diagnostics: phase_timing, host_timing, blo
                        s2_bwd=<n>, s1_bwd=<n>, enc_splits=<n>, sync_every=<n>, rec_lds_pad=<n>, rec_stamps / attn_stamps (phase
                        stamps of the attention LSTM's launch and of the attention step: tools/rec_stamps.py), attn2=<bits>
                        (knock-outs of the attention step), rec_tail_kb=<n>, amax (prints the operand maxima every fp16-plane product is
-                       scaled by; synchronises).
+                       scaled by; synchronises), h2_skip=<bits> / h2_wide=<0..4> (fp16-plane products: pass knock-outs / tile-shape rule,
+                       csrc/gemm.hip).
 An unknown name in any of the three lists raises at import with the valid names (a mistyped switch would otherwise run
 the default schedule silently); values are decimal integers.  (The C side parses the same variables with the same
 trimming rules: csrc/api.hip, gt_env_item.)  bench.py / the tests additionally use
