@@ -817,7 +817,8 @@ __global__ __launch_bounds__(256, (BM * BN > 128 * 128 ? 2 : 1)) void xgemm_kern
 // ruining the scale of every row).  grid (blocks, 2): blockIdx.y = operand; an operand with rows == 0 is skipped.  The maxima meet in two 64-bit
 // words of g_amax_ring whose HIGH half is the call's epoch: a later call's values are always larger than an earlier call's,
 // so a slot is never reset (no memset in front of the launch, and a slot that comes round again after 8192 calls needs no
-// care beyond the earlier product having finished).
+// care beyond the earlier product having finished) -- until the 32-bit tags run out, after 2^32 calls: amax_ring_slot then
+// drains the device and clears the ring once.
 struct AbsmaxOp { const float* p; long rows, cols, ld, batch_stride; int batch, vec; };
 __device__ __forceinline__ unsigned finite_abs_bits(float x) {
     const unsigned u = __float_as_uint(x) & 0x7fffffffu;
@@ -1338,25 +1339,38 @@ AbsmaxOp absmax_extent(const GtOperand& s, const OpDev& o, int rows, int K, int 
 #define GT_TRY_RC(call) do { int rc__ = (call); if (rc__ != 0) return rc__; } while (0)
 // next pair of words of the device's g_amax_ring + a fresh epoch (see absmax2_kernel)
 int amax_ring_slot(unsigned long long** ring, int* slot, unsigned* epoch) {
-    static std::atomic<unsigned> next_slot{0}, next_epoch{0};
+    struct Ring { unsigned long long* base; unsigned next_slot, next_epoch; };
     static std::mutex mu;
-    static std::map<int, unsigned long long*> base;          // per device
+    static std::map<int, Ring> rings;                        // per device
+    // GANTRON_DEBUG=amax_wrap=<n> (tests): the tags of a device start n calls in front of their wrap
+    static const int wrap_in = gt_env_item("GANTRON_DEBUG", "amax_wrap", 0);
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);
     GT_REQUIRE(e == hipSuccess, (int)e, "gt_sgemm: hipGetDevice failed");
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        auto it = base.find(dev);
-        if (it == base.end()) {
-            void* p = nullptr;
-            e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_amax_ring));
-            GT_REQUIRE(e == hipSuccess && p != nullptr, (int)e, "gt_sgemm: hipGetSymbolAddress(g_amax_ring) failed");
-            it = base.emplace(dev, (unsigned long long*)p).first;
-        }
-        *ring = it->second;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = rings.find(dev);
+    if (it == rings.end()) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_amax_ring));
+        GT_REQUIRE(e == hipSuccess && p != nullptr, (int)e, "gt_sgemm: hipGetSymbolAddress(g_amax_ring) failed");
+        Ring r = {(unsigned long long*)p, 0u, wrap_in > 0 ? 0xffffffffu - (unsigned)wrap_in : 0u};
+        it = rings.emplace(dev, r).first;
     }
-    *slot = AMAX_STRIDE * (int)(next_slot.fetch_add(1u) % (unsigned)AMAX_SLOTS);
-    *epoch = next_epoch.fetch_add(1u) + 1u;
+    Ring& r = it->second;
+    if (r.next_epoch == 0xffffffffu) {
+        // the 32-bit tags are used up (2^32 calls: days of training).  A word only ever grows, so the tags cannot simply start
+        // over: wait until every product that may still read a word has finished, clear the ring, begin again at 1
+        e = hipDeviceSynchronize();
+        GT_REQUIRE(e == hipSuccess, (int)e, "gt_sgemm: hipDeviceSynchronize failed (tag wrap of the maxima ring)");
+        e = hipMemset(r.base, 0, sizeof(unsigned long long) * AMAX_SLOTS * AMAX_STRIDE);
+        GT_REQUIRE(e == hipSuccess, (int)e, "gt_sgemm: hipMemset failed (tag wrap of the maxima ring)");
+        e = hipDeviceSynchronize();
+        GT_REQUIRE(e == hipSuccess, (int)e, "gt_sgemm: hipDeviceSynchronize failed (tag wrap of the maxima ring)");
+        r.next_epoch = 0u;
+    }
+    *ring = r.base;
+    *slot = AMAX_STRIDE * (int)(r.next_slot++ % (unsigned)AMAX_SLOTS);
+    *epoch = ++r.next_epoch;
     return 0;
 }
 

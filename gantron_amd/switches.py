@@ -28,7 +28,7 @@ GANTRON_DEBUG          comma list of diagnostics: phase_timing, host_timing, blo
                        stamps of the attention LSTM's launch and of the attention step: tools/rec_stamps.py), attn2=<bits>
                        (knock-outs of the attention step), rec_tail_kb=<n>, amax (prints the operand maxima every fp16-plane product is
                        scaled by; synchronises), h2_skip=<bits> / h2_wide=<0..4> (fp16-plane products: pass knock-outs / tile-shape rule,
-                       csrc/gemm.hip).
+                       csrc/gemm.hip), amax_wrap=<n> (tests: the tags of the maxima ring start n calls before their 32-bit wrap).
 An unknown name in any of the three lists raises at import with the valid names (a mistyped switch would otherwise run
 the default schedule silently); values are decimal integers.  (The C side parses the same variables with the same
 trimming rules: csrc/api.hip, gt_env_item.)  bench.py / the tests additionally use
@@ -45,7 +45,7 @@ _KNOWN = {
                          'no_dist_overlap'},
     'GANTRON_DEBUG': {'phase_timing', 'host_timing', 'block_timing', 'dist_timing', 'attn_valu', 'rec', 'fused', 'pgemm',
                       'rec_splits', 's1_fwd', 's2_fwd', 's2_bwd', 's1_bwd', 'enc_splits', 'sync_every', 'rec_lds_pad',
-                      'rec_stamps', 'attn_stamps', 'attn2', 'rec_tail_kb', 'amax', 'h2_skip', 'h2_wide'},
+                      'rec_stamps', 'attn_stamps', 'attn2', 'rec_tail_kb', 'amax', 'h2_skip', 'h2_wide', 'amax_wrap'},
 }
 
 

@@ -114,6 +114,47 @@ def test_sgemm_fp16_planes_scales_and_given_maxima(dev):
     close(C[torch.arange(M) != 5], ref[torch.arange(M) != 5], rtol=1e-5, atol=0.0, what='rows beside the NaN row')
 
 
+_WRAP_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from gantron_amd import ops
+dev = torch.device('cuda:0')
+torch.manual_seed(0)
+M = N = K = 64
+def product(scale):
+    A, B = (torch.randn(M, K) * scale).to(dev), torch.randn(N, K).to(dev)
+    C = torch.empty(M, N, device=dev)
+    ops.sgemm(ops.Operand(A, ops.KC, ld=K), ops.Operand(B, ops.KC, ld=K), C, M, N, K, bf16=4)
+    ref = A.double() @ B.double().t()
+    err = float((C.double() - ref).abs().max() / ref.abs().max())
+    assert torch.isfinite(C).all() and err < 1e-5, (scale, err)
+# the tags run out after four calls (GANTRON_DEBUG=amax_wrap=4): slots 0..3 keep words with the largest tags there are
+for _ in range(4):
+    product(1e-3)
+A, B = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev)
+C = torch.empty(M, N, device=dev)
+for _ in range(8192 - 4):           # once round the ring
+    ops.sgemm(ops.Operand(A, ops.KC, ld=K), ops.Operand(B, ops.KC, ld=K), C, M, N, K, bf16=4)
+# slots 0..3 again, with small tags and operands 1e9 times larger: a stale maximum would overflow the fp16 planes
+for _ in range(4):
+    product(1e6)
+torch.cuda.synchronize()
+print('WRAP-OK')
+"""
+
+
+def test_sgemm_fp16_planes_survive_the_wrap_of_their_tags(tmp_path):
+    """The maxima of mode 4 meet in words tagged by a 32-bit call counter; when it runs out (days of training) the ring is
+    drained and cleared once.  GANTRON_DEBUG=amax_wrap=4 puts the wrap four calls into a fresh process."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'wrap.py'
+    script.write_text(_WRAP_SCRIPT)
+    env = dict(os.environ, GANTRON_DEBUG='amax_wrap=4')
+    r = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'WRAP-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 @pytest.mark.parametrize('bf16', PRECISIONS)
 def test_sgemm_modes_accumulate_splitk_batch(dev, bf16):
     with native_if_false(bf16):
