@@ -92,7 +92,8 @@ def lib():
             raise GantronHipError(f'ABI mismatch: {LIB_PATH} was built as version {handle.gt_version()}, {HEADER} declares '
                                   f'GT_ABI_VERSION {ABI_VERSION}: rebuild it (python -m gantron_amd.csrc.build)')
         for which, sname in enumerate(('GtOperand', 'GtGemm', 'GtSlabs', 'GtAttnDims', 'GtDecoderFwd',
-                                       'GtDecoderBwd', 'GtBiLstm', 'GtDecoderInfer', 'GtPlstm', 'GtPlstmBwd', 'GtRecTail')):
+                                       'GtDecoderBwd', 'GtBiLstm', 'GtDecoderInfer', 'GtPlstm', 'GtPlstmBwd', 'GtRecTail',
+                                       'GtCellBwdTail')):
             want, got = handle.gt_abi_sizeof(which), ctypes.sizeof(STRUCTS[sname])
             if want != got:
                 raise GantronHipError(f'ABI mismatch: sizeof({sname}) is {want} in the library, {got} in the binding')

@@ -57,6 +57,7 @@ extern "C" int64_t gt_abi_sizeof(int32_t which) {
         case 8: return sizeof(GtPlstm);
         case 9: return sizeof(GtPlstmBwd);
         case 10: return sizeof(GtRecTail);
+        case 11: return sizeof(GtCellBwdTail);
         default: return -1;
     }
 }

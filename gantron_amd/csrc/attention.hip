@@ -48,7 +48,7 @@ void gt_launch_attn_bwd_step_mfma(GtAttnDims d, GtSlabs da, GtSlabs db, const fl
                                   const float* dw_extern, float* dctx_out, long ld_dctx_out, const float* w, const float* u,
                                   const float* v, const float* p, const float* sum_prev, const float* dwcat2_prev,
                                   float* sum_out, float* dq, long ld_dq, float* dwcat_out, float* e1_out, bool vec,
-                                  bool vec_slabs, hipStream_t st);
+                                  bool vec_slabs, hipStream_t st, const GtCellBwdTail* cell);
 void gt_launch_attn_bwd_fixup(GtAttnDims d, int nsteps, int nch, const float* sum, const float* w, long w_step, float* de,
                               float* dq, long dq_step, long ld_dq, const float* dq2, hipStream_t st);
 int gt_attn_wpack_elems_mfma();
@@ -835,11 +835,12 @@ extern "C" int gt_attn_bwd_wterms(GtAttnDims d, int32_t nsteps, const float* w, 
     return 0;
 }
 
-extern "C" int gt_attn_bwd_step(GtAttnDims d, GtSlabs dctx_a, GtSlabs dctx_b, const float* dctx_direct, int64_t ld_direct,
-                                const float* memory, int64_t ld_mem, const int32_t* lengths, float* dwcat_in, float* dcum_acc,
-                                const float* dw_extern, float* dctx_out, int64_t ld_dctx_out, const float* w, const float* u,
-                                const float* v, const float* p, const float* sum_prev, const float* dwcat2_prev,
-                                float* sum_out, float* dq, int64_t ld_dq, float* dwcat_out, float* e1_out, void* stream) {
+static int attn_bwd_step_impl(GtAttnDims d, GtSlabs dctx_a, GtSlabs dctx_b, const float* dctx_direct, int64_t ld_direct,
+                              const float* memory, int64_t ld_mem, const int32_t* lengths, float* dwcat_in, float* dcum_acc,
+                              const float* dw_extern, float* dctx_out, int64_t ld_dctx_out, const float* w, const float* u,
+                              const float* v, const float* p, const float* sum_prev, const float* dwcat2_prev,
+                              float* sum_out, float* dq, int64_t ld_dq, float* dwcat_out, float* e1_out,
+                              const GtCellBwdTail* cell, void* stream) {
     int rc = check_dims(d, "gt_attn_bwd_step");
     if (rc) return rc;
     GT_REQUIRE(use_mfma(d), GT_E_ARG, "gt_attn_bwd_step: needs the (128, 32, 31) dimensions");
@@ -849,18 +850,54 @@ extern "C" int gt_attn_bwd_step(GtAttnDims d, GtSlabs dctx_a, GtSlabs dctx_b, co
     GT_REQUIRE((sum_prev == nullptr) == (dwcat2_prev == nullptr), GT_E_ARG, "gt_attn_bwd_step: sum_prev and dwcat2_prev go together");
     GT_REQUIRE((size_t)d.E * 4 <= 32 * 1024, GT_E_LIMIT, "gt_attn_bwd_step: E too large for LDS");
     const double ctx_rows = g_gt_prof_ctx_rows > 0.0 ? g_gt_prof_ctx_rows : (double)d.B * d.Ti;
-    GtProfScope prof(GT_FAM_ATTN_C_BWD, 2.0 * ctx_rows * (double)d.E + 2.0 * d.B * d.Ti * (double)(d.A + 2 * d.Kc),
-                     4.0 * (ctx_rows * d.E + d.B * ((1.0 + dctx_a.n + dctx_b.n) * d.E + 6.0 * d.Ti) + d.B * d.Ti * (d.A + 64 + 6.0)),
+    // (with the cell inside: + dq . Wq of every row and what gt_cell_bwd_query_c reads and writes; Wq once per ROW here)
+    const double cell_flop = cell != nullptr ? 2.0 * d.B * (double)cell->H * d.A : 0.0;
+    const double cell_bytes = cell != nullptr ? 4.0 * d.B * (double)cell->H * (d.A + cell->dh_a.n + cell->dh_c.n + 1 + 4 + 2 + 4 + 1) : 0.0;
+    GtProfScope prof(GT_FAM_ATTN_C_BWD, 2.0 * ctx_rows * (double)d.E + 2.0 * d.B * d.Ti * (double)(d.A + 2 * d.Kc) + cell_flop,
+                     4.0 * (ctx_rows * d.E + d.B * ((1.0 + dctx_a.n + dctx_b.n) * d.E + 6.0 * d.Ti) + d.B * d.Ti * (d.A + 64 + 6.0)) + cell_bytes,
                      (hipStream_t)stream);
     const bool vec = (d.E % 4 == 0) && (ld_mem % 4 == 0) && aligned16(memory);
     auto sl4 = [](const GtSlabs& sl) { return sl.p == nullptr || (aligned16(sl.p) && sl.ld % 4 == 0 && sl.slab_stride % 4 == 0); };
     const bool vec_slabs = sl4(dctx_a) && sl4(dctx_b) && (dctx_direct == nullptr || (aligned16(dctx_direct) && ld_direct % 4 == 0)) &&
                            (dctx_out == nullptr || (aligned16(dctx_out) && ld_dctx_out % 4 == 0));
+    if (cell != nullptr) {
+        auto sl16 = [](const GtSlabs& sl) { return sl.p == nullptr || (sl.n >= 1 && aligned16(sl.p) && sl.ld % 4 == 0 && sl.slab_stride % 4 == 0); };
+        GT_REQUIRE(cell->dq2 && cell->Wq && cell->gates && cell->c_new && cell->c_prev && cell->dgates && cell->dc_prev &&
+                       cell->row_cnt && cell->launch >= 1 && cell->H > 0 && cell->H % 4 == 0 && cell->ldwq >= cell->H &&
+                       cell->p_drop >= 0.f && cell->p_drop < 1.f,
+                   GT_E_ARG, "gt_attn_bwd_step_cell: bad cell argument (H %% 4 == 0, launch >= 1, row_cnt ...)");
+        GT_REQUIRE(sl16(cell->dh_a) && sl16(cell->dh_c) && aligned16(cell->Wq) && cell->ldwq % 4 == 0 && aligned16(cell->gates) &&
+                       aligned16(cell->c_new) && aligned16(cell->c_prev) && aligned16(cell->dgates) && aligned16(cell->dc_prev) &&
+                       (cell->dc_next == nullptr || aligned16(cell->dc_next)) && (cell->keep == nullptr || (((uintptr_t)cell->keep) & 3) == 0),
+                   GT_E_ALIGN, "gt_attn_bwd_step_cell: cell pointers must be 16-byte aligned with leading dimensions %% 4 == 0");
+        GT_REQUIRE((uint64_t)cell->launch * 16u < 0xffffffffull, GT_E_LIMIT,
+                   "gt_attn_bwd_step_cell: launch number too large for the row counters");
+    }
     gt_launch_attn_bwd_step_mfma(d, dctx_a, dctx_b, dctx_direct, (long)ld_direct, memory, (long)ld_mem, lengths, dwcat_in,
                                  dcum_acc, dw_extern, dctx_out, (long)ld_dctx_out, w, u, v, p, sum_prev, dwcat2_prev,
-                                 sum_out, dq, (long)ld_dq, dwcat_out, e1_out, vec, vec_slabs, (hipStream_t)stream);
+                                 sum_out, dq, (long)ld_dq, dwcat_out, e1_out, vec, vec_slabs, (hipStream_t)stream, cell);
     GT_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int gt_attn_bwd_step(GtAttnDims d, GtSlabs dctx_a, GtSlabs dctx_b, const float* dctx_direct, int64_t ld_direct,
+                                const float* memory, int64_t ld_mem, const int32_t* lengths, float* dwcat_in, float* dcum_acc,
+                                const float* dw_extern, float* dctx_out, int64_t ld_dctx_out, const float* w, const float* u,
+                                const float* v, const float* p, const float* sum_prev, const float* dwcat2_prev,
+                                float* sum_out, float* dq, int64_t ld_dq, float* dwcat_out, float* e1_out, void* stream) {
+    return attn_bwd_step_impl(d, dctx_a, dctx_b, dctx_direct, ld_direct, memory, ld_mem, lengths, dwcat_in, dcum_acc, dw_extern, dctx_out,
+                              ld_dctx_out, w, u, v, p, sum_prev, dwcat2_prev, sum_out, dq, ld_dq, dwcat_out, e1_out, nullptr, stream);
+}
+
+extern "C" int gt_attn_bwd_step_cell(GtAttnDims d, GtSlabs dctx_a, GtSlabs dctx_b, const float* dctx_direct, int64_t ld_direct,
+                                     const float* memory, int64_t ld_mem, const int32_t* lengths, float* dwcat_in, float* dcum_acc,
+                                     const float* dw_extern, float* dctx_out, int64_t ld_dctx_out, const float* w, const float* u,
+                                     const float* v, const float* p, const float* sum_prev, const float* dwcat2_prev,
+                                     float* sum_out, float* dq, int64_t ld_dq, float* dwcat_out, float* e1_out,
+                                     const GtCellBwdTail* cell, void* stream) {
+    GT_REQUIRE(cell != nullptr, GT_E_ARG, "gt_attn_bwd_step_cell: NULL cell");
+    return attn_bwd_step_impl(d, dctx_a, dctx_b, dctx_direct, ld_direct, memory, ld_mem, lengths, dwcat_in, dcum_acc, dw_extern, dctx_out,
+                              ld_dctx_out, w, u, v, p, sum_prev, dwcat2_prev, sum_out, dq, ld_dq, dwcat_out, e1_out, cell, stream);
 }
 
 extern "C" int gt_attn_bwd_fixup(GtAttnDims d, int32_t nsteps, const float* sum, const float* w, int64_t w_step_stride,

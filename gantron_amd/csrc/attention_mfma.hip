@@ -1030,6 +1030,17 @@ struct AttnBwdStep {
     const float* sum_prev; const float* dwcat2_prev;      // NULL on the last step (nothing carried yet)
     float* sum_out;                                       // (B, chunks) this step's partial row sums
     float* dq; long ld_dq; float* dwcat_out; float* e1_out;
+    // TAIL instantiation (gt_attn_bwd_step_cell): the attention LSTM's cell backward of the step, done by each row's LAST
+    // workgroup -- what gt_cell_bwd_query_c computes in a launch of its own
+    struct Tail {
+        GtSlabs dh_a, dh_c;
+        const float* dq2; const float* Wq; long ldwq;
+        const float* dc_next; const float* gates; const float* c_new; const float* c_prev;
+        const uint8_t* keep; float scale;
+        float* dgates; float* dc_prev;
+        int H;
+        unsigned* row_cnt; unsigned launch;
+    } tail;
 };
 static_assert(sizeof(AttnBwdStep) <= 1024, "AttnBwdStep is a by-value kernel argument: keep it well below the 4 KB kernel-argument segment");
 
@@ -1040,7 +1051,7 @@ struct SharedStep {
     float dots[CT];
 };
 
-template <bool VEC, int NE4>
+template <bool VEC, int NE4, bool TAIL = false>
 __global__ __launch_bounds__(256) void attn_bwd_step_kernel(AttnBwdStep a) {
     __builtin_amdgcn_s_setprio(3);      // the attention chain is the serial critical path of the decoder loops
     extern __shared__ __attribute__((aligned(16))) float dctx[];   // E floats
@@ -1103,10 +1114,109 @@ __global__ __launch_bounds__(256) void attn_bwd_step_kernel(AttnBwdStep a) {
         if (threadIdx.x < CT) S.e[threadIdx.x] = e1;
         if (pos) a.e1_out[(long)b * d.Ti + t0 + threadIdx.x] = e1;
         const float tot = wave_sum(threadIdx.x < CT ? e1 : 0.f);
-        if (threadIdx.x == 0) a.sum_out[(long)b * nch + chunk] = tot;
+        if (threadIdx.x == 0) {
+            // (TAIL: the row's last workgroup reads it inside this launch -> written through)
+            if constexpr (TAIL) __hip_atomic_store(&a.sum_out[(long)b * nch + chunk], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else a.sum_out[(long)b * nch + chunk] = tot;
+        }
     }
     __syncthreads();
     apply_e(S.e, S.M, S.P, d, b, t0, a.dq, a.ld_dq, a.dwcat_out);
+    if constexpr (TAIL) {
+        // ---- the row's last arriver runs the attention LSTM's cell backward for the row (gt_cell_bwd_query_c's arithmetic:
+        // dh = slabs + (dq - s dq2) . Wq, dropout, cell).  Hand-off as in the forward step: every wave's atomics and stores
+        // have left (vmcnt), barrier, one agent-scope ticket per workgroup on the row's monotonic counter; what the last
+        // arriver reads of this launch's results (dq, the tile sums) it reads with agent-scope loads.
+        const AttnBwdStep::Tail& c = a.tail;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int nv_row = (Tv + CT - 1) / CT;
+        if (threadIdx.x == 0) {
+            const unsigned ticket = __hip_atomic_fetch_add(c.row_cnt + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            S.dots[0] = ticket == (unsigned)nv_row * c.launch - 1u ? 1.f : 0.f;
+        }
+        __syncthreads();
+        if (S.dots[0] == 0.f) return;
+        float* dqe = S.M;                                   // (apply_e is done with M, P, e in every wave: barriers above)
+        if (threadIdx.x < A) {
+            float sp[16];
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc)
+                sp[cc] = __hip_atomic_load(&a.sum_out[(long)b * nch + min(cc, nv_row - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float sm = 0.f;
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc) sm += cc < nv_row ? sp[cc] : 0.f;    // (the tiles beyond the row's length write zeros --
+                                                                                 // perhaps later than this: not read)
+            const float q = __hip_atomic_load(&a.dq[(long)b * a.ld_dq + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float q2 = c.dq2[(long)b * a.ld_dq + threadIdx.x];
+            dqe[threadIdx.x] = q - sm * q2;
+        }
+        const int H = c.H;
+        for (int uq0 = 0; uq0 < (H >> 2); uq0 += 256) {     // (uniform trip count: the barrier below is legal)
+            const bool on = uq0 + (int)threadIdx.x < (H >> 2);
+            const int u = 4 * (on ? uq0 + (int)threadIdx.x : 0);
+            const long idx = (long)b * H + u;
+            // the cell's own inputs first: they do not wait for dqe
+            float4 dh = make_float4(0.f, 0.f, 0.f, 0.f), dcn = dh;
+            auto add_slabs = [&](const GtSlabs& sl) __attribute__((always_inline)) {
+                if (sl.p == nullptr) return;
+                const float* p = sl.p + (long)b * sl.ld + u;
+#pragma unroll 4
+                for (int s_ = 0; s_ < sl.n; ++s_) {
+                    const float4 t = *reinterpret_cast<const float4*>(p + (long)s_ * sl.slab_stride);
+                    dh.x += t.x; dh.y += t.y; dh.z += t.z; dh.w += t.w;
+                }
+            };
+            add_slabs(c.dh_a);
+            add_slabs(c.dh_c);
+            if (c.dc_next != nullptr) dcn = *reinterpret_cast<const float4*>(c.dc_next + idx);
+            const float* gt = c.gates + (long)b * 4 * H + u;
+            const float4 gi = *reinterpret_cast<const float4*>(gt), gf = *reinterpret_cast<const float4*>(gt + H);
+            const float4 gg = *reinterpret_cast<const float4*>(gt + 2 * H), go = *reinterpret_cast<const float4*>(gt + 3 * H);
+            const float4 cn = *reinterpret_cast<const float4*>(c.c_new + idx);
+            const float4 cp = *reinterpret_cast<const float4*>(c.c_prev + idx);
+            uchar4 kp = make_uchar4(1, 1, 1, 1);
+            if (c.keep != nullptr) kp = *reinterpret_cast<const uchar4*>(c.keep + idx);
+            if (uq0 == 0) __syncthreads();                  // dqe is there
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float* wq = c.Wq + u;
+            // (512 KB of Wq per row through one CU's vector cache: ~3.5 us, the larger part of what this tail adds -- 8.9 us on
+            // average against gt_cell_bwd_query_c's 9.8 in a launch of its own.  Requesting the first 16 rows in front of the
+            // barrier changes nothing.)
+#pragma unroll 16
+            for (int k = 0; k < A; ++k) {
+                const float4 w = *reinterpret_cast<const float4*>(wq + (long)k * c.ldwq);
+                const float q = dqe[k];
+                acc.x += q * w.x; acc.y += q * w.y; acc.z += q * w.z; acc.w += q * w.w;
+            }
+            const float dhv[4] = {dh.x + acc.x, dh.y + acc.y, dh.z + acc.z, dh.w + acc.w};
+            const float dcv[4] = {dcn.x, dcn.y, dcn.z, dcn.w};
+            const float giv[4] = {gi.x, gi.y, gi.z, gi.w}, gfv[4] = {gf.x, gf.y, gf.z, gf.w};
+            const float ggv[4] = {gg.x, gg.y, gg.z, gg.w}, gov[4] = {go.x, go.y, go.z, go.w};
+            const float cnv[4] = {cn.x, cn.y, cn.z, cn.w}, cpv[4] = {cp.x, cp.y, cp.z, cp.w};
+            const unsigned char kpv[4] = {kp.x, kp.y, kp.z, kp.w};
+            float dgi[4], dgf[4], dgg[4], dgo[4], dcp[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float dd = dhv[e];
+                if (c.keep != nullptr) dd *= (kpv[e] ? c.scale : 0.f);
+                const float tc = tanhf_(cnv[e]);
+                const float dcell = dcv[e] + dd * gov[e] * (1.f - tc * tc);
+                dgi[e] = dcell * ggv[e] * giv[e] * (1.f - giv[e]);
+                dgf[e] = dcell * cpv[e] * gfv[e] * (1.f - gfv[e]);
+                dgg[e] = dcell * giv[e] * (1.f - ggv[e] * ggv[e]);
+                dgo[e] = dd * tc * gov[e] * (1.f - gov[e]);
+                dcp[e] = dcell * gfv[e];
+            }
+            if (!on) continue;
+            float* dg = c.dgates + (long)b * 4 * H + u;
+            *reinterpret_cast<float4*>(dg) = make_float4(dgi[0], dgi[1], dgi[2], dgi[3]);
+            *reinterpret_cast<float4*>(dg + H) = make_float4(dgf[0], dgf[1], dgf[2], dgf[3]);
+            *reinterpret_cast<float4*>(dg + 2 * H) = make_float4(dgg[0], dgg[1], dgg[2], dgg[3]);
+            *reinterpret_cast<float4*>(dg + 3 * H) = make_float4(dgo[0], dgo[1], dgo[2], dgo[3]);
+            *reinterpret_cast<float4*>(c.dc_prev + idx) = make_float4(dcp[0], dcp[1], dcp[2], dcp[3]);
+        }
+    }
 }
 
 // de[t] = e1[t] - s_t w_t and dq[t] -= s_t dq2[t] for `nsteps` steps (the histories the weight-gradient passes read):
@@ -1395,14 +1505,26 @@ void gt_launch_attn_bwd_step_mfma(GtAttnDims d, GtSlabs da, GtSlabs db, const fl
                                   const float* dw_extern, float* dctx_out, long ld_dctx_out, const float* w, const float* u,
                                   const float* v, const float* p, const float* sum_prev, const float* dwcat2_prev,
                                   float* sum_out, float* dq, long ld_dq, float* dwcat_out, float* e1_out, bool vec,
-                                  bool vec_slabs, hipStream_t st) {
+                                  bool vec_slabs, hipStream_t st, const GtCellBwdTail* cell) {
     AttnBwdStep a;
     a.d = d; a.da = da; a.db = db; a.dctx_direct = dctx_direct; a.ld_direct = ld_direct; a.memory = memory; a.ld_mem = ld_mem;
     a.lengths = lengths; a.dwcat_in = dwcat_in; a.dcum_acc = dcum_acc; a.dw_extern = dw_extern; a.dctx_out = dctx_out;
     a.ld_dctx_out = ld_dctx_out; a.w = w; a.u = u; a.v = v; a.p = p; a.sum_prev = sum_prev;
     a.dwcat2_prev = dwcat2_prev; a.sum_out = sum_out; a.dq = dq; a.ld_dq = ld_dq; a.dwcat_out = dwcat_out; a.e1_out = e1_out;
+    a.tail = {};
     dim3 grid(d.B, cdiv(d.Ti, CT));
     const size_t dyn = (size_t)d.E * 4;
+    if (cell != nullptr) {
+        AttnBwdStep::Tail& c = a.tail;
+        c.dh_a = cell->dh_a; c.dh_c = cell->dh_c; c.dq2 = cell->dq2; c.Wq = cell->Wq; c.ldwq = (long)cell->ldwq;
+        c.dc_next = cell->dc_next; c.gates = cell->gates; c.c_new = cell->c_new; c.c_prev = cell->c_prev; c.keep = cell->keep;
+        c.scale = 1.0f / (1.0f - cell->p_drop); c.dgates = cell->dgates; c.dc_prev = cell->dc_prev; c.H = cell->H;
+        c.row_cnt = cell->row_cnt; c.launch = cell->launch;
+        if (vec && d.E == 1024 && vec_slabs) hipLaunchKernelGGL((attn_bwd_step_kernel<true, 4, true>), grid, dim3(256), dyn, st, a);
+        else if (vec) hipLaunchKernelGGL((attn_bwd_step_kernel<true, 0, true>), grid, dim3(256), dyn, st, a);
+        else hipLaunchKernelGGL((attn_bwd_step_kernel<false, 0, true>), grid, dim3(256), dyn, st, a);
+        return;
+    }
     if (vec && d.E == 1024 && vec_slabs) hipLaunchKernelGGL((attn_bwd_step_kernel<true, 4>), grid, dim3(256), dyn, st, a);
     else if (vec) hipLaunchKernelGGL((attn_bwd_step_kernel<true, 0>), grid, dim3(256), dyn, st, a);
     else hipLaunchKernelGGL((attn_bwd_step_kernel<false, 0>), grid, dim3(256), dyn, st, a);

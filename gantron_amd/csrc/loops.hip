@@ -707,6 +707,30 @@ static int decoder_bwd_hoisted(const GtDecoderBwd* a, void* stream) {
             const bool fused_attn = a->sum_hist != nullptr && a->dq2_hist != nullptr && a->dwcat2_hist != nullptr &&
                                     a->p_hist != nullptr && a->u_hist != nullptr && a->de_hist != nullptr;
             const int nch = gt_attn_chunks(a->Ti);
+            if (fused_attn && a->rowcntA != nullptr && bq) {
+                // ... and the attention LSTM's cell backward inside the same launch (each row's last workgroup): two dependent
+                // launches per step
+                GtCellBwdTail cell = {};
+                cell.dh_a = slabs(dXA_t, 1, 0, a->ldxa);
+                cell.dh_c = last ? kNoSlabs : slabs(a->partX1 + a->E, a->S1, sX1, a->N1pad);
+                cell.dq2 = a->dq2_hist + (int64_t)t * a->Bp * a->Apad; cell.Wq = a->Wq; cell.ldwq = a->Ha;
+                cell.dc_next = a->dc1; cell.gates = a->gates1 + (int64_t)t * a->Bp * N1;
+                cell.c_new = a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha; cell.c_prev = a->c1 + (int64_t)t * a->Bp * a->Ha;
+                cell.keep = k1; cell.p_drop = a->p_att; cell.dgates = dG1_t; cell.dc_prev = a->dc1; cell.H = a->Ha;
+                cell.row_cnt = a->rowcntA; cell.launch = (uint32_t)(a->To - t);
+                GT_TRY(gt_attn_bwd_step_cell(d, slabs(dXA_t + a->Ha, 1, 0, a->ldxa),
+                                             last ? kNoSlabs : slabs(a->partX1, a->S1, sX1, a->N1pad), dhc_t + a->Hd, hc_ld,
+                                             a->memory, a->ldE, a->lengths, dwcat_in, a->dcum_acc,
+                                             a->dalign ? a->dalign + (int64_t)t * BT : nullptr,
+                                             a->dctx_hist + (int64_t)t * a->B * a->E, a->E, a->w_hist + (int64_t)(t + 1) * BT,
+                                             a->u_hist + (int64_t)t * BT * a->A, a->v, a->p_hist + (int64_t)t * BT * 64,
+                                             last ? nullptr : a->sum_hist + (int64_t)(t + 1) * a->B * nch,
+                                             last ? nullptr : a->dwcat2_hist + (int64_t)(t + 1) * 2 * BT,
+                                             a->sum_hist + (int64_t)t * a->B * nch, dq_t, a->Apad, dwcat_out,
+                                             a->de_hist + (int64_t)t * BT, &cell, sA));
+                if (t > 0) GT_TRY(rec_rows(dG1_t, N1, a->W1Tp, a->partX1, a->Bp, a->N1pad, N1, a->S1, sA, a->bf16 ? 1 : (a->rec_x3 ? 3 : 0), two ? kPrioA : 0));
+                continue;
+            }
             if (fused_attn) {
                 // context + energies backward of the step in ONE launch (gt_attn_bwd_step); the row sums of the softmax
                 // backward are applied by the consumers: the next call here (carried planes), the cell backward below

@@ -50,6 +50,10 @@ HOIST2 = sw.schedule_on('hoist2')
 # Round 2: neutral (132.3 against 132.5 ms per pair); round 3, with the rest of the loop shorter: 127.3-127.8 against
 # 128.1-128.4 in three alternating runs.  On (GANTRON_SCHEDULE=no_attn_bwd_fused: the two launches).
 ATTN_BWD_FUSED = sw.schedule_on('attn_bwd_fused')
+# ... with the attention LSTM's cell backward of the step inside the same launch, done by each batch row's last workgroup
+# (gt_attn_bwd_step_cell): two dependent launches per backward step instead of three.  Round 4, one box, 24 pairs per run,
+# alternating: 113.12-113.22 against 113.63-113.78 ms (medians of the pairs).  On (GANTRON_SCHEDULE=no_attn_bwd_cell: three).
+ATTN_BWD_CELL = sw.schedule_on('attn_bwd_cell')
 # gt_attn_bwd_wterms (the per-position terms of that launch for ALL steps, forward quantities only) issued by the training
 # forward right behind the decoder loop instead of at the top of the backward pass (round 4: the launch took 7.6 ms beside the
 # PostNet backward's 5.5 ms and the backward loop waited 2.1 ms for it)
@@ -1168,6 +1172,9 @@ class GeneratorEngine:
             torch.cuda.current_stream().wait_event(early['ready'])
             b.sum_hist, b.dq2_hist, b.dwcat2_hist, b.p_hist = (ptr(fz['sum_hist']), ptr(fz['dq2_hist']), ptr(fz['dwcat2_hist']),
                                                                ptr(fz['p_hist']))
+            if ATTN_BWD_CELL and Ha % 4 == 0:
+                buf['rowcntA'] = torch.zeros(B, dtype=torch.int32, device=dev)
+                b.rowcntA = ptr(buf['rowcntA'])
         dG1, dG2 = buf['dG1'], buf['dG2']
         g1ih, g1hh = G['decoder.attention_rnn.weight_ih'], G['decoder.attention_rnn.weight_hh']
         g2ih, g2hh = G['decoder.decoder_rnn.weight_ih'], G['decoder.decoder_rnn.weight_hh']

@@ -18,7 +18,8 @@ GANTRON_SCHEDULE       comma list switching OFF parts of the default schedule (w
                        no_fwd_splitk, no_rec_cell (per-step product + cell launches instead of the fused ones), no_attn_step2 (energies
                        and softmax + context of a forward step as two launches instead of gt_attn_step2_fwd), no_plstm (per-step
                        launches instead of the persistent LSTM recurrences), no_attn_bwd_fused (context and energies backward
-                       of a step as two launches), no_blk_gemm_aside (the forward loop's block GEMMs on the decoder-LSTM
+                       of a step as two launches), no_attn_bwd_cell (the attention LSTM's cell backward as a launch of its own
+                       instead of inside the backward attention step's: gt_attn_bwd_step_cell), no_blk_gemm_aside (the forward loop's block GEMMs on the decoder-LSTM
                        chain's own stream instead of a third one),
                        no_wterms_in_forward (gt_attn_bwd_wterms at the top of the backward pass instead of behind the forward
                        loop), no_dist_overlap.
@@ -41,7 +42,7 @@ _KNOWN = {
     'GANTRON_EXPERIMENTAL': {'fused_cell', 'attn_step', 'leaf_defer', 'rec_cellbwd', 'plane_gemms', 'plstm', 'rec_x3', 'graph',
                              'no_pgemm2', 'rec_tail'},
     'GANTRON_SCHEDULE': {'no_cell_query', 'no_attn_hoist', 'no_hoist2', 'no_leaf_stream', 'no_fwd_splitk', 'no_rec_cell',
-                         'no_attn_step2', 'no_plstm', 'no_attn_bwd_fused', 'no_blk_gemm_aside', 'no_wterms_in_forward',
+                         'no_attn_step2', 'no_plstm', 'no_attn_bwd_fused', 'no_attn_bwd_cell', 'no_blk_gemm_aside', 'no_wterms_in_forward',
                          'no_dist_overlap'},
     'GANTRON_DEBUG': {'phase_timing', 'host_timing', 'block_timing', 'dist_timing', 'attn_valu', 'rec', 'fused', 'pgemm',
                       'rec_splits', 's1_fwd', 's2_fwd', 's2_bwd', 's1_bwd', 'enc_splits', 'sync_every', 'rec_lds_pad',

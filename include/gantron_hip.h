@@ -31,7 +31,7 @@ extern "C" {
 #define GT_E_ALIGN (-2)   /* pointer or leading dimension violates an alignment requirement */
 #define GT_E_LIMIT (-3)   /* size exceeds a compiled-in limit */
 
-#define GT_ABI_VERSION 401      /* bumped whenever a declared signature, struct layout or buffer size changes */
+#define GT_ABI_VERSION 402      /* bumped whenever a declared signature, struct layout or buffer size changes */
 int gt_version(void);           /* GT_ABI_VERSION of the library that was built: compare it with the header's at load */
 const char* gt_last_error_string(void);
 /* sizeof of ABI structs: 0 GtOperand, 1 GtGemm, 2 GtSlabs, 3 GtAttnDims, 4 GtDecoderFwd,
@@ -523,6 +523,10 @@ typedef struct GtDecoderBwd {
     /* 1 (fp32 mode only, bf16 = 0): W1Tp is a gt_pack_rec_weight_x3 image and the attention LSTM's backward product runs as
      * gt_rec_gemm_x3 */
     int32_t rec_x3;
+    /* != NULL (with the fused backward attention step above and Wq): B zero-initialised words -- the attention LSTM's cell
+     * backward rides in the attention step's launch (gt_attn_bwd_step_cell), two dependent launches per step instead of
+     * three.  The words are shared by ALL calls of one backward pass (the step's launch number is To - t). */
+    uint32_t* rowcntA;
 } GtDecoderBwd;
 
 typedef struct GtBiLstm {
@@ -611,6 +615,32 @@ int gt_attn_bwd_step(GtAttnDims d, GtSlabs dctx_a, GtSlabs dctx_b, const float* 
                      float* dq, int64_t ld_dq, float* dwcat_out, float* e1_out, void* stream);
 int gt_attn_bwd_fixup(GtAttnDims d, int32_t nsteps, const float* sum, const float* w, int64_t w_step_stride,
                       float* de, float* dq, int64_t dq_step_stride, int64_t ld_dq, const float* dq2, void* stream);
+/* gt_attn_bwd_step with the attention LSTM's cell backward of the same step inside the launch (round 4): each batch row's
+ * LAST workgroup -- the one whose ticket on row_cnt[b] completes the row -- computes what gt_cell_bwd_query_c would in a
+ * launch of its own: dh = dh_a + dh_c + (dq - s dq2) . Wq for the row, dropout, cell backward, dgates / dc_prev of the row
+ * (model.py:391-394 through autograd).  dq2 is this step's row block of the dq2 history (laid out like dq), Wq (A, H) with rows
+ * ldwq apart; the other fields as gt_cell_bwd_query_c's arguments; H % 4 == 0, every pointer 16-byte aligned.  row_cnt: B
+ * words, zero-initialised once; `launch` = 1, 2, 3 ... for consecutive calls that share them (the counters only grow: no reset
+ * between the steps of a backward pass).  No workgroup waits for another.  Rows m >= B of dgates / dc_prev are not written. */
+typedef struct GtCellBwdTail {
+    GtSlabs dh_a, dh_c;
+    const float* dq2;
+    const float* Wq; int64_t ldwq;
+    const float* dc_next;
+    const float* gates;
+    const float* c_new;
+    const float* c_prev;
+    const uint8_t* keep; float p_drop;
+    float* dgates;
+    float* dc_prev;
+    int32_t H;
+    uint32_t* row_cnt; uint32_t launch;
+} GtCellBwdTail;
+int gt_attn_bwd_step_cell(GtAttnDims d, GtSlabs dctx_a, GtSlabs dctx_b, const float* dctx_direct, int64_t ld_direct,
+                          const float* memory, int64_t ld_mem, const int32_t* lengths, float* dwcat_in, float* dcum_acc,
+                          const float* dw_extern, float* dctx_out, int64_t ld_dctx_out, const float* w, const float* u,
+                          const float* v, const float* p, const float* sum_prev, const float* dwcat2_prev, float* sum_out,
+                          float* dq, int64_t ld_dq, float* dwcat_out, float* e1_out, const GtCellBwdTail* cell, void* stream);
 
 /* Persistent, weight-resident LSTM recurrence: ONE launch walks steps [s_lo, s_hi) of
  *   G_s = pre_s + h_{s-1} . W_hh^T,  cell,  h_s = dropout(o tanh c_s)

@@ -1079,6 +1079,78 @@ def test_attention_bwd_step_fused(dev, B, Ti, E):
         close(a, bb, rtol=2e-5, atol=2e-6, what=name)
 
 
+@pytest.mark.parametrize('B,Ti,E,H', [(3, 150, 1024, 1024), (5, 77, 64, 48), (64, 187, 1024, 1024), (7, 40, 512, 1280)])
+def test_attention_bwd_step_with_cell(dev, B, Ti, E, H):
+    """gt_attn_bwd_step_cell == gt_attn_bwd_step + gt_cell_bwd_query_c over a chain of 4 backward steps that share the row
+    counters (launch = 1 .. 4) and carry dc from step to step: gate gradients and dc of the attention LSTM, computed by each
+    row's last workgroup inside the attention step's launch, against the two-launch form (same dq: atomics, so 1e-5)."""
+    import ctypes
+    from gantron_amd import ops
+    from gantron_amd._lib import lib, STRUCTS
+    A, Fn, Kc, S = 128, 32, 31, 4
+    d = ops.attn_dims(B, Ti, E, A, Fn, Kc)
+    nch = int(lib().gt_attn_chunks(Ti))
+    Bp = 16 * ((B + 15) // 16)
+    lens = torch.tensor(([Ti, Ti - 7, max(Ti - 20, 3), Ti - 1, 5] * 13)[:B])
+    lens32 = lens.to(torch.int32).to(dev)
+    Wc, Wd, v = g(Fn, 2, Kc, seed=1, scale=0.3).to(dev), g(A, Fn, seed=2, scale=0.3).to(dev), g(1, A, seed=3, scale=0.5).to(dev)
+    wpack = torch.empty(int(lib().gt_attn_wpack_elems(d)), device=dev)
+    ops.call('gt_attn_pack_weights', d, Wc, Wd, wpack)
+    memory = g(B, Ti, E, seed=4, scale=0.5).to(dev)
+    mask = (torch.arange(Ti)[None, :] < lens[:, None])
+    w = torch.stack([torch.softmax(g(B, Ti, seed=20 + s).masked_fill(~mask, float('-inf')), 1) for s in range(S)]).to(dev)
+    u = torch.stack([torch.tanh(g(B, Ti, A, seed=30 + s)) for s in range(S)]).to(dev)
+    dctx_dir = torch.stack([g(B, E, seed=40 + s, scale=0.2) for s in range(S)]).to(dev)
+    dslab = torch.stack([g(3, B, E + 8, seed=50 + s, scale=0.2) for s in range(S)]).to(dev)
+    Apad = 144
+    # the cell's side: gates in (0, 1) / (-1, 1), cell states, a dropout mask, d h_att from two sources, Wq
+    gates = torch.stack([torch.cat((torch.sigmoid(g(Bp, 2 * H, seed=70 + s)), torch.tanh(g(Bp, H, seed=75 + s)),
+                                    torch.sigmoid(g(Bp, H, seed=80 + s))), 1) for s in range(S)]).to(dev)
+    cst = g(S + 1, Bp, H, seed=85).to(dev)
+    keep = (torch.rand(S, Bp, H, generator=torch.Generator().manual_seed(86)) >= 0.1).to(torch.uint8).to(dev)
+    dha = g(S, Bp, H + 4, seed=87, scale=0.2).to(dev)                    # one slab, ld = H + 4
+    dhc = g(S, 2, Bp, H + 8, seed=88, scale=0.2).to(dev)                 # two slabs, offset columns
+    Wq = g(A, H, seed=89, scale=0.1).to(dev)
+
+    def run(cell_inside):
+        dwcat = torch.zeros(2, 2, B, Ti, device=dev); dcum = torch.zeros(B, Ti, device=dev)
+        dq = torch.zeros(S, Bp, Apad, device=dev); de = torch.full((S, B, Ti), float('nan'), device=dev)
+        dctx_out = torch.full((S, B, E), float('nan'), device=dev)
+        sums = torch.full((S, B, nch), float('nan'), device=dev)
+        dq2 = torch.zeros(S, Bp, Apad, device=dev); dwc2 = torch.zeros(S, 2, B, Ti, device=dev)
+        ph = torch.full((S, B, Ti, 64), float('nan'), device=dev)
+        ops.call('gt_attn_bwd_wterms', d, S, w, B * Ti, u, Wc, Wd, v, lens32, dq2, Bp * Apad, Apad, dwc2, ph, wpack)
+        dG = torch.full((S, Bp, 4 * H), 7.0, device=dev)
+        dc = torch.zeros(Bp, H, device=dev)
+        cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+        for n, s in enumerate(reversed(range(S))):             # backward order
+            din, dout = dwcat[(s + 1) & 1], dwcat[s & 1]
+            sl = ops.slabs(dslab[s], 3, B * (E + 8), E + 8, offset=4)
+            prev = s + 1 < S
+            a_sl = ops.slabs(dha[s], 1, 0, H + 4)
+            c_sl = ops.slabs(dhc[s], 2, Bp * (H + 8), H + 8, offset=4) if prev else ops.NO_SLABS
+            common = (d, sl, ops.NO_SLABS, dctx_dir[s], E, memory, E, lens32, din, dcum, None, dctx_out[s], E, w[s], u[s], v, ph[s],
+                      sums[s + 1] if prev else None, dwc2[s + 1] if prev else None, sums[s], dq[s], Apad, dout, de[s])
+            if cell_inside:
+                c = STRUCTS['GtCellBwdTail']()
+                c.dh_a, c.dh_c = a_sl, c_sl
+                c.dq2, c.Wq, c.ldwq = ops.ptr(dq2[s]), ops.ptr(Wq), H
+                c.dc_next, c.gates, c.c_new, c.c_prev = ops.ptr(dc), ops.ptr(gates[s]), ops.ptr(cst[s + 1]), ops.ptr(cst[s])
+                c.keep, c.p_drop, c.dgates, c.dc_prev, c.H = ops.ptr(keep[s]), 0.1, ops.ptr(dG[s]), ops.ptr(dc), H
+                c.row_cnt, c.launch = ops.ptr(cnt), n + 1
+                ops.call('gt_attn_bwd_step_cell', *common, ctypes.byref(c))
+            else:
+                ops.call('gt_attn_bwd_step', *common)
+                ops.call('gt_cell_bwd_query_c', a_sl, c_sl, dq[s], Apad, sums[s], nch, dq2[s], Wq, H, dc, gates[s], cst[s + 1], cst[s],
+                         keep[s], 0.1, dG[s], dc, B, Bp, H, A)
+        return dG[:, :B], dc[:B], dq[:, :B], de
+
+    ref, got = run(False), run(True)
+    for name, a, bb in zip(('dgates', 'dc', 'dq', 'e1'), got, ref):
+        close(a, bb, rtol=2e-5, atol=2e-6, what=name)
+    assert bool((got[0] != 7.0).all()), 'every gate gradient of the valid rows must have been written'
+
+
 # ------------------------------------------------------------------------- BN / elementwise
 @pytest.mark.parametrize('det', [True, False])
 @pytest.mark.parametrize('rows,C,act', [(300, 24, 1), (1000, 80, 2), (77, 8, 0)])

@@ -183,13 +183,17 @@ def test_midsize_against_oracle(dev, case, monkeypatch):
         return _midsize_against_oracle(dev, case)
 
 
-@pytest.mark.parametrize('fused,case', [(True, 'full_dims_b20'), (False, 'full_dims_b20')])
-def test_attention_backward_step_forms_against_oracle(dev, monkeypatch, fused, case):
-    """The backward attention step as ONE launch (the default: gt_attn_bwd_wterms + gt_attn_bwd_step + gt_cell_bwd_query_c +
-    gt_attn_bwd_fixup) and as two (GANTRON_SCHEDULE=no_attn_bwd_fused: gt_attn_context_bwd + gt_attn_energies_bwd_rec) through
-    whole generator + discriminator pairs at the reference's attention dimensions, against the oracle."""
+@pytest.mark.parametrize('fused,cell,case', [(True, True, 'full_dims_b20'), (True, False, 'full_dims_b20'), (True, False, 'full_dims_b64'),
+                                             (False, False, 'full_dims_b20')])
+def test_attention_backward_step_forms_against_oracle(dev, monkeypatch, fused, cell, case):
+    """The backward attention step as ONE launch with the attention cell's backward inside (the default: gt_attn_bwd_wterms +
+    gt_attn_bwd_step_cell + gt_attn_bwd_fixup), as one launch + the cell's own (GANTRON_SCHEDULE=no_attn_bwd_cell:
+    gt_attn_bwd_step + gt_cell_bwd_query_c) and as two + the cell's (no_attn_bwd_fused: gt_attn_context_bwd +
+    gt_attn_energies_bwd_rec) through whole generator + discriminator pairs at the reference's attention dimensions, against the
+    oracle."""
     from gantron_amd import engine
     monkeypatch.setattr(engine, 'ATTN_BWD_FUSED', fused)
+    monkeypatch.setattr(engine, 'ATTN_BWD_CELL', cell)
     assert engine.ATTN_HOIST and engine.HOIST2
     _midsize_against_oracle(dev, case)
 
@@ -239,6 +243,21 @@ def test_rec_tail_against_oracle(dev, monkeypatch, case, slices, kb):
     from gantron_amd import engine
     monkeypatch.setattr(engine, 'REC_TAIL_FWD', slices)
     monkeypatch.setattr(engine, 'REC_TAIL_KB', kb)
+    if case.endswith('_poison'):
+        monkeypatch.setattr(engine, 'POISON', True)
+        case = case[:-len('_poison')]
+    _midsize_against_oracle(dev, case)
+    engine.check_handoffs()
+
+
+@pytest.mark.parametrize('case', ['full_dims_b64', 'full_dims_b64_poison', 'full_dims_b20', 'vesus_b64'])
+def test_attention_backward_step_with_cell_against_oracle(dev, monkeypatch, case):
+    """The attention LSTM's cell backward inside the backward attention step's launch (the default; gt_attn_bwd_step_cell: each
+    batch row's last workgroup; two dependent launches per backward step instead of three) through whole pairs at the
+    reference's dimensions: 64 rows, ragged 20 rows, NaN-poisoned buffers, the VESUS memory width."""
+    from gantron_amd import engine
+    monkeypatch.setattr(engine, 'ATTN_BWD_CELL', True)
+    assert engine.ATTN_BWD_FUSED and engine.ATTN_HOIST and engine.HOIST2
     if case.endswith('_poison'):
         monkeypatch.setattr(engine, 'POISON', True)
         case = case[:-len('_poison')]
@@ -699,7 +718,7 @@ def test_full_size_training_step_is_schedule_invariant(dev, monkeypatch):
     monkeypatch.undo()
     monkeypatch.setattr(ops, 'FWD_SPLITK', False)
     assert engine.DEC_RING > 1 and engine.BWD_CHUNKS > 1 and engine.ATTN_HOIST and engine.LEAF.enabled and engine.HOIST2 and engine.PLSTM == 7 and \
-        engine.ATTN_BWD_FUSED
+        engine.ATTN_BWD_FUSED and engine.ATTN_BWD_CELL
     out1, g1 = run()
     for name, a, b in zip(('mel', 'mel_post', 'gate', 'align'), out1, out0):
         close(a, b, rtol=1e-4, atol=1e-6, what=f'out.{name}')
