@@ -666,7 +666,10 @@ static int decoder_bwd_hoisted(const GtDecoderBwd* a, void* stream) {
             q.keep = a->dec_keep; q.active = nullptr; q.counters = a->pl_counters; q.timeout_flag = a->pl_timeout;
             GT_TRY(gt_plstm_bwd(&q, sB));
         }
-        for (int t = b1; t >= b0 && !persistB; --t) {
+        // GANTRON_DEBUG=bwd_skip=<bits> (diagnostics, results invalid): 1 = no per-step launches of the decoder-LSTM chain,
+        // 2 = no block GEMM behind them -- what do they cost the attention chain they run beside?
+        static const int bwd_skip = gt_env_item("GANTRON_DEBUG", "bwd_skip", 0);
+        for (int t = b1; t >= b0 && !persistB && !(bwd_skip & 1); --t) {
             const bool last = (t == a->To - 1);
             const uint8_t* k2 = a->dec_keep ? a->dec_keep + (int64_t)t * a->Bp * a->Hd : nullptr;
             const float* dhc_t = a->dHC + (int64_t)t * a->Bp * hc_ld;
@@ -685,6 +688,7 @@ static int decoder_bwd_hoisted(const GtDecoderBwd* a, void* stream) {
             if (t > 0 && !fusedB) GT_TRY(rec_rows(dG2_t, N2, a->W2hTp, a->partXh, a->Bp, Hdpad, N2, a->S2, sB, a->bf16, two ? kPrioB : 0));
         }
         mark(&bt.b1, sB);
+        if (!(bwd_skip & 2))
         GT_TRY(block_gemm(op_kc(a->dG2 + (int64_t)b0 * a->Bp * N2, N2), op_rc(a->W2ih, a->ldw2), nullptr,
                           a->dXA + (int64_t)b0 * a->Bp * a->ldxa, a->ldxa, (b1 - b0 + 1) * a->Bp, a->Ha + a->E, N2, 0, a->bf16, sB, w2_amax));
         mark(&bt.g1, sB);

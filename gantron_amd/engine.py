@@ -77,10 +77,13 @@ S2_BWD = sw.debug('s2_bwd')
 # feeds.  On their own bits 0-1 changed nothing (the attention chain's 256-workgroup kernels then ran on 192 CUs:
 # 134.0-134.6 vs 133.3-134.2 ms per pair); with the attention LSTM re-split for the 192 CUs that are left (3 K-splits
 # instead of 4, done below) and the one-launch attention step: 131.0-132.1 against 133.0-133.4.  Bit 2: the BiLSTM backward
-# phase 2.9 -> 2.35 ms (pair 130.4 against 130.9).  Bit 3 LOSES (132.0): in the backward loop the 64 CUs it holds for the
-# whole block are taken from the weight-gradient GEMMs that fill the chip beside the attention chain; it stays opt-in
-# (GANTRON_EXPERIMENTAL=plstm=15).  Default 7 (GANTRON_SCHEDULE=no_plstm or GANTRON_EXPERIMENTAL=plstm=<bits> to change it).
-PLSTM = sw.experimental('plstm', 7 if sw.schedule_on('plstm') else 0)
+# phase 2.9 -> 2.35 ms (pair 130.4 against 130.9).  Bit 3 lost for two rounds (132.0 against 130.4 in round 3, 118.2-118.5
+# against 114.4-114.9 early in round 4: the 64 CUs it holds for a whole block were missed by the attention chain's three
+# launches per step, the one-wave cell backward most of all); with the cell backward inside the attention step's launch
+# (ATTN_BWD_CELL) it pays: 112.2 / 112.4 / 112.6 against 113.5 / 113.1 / 112.7 ms (medians of 24 pairs, one box, alternating;
+# with ATTN_BWD_CELL off it still loses: 118.2), and 1 740 launches and 14 GB of weight stream per pair are gone.
+# Default 15 (GANTRON_SCHEDULE=no_plstm or GANTRON_EXPERIMENTAL=plstm=<bits> to change it).
+PLSTM = sw.experimental('plstm', 15 if sw.schedule_on('plstm') else 0)
 # The attention LSTM's per-step products as exact fp32 products on the bf16 matrix pipe (three bf16 planes, csrc/recurrent_bf16.hip
 # NP = 3): bit 0 = the forward fused product + cell (gt_rec_cell_fwd_x3), bit 1 = the backward product (gt_rec_gemm_x3).
 # Measured (round 3) and not adopted: 31.1 us per forward launch against 26.7, 25.6 per backward product against 19.6, pair

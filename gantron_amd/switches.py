@@ -8,7 +8,7 @@ GANTRON_EXPERIMENTAL   comma list `name[=int]` of paths that were built, are par
                        than the default ("measured and not adopted"); nothing here is needed for
                        correctness and the default path never runs them:
                          fused_cell, attn_step, leaf_defer, rec_cellbwd (the decoder LSTM's fused backward step), plane_gemms
-                         (pre-split GEMM operands), plstm=<bits> (persistent LSTM recurrences, default 7: 1 encoder forward, 2
+                         (pre-split GEMM operands), plstm=<bits> (persistent LSTM recurrences, default 15: 1 encoder forward, 2
                          decoder forward blocks, 4 encoder backward, 8 decoder backward blocks; 0 = per-step launches),
                          rec_x3=<bits> (attention-LSTM products from three bf16 planes: 1 forward, 2 backward), graph[=2] (hipGraph replay of the decoder loops; 2 also reports capture / replay),
                          no_pgemm2 (keep the plane GEMMs on 128 x 128 tiles), rec_tail[=slices] (the h_att half of the
@@ -29,7 +29,8 @@ GANTRON_DEBUG          comma list of diagnostics: phase_timing, host_timing, blo
                        stamps of the attention LSTM's launch and of the attention step: tools/rec_stamps.py), attn2=<bits>
                        (knock-outs of the attention step), rec_tail_kb=<n>, amax (prints the operand maxima every fp16-plane product is
                        scaled by; synchronises), h2_skip=<bits> / h2_wide=<0..4> (fp16-plane products: pass knock-outs / tile-shape rule,
-                       csrc/gemm.hip), amax_wrap=<n> (tests: the tags of the maxima ring start n calls before their 32-bit wrap).
+                       csrc/gemm.hip), amax_wrap=<n> (tests: the tags of the maxima ring start n calls before their 32-bit wrap),
+                       bwd_skip=<bits> (knock-outs of the backward loop's decoder-LSTM chain: results invalid).
 An unknown name in any of the three lists raises at import with the valid names (a mistyped switch would otherwise run
 the default schedule silently); values are decimal integers.  (The C side parses the same variables with the same
 trimming rules: csrc/api.hip, gt_env_item.)  bench.py / the tests additionally use
@@ -46,7 +47,7 @@ _KNOWN = {
                          'no_dist_overlap'},
     'GANTRON_DEBUG': {'phase_timing', 'host_timing', 'block_timing', 'dist_timing', 'attn_valu', 'rec', 'fused', 'pgemm',
                       'rec_splits', 's1_fwd', 's2_fwd', 's2_bwd', 's1_bwd', 'enc_splits', 'sync_every', 'rec_lds_pad',
-                      'rec_stamps', 'attn_stamps', 'attn2', 'rec_tail_kb', 'amax', 'h2_skip', 'h2_wide', 'amax_wrap'},
+                      'rec_stamps', 'attn_stamps', 'attn2', 'rec_tail_kb', 'amax', 'h2_skip', 'h2_wide', 'amax_wrap', 'bwd_skip'},
 }
 
 

@@ -198,7 +198,7 @@ def test_attention_backward_step_forms_against_oracle(dev, monkeypatch, fused, c
     _midsize_against_oracle(dev, case)
 
 
-@pytest.mark.parametrize('case,bits', [('full_dims_b64', 15), ('full_dims_b64_poison', 15), ('vesus_b64', 15), ('full_dims_b64', 3)])
+@pytest.mark.parametrize('case,bits', [('full_dims_b64', 15), ('full_dims_b64_poison', 15), ('vesus_b64', 15), ('full_dims_b64', 3), ('full_dims_b64', 7)])
 def test_persistent_lstm_recurrences_against_oracle(dev, monkeypatch, case, bits):
     """The persistent recurrences (gt_plstm_fwd for the encoder BiLSTM -- both directions, packed sequences, one launch -- and
     for the decoder LSTM's h_dec recurrence, one launch per block of 16 steps with W_hh resident in registers; gt_plstm_bwd
@@ -717,7 +717,7 @@ def test_full_size_training_step_is_schedule_invariant(dev, monkeypatch):
     out0, g0 = run()
     monkeypatch.undo()
     monkeypatch.setattr(ops, 'FWD_SPLITK', False)
-    assert engine.DEC_RING > 1 and engine.BWD_CHUNKS > 1 and engine.ATTN_HOIST and engine.LEAF.enabled and engine.HOIST2 and engine.PLSTM == 7 and \
+    assert engine.DEC_RING > 1 and engine.BWD_CHUNKS > 1 and engine.ATTN_HOIST and engine.LEAF.enabled and engine.HOIST2 and engine.PLSTM == 15 and \
         engine.ATTN_BWD_FUSED and engine.ATTN_BWD_CELL
     out1, g1 = run()
     for name, a, b in zip(('mel', 'mel_post', 'gate', 'align'), out1, out0):
