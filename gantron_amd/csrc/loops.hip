@@ -330,9 +330,11 @@ static int decoder_fwd_hoisted(const GtDecoderFwd* a, void* stream) {
         // blk_gemm_aside, the default of round 3: the block GEMM on a stream of its own (C), beside the recurrence of the block
         // before -- with three bf16 planes per operand the GEMM took 170 us and stream B's 700 us per block had fallen behind the
         // attention chain's 620.  On fp16 planes it takes ~120 and the extra stream loses: 112.2-112.4 against 111.7 ms per pair,
-        // three alternating runs.)
+        // three alternating runs.)  Where the GEMM is wide -- the VESUS memory, K = Ha + E = 2120 -- stream B is the longer chain
+        // again and the third stream still pays (122.9 against 124.7 ms): it is used from K = 2048 on.
         hipStream_t sG = sB;
-        static const int gemm_aside = gt_env_item("GANTRON_EXPERIMENTAL", "blk_gemm_aside", 0) != 0;
+        static const int gemm_aside_forced = gt_env_item("GANTRON_EXPERIMENTAL", "blk_gemm_aside", 0) != 0;
+        const bool gemm_aside = gemm_aside_forced || a->Ha + a->E >= 2048;
         if (two && persistB && gemm_aside && !g_gt_capturing) GT_TRY(aux2_stream(ctx, &sG));
         if (two) {
             GT_TRY(loop_event(ctx, 1 + (size_t)(nblock % 32), &ev));

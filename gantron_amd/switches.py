@@ -13,7 +13,8 @@ GANTRON_EXPERIMENTAL   comma list `name[=int]` of paths that were built, are par
                          rec_x3=<bits> (attention-LSTM products from three bf16 planes: 1 forward, 2 backward), graph[=2] (hipGraph replay of the decoder loops; 2 also reports capture / replay),
                          no_pgemm2 (keep the plane GEMMs on 128 x 128 tiles), rec_tail[=slices] (the h_att half of the
                          attention LSTM's forward product rides in the attention step in front of it: csrc/rec_tail.h), blk_gemm_aside (the
-                         forward loop's block GEMMs on a third stream instead of the decoder-LSTM chain's own).
+                         forward loop's block GEMMs on a third stream instead of the decoder-LSTM chain's own whatever their
+                         width; the default does so from K = Ha + E = 2048 on).
 GANTRON_SCHEDULE       comma list switching OFF parts of the default schedule (what the schedule-invariance test toggles
                        through the module attributes instead): no_cell_query, no_attn_hoist, no_hoist2, no_leaf_stream,
                        no_fwd_splitk, no_rec_cell (per-step product + cell launches instead of the fused ones), no_attn_step2 (energies
