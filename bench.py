@@ -40,12 +40,14 @@ VESUS_HPARAMS = 'use_labels=True,use_noise=True,vesus_path=/synthetic/vesus/'   
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (the headline figures with 2:1 sparsity are not used)
 HBM_PEAK_GBS = 8000.0
+# ('attn_context_bwd' = the backward attention step: since round 4 ONE launch per decoder step with the attention LSTM's cell backward
+# inside, attn_bwd_step_kernel; 'attn_energies_fwd' = the one-launch forward attention step)
 FAMILIES = ['rec_gemm', 'sgemm', 'attn_energies_fwd', 'attn_context_fwd', 'attn_context_bwd', 'attn_energies_bwd',
             'lstm_cell_fwd', 'lstm_cell_bwd', 'rec_cell', 'plstm']
 NF = len(FAMILIES)                 # GT_PROF_FAMILIES of include/gantron_hip.h
 # kernel symbol of each family as rocprofv3 / profiles/rNN_pmc_traffic.json name it
 KERNEL_OF = {'rec_gemm': 'rec_gemm_kernel', 'sgemm': 'sgemm_kernel', 'attn_energies_fwd': 'attn_step2_fwd',
-             'attn_context_fwd': 'attn_context_fwd_kernel', 'attn_context_bwd': 'attn_context_bwd_kernel',
+             'attn_context_fwd': 'attn_context_fwd_kernel', 'attn_context_bwd': 'attn_bwd_step_kernel',
              'attn_energies_bwd': 'attn_energies_bwd', 'lstm_cell_fwd': 'lstm_cell_fwd_kernel',
              'lstm_cell_bwd': 'lstm_cell_bwd_kernel', 'rec_cell': 'rec_cell_kernel', 'plstm': 'plstm_fwd_kernel'}
 MFMA_BOUND = {'rec_gemm', 'sgemm', 'rec_cell', 'plstm'}
@@ -554,7 +556,8 @@ def main():
                 prof_us = total_ns / calls / 1e3
                 roof['rocprofv3'] = dict(avg_launch_us=prof_us, calls=calls, source=os.path.relpath(stats_path, ROOT),
                                          frac_at_that_duration=(dom['flops'] / max(dom['launches'], 1)) / (prof_us * 1e-6) / 1e12 / roof['peak']
-                                         if dom['name'] in MFMA_BOUND else None,
+                                         if dom['name'] in MFMA_BOUND else
+                                         (dom['bytes'] / max(dom['launches'], 1)) / (prof_us * 1e-6) / 1e9 / roof['peak'],
                                          note='committed kernel-trace summary of this command; under the profiler the weight-gradient GEMMs do '
                                               'not overlap the decoder loops, so this is the uncontended duration -- avg_launch_us above is '
                                               'measured live, inside the timed region, beside them')

@@ -850,9 +850,10 @@ static int attn_bwd_step_impl(GtAttnDims d, GtSlabs dctx_a, GtSlabs dctx_b, cons
     GT_REQUIRE((sum_prev == nullptr) == (dwcat2_prev == nullptr), GT_E_ARG, "gt_attn_bwd_step: sum_prev and dwcat2_prev go together");
     GT_REQUIRE((size_t)d.E * 4 <= 32 * 1024, GT_E_LIMIT, "gt_attn_bwd_step: E too large for LDS");
     const double ctx_rows = g_gt_prof_ctx_rows > 0.0 ? g_gt_prof_ctx_rows : (double)d.B * d.Ti;
-    // (with the cell inside: + dq . Wq of every row and what gt_cell_bwd_query_c reads and writes; Wq once per ROW here)
+    // (with the cell inside: + dq . Wq of every row and what gt_cell_bwd_query_c reads and writes; algorithmic bytes: Wq ONCE --
+    // the 512 KB per row that the tails actually pull come out of L2)
     const double cell_flop = cell != nullptr ? 2.0 * d.B * (double)cell->H * d.A : 0.0;
-    const double cell_bytes = cell != nullptr ? 4.0 * d.B * (double)cell->H * (d.A + cell->dh_a.n + cell->dh_c.n + 1 + 4 + 2 + 4 + 1) : 0.0;
+    const double cell_bytes = cell != nullptr ? 4.0 * ((double)d.A * cell->H + d.B * (double)cell->H * (cell->dh_a.n + cell->dh_c.n + 1 + 4 + 2 + 4 + 1)) : 0.0;
     GtProfScope prof(GT_FAM_ATTN_C_BWD, 2.0 * ctx_rows * (double)d.E + 2.0 * d.B * d.Ti * (double)(d.A + 2 * d.Kc) + cell_flop,
                      4.0 * (ctx_rows * d.E + d.B * ((1.0 + dctx_a.n + dctx_b.n) * d.E + 6.0 * d.Ti) + d.B * d.Ti * (d.A + 64 + 6.0)) + cell_bytes,
                      (hipStream_t)stream);
