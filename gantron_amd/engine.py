@@ -720,6 +720,8 @@ class GeneratorEngine:
             keep_t.update(W1g=pack_gates(W1cat, Ha, K1), W2g=pack_gates(W2cat, Hd, K2))
         else:
             keep_t.update(W1p=pack_rec(W1cat, 4 * Ha, 4 * Ha, K1), W2p=pack_rec(W2cat, 4 * Hd, 4 * Hd, K2))
+        # (the one-launch attention steps finish a batch row in its last VALID tile's workgroup: a row without a symbol has none)
+        assert min(int(n) for n in in_lens) >= 1, 'every text needs at least one symbol'
         lens32 = ops.h2d(in_lens, torch.int32, dev)
         ld1, ld2 = (int(lib().gt_fused_k_padded(K1)), int(lib().gt_fused_k_padded(K2))) if fused else \
             (roundup(K1, 16), roundup(K2, 16))

@@ -621,7 +621,8 @@ int gt_attn_bwd_fixup(GtAttnDims d, int32_t nsteps, const float* sum, const floa
  * (model.py:391-394 through autograd).  dq2 is this step's row block of the dq2 history (laid out like dq), Wq (A, H) with rows
  * ldwq apart; the other fields as gt_cell_bwd_query_c's arguments; H % 4 == 0, every pointer 16-byte aligned.  row_cnt: B
  * words, zero-initialised once; `launch` = 1, 2, 3 ... for consecutive calls that share them (the counters only grow: no reset
- * between the steps of a backward pass).  No workgroup waits for another.  Rows m >= B of dgates / dc_prev are not written. */
+ * between the steps of a backward pass).  No workgroup waits for another.  Rows m >= B of dgates / dc_prev are not written; a
+ * row with lengths[b] == 0 has no workgroup that could finish it (the loops' text lengths are >= 1: data_utils.py:38-49). */
 typedef struct GtCellBwdTail {
     GtSlabs dh_a, dh_c;
     const float* dq2;
