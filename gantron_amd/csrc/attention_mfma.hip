@@ -1040,6 +1040,7 @@ struct AttnBwdStep {
         float* dgates; float* dc_prev;
         int H;
         unsigned* row_cnt; unsigned launch;
+        unsigned long long* dg_amax;            // optional: max |dgates| of the step (gt_absmax format), for the product behind it
     } tail;
 };
 static_assert(sizeof(AttnBwdStep) <= 1024, "AttnBwdStep is a by-value kernel argument: keep it well below the 4 KB kernel-argument segment");
@@ -1207,6 +1208,23 @@ __global__ __launch_bounds__(256) void attn_bwd_step_kernel(AttnBwdStep a) {
                 dgg[e] = dcell * giv[e] * (1.f - ggv[e] * ggv[e]);
                 dgo[e] = dd * tc * gov[e] * (1.f - gov[e]);
                 dcp[e] = dcell * gfv[e];
+            }
+            if (c.dg_amax != nullptr) {
+                // the largest finite |gate gradient| of the step, for the fp16-plane product that multiplies them next (a launch
+                // boundary away): one 64-bit atomicMax per wave, tag 1 in the high half as gt_absmax leaves it
+                unsigned mx = 0u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float g4[4] = {dgi[e], dgf[e], dgg[e], dgo[e]};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned ub = __float_as_uint(g4[j]) & 0x7fffffffu;
+                        mx = max(mx, (on && ub < 0x7f800000u) ? ub : 0u);
+                    }
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
+                if ((threadIdx.x & 63) == 0) atomicMax(c.dg_amax, (1ull << 32) | mx);
             }
             if (!on) continue;
             float* dg = c.dgates + (long)b * 4 * H + u;
@@ -1519,7 +1537,7 @@ void gt_launch_attn_bwd_step_mfma(GtAttnDims d, GtSlabs da, GtSlabs db, const fl
         c.dh_a = cell->dh_a; c.dh_c = cell->dh_c; c.dq2 = cell->dq2; c.Wq = cell->Wq; c.ldwq = (long)cell->ldwq;
         c.dc_next = cell->dc_next; c.gates = cell->gates; c.c_new = cell->c_new; c.c_prev = cell->c_prev; c.keep = cell->keep;
         c.scale = 1.0f / (1.0f - cell->p_drop); c.dgates = cell->dgates; c.dc_prev = cell->dc_prev; c.H = cell->H;
-        c.row_cnt = cell->row_cnt; c.launch = cell->launch;
+        c.row_cnt = cell->row_cnt; c.launch = cell->launch; c.dg_amax = (unsigned long long*)cell->dg_amax;
         if (vec && d.E == 1024 && vec_slabs) hipLaunchKernelGGL((attn_bwd_step_kernel<true, 4, true>), grid, dim3(256), dyn, st, a);
         else if (vec) hipLaunchKernelGGL((attn_bwd_step_kernel<true, 0, true>), grid, dim3(256), dyn, st, a);
         else hipLaunchKernelGGL((attn_bwd_step_kernel<false, 0, true>), grid, dim3(256), dyn, st, a);

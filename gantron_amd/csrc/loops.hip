@@ -33,8 +33,9 @@ static const GtSlabs kNoSlabs = {nullptr, 0, 0, 0};
 // prio: 1 for the products of the attention chain (the loops' serial critical path): raised wave priority.
 static int rec_rows(const float* X, int64_t ldx, const float* Wp, float* part, int Bp, int N, int K, int S,
                     void* stream, int bf16 = 0, int prio = 0) {
-    if (bf16) {         // Wp is a bf16 fragment image (gt_pack_rec_weight_bf16), or three planes of them (bf16 == 3: _x3)
-        const int planes = bf16 == 3 ? 3 : 1;
+    if (bf16) {         // Wp is a bf16 fragment image (gt_pack_rec_weight_bf16), three planes of them (bf16 == 3: _x3) or two
+                        // scaled fp16 planes (bf16 == 2: _h2; the caller has named the activations' bound in g_rec_h2x)
+        const int planes = bf16 == 3 ? 3 : bf16 == 2 ? 2 : 1;
         if (Bp <= 64) return gt_rec_gemm_bf16_prio(X, ldx, Wp, part, Bp / 16, N, K, S, (int64_t)Bp * N, 1, 0, 0, 0, prio, stream, planes);
         return gt_rec_gemm_bf16_prio(X, ldx, Wp, part, 4, N, K, S, (int64_t)Bp * N, Bp / 64, 64 * ldx, 0, (int64_t)64 * N, prio,
                                      stream, planes);
@@ -269,7 +270,9 @@ static int decoder_fwd_hoisted(const GtDecoderFwd* a, void* stream) {
             float* X1c = a->X1 + (t & 1) * x1_slot;            // [ctx_{t-1} | h_att_{t-1}]
             float* X1n = a->X1 + ((t + 1) & 1) * x1_slot;      // receives h_att_t (cell) and ctx_t (context kernel)
             if (fusedA) {       // product + cell + dropout + query slabs: one launch
-                GT_TRY(gt_rec_cell_fwd_z(X1c, a->ld1, a->W1c, a->bf16 ? 1 : (a->rec_x3 ? 3 : 0), a->part, a->counters1, a->Bp, a->B, a->Ha, K1, a->S1,
+                const int fmt1 = a->bf16 ? 1 : (a->rec_x3 == 2 ? 2 : a->rec_x3 ? 3 : 0);
+                if (fmt1 == 2) g_rec_h2x = {a->x1max, a->x1floor};
+                GT_TRY(gt_rec_cell_fwd_z(X1c, a->ld1, a->W1c, fmt1, a->part, a->counters1, a->Bp, a->B, a->Ha, K1, a->S1,
                                        a->pre1 + (int64_t)t * a->Bp * N1, N1, a->c1 + (int64_t)t * a->Bp * a->Ha, k1, a->p_att,
                                        a->gates1 + (int64_t)t * a->Bp * N1, a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha,
                                        a->hatt + (int64_t)t * a->Bp * a->Ha, X1n + a->E, a->ld1, XAt, a->ld2, nullptr, 0, a->Wq,
@@ -606,6 +609,9 @@ static int decoder_bwd_hoisted(const GtDecoderBwd* a, void* stream) {
     const int Hdpad = 16 * cdiv(a->Hd, 16);
     GT_REQUIRE(a->W2ih && a->dXA && a->partXh && a->ldw2 >= a->Ha + a->E && a->ldxa >= a->Ha + a->E && a->ldxa % 4 == 0, GT_E_ARG,
                "gt_decoder_bwd: hoisted mode needs W2ih, dXA (ldxa %% 4 == 0) and partXh");
+    GT_REQUIRE(a->rec_x3 != 2 || (a->amaxG1 && a->rowcntA && a->Wq && a->sum_hist && a->dq2_hist && a->dwcat2_hist && a->p_hist &&
+                                  a->u_hist && a->de_hist && !a->bf16), GT_E_ARG,
+               "gt_decoder_bwd: rec_x3 = 2 (fp16-plane backward product) needs amaxG1 and the attention step with the cell inside (rowcntA ...)");
     const int64_t hc_ld = a->Hd + a->E;
     GtAttnDims d; d.B = a->B; d.Ti = a->Ti; d.E = a->E; d.A = a->A; d.F = a->F; d.Kc = a->Kc;
     const int64_t BT = (int64_t)a->B * a->Ti;
@@ -726,6 +732,8 @@ static int decoder_bwd_hoisted(const GtDecoderBwd* a, void* stream) {
                 cell.c_new = a->c1 + (int64_t)(t + 1) * a->Bp * a->Ha; cell.c_prev = a->c1 + (int64_t)t * a->Bp * a->Ha;
                 cell.keep = k1; cell.p_drop = a->p_att; cell.dgates = dG1_t; cell.dc_prev = a->dc1; cell.H = a->Ha;
                 cell.row_cnt = a->rowcntA; cell.launch = (uint32_t)(a->To - t);
+                const bool h2b = !a->bf16 && a->rec_x3 == 2 && a->amaxG1 != nullptr;
+                cell.dg_amax = h2b ? a->amaxG1 + t : nullptr;
                 GT_TRY(gt_attn_bwd_step_cell(d, slabs(dXA_t + a->Ha, 1, 0, a->ldxa),
                                              last ? kNoSlabs : slabs(a->partX1, a->S1, sX1, a->N1pad), dhc_t + a->Hd, hc_ld,
                                              a->memory, a->ldE, a->lengths, dwcat_in, a->dcum_acc,
@@ -736,7 +744,11 @@ static int decoder_bwd_hoisted(const GtDecoderBwd* a, void* stream) {
                                              last ? nullptr : a->dwcat2_hist + (int64_t)(t + 1) * 2 * BT,
                                              a->sum_hist + (int64_t)t * a->B * nch, dq_t, a->Apad, dwcat_out,
                                              a->de_hist + (int64_t)t * BT, &cell, sA));
-                if (t > 0) GT_TRY(rec_rows(dG1_t, N1, a->W1Tp, a->partX1, a->Bp, a->N1pad, N1, a->S1, sA, a->bf16 ? 1 : (a->rec_x3 ? 3 : 0), two ? kPrioA : 0));
+                if (t > 0) {
+                    if (h2b) g_rec_h2x = {a->amaxG1 + t, 0.f};
+                    GT_TRY(rec_rows(dG1_t, N1, a->W1Tp, a->partX1, a->Bp, a->N1pad, N1, a->S1, sA,
+                                    a->bf16 ? 1 : h2b ? 2 : (a->rec_x3 ? 3 : 0), two ? kPrioA : 0));
+                }
                 continue;
             }
             if (fused_attn) {
@@ -828,6 +840,7 @@ int gt_decoder_bwd(const GtDecoderBwd* a, void* stream) {
             return run_graphed(a, sizeof(*a), (hipStream_t)stream, [&]() { return decoder_bwd_hoisted(a, stream); });
         return decoder_bwd_hoisted(a, stream);
     }
+    GT_REQUIRE(a->rec_x3 != 2, GT_E_ARG, "gt_decoder_bwd: rec_x3 = 2 needs the hoisted mode");
     const int N1 = 4 * a->Ha, N2 = 4 * a->Hd;
     const int64_t hc_ld = a->Hd + a->E;
     GtAttnDims d; d.B = a->B; d.Ti = a->Ti; d.E = a->E; d.A = a->A; d.F = a->F; d.Kc = a->Kc;

@@ -721,10 +721,11 @@ int gt_rec_cell_fwd_z(const float* X, int64_t ldx, const void* Wpv, int wbf16, f
     hipStream_t st = (hipStream_t)stream;
     const double Kown = 16.0 * KBlim < K ? 16.0 * KBlim : (double)K;        // the reduction columns this launch multiplies
     GtProfScope prof(GT_FAM_REC_CELL, ndir * (2.0 * Bp * (double)N * Kown + (Wq ? 2.0 * Bp * (double)H * A : 0.0)),
-                     ndir * ((wbf16 == 3 ? 6.0 : wbf16 ? 2.0 : 4.0) * (double)N * Kown +
+                     ndir * ((wbf16 == 3 ? 6.0 : wbf16 == 1 ? 2.0 : 4.0) * (double)N * Kown +
                              4.0 * ((double)Bp * Kown + (double)Bp * N * ((splits > 1 ? 2 * splits - 1 : 0) + extra_slabs) +
                                     (double)B * H * 12)), st, true);
-    if (wbf16) return gt_launch_rec_cell_bf16(X, ldx, Wpv, part, Bp, N, K, splits, ndir, prio, e, prof.e0, prof.e1, stream, wbf16 == 3 ? 3 : 1);
+    if (wbf16) return gt_launch_rec_cell_bf16(X, ldx, Wpv, part, Bp, N, K, splits, ndir, prio, e, prof.e0, prof.e1, stream,
+                                              wbf16 == 3 ? 3 : wbf16 == 2 ? 2 : 1);
     const long ps = (long)Bp * N;
 #define GT_RC(MT)                                                                                                      \
     GT_LAUNCH_TIMED((rec_cell_kernel<MT>), grid, dim3(REC_THREADS), 0, st, prof.e0, prof.e1, X, (long)ldx, Wp, part,  \
@@ -769,6 +770,18 @@ extern "C" int gt_rec_cell_fwd_bf16(const float* X, int64_t ldx, const void* Wp,
                                     const float* Wq, int64_t ldwq, float* qpart, int64_t q_sstride, int32_t A, int32_t Apad,
                                     int32_t prio, void* stream) {
     return gt_rec_cell_fwd_z(X, ldx, Wp, 1, part, counters, Bp, B, H, K, splits, pre, ld_pre, c_prev, keep, p_drop, gates, c_out,
+                             h_raw, h0, ld0, h1, ld1, h2, ld2, Wq, ldwq, qpart, q_sstride, A, Apad, nullptr, nullptr, 0, 1,
+                             nullptr, prio, stream);
+}
+
+extern "C" int gt_rec_cell_fwd_h2(const float* X, int64_t ldx, const void* Wp, float* part, uint32_t* counters, int32_t Bp,
+                                  int32_t B, int32_t H, int32_t K, int32_t splits, const float* pre, int64_t ld_pre,
+                                  const float* c_prev, const uint8_t* keep, float p_drop, float* gates, float* c_out,
+                                  float* h_raw, float* h0, int64_t ld0, float* h1, int64_t ld1, float* h2, int64_t ld2,
+                                  const float* Wq, int64_t ldwq, float* qpart, int64_t q_sstride, int32_t A, int32_t Apad,
+                                  const uint64_t* xmax, float xfloor, int32_t prio, void* stream) {
+    g_rec_h2x = {xmax, xfloor};
+    return gt_rec_cell_fwd_z(X, ldx, Wp, 2, part, counters, Bp, B, H, K, splits, pre, ld_pre, c_prev, keep, p_drop, gates, c_out,
                              h_raw, h0, ld0, h1, ld1, h2, ld2, Wq, ldwq, qpart, q_sstride, A, Apad, nullptr, nullptr, 0, 1,
                              nullptr, prio, stream);
 }

@@ -17,6 +17,12 @@
 // product exact, dropped terms <= 2^-24 |a||b|, the arithmetic of xgemm_kernel (gemm.hip).  At M = 64 rows the fp32 pipe
 // needs 6.8 us for a workgroup's 64 columns x 512 k (v_mfma_f32_16x16x4_f32: 256 flop per clock and CU); the six bf16
 // products take 2.6 us.  The three weight planes are held two chunks at a time and refilled two chunks ahead.
+//
+// NP = 2 ("h2", round 4: gt_rec_gemm_h2 / gt_rec_cell_fwd_h2): the fp32 product from two SCALED fp16 planes per operand, the
+// arithmetic of gemm.hip's mode 4 -- x s = h0 + h1 (+ r), |r| <= 2^-22 |x s|, a . b = (a0 b0 + a0 b1 + a1 b0) / (sa sb) as three
+// v_mfma_f32_16x16x32_f16 -- at 4 bytes per weight (what fp32 streams) and 3/16 of the fp32 pipe's matrix time.  The weights'
+// power-of-two scale comes from max |W|, found when they are packed and kept in a 16-byte trailer of the image; the activations'
+// from a device word the caller names (gt_absmax format) and a floor (a bound known a priori: h = o tanh c / (1 - p)).
 #include <stdint.h>
 #include "common.h"
 #include "rec_cell.h"
@@ -25,6 +31,27 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+
+// power-of-two scale that puts a tensor's largest magnitude (fp32 bit pattern) into [2^14, 2^15): gemm.hip's h2_scale_exp
+__device__ __forceinline__ int rb_h2_exp(unsigned maxbits) {
+    const int e = (int)((maxbits >> 23) & 0xffu);
+    return min(127, max(-126, 141 - e));
+}
+__device__ __forceinline__ float rb_pow2(int k) { return __uint_as_float((unsigned)(127 + k) << 23); }
+// (x, y) scaled by s -> the pair's two fp16 planes, first element in the low half
+__device__ __forceinline__ void rb_split_h2(float x, float y, float s, unsigned& p0, unsigned& p1) {
+    float ra, rb;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(p0) : "s"(s), "v"(x));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(p0) : "s"(s), "v"(y));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(ra) : "s"(s), "v"(x), "v"(p0));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rb) : "s"(s), "v"(y), "v"(p0));
+    const f16x2 q = __builtin_convertvector((f32x2_){ra, rb}, f16x2);
+    p1 = __builtin_bit_cast(unsigned, q);
+}
 
 constexpr int RB_THREADS = 512;
 constexpr int RB_CB = 8;               // 32-wide k-blocks per chunk (256 k)
@@ -43,9 +70,13 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 // cellH > 0 (gt_pack_rec_cell_weight_bf16): W is a (4 cellH x K) LSTM weight and packed column 64 cg + 16 g + u is its row
 // g * cellH + 16 cg + u, so that a 64-column group holds the four gates of 16 hidden units (gt_rec_cell_fwd_bf16).
 // planes = 3: block (nb, kb) is followed by its second and third plane (residuals), ((nb KB + kb) planes + p) 64 + lane.
+// planes = 2: two fp16 planes of W scaled by the power of two of *wmax (gt_absmax word of W).
 __global__ __launch_bounds__(256) void pack_rec_weight_bf16_kernel(const float* W, long ldw, int transposed, int N,
-                                                                   int n_valid, int K, int KB, int cellH, uint4* Wp, int planes) {
+                                                                   int n_valid, int K, int KB, int cellH, uint4* Wp, int planes,
+                                                                   const unsigned long long* wmax) {
     const long total = (long)(N / 16) * KB * 64;
+    float hs = 1.f;
+    if (planes == 2) hs = rb_pow2(rb_h2_exp(__builtin_amdgcn_readfirstlane((unsigned)*wmax)));
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int lane = (int)(idx & 63);
         const long blk = idx >> 6;
@@ -58,6 +89,14 @@ __global__ __launch_bounds__(256) void pack_rec_weight_bf16_kernel(const float* 
         for (int j = 0; j < 8; ++j) {
             const int kk = k + j;
             v[j] = (kk < K && n < n_valid) ? (transposed ? W[(long)kk * ldw + n] : W[(long)n * ldw + kk]) : 0.f;
+        }
+        if (planes == 2) {
+            unsigned h0[4], h1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rb_split_h2(v[2 * j], v[2 * j + 1], hs, h0[j], h1[j]);
+            Wp[(blk * 2 + 0) * 64 + lane] = make_uint4(h0[0], h0[1], h0[2], h0[3]);
+            Wp[(blk * 2 + 1) * 64 + lane] = make_uint4(h1[0], h1[1], h1[2], h1[3]);
+            continue;
         }
         for (int p = 0; p < planes; ++p) {
             const uint4 o = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
@@ -74,7 +113,15 @@ __global__ __launch_bounds__(256) void pack_rec_weight_bf16_kernel(const float* 
 
 // float4 -> its NP bf16 planes, (x, y) packed in .x and (z, w) in .y of plane p
 template <int NP>
-__device__ __forceinline__ void split_planes(float4 x, uint2 (&out)[NP]) {
+__device__ __forceinline__ void split_planes(float4 x, uint2 (&out)[NP], float hs) {
+    if constexpr (NP == 2) {
+        unsigned a0, a1, b0, b1;
+        rb_split_h2(x.x, x.y, hs, a0, a1);
+        rb_split_h2(x.z, x.w, hs, b0, b1);
+        out[0] = make_uint2(a0, b0);
+        out[1] = make_uint2(a1, b1);
+        return;
+    }
     float v[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
@@ -89,6 +136,18 @@ __device__ __forceinline__ void split_planes(float4 x, uint2 (&out)[NP]) {
     }
 }
 
+// NP = 2: where the operand scales come from (kernel argument; zeros for the other formats)
+struct RecH2 { const unsigned long long* wmax; const unsigned long long* xmax; float xfloor; };
+__device__ __forceinline__ void rb_h2_scales(const RecH2& h, float& hs, int& hk) {
+    // (wave-uniform; agent-scope loads: the activations' word may have been written by atomics of the launch in front of this one)
+    const unsigned wb = (unsigned)__hip_atomic_load(h.wmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned xb = h.xmax != nullptr ? (unsigned)__hip_atomic_load(h.xmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    xb = max(xb, __float_as_uint(h.xfloor));              // (non-negative floats order like their bit patterns)
+    const int kw = rb_h2_exp(__builtin_amdgcn_readfirstlane(wb)), kx = rb_h2_exp(__builtin_amdgcn_readfirstlane(xb));
+    hs = rb_pow2(kx);
+    hk = kw + kx;
+}
+
 __device__ __forceinline__ void rb_setprio(int prio) {
     // issue priority of the waves: 3 = the loops' critical (attention) chain, 2 = the other chain, 0 = everything else
     if (prio == 3) __builtin_amdgcn_s_setprio(3);
@@ -101,13 +160,14 @@ __device__ __forceinline__ void rb_setprio(int prio) {
 template <int MT, int NCH, int NP>
 __device__ __forceinline__ float* rec_bf16_tile(unsigned short* Xs, const float* __restrict__ Xz, long ldx, int kvalid,
                                                 const uint4* __restrict__ Wz, int N, int KB, int kb0, int kb1, int cg,
-                                                long long* stamps = nullptr) {
+                                                long long* stamps = nullptr, float hs = 1.f, int hk = 0) {
+    // (NP = 2: hs = the activations' scale 2^kx, hk = kx + kw: the folded tile leaves as acc 2^-hk)
     constexpr int PL = MT * 16 * RB_LD;      // bf16 elements per activation plane in LDS
     constexpr int XV = MT * 2;         // float4 per thread per chunk (MT*16 rows x 64 float4 / 512 threads)
-    constexpr int XR = NP == 3 ? (NCH < 2 ? NCH : 2) : (NCH < RB_XR ? NCH : RB_XR);
+    constexpr int XR = NP >= 2 ? (NCH < 2 ? NCH : 2) : (NCH < RB_XR ? NCH : RB_XR);
     // weight chunks held in registers: all of the slice (NP = 1), or two at a time, refilled two chunks ahead (NP = 3:
-    // three planes of a chunk are 48 registers)
-    constexpr int WR = NP == 3 ? (NCH < 2 ? NCH : 2) : NCH;
+    // three planes of a chunk are 48 registers; NP = 2: 32)
+    constexpr int WR = NP >= 2 ? (NCH < 2 ? NCH : 2) : NCH;
     constexpr int EP_LD = REC_EP_LD;
     static_assert(MT * 16 * RB_LD * 2 >= (MT * 16 * (EP_LD + 20) + 4) * 4, "epilogue tile + scratch fit the staging buffer");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -157,7 +217,7 @@ __device__ __forceinline__ float* rec_bf16_tile(unsigned short* Xs, const float*
                 const int f = tid + RB_THREADS * i, row = f >> 6, c4 = f & 63;
                 // activations beyond the valid columns meet zero weights; the clamped load keeps them finite
                 uint2 pl[NP];
-                split_planes<NP>(x[c % XR][i], pl);
+                split_planes<NP>(x[c % XR][i], pl, hs);
 #pragma unroll
                 for (int p = 0; p < NP; ++p) *reinterpret_cast<uint2*>(&Xs[p * PL + row * RB_LD + 4 * c4]) = pl[p];
             }
@@ -179,7 +239,13 @@ __device__ __forceinline__ float* rec_bf16_tile(unsigned short* Xs, const float*
                     for (int pa = 0; pa <= ord; ++pa) {
                         const bf16x8 b = __builtin_bit_cast(bf16x8, w[c % WR][u][ord - pa]);
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[pa][mt], b, acc[mt], 0, 0, 0);
+                        for (int mt = 0; mt < MT; ++mt) {
+                            if constexpr (NP == 2)
+                                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[pa][mt]),
+                                                                                 __builtin_bit_cast(f16x8, b), acc[mt], 0, 0, 0);
+                            else
+                                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[pa][mt], b, acc[mt], 0, 0, 0);
+                        }
                     }
             }
             if (c + WR < NCH) wload(w[c % WR], c + WR);      // registers of this chunk's weights are free again
@@ -190,6 +256,12 @@ __device__ __forceinline__ float* rec_bf16_tile(unsigned short* Xs, const float*
     // ---- epilogue through LDS: fold the two K-halves, write the slab with full-line float4 stores
     float* red = reinterpret_cast<float*>(Xs);
     const int ecol = (wave & 3) * 16 + (lane & 15), erow = 4 * (lane >> 4);
+    if constexpr (NP == 2) {           // the operand scales leave, exactly
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mt][r] = ldexpf(acc[mt][r], -hk);
+    }
     if (half == 1) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -211,12 +283,16 @@ template <int MT, int NCH, int NP>
 __global__ __launch_bounds__(RB_THREADS) void rec_gemm_bf16_kernel(const float* __restrict__ X, long ldx, int kvalid,
                                                                    const uint4* __restrict__ Wp, float* __restrict__ part,
                                                                    int N, int KB, int KBS, long xz, long wz, long pz,
-                                                                   long ps, int prio) {
+                                                                   long ps, int prio, RecH2 h2) {
     rb_setprio(prio);
     __shared__ __attribute__((aligned(16))) unsigned short Xs[NP * MT * 16 * RB_LD];
     const int s = blockIdx.y, z = blockIdx.z, cg = blockIdx.x;
     const int kb0 = s * KBS;
-    const float* red = rec_bf16_tile<MT, NCH, NP>(Xs, X + (long)z * xz, ldx, kvalid, Wp + (long)z * wz, N, KB, kb0, min(KB, kb0 + KBS), cg);
+    float hs = 1.f;
+    int hk = 0;
+    if constexpr (NP == 2) rb_h2_scales(h2, hs, hk);
+    const float* red = rec_bf16_tile<MT, NCH, NP>(Xs, X + (long)z * xz, ldx, kvalid, Wp + (long)z * wz, N, KB, kb0, min(KB, kb0 + KBS), cg,
+                                                  nullptr, hs, hk);
     constexpr int EP_LD = REC_EP_LD;
     const int tid = threadIdx.x;
     float* out = part + (long)z * pz + (long)s * ps + (long)cg * 64;
@@ -235,10 +311,14 @@ __global__ __launch_bounds__(RB_THREADS) void rec_gemm_bf16_kernel(const float* 
 template <int MT, int NCH, int NP>
 __global__ __launch_bounds__(RB_THREADS) void rec_cell_bf16_kernel(const float* __restrict__ X, long ldx, int kvalid,
                                                                    const uint4* __restrict__ Wp, float* part, int N, int KB,
-                                                                   int KBS, long xz, long pz, long ps, int prio, RecCellEpi e) {
+                                                                   int KBS, long xz, long pz, long ps, int prio, RecCellEpi e,
+                                                                   RecH2 h2) {
     rb_setprio(prio);
     __shared__ __attribute__((aligned(16))) unsigned short Xs[NP * MT * 16 * RB_LD];
     const int cg = blockIdx.x, s = blockIdx.y, z = blockIdx.z;
+    float hs = 1.f;
+    int hk = 0;
+    if constexpr (NP == 2) rb_h2_scales(h2, hs, hk);
     const int dir = z / e.nzb, rb = z - dir * e.nzb;
     const int kb0 = s * KBS;
     if (dir != 0) {
@@ -247,7 +327,8 @@ __global__ __launch_bounds__(RB_THREADS) void rec_cell_bf16_kernel(const float* 
     }
     REC_STAMP(e, 0);
     float* red = rec_bf16_tile<MT, NCH, NP>(Xs, X + (long)rb * xz, ldx, kvalid, Wp, N, KB, kb0, min(KB, kb0 + KBS), cg,
-                                            e.stamp_on ? g_rec_stamps_dev + ((long)blockIdx.x + (long)gridDim.x * blockIdx.y) * 8 : nullptr);
+                                            e.stamp_on ? g_rec_stamps_dev + ((long)blockIdx.x + (long)gridDim.x * blockIdx.y) * 8 : nullptr,
+                                            hs, hk);
     rec_cell_epilogue<MT>(red, e, part + (long)rb * pz, ps, N, cg, s, rb, e.counters + (long)z * gridDim.x + cg);
 }
 
@@ -257,6 +338,13 @@ extern "C" int64_t gt_rec_weight_bf16_elems(int32_t N, int32_t K) {
     return (int64_t)(N / 16) * cdiv(K, 32) * 64 * 8;
 }
 extern "C" int64_t gt_rec_weight_x3_elems(int32_t N, int32_t K) { return 3 * gt_rec_weight_bf16_elems(N, K); }
+// two fp16 planes + a 16-byte trailer: the gt_absmax word of W (its low half = the bits of max |W|) the scale was taken from
+extern "C" int64_t gt_rec_weight_h2_elems(int32_t N, int32_t K) { return 2 * gt_rec_weight_bf16_elems(N, K) + 8; }
+static const unsigned long long* h2_trailer(const void* Wp, int N, int K) {
+    return reinterpret_cast<const unsigned long long*>(static_cast<const unsigned short*>(Wp) + 2 * gt_rec_weight_bf16_elems(N, K));
+}
+// the activations' side of a planes == 2 launch: named by the caller right before it (this thread's next launch)
+thread_local GtRecH2X g_rec_h2x = {nullptr, 0.f};
 
 extern "C" int32_t gt_rec_bf16_min_splits(int32_t K) { return cdiv(cdiv(K, 32), RB_NCH * RB_CB); }
 constexpr int RB_NCH_X3 = 4;           // chunks per K-slice (the three weight planes are held two chunks at a time)
@@ -270,8 +358,14 @@ static int pack_rec_planes(const char* what, const float* W, int64_t ldw, int32_
     const int KB = cdiv(K, 32);
     const long total = (long)(N / 16) * KB * 64;
     const int blocks = (int)std::min<long>(cdiv64(total, 256), 4096);
+    const unsigned long long* wmax = nullptr;
+    if (planes == 2) {              // max |W| over the valid part, into the image's trailer (same stream: in front of the pack)
+        wmax = h2_trailer(Wp, N, K);
+        int rc = transposed ? gt_absmax(W, K, n_valid, ldw, (uint64_t*)wmax, stream) : gt_absmax(W, n_valid, K, ldw, (uint64_t*)wmax, stream);
+        if (rc != 0) return rc;
+    }
     hipLaunchKernelGGL(pack_rec_weight_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, W, (long)ldw,
-                       transposed, N, n_valid, K, KB, cellH, reinterpret_cast<uint4*>(Wp), planes);
+                       transposed, N, n_valid, K, KB, cellH, reinterpret_cast<uint4*>(Wp), planes, wmax);
     GT_LAUNCH_CHECK();
     return 0;
 }
@@ -283,6 +377,17 @@ extern "C" int gt_pack_rec_weight_bf16(const float* W, int64_t ldw, int32_t tran
 extern "C" int gt_pack_rec_weight_x3(const float* W, int64_t ldw, int32_t transposed, int32_t N, int32_t n_valid,
                                      int32_t K, void* Wp, void* stream) {
     return pack_rec_planes("gt_pack_rec_weight_x3", W, ldw, transposed, N, n_valid, K, 0, Wp, 3, stream);
+}
+
+extern "C" int gt_pack_rec_weight_h2(const float* W, int64_t ldw, int32_t transposed, int32_t N, int32_t n_valid,
+                                     int32_t K, void* Wp, void* stream) {
+    return pack_rec_planes("gt_pack_rec_weight_h2", W, ldw, transposed, N, n_valid, K, 0, Wp, 2, stream);
+}
+extern "C" int gt_rec_gemm_h2(const float* X, int64_t ldx, const void* Wp, float* part, int32_t mtiles, int32_t N,
+                              int32_t K, int32_t splits, int64_t part_sstride, int32_t nz, int64_t x_zstride,
+                              int64_t part_zstride, const uint64_t* xmax, float xfloor, void* stream) {
+    g_rec_h2x = {xmax, xfloor};
+    return gt_rec_gemm_bf16_prio(X, ldx, Wp, part, mtiles, N, K, splits, part_sstride, nz, x_zstride, 0, part_zstride, 0, stream, 2);
 }
 
 extern "C" int gt_rec_gemm_bf16(const float* X, int64_t ldx, const void* Wp, float* part, int32_t mtiles, int32_t N,
@@ -302,8 +407,15 @@ int gt_rec_gemm_bf16_prio(const float* X, int64_t ldx, const void* Wp, float* pa
                           int32_t splits, int64_t part_sstride, int32_t nz, int64_t x_zstride, int64_t w_zstride,
                           int64_t part_zstride, int prio, void* stream, int planes) {
     GT_REQUIRE(X && Wp && part, GT_E_ARG, "gt_rec_gemm_bf16: NULL pointer");
-    GT_REQUIRE(mtiles >= 1 && mtiles <= 4 && N > 0 && N % 16 == 0 && K >= 4 && splits >= 1 && nz >= 1 && (planes == 1 || planes == 3),
+    GT_REQUIRE(mtiles >= 1 && mtiles <= 4 && N > 0 && N % 16 == 0 && K >= 4 && splits >= 1 && nz >= 1 && planes >= 1 && planes <= 3,
                GT_E_ARG, "gt_rec_gemm_bf16: bad sizes mtiles=%d N=%d K=%d splits=%d planes=%d", mtiles, N, K, splits, planes);
+    RecH2 h2 = {nullptr, nullptr, 0.f};
+    if (planes == 2) {
+        GT_REQUIRE(w_zstride == 0, GT_E_ARG, "gt_rec_gemm_h2: one weight image (its trailer holds the scale)");
+        GT_REQUIRE(g_rec_h2x.xmax != nullptr || g_rec_h2x.xfloor > 0.f, GT_E_ARG, "gt_rec_gemm_h2: no bound for the activations (xmax word or xfloor > 0)");
+        h2.wmax = h2_trailer(Wp, N, K); h2.xmax = (const unsigned long long*)g_rec_h2x.xmax; h2.xfloor = g_rec_h2x.xfloor;
+        g_rec_h2x = {nullptr, 0.f};
+    }
     const int KB = cdiv(K, 32);
     const int kvalid = cdiv(K, 16) * 16;        // columns the caller guarantees (zero padded beyond K), as gt_rec_gemm
     GT_REQUIRE(ldx >= kvalid && ldx % 4 == 0 && aligned16(X) && aligned16(Wp) && x_zstride % 4 == 0 && w_zstride % 8 == 0,
@@ -311,7 +423,7 @@ int gt_rec_gemm_bf16_prio(const float* X, int64_t ldx, const void* Wp, float* pa
     GT_REQUIRE(part_sstride >= (int64_t)mtiles * 16 * N && aligned16(part) && part_sstride % 4 == 0 && part_zstride % 4 == 0,
                GT_E_ARG, "gt_rec_gemm_bf16: part slabs too small or misaligned");
     const int KBS = cdiv(KB, splits);
-    const int max_nch = planes == 3 ? RB_NCH_X3 : RB_NCH;
+    const int max_nch = planes >= 2 ? RB_NCH_X3 : RB_NCH;
     GT_REQUIRE(cdiv(KB, KBS) == splits, GT_E_ARG, "gt_rec_gemm_bf16: splits=%d leaves empty slabs for K=%d", splits, K);
     GT_REQUIRE(KBS <= max_nch * RB_CB, GT_E_ARG, "gt_rec_gemm_bf16: K-slice of %d exceeds %d (use >= %d splits)", KBS * 32,
                max_nch * RB_CB * 32, cdiv(KB, max_nch * RB_CB));
@@ -319,18 +431,24 @@ int gt_rec_gemm_bf16_prio(const float* X, int64_t ldx, const void* Wp, float* pa
     hipStream_t st = (hipStream_t)stream;
     GtProfScope prof(GT_FAM_REC_GEMM, 2.0 * 16 * mtiles * (double)N * K * nz,
                      (double)nz * (2.0 * planes * N * K + 4.0 * (16.0 * mtiles * K + 16.0 * mtiles * N * splits)), st, true);
+    // (planes == 2: 4 bytes per weight, as fp32)
     const uint4* wp = reinterpret_cast<const uint4*>(Wp);
     const int nch = cdiv(KBS, RB_CB);           // chunks of a slice: one instantiation each (all loads issued up front)
 #define GT_RECB(MT, NCH, NP)                                                                                          \
     GT_LAUNCH_TIMED((rec_gemm_bf16_kernel<MT, NCH, NP>), grid, dim3(RB_THREADS), 0, st, prof.e0, prof.e1, X, (long)ldx, \
                           kvalid, wp, part, N, KB, KBS, (long)x_zstride, (long)(w_zstride / 8), (long)part_zstride,        \
-                          (long)part_sstride, prio)
+                          (long)part_sstride, prio, h2)
 #define GT_RECB_M(MT)                                  \
     if (planes == 3) switch (nch) {                    \
         case 1: GT_RECB(MT, 1, 3); break;              \
         case 2: GT_RECB(MT, 2, 3); break;              \
         case 3: GT_RECB(MT, 3, 3); break;              \
         default: GT_RECB(MT, 4, 3); break;             \
+    } else if (planes == 2) switch (nch) {             \
+        case 1: GT_RECB(MT, 1, 2); break;              \
+        case 2: GT_RECB(MT, 2, 2); break;              \
+        case 3: GT_RECB(MT, 3, 2); break;              \
+        default: GT_RECB(MT, 4, 2); break;             \
     } else switch (nch) {                              \
         case 1: GT_RECB(MT, 1, 1); break;              \
         case 2: GT_RECB(MT, 2, 1); break;              \
@@ -359,7 +477,12 @@ extern "C" int gt_pack_rec_cell_weight_x3(const float* W, int64_t ldw, int32_t H
     return pack_rec_planes("gt_pack_rec_cell_weight_x3", W, ldw, 0, 4 * H, 4 * H, K, H, Wp, 3, stream);
 }
 
-// launch of the bf16-operand (planes = 1) or three-plane fp32 (planes = 3) fused product + cell; arguments already
+extern "C" int gt_pack_rec_cell_weight_h2(const float* W, int64_t ldw, int32_t H, int32_t K, void* Wp, void* stream) {
+    GT_REQUIRE(H > 0 && H % 16 == 0, GT_E_ARG, "gt_pack_rec_cell_weight_h2: H=%d must be a multiple of 16", H);
+    return pack_rec_planes("gt_pack_rec_cell_weight_h2", W, ldw, 0, 4 * H, 4 * H, K, H, Wp, 2, stream);
+}
+
+// launch of the bf16-operand (planes = 1), two-fp16-plane (2) or three-bf16-plane fp32 (3) fused product + cell; arguments already
 // validated by gt_rec_cell_fwd_z (recurrent.hip)
 int gt_launch_rec_cell_bf16(const float* X, int64_t ldx, const void* Wp, float* part, int32_t Bp, int32_t N, int32_t K,
                             int32_t splits, int32_t ndir, int prio, const RecCellEpi& e, hipEvent_t e0, hipEvent_t e1,
@@ -367,8 +490,15 @@ int gt_launch_rec_cell_bf16(const float* X, int64_t ldx, const void* Wp, float* 
     const int KB = cdiv(K, 32);
     const int kvalid = cdiv(K, 16) * 16;
     const int KBS = cdiv(KB, splits);
-    const int max_nch = planes == 3 ? RB_NCH_X3 : RB_NCH;
-    GT_REQUIRE(planes == 1 || planes == 3, GT_E_ARG, "gt_rec_cell_fwd_bf16: planes");
+    const int max_nch = planes >= 2 ? RB_NCH_X3 : RB_NCH;
+    GT_REQUIRE(planes >= 1 && planes <= 3, GT_E_ARG, "gt_rec_cell_fwd_bf16: planes");
+    RecH2 h2 = {nullptr, nullptr, 0.f};
+    if (planes == 2) {
+        GT_REQUIRE(ndir == 1, GT_E_ARG, "gt_rec_cell_fwd_h2: one direction (one weight image: its trailer holds the scale)");
+        GT_REQUIRE(g_rec_h2x.xmax != nullptr || g_rec_h2x.xfloor > 0.f, GT_E_ARG, "gt_rec_cell_fwd_h2: no bound for the activations (xmax word or xfloor > 0)");
+        h2.wmax = h2_trailer(Wp, N, K); h2.xmax = (const unsigned long long*)g_rec_h2x.xmax; h2.xfloor = g_rec_h2x.xfloor;
+        g_rec_h2x = {nullptr, 0.f};
+    }
     GT_REQUIRE(cdiv(KB, KBS) == splits, GT_E_ARG, "gt_rec_cell_fwd_bf16: splits=%d leaves empty slabs for K=%d", splits, K);
     GT_REQUIRE(KBS <= max_nch * RB_CB, GT_E_ARG, "gt_rec_cell_fwd_bf16: K-slice of %d exceeds %d (use >= %d splits)", KBS * 32,
                max_nch * RB_CB * 32, cdiv(KB, max_nch * RB_CB));
@@ -381,13 +511,18 @@ int gt_launch_rec_cell_bf16(const float* X, int64_t ldx, const void* Wp, float* 
     const int nch = cdiv(KBS, RB_CB);
 #define GT_RCB(MT, NCH, NP)                                                                                              \
     GT_LAUNCH_TIMED((rec_cell_bf16_kernel<MT, NCH, NP>), grid, dim3(RB_THREADS), 0, st, e0, e1, X, (long)ldx, kvalid, wp, \
-                          part, N, KB, KBS, (long)(64 * ldx), (long)64 * N, ps, prio, e)
+                          part, N, KB, KBS, (long)(64 * ldx), (long)64 * N, ps, prio, e, h2)
 #define GT_RCB_M(MT)                                   \
     if (planes == 3) switch (nch) {                    \
         case 1: GT_RCB(MT, 1, 3); break;               \
         case 2: GT_RCB(MT, 2, 3); break;               \
         case 3: GT_RCB(MT, 3, 3); break;               \
         default: GT_RCB(MT, 4, 3); break;              \
+    } else if (planes == 2) switch (nch) {             \
+        case 1: GT_RCB(MT, 1, 2); break;               \
+        case 2: GT_RCB(MT, 2, 2); break;               \
+        case 3: GT_RCB(MT, 3, 2); break;               \
+        default: GT_RCB(MT, 4, 2); break;              \
     } else switch (nch) {                              \
         case 1: GT_RCB(MT, 1, 1); break;               \
         case 2: GT_RCB(MT, 2, 1); break;               \

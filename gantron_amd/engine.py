@@ -84,6 +84,17 @@ S2_BWD = sw.debug('s2_bwd')
 # with ATTN_BWD_CELL off it still loses: 118.2), and 1 740 launches and 14 GB of weight stream per pair are gone.
 # Default 15 (GANTRON_SCHEDULE=no_plstm or GANTRON_EXPERIMENTAL=plstm=<bits> to change it).
 PLSTM = sw.experimental('plstm', 15 if sw.schedule_on('plstm') else 0)
+# The attention LSTM's per-step products from two scaled fp16 planes per operand (gt_rec_cell_fwd_h2 forward, gt_rec_gemm_h2
+# backward: gt_sgemm's mode-4 arithmetic, 4 bytes per weight as fp32, 3/16 of the fp32 pipe's matrix time; bit 0 = forward,
+# bit 1 = backward).  Stand-alone (tools/rec_h2_probe.py, M = 64): backward product 8.7 against 13.3 us, forward product 8.8
+# against 11.6, error against float64 2-3e-8 of max sum |x||w| against the fp32 pipe's 3-5e-8.  In the step (one box, 16 pairs
+# per run): forward only 110.5 / 110.9 / 110.5 / 110.6 against 113.0 / 113.1 ms -- the forward loop 35.3 instead of 37.6 ms;
+# backward only 118.4; both 115.9 (111.0-111.7 with 8 or 16 K-splits of the backward product instead of 6): the backward
+# kernel is faster under the profiler too (14.4 against 15.8 us) but its 512-thread, 68 KB workgroups leave the weight-gradient
+# GEMMs beside the loop less room than the fp32 kernel's do.  Default 1 (GANTRON_SCHEDULE=no_rec_h2: the fp32 MFMA kernels in
+# both directions; engine.REC_H2 = 3 for both).  The backward form needs the step's max |dG1_t|, which the attention step's
+# cell tail leaves (ATTN_BWD_CELL).
+REC_H2 = 1 if sw.schedule_on('rec_h2') else 0
 # The attention LSTM's per-step products as exact fp32 products on the bf16 matrix pipe (three bf16 planes, csrc/recurrent_bf16.hip
 # NP = 3): bit 0 = the forward fused product + cell (gt_rec_cell_fwd_x3), bit 1 = the backward product (gt_rec_gemm_x3).
 # Measured (round 3) and not adopted: 31.1 us per forward launch against 26.7, 25.6 per backward product against 19.6, pair
@@ -323,6 +334,14 @@ def pack_rec_x3(W2d, N, n_valid, K, transposed=False):
     return out
 
 
+def pack_rec_h2(W2d, N, n_valid, K, transposed=False):
+    """Pack a (n_valid x K) [or (K x n_valid) when transposed] matrix as two scaled fp16 planes of MFMA fragments for
+    gt_rec_gemm_h2 (the scale's source, max |W|, is found here and kept in the image's trailer)."""
+    out = torch.empty(int(lib().gt_rec_weight_h2_elems(N, K)), device=W2d.device, dtype=torch.float16)
+    call('gt_pack_rec_weight_h2', W2d, W2d.stride(0), int(transposed), N, n_valid, K, out)
+    return out
+
+
 def rec_splits_x3(N, K, cus=256):
     """K-splits of the three-plane products (K-slices of at most 1024, gt_rec_x3_min_splits): the most splits whose
     workgroups (64 columns x one slice, one per CU: 101 KB of LDS) still fit `cus` CUs in one round; at least the minimum."""
@@ -340,6 +359,10 @@ def pack_rec_cell(W2d, H, K, bf16=False):
     if bf16 == 3 and bf16 is not True:
         out = torch.empty(int(lib().gt_rec_weight_x3_elems(4 * H, K)), device=W2d.device, dtype=torch.bfloat16)
         call('gt_pack_rec_cell_weight_x3', W2d, W2d.stride(0), H, K, out)
+        return out
+    if bf16 == 2 and bf16 is not True:          # two scaled fp16 planes (gt_rec_cell_fwd_h2)
+        out = torch.empty(int(lib().gt_rec_weight_h2_elems(4 * H, K)), device=W2d.device, dtype=torch.float16)
+        call('gt_pack_rec_cell_weight_h2', W2d, W2d.stride(0), H, K, out)
         return out
     if bf16:
         out = torch.empty(int(lib().gt_rec_weight_bf16_elems(4 * H, K)), device=W2d.device, dtype=torch.bfloat16)
@@ -708,7 +731,13 @@ class GeneratorEngine:
             if x3:      # the attention LSTM's product on the bf16 pipe, exactly (three planes): K-slices of at most 512
                 d.rec_x3 = 1
                 d.S1 = rec_splits_x3(4 * Ha, K1, 192 if ((PLSTM & 2) and lib().gt_plstm_supported(Bp, Hd)) else 256)
-            keep_t['W1c' if use_c1 else 'W1p'] = pack_rec_cell(W1cat, Ha, K1, 3 if x3 else self.bf16) if use_c1 else \
+            h2f = bool(REC_H2 & 1) and use_c1 and not self.bf16 and not x3
+            if h2f:     # ... from two scaled fp16 planes: [ctx | h_att] is bounded by max |memory| and 1 / (1 - p)
+                d.rec_x3 = 2
+                d.S1 = rec_splits_x3(4 * Ha, K1, 192 if ((PLSTM & 2) and lib().gt_plstm_supported(Bp, Hd)) else 256)
+                keep_t['x1max'] = ops.absmax(memory)
+                d.x1max, d.x1floor = ptr(keep_t['x1max']), 1.0625 / (1.0 - d.p_att)
+            keep_t['W1c' if use_c1 else 'W1p'] = pack_rec_cell(W1cat, Ha, K1, 3 if x3 else 2 if h2f else self.bf16) if use_c1 else \
                 pack(W1cat, 4 * Ha, 4 * Ha, K1)
             keep_t['W2hc' if use_c2 else 'W2hp'] = pack_rec_cell(W2hh, Hd, Hd, self.bf16) if use_c2 else \
                 pack(W2hh, 4 * Hd, 4 * Hd, Hd)
@@ -1092,7 +1121,11 @@ class GeneratorEngine:
         hoist2 = HOIST2 and not FUSED_CELL
         Hdpad = roundup(Hd, 16)
         x3b = bool(REC_X3 & 2) and not self.bf16 and Bp <= 64 and N1pad % 64 == 0
-        W1Tp = pack_rec_x3(W1cat, N1pad, K1, 4 * Ha, transposed=True) if x3b else packT(W1cat, N1pad, K1, 4 * Ha, transposed=True)
+        # two scaled fp16 planes: only with the attention step that carries the cell backward (it leaves max |dG1_t|) -- the
+        # conditions of `fused_attn` + ATTN_BWD_CELL below
+        h2b = (bool(REC_H2 & 2) and not self.bf16 and not x3b and ATTN_BWD_CELL and early is not None and 'u_hist' in hist and hoist2 and
+               N1pad % 16 == 0 and Ha % 16 == 0 and Ep % 4 == 0 and CELL_QUERY)
+        W1Tp = (pack_rec_x3 if x3b else pack_rec_h2 if h2b else packT)(W1cat, N1pad, K1, 4 * Ha, transposed=True)
         W2Tp = None if hoist2 else packT(W2cat, N2pad, K2, 4 * Hd, transposed=True)
         W2hTp = packT(W2hh, Hdpad, Hd, 4 * Hd, transposed=True) if hoist2 else None
         WqTp = pack_rec(Wq, Ha, Ha, A, transposed=True)
@@ -1110,6 +1143,9 @@ class GeneratorEngine:
         if x3b:
             b.rec_x3 = 1
             b.S1 = rec_splits_x3(N1pad, 4 * Ha)
+        if h2b:
+            b.rec_x3 = 2
+            b.S1 = rec_splits_x3(N1pad, 4 * Ha, 256)        # (8 splits at N1pad = 2048: measured best of 4 / 6 / 8 / 10 / 12 / 16)
         if S1_BWD and not self.bf16:
             b.S1 = S1_BWD
         b.N1pad, b.N2pad = N1pad, N2pad
@@ -1135,6 +1171,8 @@ class GeneratorEngine:
                    partX1=_f32(b.S1, Bp, N1pad, device=dev),
                    partX2=None if hoist2 else _f32(DEC_RING, b.S2, Bp, N2pad, device=dev),
                    partQ=_f32(b.Sq, Bp, Ha, device=dev))
+        if h2b:
+            buf['amaxG1'] = torch.zeros(To, dtype=torch.int64, device=dev)
         if hoist2:
             ldxa = roundup(Ha + Ep, 4)
             W2ih_c = W2ihp

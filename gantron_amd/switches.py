@@ -22,6 +22,8 @@ GANTRON_SCHEDULE       comma list switching OFF parts of the default schedule (w
                        launches instead of the persistent LSTM recurrences), no_attn_bwd_fused (context and energies backward
                        of a step as two launches), no_attn_bwd_cell (the attention LSTM's cell backward as a launch of its own
                        instead of inside the backward attention step's: gt_attn_bwd_step_cell),
+                       no_rec_h2 (the attention LSTM's forward step on the fp32 matrix pipe instead of from two scaled fp16 planes:
+                       gt_rec_cell_fwd_h2),
                        no_wterms_in_forward (gt_attn_bwd_wterms at the top of the backward pass instead of behind the forward
                        loop), no_dist_overlap.
 GANTRON_DEBUG          comma list of diagnostics: phase_timing, host_timing, block_timing, dist_timing, attn_valu,
@@ -44,7 +46,7 @@ _KNOWN = {
     'GANTRON_EXPERIMENTAL': {'fused_cell', 'attn_step', 'leaf_defer', 'rec_cellbwd', 'plane_gemms', 'plstm', 'rec_x3', 'graph',
                              'no_pgemm2', 'rec_tail', 'blk_gemm_aside'},
     'GANTRON_SCHEDULE': {'no_cell_query', 'no_attn_hoist', 'no_hoist2', 'no_leaf_stream', 'no_fwd_splitk', 'no_rec_cell',
-                         'no_attn_step2', 'no_plstm', 'no_attn_bwd_fused', 'no_attn_bwd_cell', 'no_wterms_in_forward',
+                         'no_attn_step2', 'no_plstm', 'no_attn_bwd_fused', 'no_attn_bwd_cell', 'no_rec_h2', 'no_wterms_in_forward',
                          'no_dist_overlap'},
     'GANTRON_DEBUG': {'phase_timing', 'host_timing', 'block_timing', 'dist_timing', 'attn_valu', 'rec', 'fused', 'pgemm',
                       'rec_splits', 's1_fwd', 's2_fwd', 's2_bwd', 's1_bwd', 'enc_splits', 'sync_every', 'rec_lds_pad',

@@ -31,7 +31,7 @@ extern "C" {
 #define GT_E_ALIGN (-2)   /* pointer or leading dimension violates an alignment requirement */
 #define GT_E_LIMIT (-3)   /* size exceeds a compiled-in limit */
 
-#define GT_ABI_VERSION 402      /* bumped whenever a declared signature, struct layout or buffer size changes */
+#define GT_ABI_VERSION 403      /* bumped whenever a declared signature, struct layout or buffer size changes */
 int gt_version(void);           /* GT_ABI_VERSION of the library that was built: compare it with the header's at load */
 const char* gt_last_error_string(void);
 /* sizeof of ABI structs: 0 GtOperand, 1 GtGemm, 2 GtSlabs, 3 GtAttnDims, 4 GtDecoderFwd,
@@ -441,9 +441,14 @@ typedef struct GtDecoderFwd {
     /* attn_xbuf != NULL (with row_cnt, and gt_attn_step2_supported): energies + softmax + context of a step are ONE launch
      * with NO in-launch wait (gt_attn_step2_fwd): B * ceil(Ti / 32) rows of gt_attn_step2_xstride(d) floats. */
     float* attn_xbuf;
-    /* 1 (fp32 mode only, bf16 = 0): W1c is a gt_pack_rec_cell_weight_x3 image and the attention LSTM's fused product + cell
-     * runs as gt_rec_cell_fwd_x3 -- the exact fp32 product from three bf16 planes, on the bf16 matrix pipe */
+    /* fp32 mode only (bf16 = 0).  1: W1c is a gt_pack_rec_cell_weight_x3 image and the attention LSTM's fused product + cell
+     * runs as gt_rec_cell_fwd_x3 (three bf16 planes).  2 (round 4, the engine's default): W1c is a gt_pack_rec_cell_weight_h2
+     * image and the step runs as gt_rec_cell_fwd_h2 (two scaled fp16 planes); its activations [ctx | h_att] are bounded by
+     * max(x1floor, the value in *x1max): x1max = gt_absmax word of `memory` (every context is a convex combination of its
+     * rows), x1floor = 1 / (1 - p_att) (|h_att| = |o tanh c| / (1 - p)) */
     int32_t rec_x3;
+    const uint64_t* x1max;
+    float x1floor;
     /* tail_work != NULL (with W1c, attn_xbuf, fp32, Bp <= 64, E % 16 == 0, Sx1 >= 1): the h_att half of the attention LSTM's
      * product leaves its launch (GtRecTail): the workgroups of attention step t that have nothing (more) to do compute
      * h_att_t . W1[:, E:]^T in Sx1 K-slices into slabs S1 .. S1 + Sx1 - 1 of `part` (which then holds S1 + Sx1 slabs), and
@@ -523,6 +528,10 @@ typedef struct GtDecoderBwd {
     /* 1 (fp32 mode only, bf16 = 0): W1Tp is a gt_pack_rec_weight_x3 image and the attention LSTM's backward product runs as
      * gt_rec_gemm_x3 */
     int32_t rec_x3;
+    /* rec_x3 == 2 (round 4; needs rowcntA): W1Tp is a gt_pack_rec_weight_h2 image and the attention LSTM's backward product
+     * runs as gt_rec_gemm_h2; amaxG1 = To zero-initialised words, word t receives max |dG1_t| from the attention step's
+     * cell tail (GtCellBwdTail.dg_amax) one launch in front of the product that reads it */
+    uint64_t* amaxG1;
     /* != NULL (with the fused backward attention step above and Wq): B zero-initialised words -- the attention LSTM's cell
      * backward rides in the attention step's launch (gt_attn_bwd_step_cell), two dependent launches per step instead of
      * three.  The words are shared by ALL calls of one backward pass (the step's launch number is To - t). */
@@ -636,6 +645,8 @@ typedef struct GtCellBwdTail {
     float* dc_prev;
     int32_t H;
     uint32_t* row_cnt; uint32_t launch;
+    uint64_t* dg_amax;      /* optional: zero-initialised word that receives max |dgates| of the step in gt_absmax's format (for
+                               gt_rec_gemm_h2 behind this launch) */
 } GtCellBwdTail;
 int gt_attn_bwd_step_cell(GtAttnDims d, GtSlabs dctx_a, GtSlabs dctx_b, const float* dctx_direct, int64_t ld_direct,
                           const float* memory, int64_t ld_mem, const int32_t* lengths, float* dwcat_in, float* dcum_acc,
@@ -879,6 +890,27 @@ int gt_rec_cell_fwd_x3(const float* X, int64_t ldx, const void* Wp, float* part,
                          float* h_raw, float* h0, int64_t ld0, float* h1, int64_t ld1, float* h2, int64_t ld2,
                          const float* Wq, int64_t ldwq, float* qpart, int64_t q_sstride, int32_t A, int32_t Apad,
                          int32_t prio, void* stream);
+
+/* The same two kernels from TWO SCALED fp16 planes per operand ("h2", round 4): gt_sgemm's mode-4 arithmetic for the recurrent
+ * products -- x s = h0 + h1 with s a power of two that puts the operand tensor's largest magnitude into [2^14, 2^15), a . b =
+ * (a0 b0 + a0 b1 + a1 b0) / (sa sb) as three fp16 MFMAs with fp32 accumulation, 22 significand bits per operand -- at 4 bytes
+ * per weight (what the fp32 kernels stream) and 3/16 of their matrix time.  The pack finds max |W| itself (gt_absmax) and
+ * keeps the word in a 16-byte trailer of the image (gt_rec_weight_h2_elems counts it); the activations' bound is `xmax` (a
+ * gt_absmax-format device word of a superset of X, or NULL) and / or `xfloor` (a magnitude known a priori, 0: none).
+ * One weight image per launch (no w_zstride, one direction). */
+int64_t gt_rec_weight_h2_elems(int32_t N, int32_t K);
+int gt_pack_rec_weight_h2(const float* W, int64_t ldw, int32_t transposed, int32_t N, int32_t n_valid,
+                          int32_t K, void* Wp, void* stream);
+int gt_rec_gemm_h2(const float* X, int64_t ldx, const void* Wp, float* part, int32_t mtiles, int32_t N,
+                   int32_t K, int32_t splits, int64_t part_sstride, int32_t nz, int64_t x_zstride,
+                   int64_t part_zstride, const uint64_t* xmax, float xfloor, void* stream);
+int gt_pack_rec_cell_weight_h2(const float* W, int64_t ldw, int32_t H, int32_t K, void* Wp, void* stream);
+int gt_rec_cell_fwd_h2(const float* X, int64_t ldx, const void* Wp, float* part, uint32_t* counters, int32_t Bp,
+                       int32_t B, int32_t H, int32_t K, int32_t splits, const float* pre, int64_t ld_pre,
+                       const float* c_prev, const uint8_t* keep, float p_drop, float* gates, float* c_out,
+                       float* h_raw, float* h0, int64_t ld0, float* h1, int64_t ld1, float* h2, int64_t ld2,
+                       const float* Wq, int64_t ldwq, float* qpart, int64_t q_sstride, int32_t A, int32_t Apad,
+                       const uint64_t* xmax, float xfloor, int32_t prio, void* stream);
 
 /* diagnostics (GANTRON_DEBUG=rec_stamps): wall-clock stamps (10 ns ticks) of the phases of the last attention-LSTM
  * gt_rec_cell_fwd launch, 8 per workgroup (0 start, 1 first operands in LDS, 2 MFMAs done, 3 tile published, 4 other slabs

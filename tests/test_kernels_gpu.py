@@ -457,9 +457,52 @@ def test_rec_gemm_x3(dev, Bsz, N, K):
         assert float(part2.sum(0)[:, K:].abs().max()) == 0.0          # padded columns meet zero weights
 
 
+@pytest.mark.parametrize('Bsz,N,K,xs', [(64, 4096, 1536, 1.0), (64, 1536, 4096, 1e-7), (5, 128, 40, 3e4), (33, 192, 1100, 1.0),
+                                        (64, 4096, 2117, 1e-3), (128, 1536, 4096, 1e-5)])
+def test_rec_gemm_h2(dev, Bsz, N, K, xs):
+    """gt_rec_gemm_h2: the fp32 product from two SCALED fp16 planes per operand (three exact fp16 MFMA products, fp32
+    accumulation; the weights' scale from the image's trailer, the activations' from a gt_absmax word or a floor) against
+    float64, held to the accuracy of an fp32 product over operands that span five decades inside one reduction and activations
+    far outside fp16's range (gradient-sized 1e-7, 3e4); plain and transposed packing; two 64-row blocks on one weight image."""
+    from gantron_amd import ops
+    from gantron_amd._lib import lib
+    from gantron_amd.engine import pack_rec_h2, rec_splits_x3
+    Bp = ops.roundup(Bsz, 16) if Bsz <= 64 else ops.roundup(Bsz, 64)
+    ld = ops.roundup(K, 16)
+    mt, nz = (Bp // 16, 1) if Bp <= 64 else (4, Bp // 64)
+    gen = torch.Generator().manual_seed(N + K)
+    W = g(N, K, scale=0.1) * torch.pow(10.0, torch.randint(-3, 2, (N, K), generator=gen).float())
+    X = torch.zeros(Bp, ld)
+    X[:Bsz, :K] = g(Bsz, K, seed=1) * xs * torch.pow(10.0, torch.randint(-2, 3, (Bsz, K), generator=gen).float())
+    S = rec_splits_x3(N, K)
+    Wp = pack_rec_h2(W.to(dev), N, N, K)
+    Xd = X.to(dev)
+    ref = X[:Bsz, :K].double() @ W.double().t()
+    mag = X[:Bsz, :K].double().abs() @ W.double().abs().t()
+    for xmax, floor in ((ops.absmax(Xd), 0.0), (None, float(X.abs().max()) * 1.7)):        # a measured maximum; an a-priori bound
+        part = torch.full((S, Bp, N), float('nan'), device=dev)
+        ops.call('gt_rec_gemm_h2', Xd, ld, Wp, part, mt, N, K, S, Bp * N, nz, 64 * ld, 64 * N, xmax, floor)
+        err = ((part.sum(0)[:Bsz].cpu().double() - ref).abs() / mag).max()
+        assert float(err) < 4e-7, f'rec_gemm_h2: error {float(err):.3g} of sum |a||b|'
+    N2 = ops.roundup(K, 16)
+    WTp = pack_rec_h2(W.to(dev), N2, K, N, transposed=True)
+    X2 = torch.zeros(Bp, N)
+    X2[:Bsz] = g(Bsz, N, seed=2) * xs
+    S2 = rec_splits_x3(N2, N)
+    part2 = torch.full((S2, Bp, N2), float('nan'), device=dev)
+    X2d = X2.to(dev)
+    ops.call('gt_rec_gemm_h2', X2d, N, WTp, part2, mt, N2, N, S2, Bp * N2, nz, 64 * N, 64 * N2, ops.absmax(X2d), 0.0)
+    ref2 = X2[:Bsz].double() @ W.double()
+    mag2 = X2[:Bsz].double().abs() @ W.double().abs()
+    err2 = ((part2.sum(0)[:Bsz, :K].cpu().double() - ref2).abs() / mag2).max()
+    assert float(err2) < 4e-7, f'rec_gemm_h2 transposed: error {float(err2):.3g} of sum |a||b|'
+    if N2 > K:
+        assert float(part2.sum(0)[:, K:].abs().max()) == 0.0          # padded columns meet zero weights
+
+
 @pytest.mark.parametrize('Bsz,H,K,S,A', [(64, 1024, 2048, 4, 128), (5, 32, 100, 2, 8), (70, 64, 333, 3, 40), (64, 1024, 1024, 4, 0),
                                          (33, 48, 50, 1, 24), (64, 1024, 3072, 6, 0)])
-@pytest.mark.parametrize('bf16', [False, True, 3])
+@pytest.mark.parametrize('bf16', [False, True, 3, 2])
 def test_rec_cell_fused(dev, Bsz, H, K, S, A, bf16):
     """gt_rec_cell_fwd = gt_rec_gemm + gt_lstm_cell_fwd (+ the query projection) in ONE launch: the K-splits of a
     column group meet through write-through slabs and a ticket, the last one runs the cell.  Three launches in a
@@ -477,13 +520,13 @@ def test_rec_cell_fused(dev, Bsz, H, K, S, A, bf16):
         kb = -(-K // 32)
         S = next(s for s in range(max(S, int(lib().gt_rec_bf16_min_splits(K))), 17) if -(-kb // -(-kb // s)) == s)
         W = W.bfloat16().float()
-    elif bf16 == 3:           # gt_rec_cell_fwd_x3: the exact fp32 product from three bf16 planes, K-slices of at most 512
+    elif bf16 in (3, 2):      # gt_rec_cell_fwd_x3 / _h2: the fp32 product from three bf16 / two scaled fp16 planes, K-slices of at most 1024
         kb = -(-K // 32)
         S = next(s for s in range(max(S, int(lib().gt_rec_x3_min_splits(K))), 17) if -(-kb // -(-kb // s)) == s)
     else:
         S = ops.pick_splits(K, S)
     Wp = pack_rec_cell(W.to(dev), H, K, bf16)
-    fn = 'gt_rec_cell_fwd_bf16' if bf16 is True else 'gt_rec_cell_fwd_x3' if bf16 == 3 else 'gt_rec_cell_fwd'
+    fn = 'gt_rec_cell_fwd_bf16' if bf16 is True else 'gt_rec_cell_fwd_x3' if bf16 == 3 else 'gt_rec_cell_fwd_h2' if bf16 == 2 else 'gt_rec_cell_fwd'
     Wq = g(max(A, 1), H, seed=4, scale=0.1)
     part = torch.full((S, Bp, 4 * H), float('nan'), device=dev)
     counters = torch.zeros((Bp // 64 if Bp > 64 else 1) * (H // 16), dtype=torch.int32, device=dev)
@@ -502,9 +545,12 @@ def test_rec_cell_fused(dev, Bsz, H, K, S, A, bf16):
         c_out = torch.zeros(Bp, H, device=dev); h_raw = torch.zeros(Bp, H, device=dev)
         h0 = torch.zeros(Bp, H + 8, device=dev); h1 = torch.zeros(Bp, H, device=dev)
         qpart = torch.full((H // 16, Bp, Apad), float('nan'), device=dev)
-        ops.call(fn, X.to(dev), ld, Wp, part, counters, Bp, Bsz, H, K, S, gates, 4 * H, c_prev.to(dev),
+        Xd = X.to(dev)
+        # (h2: the activations' bound is a measured maximum on even launches, an a-priori one on odd launches)
+        h2x = () if bf16 != 2 or bf16 is True else ((ops.absmax(Xd), 0.0) if rep % 2 == 0 else (None, float(X.abs().max()) * 1.3))
+        ops.call(fn, Xd, ld, Wp, part, counters, Bp, Bsz, H, K, S, gates, 4 * H, c_prev.to(dev),
                  keep.to(torch.uint8).to(dev), p, gates, c_out, h_raw, ops.ptr(h0, 4), H + 8, h1, H, None, 0,
-                 Wq.to(dev) if A else None, H, qpart if A else None, Bp * Apad, A, Apad, 3)
+                 Wq.to(dev) if A else None, H, qpart if A else None, Bp * Apad, A, Apad, *h2x, 3)
         close(c_out[:Bsz], c, rtol=1e-5, atol=2e-5, what=f'c (launch {rep})')
         close(h_raw[:Bsz], h, rtol=1e-5, atol=2e-5, what=f'h (launch {rep})')
         close(h0[:Bsz, 4:4 + H], h, rtol=1e-5, atol=2e-5, what='h strided')
