@@ -621,7 +621,11 @@ def main():
                                 valid_frames_per_rank=frames, padded_frames_per_rank=args.batch * To,
                                 parallelism='dp%d' % world, pair_tflop=fl / 1e12,
                                 tiled_gemm_arithmetic='bf16 operands, fp32 accumulation' if args.bf16 else GEMM_ARITH,
-                                recurrent_product_arithmetic='bf16 operands, fp32 accumulation' if args.bf16 else 'fp32 MFMA (v_mfma_f32_16x16x4_f32)',
+                                recurrent_product_arithmetic='bf16 operands, fp32 accumulation' if args.bf16 else
+                                ('fp32 MFMA (v_mfma_f32_16x16x4_f32); the attention LSTM\'s forward step (bit 0 of engine.REC_H2 = %d; bit 1: its '
+                                 'backward product) from two scaled fp16 planes per operand, three v_mfma_f32_16x16x32_f16, fp32 accumulation '
+                                 '(22 significand bits per operand: tests/test_kernels_gpu.py::test_rec_gemm_h2)' % _engine.REC_H2
+                                 if _engine.REC_H2 else 'fp32 MFMA (v_mfma_f32_16x16x4_f32)'),
                                 padded_frames_per_s=args.batch * To * world * args.steps / elapsed,
                                 pair_ms_min_median_max=[round(pair_ms[0], 2), round(pair_ms[len(pair_ms) // 2], 2), round(pair_ms[-1], 2)],
                                 g_step_ms=g_s * 1e3, d_step_ms=d_s * 1e3,

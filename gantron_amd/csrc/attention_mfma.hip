@@ -1052,8 +1052,11 @@ struct SharedStep {
     float dots[CT];
 };
 
+// (amdgpu_waves_per_eu(1, 2): the grid never puts more than two of these workgroups on a CU, so the compiler may spend registers
+// -- without it the generic-width instantiation, 79 registers, keeps the tail's 128 loads of Wq to a handful in flight so as not to
+// lose an occupancy it cannot use: 50.6 us per launch at E = 1096 against 21.7 at E = 1024, tools/attn_bwd_cell_bench.py)
 template <bool VEC, int NE4, bool TAIL = false>
-__global__ __launch_bounds__(256) void attn_bwd_step_kernel(AttnBwdStep a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void attn_bwd_step_kernel(AttnBwdStep a) {
     __builtin_amdgcn_s_setprio(3);      // the attention chain is the serial critical path of the decoder loops
     extern __shared__ __attribute__((aligned(16))) float dctx[];   // E floats
     __shared__ SharedStep S;

@@ -329,15 +329,15 @@ static int decoder_fwd_hoisted(const GtDecoderFwd* a, void* stream) {
                                        a->cum_hist + (int64_t)t * BT, a->cum_hist + (int64_t)(t + 1) * BT, X1n, a->ld1,
                                        XAt + a->Ha, a->ld2, hc_t + a->Hd, hc_ld, sA));
         }
-        // ---- decoder LSTM (stream B): input pre-activations of the block, then its recurrence.  (GANTRON_EXPERIMENTAL=
-        // blk_gemm_aside, the default of round 3: the block GEMM on a stream of its own (C), beside the recurrence of the block
-        // before -- with three bf16 planes per operand the GEMM took 170 us and stream B's 700 us per block had fallen behind the
-        // attention chain's 620.  On fp16 planes it takes ~120 and the extra stream loses: 112.2-112.4 against 111.7 ms per pair,
-        // three alternating runs.)  Where the GEMM is wide -- the VESUS memory, K = Ha + E = 2120 -- stream B is the longer chain
-        // again and the third stream still pays (122.9 against 124.7 ms): it is used from K = 2048 on.
+        // ---- decoder LSTM (stream B): input pre-activations of the block, then its recurrence.  With the persistent recurrence
+        // the block GEMM goes to a stream of its own (C): the GEMM of block n + 1 then runs beside the recurrence of block n
+        // instead of in front of it -- 530 us per block on stream B instead of 700, which the attention chain (620) had overtaken.
+        // (Round 4: whether this pays follows which chain is the longer one.  With the block GEMM on fp16 planes, ~120 us, and the
+        // attention LSTM's step still on the fp32 pipe, stream B alone was enough: 111.7 against 112.2-112.4 ms per pair without the
+        // third stream; with the attention chain itself shortened -- gt_rec_cell_fwd_h2 -- stream B is the longer chain again and
+        // the third stream wins 109.3-109.4 against 110.2-110.5; the VESUS memory width, K = 2120: 122.9 against 124.7.)
         hipStream_t sG = sB;
-        static const int gemm_aside_forced = gt_env_item("GANTRON_EXPERIMENTAL", "blk_gemm_aside", 0) != 0;
-        const bool gemm_aside = gemm_aside_forced || a->Ha + a->E >= 2048;
+        static const int gemm_aside = gt_env_item("GANTRON_SCHEDULE", "no_blk_gemm_aside", 0) == 0;
         if (two && persistB && gemm_aside && !g_gt_capturing) GT_TRY(aux2_stream(ctx, &sG));
         if (two) {
             GT_TRY(loop_event(ctx, 1 + (size_t)(nblock % 32), &ev));

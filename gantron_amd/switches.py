@@ -12,9 +12,7 @@ GANTRON_EXPERIMENTAL   comma list `name[=int]` of paths that were built, are par
                          decoder forward blocks, 4 encoder backward, 8 decoder backward blocks; 0 = per-step launches),
                          rec_x3=<bits> (attention-LSTM products from three bf16 planes: 1 forward, 2 backward), graph[=2] (hipGraph replay of the decoder loops; 2 also reports capture / replay),
                          no_pgemm2 (keep the plane GEMMs on 128 x 128 tiles), rec_tail[=slices] (the h_att half of the
-                         attention LSTM's forward product rides in the attention step in front of it: csrc/rec_tail.h), blk_gemm_aside (the
-                         forward loop's block GEMMs on a third stream instead of the decoder-LSTM chain's own whatever their
-                         width; the default does so from K = Ha + E = 2048 on).
+                         attention LSTM's forward product rides in the attention step in front of it: csrc/rec_tail.h).
 GANTRON_SCHEDULE       comma list switching OFF parts of the default schedule (what the schedule-invariance test toggles
                        through the module attributes instead): no_cell_query, no_attn_hoist, no_hoist2, no_leaf_stream,
                        no_fwd_splitk, no_rec_cell (per-step product + cell launches instead of the fused ones), no_attn_step2 (energies
@@ -22,6 +20,7 @@ GANTRON_SCHEDULE       comma list switching OFF parts of the default schedule (w
                        launches instead of the persistent LSTM recurrences), no_attn_bwd_fused (context and energies backward
                        of a step as two launches), no_attn_bwd_cell (the attention LSTM's cell backward as a launch of its own
                        instead of inside the backward attention step's: gt_attn_bwd_step_cell),
+                       no_blk_gemm_aside (the forward loop's block GEMMs on the decoder-LSTM chain's own stream instead of a third one),
                        no_rec_h2 (the attention LSTM's forward step on the fp32 matrix pipe instead of from two scaled fp16 planes:
                        gt_rec_cell_fwd_h2),
                        no_wterms_in_forward (gt_attn_bwd_wterms at the top of the backward pass instead of behind the forward
@@ -44,9 +43,9 @@ import os as _os
 # every name the package (Python or C side) looks up; keep in step with the docstring above
 _KNOWN = {
     'GANTRON_EXPERIMENTAL': {'fused_cell', 'attn_step', 'leaf_defer', 'rec_cellbwd', 'plane_gemms', 'plstm', 'rec_x3', 'graph',
-                             'no_pgemm2', 'rec_tail', 'blk_gemm_aside'},
+                             'no_pgemm2', 'rec_tail'},
     'GANTRON_SCHEDULE': {'no_cell_query', 'no_attn_hoist', 'no_hoist2', 'no_leaf_stream', 'no_fwd_splitk', 'no_rec_cell',
-                         'no_attn_step2', 'no_plstm', 'no_attn_bwd_fused', 'no_attn_bwd_cell', 'no_rec_h2', 'no_wterms_in_forward',
+                         'no_attn_step2', 'no_plstm', 'no_attn_bwd_fused', 'no_attn_bwd_cell', 'no_rec_h2', 'no_blk_gemm_aside', 'no_wterms_in_forward',
                          'no_dist_overlap'},
     'GANTRON_DEBUG': {'phase_timing', 'host_timing', 'block_timing', 'dist_timing', 'attn_valu', 'rec', 'fused', 'pgemm',
                       'rec_splits', 's1_fwd', 's2_fwd', 's2_bwd', 's1_bwd', 'enc_splits', 'sync_every', 'rec_lds_pad',

@@ -326,7 +326,7 @@ def test_switch_lists_reject_unknown_names_and_trim_like_the_c_parser(monkeypatc
     if fn is None:
         pytest.skip('gt_env_item is not exported under its mangled name')
     fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int]
-    monkeypatch.setenv('GT_TEST_LIST', ' plstm = 5 ; rec_tail ,graph=2, blk_gemm_aside ,x')
+    monkeypatch.setenv('GT_TEST_LIST', ' plstm = 5 ; rec_tail ,graph=2, no_blk_gemm_aside ,x')
     assert fn(b'GT_TEST_LIST', b'plstm', 0) == 5 and fn(b'GT_TEST_LIST', b'rec_tail', 0) == 1
-    assert fn(b'GT_TEST_LIST', b'graph', 0) == 2 and fn(b'GT_TEST_LIST', b'blk_gemm_aside', 0) == 1
+    assert fn(b'GT_TEST_LIST', b'graph', 0) == 2 and fn(b'GT_TEST_LIST', b'no_blk_gemm_aside', 0) == 1
     assert fn(b'GT_TEST_LIST', b'rec', 7) == 7 and fn(b'GT_TEST_LIST', b'pl', 9) == 9        # prefixes are not matches

@@ -783,16 +783,16 @@ def test_graph_replayed_decoder_loops_against_oracle(dev, tmp_path, case, passes
     assert out.stderr.count('[graph] capture') >= 2, out.stderr[-2000:]       # forward loop + at least one backward chunk
 
 
-def test_block_gemms_on_a_third_stream_against_oracle(dev, tmp_path):
-    """GANTRON_EXPERIMENTAL=blk_gemm_aside (round 3's default, opt-in since round 4): the forward loop's block GEMMs on a stream of
-    their own beside the decoder LSTM's persistent recurrence, with the two extra cross-stream hand-offs per block.  Read once per
-    process by the C side, so the case runs in a child process: a whole pair at the reference's dimensions, 64 rows."""
+def test_block_gemms_on_the_decoder_chains_own_stream_against_oracle(dev, tmp_path):
+    """GANTRON_SCHEDULE=no_blk_gemm_aside: the forward loop's block GEMMs in front of the decoder LSTM's persistent recurrence on ITS
+    stream instead of a third one (the default, with two extra cross-stream hand-offs per block).  Read once per process by the C
+    side, so the case runs in a child process: a whole pair at the reference's dimensions, 64 rows."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / 'aside_worker.py'
     script.write_text(_GRAPH_WORKER)
-    env = dict(os.environ, GANTRON_EXPERIMENTAL='blk_gemm_aside')
+    env = dict(os.environ, GANTRON_SCHEDULE='no_blk_gemm_aside')
     out = subprocess.run([sys.executable, str(script), root, 'full_dims_b64', '1'], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
     assert 'graph worker OK' in out.stdout

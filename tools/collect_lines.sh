@@ -15,5 +15,6 @@ line fp32pipe --no-cpu-baseline --fp32-split 0 &&
 GANTRON_SCHEDULE=no_attn_bwd_cell line schedule_no_attn_bwd_cell --no-cpu-baseline --no-data-path --steps 16 &&
 GANTRON_EXPERIMENTAL=plstm=7 line experimental_plstm7 --no-cpu-baseline --no-data-path --steps 16 &&
 GANTRON_SCHEDULE=no_plstm line schedule_no_plstm --no-cpu-baseline --no-data-path --steps 16 &&
-GANTRON_EXPERIMENTAL=blk_gemm_aside line experimental_blk_gemm_aside --no-cpu-baseline --no-data-path --steps 16 &&
+GANTRON_SCHEDULE=no_blk_gemm_aside line schedule_no_blk_gemm_aside --no-cpu-baseline --no-data-path --steps 16 &&
+GANTRON_SCHEDULE=no_rec_h2 line schedule_no_rec_h2 --no-cpu-baseline --no-data-path --steps 16 &&
 line same_box_default --no-cpu-baseline --no-data-path --steps 16
