@@ -731,7 +731,7 @@ class GeneratorEngine:
             if x3:      # the attention LSTM's product on the bf16 pipe, exactly (three planes): K-slices of at most 512
                 d.rec_x3 = 1
                 d.S1 = rec_splits_x3(4 * Ha, K1, 192 if ((PLSTM & 2) and lib().gt_plstm_supported(Bp, Hd)) else 256)
-            h2f = bool(REC_H2 & 1) and use_c1 and not self.bf16 and not x3
+            h2f = bool(REC_H2 & 1) and use_c1 and not self.bf16 and not x3 and not REC_TAIL_FWD     # (rec_tail rides on the fp32 kernel)
             if h2f:     # ... from two scaled fp16 planes: [ctx | h_att] is bounded by max |memory| and 1 / (1 - p)
                 d.rec_x3 = 2
                 d.S1 = rec_splits_x3(4 * Ha, K1, 192 if ((PLSTM & 2) and lib().gt_plstm_supported(Bp, Hd)) else 256)
