@@ -622,8 +622,8 @@ def main():
                                 parallelism='dp%d' % world, pair_tflop=fl / 1e12,
                                 tiled_gemm_arithmetic='bf16 operands, fp32 accumulation' if args.bf16 else GEMM_ARITH,
                                 recurrent_product_arithmetic='bf16 operands, fp32 accumulation' if args.bf16 else
-                                ('fp32 MFMA (v_mfma_f32_16x16x4_f32); the attention LSTM\'s forward step (bit 0 of engine.REC_H2 = %d; bit 1: its '
-                                 'backward product) from two scaled fp16 planes per operand, three v_mfma_f32_16x16x32_f16, fp32 accumulation '
+                                ('fp32 MFMA (v_mfma_f32_16x16x4_f32) in the persistent recurrences; the attention LSTM\'s forward step and backward product '
+                                 '(bits 0 / 1 of engine.REC_H2 = %d) from two scaled fp16 planes per operand, three v_mfma_f32_16x16x32_f16, fp32 accumulation '
                                  '(22 significand bits per operand: tests/test_kernels_gpu.py::test_rec_gemm_h2)' % _engine.REC_H2
                                  if _engine.REC_H2 else 'fp32 MFMA (v_mfma_f32_16x16x4_f32)'),
                                 padded_frames_per_s=args.batch * To * world * args.steps / elapsed,

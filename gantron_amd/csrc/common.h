@@ -54,6 +54,9 @@ int gt_rec_gemm_prio(const float* X, int64_t ldx, const float* Wp, float* part, 
 // gt_absmax-format device word (NULL: none) and / or a floor known a priori; the launcher takes it and clears it
 struct GtRecH2X { const uint64_t* xmax; float xfloor; };
 extern thread_local GtRecH2X g_rec_h2x;
+int gt_rec_gemm_h2_lean(const float* X, int64_t ldx, const void* Wp, float* part, int32_t mtiles, int32_t N, int32_t K,
+                        int32_t splits, int64_t part_sstride, int32_t nz, int64_t x_zstride, int64_t part_zstride,
+                        const uint64_t* xmax, float xfloor, int prio, void* stream);      // recurrent.hip
 int gt_rec_gemm_bf16_prio(const float* X, int64_t ldx, const void* Wp, float* part, int32_t mtiles, int32_t N, int32_t K,
                           int32_t splits, int64_t part_sstride, int32_t nz, int64_t x_zstride, int64_t w_zstride,
                           int64_t part_zstride, int prio, void* stream, int planes = 1);

@@ -36,6 +36,13 @@ static int rec_rows(const float* X, int64_t ldx, const float* Wp, float* part, i
     if (bf16) {         // Wp is a bf16 fragment image (gt_pack_rec_weight_bf16), three planes of them (bf16 == 3: _x3) or two
                         // scaled fp16 planes (bf16 == 2: _h2; the caller has named the activations' bound in g_rec_h2x)
         const int planes = bf16 == 3 ? 3 : bf16 == 2 ? 2 : 1;
+        static const int h2_big = gt_env_item("GANTRON_DEBUG", "rec_h2_big", 0);
+        if (planes == 2 && !h2_big) {       // the fp16-plane product in the fp32 kernel's geometry (recurrent.hip)
+            const GtRecH2X hx = g_rec_h2x;
+            g_rec_h2x = {nullptr, 0.f};
+            if (Bp <= 64) return gt_rec_gemm_h2_lean(X, ldx, Wp, part, Bp / 16, N, K, S, (int64_t)Bp * N, 1, 0, 0, hx.xmax, hx.xfloor, prio, stream);
+            return gt_rec_gemm_h2_lean(X, ldx, Wp, part, 4, N, K, S, (int64_t)Bp * N, Bp / 64, 64 * ldx, (int64_t)64 * N, hx.xmax, hx.xfloor, prio, stream);
+        }
         if (Bp <= 64) return gt_rec_gemm_bf16_prio(X, ldx, Wp, part, Bp / 16, N, K, S, (int64_t)Bp * N, 1, 0, 0, 0, prio, stream, planes);
         return gt_rec_gemm_bf16_prio(X, ldx, Wp, part, 4, N, K, S, (int64_t)Bp * N, Bp / 64, 64 * ldx, 0, (int64_t)64 * N, prio,
                                      stream, planes);

@@ -241,6 +241,162 @@ __global__ __launch_bounds__(REC_THREADS) void rec_gemm_kernel(const float* __re
                            min(KB, kb0 + KBS), blockIdx.x);
 }
 
+// ---- The same product from two SCALED fp16 planes per operand ("h2": recurrent_bf16.hip's NP = 2 arithmetic and weight image)
+// in THIS kernel's geometry: 512 threads, 64-k chunks, one 18 KB staging buffer.  recurrent_bf16.hip's own form (256-k chunks,
+// 68 KB of LDS, 156-210 registers) is 4.6 us faster than the fp32 product stand-alone and SLOWER in the backward loop, where
+// its workgroups wait for room beside the weight-gradient GEMMs' (engine.REC_H2); this one keeps the footprint the fp32
+// product has there.  Weights: Wp[N/16][KB32][2 planes][64 lanes] uint4 (lane l: B[k = 32 kb + 8 (l >> 4) + j][16 nb + (l & 15)]),
+// the gt_absmax word of W in the image's trailer.  Wave w: columns [16 (w & 3), +16), the (w >> 2)-th 32-wide k-block of every
+// chunk.  The activations are split on their way into LDS (two fp16 planes of [row][64 k + 8]).
+constexpr int RH_LD = 64 + 8;             // halfs per staged row: 144 B, 16 rows' 16-byte fragments tile all 64 banks
+typedef _Float16 rh_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 rh_f16x2 __attribute__((ext_vector_type(2)));
+typedef float rh_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int rh_exp(unsigned maxbits) { return min(127, max(-126, 141 - (int)((maxbits >> 23) & 0xffu))); }
+__device__ __forceinline__ void rh_split(float x, float y, float s, unsigned& p0, unsigned& p1) {
+    float ra, rb;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(p0) : "s"(s), "v"(x));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(p0) : "s"(s), "v"(y));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(ra) : "s"(s), "v"(x), "v"(p0));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rb) : "s"(s), "v"(y), "v"(p0));
+    const rh_f16x2 q = __builtin_convertvector((rh_f32x2){ra, rb}, rh_f16x2);
+    p1 = __builtin_bit_cast(unsigned, q);
+}
+
+template <int MT>
+__device__ __forceinline__ float* rec_h2_tile(const float* __restrict__ Xz, long ldx, int kvalid, const uint4* __restrict__ Wz,
+                                              int N, int KB, int kb0, int kb1, int cg, float hs, int hk) {
+    constexpr int PL = MT * 16 * RH_LD;                         // halfs per plane
+    constexpr int NV = (MT * 16 * 16 + REC_THREADS - 1) / REC_THREADS;      // float4 per thread per chunk (MT*16 rows x 16 float4)
+    constexpr int STAGE = 2 * PL * 2, EPI = MT * 16 * REC_EP_LD * 4;        // bytes
+    __shared__ __attribute__((aligned(16))) unsigned char raw[STAGE > EPI ? STAGE : EPI];
+    unsigned short* Xs = reinterpret_cast<unsigned short*>(raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = wave >> 2;
+    int nb = cg * 4 + (wave & 3);
+    const bool active = nb * 16 < N;
+    if (!active) nb = 0;
+    const uint4* wp = Wz + (((long)nb * KB + kb0 + half) * 2) * 64 + lane;     // this wave's block of chunk 0, plane 0
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 xv[NV];
+    uint4 wa[2], wb[2];
+    auto xload = [&](int kb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int f = tid + REC_THREADS * i, row = f >> 4, c4 = f & 15;
+            const int k = kb * 32 + 4 * c4;
+            xv[i] = (row < MT * 16 && k + 3 < kvalid && (k >> 5) < kb1) ? *reinterpret_cast<const float4*>(Xz + (long)row * ldx + k)
+                                                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto xstore = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int f = tid + REC_THREADS * i, row = f >> 4, c4 = f & 15;
+            if (row >= MT * 16) continue;
+            unsigned a0, a1, b0, b1;
+            rh_split(xv[i].x, xv[i].y, hs, a0, a1);
+            rh_split(xv[i].z, xv[i].w, hs, b0, b1);
+            *reinterpret_cast<uint2*>(&Xs[row * RH_LD + 4 * c4]) = make_uint2(a0, b0);
+            *reinterpret_cast<uint2*>(&Xs[PL + row * RH_LD + 4 * c4]) = make_uint2(a1, b1);
+        }
+    };
+    auto wload = [&](uint4 (&w)[2], const uint4* q, int kb) __attribute__((always_inline)) {
+        // (blocks beyond the slice: a valid address, the value replaced by zeros -- a predicated load would serialise the stream)
+        const bool ok = kb + half < kb1;
+        const uint4* qq = ok ? q : Wz + lane;
+        const uint4 t0 = qq[0], t1 = qq[64];
+        w[0] = ok ? t0 : make_uint4(0u, 0u, 0u, 0u);
+        w[1] = ok ? t1 : make_uint4(0u, 0u, 0u, 0u);
+    };
+    xload(kb0);
+    wload(wa, wp, kb0);
+    auto chunk = [&](const uint4 (&cur)[2], uint4 (&nxt)[2], int kb) __attribute__((always_inline)) {
+        xstore();
+        __syncthreads();
+        const int kn = kb + 2;
+        if (kn < kb1) xload(kn);
+        wload(nxt, wp + 2 * 2 * 64, kn);
+        if (kb + half < kb1) {                      // (wave-uniform)
+            const unsigned short* xs = Xs + (lane & 15) * RH_LD + half * 32 + 8 * (lane >> 4);
+            const rh_f16x8 b0 = __builtin_bit_cast(rh_f16x8, cur[0]), b1 = __builtin_bit_cast(rh_f16x8, cur[1]);
+            rh_f16x8 a0[MT], a1[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                a0[mt] = __builtin_bit_cast(rh_f16x8, *reinterpret_cast<const uint4*>(xs + mt * 16 * RH_LD));
+                a1[mt] = __builtin_bit_cast(rh_f16x8, *reinterpret_cast<const uint4*>(xs + PL + mt * 16 * RH_LD));
+            }
+            // smallest terms first; the MT row tiles lie between two MFMAs on one accumulator
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[mt], b1, acc[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[mt], b0, acc[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[mt], b0, acc[mt], 0, 0, 0);
+        }
+        __syncthreads();                  // nobody may publish the next chunk while a wave still reads this one
+        wp += 2 * 2 * 64;
+    };
+    for (int kb = kb0; kb < kb1; kb += 4) {
+        chunk(wa, wb, kb);
+        if (kb + 2 < kb1) chunk(wb, wa, kb + 2);
+    }
+    // the operand scales leave (exactly), then the two K-halves are folded as in rec_gemm_tile
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[mt][r] = ldexpf(acc[mt][r], -hk);
+    float* red = reinterpret_cast<float*>(raw);
+    const int ecol = (wave & 3) * 16 + (lane & 15), erow = 4 * (lane >> 4);
+    if (half == 1) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(mt * 16 + erow + r) * EP_LD + ecol] = acc[mt][r];
+    }
+    __syncthreads();
+    if (half == 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(mt * 16 + erow + r) * EP_LD + ecol] += acc[mt][r];
+    }
+    __syncthreads();
+    return red;
+}
+
+template <int MT>
+__global__ __launch_bounds__(REC_THREADS) void rec_gemm_h2_kernel(const float* __restrict__ X, long ldx, int kvalid,
+                                                                  const uint4* __restrict__ Wp, float* __restrict__ part, int N,
+                                                                  int KB, int KBS, long xz, long pz, long ps, int prio,
+                                                                  const unsigned long long* wmax, const unsigned long long* xmax,
+                                                                  float xfloor) {
+    if (prio == 3) __builtin_amdgcn_s_setprio(3);
+    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+    // (wave-uniform; agent-scope loads: the activations' word may come from atomics of the launch in front of this one)
+    const unsigned wbits = (unsigned)__hip_atomic_load(wmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned xbits = xmax != nullptr ? (unsigned)__hip_atomic_load(xmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    xbits = max(xbits, __float_as_uint(xfloor));
+    const int kw = rh_exp(__builtin_amdgcn_readfirstlane(wbits)), kx = rh_exp(__builtin_amdgcn_readfirstlane(xbits));
+    const float hs = __uint_as_float((unsigned)(127 + kx) << 23);
+    const int s = blockIdx.y, z = blockIdx.z, cg = blockIdx.x;
+    const int kb0 = s * KBS;
+    const float* red = rec_h2_tile<MT>(X + (long)z * xz, ldx, kvalid, Wp, N, KB, kb0, min(KB, kb0 + KBS), cg, hs, kw + kx);
+    const int tid = threadIdx.x;
+    float* out = part + (long)z * pz + (long)s * ps + (long)cg * 64;
+    const int ncols = min(64, N - cg * 64);
+#pragma unroll
+    for (int i = 0; i < (MT * 16 * 16 + REC_THREADS - 1) / REC_THREADS; ++i) {
+        const int f = tid + REC_THREADS * i;
+        const int row = f >> 4, c4 = f & 15;
+        if (row < MT * 16 && 4 * c4 < ncols)
+            *reinterpret_cast<float4*>(out + (long)row * N + 4 * c4) = *reinterpret_cast<const float4*>(&red[row * EP_LD + 4 * c4]);
+    }
+}
+
 // Two independent products with their own shapes in ONE launch (blockIdx.x is linear over both): the decoder loops
 // issue the attention-LSTM and the decoder-LSTM products of a step together, so that they share the device as two
 // co-resident workgroups per CU without any cross-stream synchronisation.
@@ -618,6 +774,44 @@ int gt_rec_gemm_prio(const float* X, int64_t ldx, const float* Wp, float* part, 
         default: GT_REC(4); break;
     }
 #undef GT_REC
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+// gt_rec_gemm_h2 in this file's geometry (rec_gemm_h2_kernel): Wp is a gt_pack_rec_weight_h2 image (its trailer holds the word
+// the weights' scale comes from), xmax / xfloor bound the activations
+int gt_rec_gemm_h2_lean(const float* X, int64_t ldx, const void* Wp, float* part, int32_t mtiles, int32_t N, int32_t K,
+                        int32_t splits, int64_t part_sstride, int32_t nz, int64_t x_zstride, int64_t part_zstride,
+                        const uint64_t* xmax, float xfloor, int prio, void* stream) {
+    GT_REQUIRE(X && Wp && part, GT_E_ARG, "gt_rec_gemm_h2: NULL pointer");
+    GT_REQUIRE(mtiles >= 1 && mtiles <= 4 && N > 0 && N % 16 == 0 && K >= 4 && splits >= 1 && nz >= 1, GT_E_ARG,
+               "gt_rec_gemm_h2: bad sizes mtiles=%d N=%d K=%d splits=%d", mtiles, N, K, splits);
+    GT_REQUIRE(xmax != nullptr || xfloor > 0.f, GT_E_ARG, "gt_rec_gemm_h2: no bound for the activations (xmax word or xfloor > 0)");
+    const int KB = cdiv(K, 32);
+    const int kvalid = cdiv(K, 16) * 16;
+    GT_REQUIRE(ldx >= kvalid && ldx % 4 == 0 && aligned16(X) && aligned16(Wp) && x_zstride % 4 == 0, GT_E_ALIGN,
+               "gt_rec_gemm_h2: X needs ldx >= 16*ceil(K/16) (=%d), ldx%%4==0 and 16-byte alignment", kvalid);
+    GT_REQUIRE(part_sstride >= (int64_t)mtiles * 16 * N && aligned16(part) && part_sstride % 4 == 0 && part_zstride % 4 == 0,
+               GT_E_ARG, "gt_rec_gemm_h2: part slabs too small or misaligned");
+    const int KBS = cdiv(KB, splits);
+    GT_REQUIRE(cdiv(KB, KBS) == splits, GT_E_ARG, "gt_rec_gemm_h2: splits=%d leaves empty slabs for K=%d", splits, K);
+    const unsigned long long* wmax = reinterpret_cast<const unsigned long long*>(
+        static_cast<const unsigned short*>(Wp) + 2 * (int64_t)(N / 16) * KB * 64 * 8);
+    dim3 grid(cdiv(N, 64), splits, nz);
+    hipStream_t st = (hipStream_t)stream;
+    GtProfScope prof(GT_FAM_REC_GEMM, 2.0 * 16 * mtiles * (double)N * K * nz,
+                     4.0 * nz * ((double)N * K + 16.0 * mtiles * K + 16.0 * mtiles * N * splits), st, true);
+#define GT_RECH(MT)                                                                                               \
+    GT_LAUNCH_TIMED((rec_gemm_h2_kernel<MT>), grid, dim3(REC_THREADS), 0, st, prof.e0, prof.e1, X, (long)ldx, kvalid, \
+                          reinterpret_cast<const uint4*>(Wp), part, N, KB, KBS, (long)x_zstride, (long)part_zstride,   \
+                          (long)part_sstride, prio, wmax, (const unsigned long long*)xmax, xfloor)
+    switch (mtiles) {
+        case 1: GT_RECH(1); break;
+        case 2: GT_RECH(2); break;
+        case 3: GT_RECH(3); break;
+        default: GT_RECH(4); break;
+    }
+#undef GT_RECH
     GT_LAUNCH_CHECK();
     return 0;
 }

@@ -86,15 +86,15 @@ S2_BWD = sw.debug('s2_bwd')
 PLSTM = sw.experimental('plstm', 15 if sw.schedule_on('plstm') else 0)
 # The attention LSTM's per-step products from two scaled fp16 planes per operand (gt_rec_cell_fwd_h2 forward, gt_rec_gemm_h2
 # backward: gt_sgemm's mode-4 arithmetic, 4 bytes per weight as fp32, 3/16 of the fp32 pipe's matrix time; bit 0 = forward,
-# bit 1 = backward).  Stand-alone (tools/rec_h2_probe.py, M = 64): backward product 8.7 against 13.3 us, forward product 8.8
+# bit 1 = backward).  Stand-alone (tools/rec_h2_probe.py, M = 64): backward product 9.3-10.2 against 12.5 us, forward product 8.8
 # against 11.6, error against float64 2-3e-8 of max sum |x||w| against the fp32 pipe's 3-5e-8.  In the step (one box, 16 pairs
-# per run): forward only 110.5 / 110.9 / 110.5 / 110.6 against 113.0 / 113.1 ms -- the forward loop 35.3 instead of 37.6 ms;
-# backward only 118.4; both 115.9 (111.0-111.7 with 8 or 16 K-splits of the backward product instead of 6): the backward
-# kernel is faster under the profiler too (14.4 against 15.8 us) but its 512-thread, 68 KB workgroups leave the weight-gradient
-# GEMMs beside the loop less room than the fp32 kernel's do.  Default 1 (GANTRON_SCHEDULE=no_rec_h2: the fp32 MFMA kernels in
-# both directions; engine.REC_H2 = 3 for both).  The backward form needs the step's max |dG1_t|, which the attention step's
-# cell tail leaves (ATTN_BWD_CELL).
-REC_H2 = 1 if sw.schedule_on('rec_h2') else 0
+# per run): forward only 110.5-110.9 against 113.0-113.1 ms (forward loop 35.3 instead of 37.6 ms); + backward 106.9 against
+# 108.9-109.1 with the product in the fp32 kernel's geometry (88 registers, 18 KB of LDS; 8 K-splits: 10 / 12 / 16 give
+# 107.2 / 107.0 / 108.8).  recurrent_bf16.hip's own form of the backward product (256-k chunks, 68 KB of LDS, 156-210
+# registers: GANTRON_DEBUG=rec_h2_big) is faster alone (8.7 us) and LOSES in the loop (115.9; 111.0 at best) -- its workgroups
+# wait for room beside the weight-gradient GEMMs'.  Default 3 (GANTRON_SCHEDULE=no_rec_h2: the fp32 MFMA kernels in both
+# directions).  The backward form needs the step's max |dG1_t|, which the attention step's cell tail leaves (ATTN_BWD_CELL).
+REC_H2 = 3 if sw.schedule_on('rec_h2') else 0
 # The attention LSTM's per-step products as exact fp32 products on the bf16 matrix pipe (three bf16 planes, csrc/recurrent_bf16.hip
 # NP = 3): bit 0 = the forward fused product + cell (gt_rec_cell_fwd_x3), bit 1 = the backward product (gt_rec_gemm_x3).
 # Measured (round 3) and not adopted: 31.1 us per forward launch against 26.7, 25.6 per backward product against 19.6, pair

@@ -21,8 +21,8 @@ GANTRON_SCHEDULE       comma list switching OFF parts of the default schedule (w
                        of a step as two launches), no_attn_bwd_cell (the attention LSTM's cell backward as a launch of its own
                        instead of inside the backward attention step's: gt_attn_bwd_step_cell),
                        no_blk_gemm_aside (the forward loop's block GEMMs on the decoder-LSTM chain's own stream instead of a third one),
-                       no_rec_h2 (the attention LSTM's forward step on the fp32 matrix pipe instead of from two scaled fp16 planes:
-                       gt_rec_cell_fwd_h2),
+                       no_rec_h2 (the attention LSTM's per-step products on the fp32 matrix pipe instead of from two scaled fp16
+                       planes: gt_rec_cell_fwd_h2 / gt_rec_gemm_h2),
                        no_wterms_in_forward (gt_attn_bwd_wterms at the top of the backward pass instead of behind the forward
                        loop), no_dist_overlap.
 GANTRON_DEBUG          comma list of diagnostics: phase_timing, host_timing, block_timing, dist_timing, attn_valu,
@@ -32,7 +32,8 @@ GANTRON_DEBUG          comma list of diagnostics: phase_timing, host_timing, blo
                        (knock-outs of the attention step), rec_tail_kb=<n>, amax (prints the operand maxima every fp16-plane product is
                        scaled by; synchronises), h2_skip=<bits> / h2_wide=<0..4> (fp16-plane products: pass knock-outs / tile-shape rule,
                        csrc/gemm.hip), amax_wrap=<n> (tests: the tags of the maxima ring start n calls before their 32-bit wrap),
-                       bwd_skip=<bits> (knock-outs of the backward loop's decoder-LSTM chain: results invalid).
+                       bwd_skip=<bits> (knock-outs of the backward loop's decoder-LSTM chain: results invalid),
+                       rec_h2_big (gt_rec_gemm_h2 in recurrent_bf16.hip's 256-k-chunk form instead of recurrent.hip's lean one).
 An unknown name in any of the three lists raises at import with the valid names (a mistyped switch would otherwise run
 the default schedule silently); values are decimal integers.  (The C side parses the same variables with the same
 trimming rules: csrc/api.hip, gt_env_item.)  bench.py / the tests additionally use
@@ -49,7 +50,7 @@ _KNOWN = {
                          'no_dist_overlap'},
     'GANTRON_DEBUG': {'phase_timing', 'host_timing', 'block_timing', 'dist_timing', 'attn_valu', 'rec', 'fused', 'pgemm',
                       'rec_splits', 's1_fwd', 's2_fwd', 's2_bwd', 's1_bwd', 'enc_splits', 'sync_every', 'rec_lds_pad',
-                      'rec_stamps', 'attn_stamps', 'attn2', 'rec_tail_kb', 'amax', 'h2_skip', 'h2_wide', 'amax_wrap', 'bwd_skip'},
+                      'rec_stamps', 'attn_stamps', 'attn2', 'rec_tail_kb', 'amax', 'h2_skip', 'h2_wide', 'amax_wrap', 'bwd_skip', 'rec_h2_big'},
 }
 
 

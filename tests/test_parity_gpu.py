@@ -265,12 +265,14 @@ def test_attention_backward_step_with_cell_against_oracle(dev, monkeypatch, case
     engine.check_handoffs()
 
 
-@pytest.mark.parametrize('case,bits', [('full_dims_b64', 3), ('full_dims_b64_poison', 3), ('vesus_b64', 3), ('full_dims_b20', 3), ('full_dims_b64', 0)])
+@pytest.mark.parametrize('case,bits', [('full_dims_b64', 3), ('full_dims_b64_poison', 3), ('vesus_b64', 3), ('full_dims_b20', 3), ('full_dims_b64', 1),
+                                       ('full_dims_b64', 0)])
 def test_rec_h2_products_against_oracle(dev, monkeypatch, case, bits):
-    """The attention LSTM's per-step products from two scaled fp16 planes per operand in BOTH directions (engine.REC_H2 = 3:
-    gt_rec_cell_fwd_h2 -- the default -- and gt_rec_gemm_h2 with the step's max |dG1_t| from the attention step's cell tail) and
-    in neither (0: the fp32 MFMA kernels, GANTRON_SCHEDULE=no_rec_h2) through whole pairs at the reference's dimensions: 64 rows,
-    NaN-poisoned buffers, the VESUS memory width (K = 2120: K-slices that do not end on a chunk), ragged 20 rows."""
+    """The attention LSTM's per-step products from two scaled fp16 planes per operand in both directions (engine.REC_H2 = 3, the
+    default: gt_rec_cell_fwd_h2 and gt_rec_gemm_h2 with the step's max |dG1_t| from the attention step's cell tail), forward
+    only (1) and in neither (0: the fp32 MFMA kernels, GANTRON_SCHEDULE=no_rec_h2) through whole pairs at the reference's
+    dimensions: 64 rows, NaN-poisoned buffers, the VESUS memory width (K = 2120: K-slices that do not end on a chunk), ragged
+    20 rows."""
     from gantron_amd import engine
     monkeypatch.setattr(engine, 'REC_H2', bits)
     if case.endswith('_poison'):
@@ -733,7 +735,7 @@ def test_full_size_training_step_is_schedule_invariant(dev, monkeypatch):
     monkeypatch.undo()
     monkeypatch.setattr(ops, 'FWD_SPLITK', False)
     assert engine.DEC_RING > 1 and engine.BWD_CHUNKS > 1 and engine.ATTN_HOIST and engine.LEAF.enabled and engine.HOIST2 and engine.PLSTM == 15 and \
-        engine.ATTN_BWD_FUSED and engine.ATTN_BWD_CELL and engine.REC_H2 == 1
+        engine.ATTN_BWD_FUSED and engine.ATTN_BWD_CELL and engine.REC_H2 == 3
     out1, g1 = run()
     for name, a, b in zip(('mel', 'mel_post', 'gate', 'align'), out1, out0):
         close(a, b, rtol=1e-4, atol=1e-6, what=f'out.{name}')
