@@ -36,7 +36,7 @@ static int rec_rows(const float* X, int64_t ldx, const float* Wp, float* part, i
     if (bf16) {         // Wp is a bf16 fragment image (gt_pack_rec_weight_bf16), three planes of them (bf16 == 3: _x3) or two
                         // scaled fp16 planes (bf16 == 2: _h2; the caller has named the activations' bound in g_rec_h2x)
         const int planes = bf16 == 3 ? 3 : bf16 == 2 ? 2 : 1;
-        static const int h2_big = gt_env_item("GANTRON_DEBUG", "rec_h2_big", 0);
+        static const int h2_big = gt_env_item("GANTRON_DEBUG", "rec_h2_form", 0) & 2;
         if (planes == 2 && !h2_big) {       // the fp16-plane product in the fp32 kernel's geometry (recurrent.hip)
             const GtRecH2X hx = g_rec_h2x;
             g_rec_h2x = {nullptr, 0.f};

@@ -263,14 +263,18 @@ __device__ __forceinline__ void rh_split(float x, float y, float s, unsigned& p0
     p1 = __builtin_bit_cast(unsigned, q);
 }
 
-template <int MT>
+// NBUF = 2 (the fused forward step, as rec_gemm_tile's): two staging buffers, ONE barrier per chunk, and room for the cell epilogue's
+// scratch behind the folded tile.
+template <int MT, int NBUF = 1>
 __device__ __forceinline__ float* rec_h2_tile(const float* __restrict__ Xz, long ldx, int kvalid, const uint4* __restrict__ Wz,
                                               int N, int KB, int kb0, int kb1, int cg, float hs, int hk) {
     constexpr int PL = MT * 16 * RH_LD;                         // halfs per plane
     constexpr int NV = (MT * 16 * 16 + REC_THREADS - 1) / REC_THREADS;      // float4 per thread per chunk (MT*16 rows x 16 float4)
-    constexpr int STAGE = 2 * PL * 2, EPI = MT * 16 * REC_EP_LD * 4;        // bytes
+    constexpr int SLOT = 2 * PL;                                            // halfs per staging buffer (two planes)
+    constexpr int STAGE = NBUF * SLOT * 2;                                  // bytes
+    constexpr int EPI = (NBUF == 1 ? MT * 16 * REC_EP_LD : MT * 16 * (REC_EP_LD + 20) + 4) * 4;
     __shared__ __attribute__((aligned(16))) unsigned char raw[STAGE > EPI ? STAGE : EPI];
-    unsigned short* Xs = reinterpret_cast<unsigned short*>(raw);
+    unsigned short* Xs0 = reinterpret_cast<unsigned short*>(raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = wave >> 2;
     int nb = cg * 4 + (wave & 3);
@@ -291,7 +295,8 @@ __device__ __forceinline__ float* rec_h2_tile(const float* __restrict__ Xz, long
                                                                          : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto xstore = [&]() __attribute__((always_inline)) {
+    auto xstore = [&](int slot) __attribute__((always_inline)) {
+        unsigned short* Xs = Xs0 + (slot % NBUF) * SLOT;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int f = tid + REC_THREADS * i, row = f >> 4, c4 = f & 15;
@@ -313,9 +318,10 @@ __device__ __forceinline__ float* rec_h2_tile(const float* __restrict__ Xz, long
     };
     xload(kb0);
     wload(wa, wp, kb0);
-    auto chunk = [&](const uint4 (&cur)[2], uint4 (&nxt)[2], int kb) __attribute__((always_inline)) {
-        xstore();
-        __syncthreads();
+    auto chunk = [&](const uint4 (&cur)[2], uint4 (&nxt)[2], int kb, int slot) __attribute__((always_inline)) {
+        xstore(slot);
+        __syncthreads();                  // (NBUF = 2: also, every wave is done with the chunk before last, which lived in this slot)
+        const unsigned short* Xs = Xs0 + (slot % NBUF) * SLOT;
         const int kn = kb + 2;
         if (kn < kb1) xload(kn);
         wload(nxt, wp + 2 * 2 * 64, kn);
@@ -336,13 +342,14 @@ __device__ __forceinline__ float* rec_h2_tile(const float* __restrict__ Xz, long
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[mt], b0, acc[mt], 0, 0, 0);
         }
-        __syncthreads();                  // nobody may publish the next chunk while a wave still reads this one
+        if (NBUF == 1) __syncthreads();   // one buffer: nobody may publish the next chunk while a wave still reads this one
         wp += 2 * 2 * 64;
     };
     for (int kb = kb0; kb < kb1; kb += 4) {
-        chunk(wa, wb, kb);
-        if (kb + 2 < kb1) chunk(wb, wa, kb + 2);
+        chunk(wa, wb, kb, 0);
+        if (kb + 2 < kb1) chunk(wb, wa, kb + 2, 1);
     }
+    if (NBUF > 1) __syncthreads();        // the staging buffers are free: the epilogue reuses them
     // the operand scales leave (exactly), then the two K-halves are folded as in rec_gemm_tile
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -449,6 +456,27 @@ __global__ __launch_bounds__(REC_THREADS) void rec_cell_kernel(const float* __re
     float* red = rec_gemm_tile<MT, 0, 2>(X + (long)rb * xz, ldx, Wp, N, KB, kb0, min(KBlim, kb0 + KBS), cg,
                                           e.stamp_on ? g_rec_stamps_dev + ((long)blockIdx.x + (long)gridDim.x * blockIdx.y) * 8 : nullptr);
     rec_cell_epilogue<MT>(red, e, part + (long)rb * pz, ps, N, cg, s, rb, e.counters + (long)z * gridDim.x + cg);
+}
+
+// gt_rec_cell_fwd_h2 in this file's geometry: rec_h2_tile (two staging buffers) + the fused cell epilogue; one direction.
+template <int MT>
+__global__ __launch_bounds__(REC_THREADS) void rec_cell_h2_kernel(const float* __restrict__ X, long ldx, int kvalid,
+                                                                  const uint4* __restrict__ Wp, float* part, int N, int KB,
+                                                                  int KBS, long xz, long pz, long ps, int prio, RecCellEpi e,
+                                                                  const unsigned long long* wmax, const unsigned long long* xmax,
+                                                                  float xfloor) {
+    if (prio == 3) __builtin_amdgcn_s_setprio(3);
+    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+    const unsigned wbits = (unsigned)__hip_atomic_load(wmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned xbits = xmax != nullptr ? (unsigned)__hip_atomic_load(xmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    xbits = max(xbits, __float_as_uint(xfloor));
+    const int kw = rh_exp(__builtin_amdgcn_readfirstlane(wbits)), kx = rh_exp(__builtin_amdgcn_readfirstlane(xbits));
+    const float hs = __uint_as_float((unsigned)(127 + kx) << 23);
+    const int cg = blockIdx.x, s = blockIdx.y, rb = blockIdx.z;
+    const int kb0 = s * KBS;
+    float* red = rec_h2_tile<MT, 2>(X + (long)rb * xz, ldx, kvalid, Wp, N, KB, kb0, min(KB, kb0 + KBS), cg, hs, kw + kx);
+    rec_cell_epilogue<MT>(red, e, part + (long)rb * pz, ps, N, cg, s, rb, e.counters + (long)rb * gridDim.x + cg);
 }
 
 // gt_rec_cellbwd: see rec_cell.h.  Same launch geometry as rec_cell_kernel: blockIdx = (64-unit column group, K-slice,
@@ -918,6 +946,36 @@ int gt_rec_cell_fwd_z(const float* X, int64_t ldx, const void* Wpv, int wbf16, f
                      ndir * ((wbf16 == 3 ? 6.0 : wbf16 == 1 ? 2.0 : 4.0) * (double)N * Kown +
                              4.0 * ((double)Bp * Kown + (double)Bp * N * ((splits > 1 ? 2 * splits - 1 : 0) + extra_slabs) +
                                     (double)B * H * 12)), st, true);
+    // (GANTRON_DEBUG=rec_h2_form=<bits>: bit 0 = the forward step in THIS file's geometry -- rec_cell_h2_kernel: 64-k chunks,
+    // 37 KB of LDS -- instead of recurrent_bf16.hip's 256-k-chunk form, which is the faster one in the forward loop: 110.5
+    // against 113.0 ms per pair where this one gives 110.3 against 111.6; bit 1 = the backward product in recurrent_bf16.hip's
+    // form, which loses in the backward loop)
+    static const int h2_form = gt_env_item("GANTRON_DEBUG", "rec_h2_form", 0);
+    if (wbf16 == 2 && (h2_form & 1)) {  // two scaled fp16 planes in this file's geometry (rec_cell_h2_kernel)
+        GT_REQUIRE(ndir == 1 && k_own == 0 && extra_slabs == 0, GT_E_ARG, "gt_rec_cell_fwd_h2: one direction, the whole reduction");
+        const GtRecH2X hx = g_rec_h2x;
+        g_rec_h2x = {nullptr, 0.f};
+        GT_REQUIRE(hx.xmax != nullptr || hx.xfloor > 0.f, GT_E_ARG, "gt_rec_cell_fwd_h2: no bound for the activations (xmax word or xfloor > 0)");
+        const int KB32 = cdiv(K, 32), KBS32 = cdiv(KB32, splits), kvalid = KB * 16;
+        GT_REQUIRE(cdiv(KB32, KBS32) == splits, GT_E_ARG, "gt_rec_cell_fwd_h2: splits=%d leaves empty slabs for K=%d", splits, K);
+        const unsigned long long* wmax = reinterpret_cast<const unsigned long long*>(
+            static_cast<const unsigned short*>(Wpv) + 2 * (int64_t)(N / 16) * KB32 * 64 * 8);
+        const long psl = (long)Bp * N;
+        dim3 grid2(N / 64, splits, nzb);
+#define GT_RCH(MT)                                                                                                     \
+    GT_LAUNCH_TIMED((rec_cell_h2_kernel<MT>), grid2, dim3(REC_THREADS), 0, st, prof.e0, prof.e1, X, (long)ldx, kvalid,   \
+                          reinterpret_cast<const uint4*>(Wpv), part, N, KB32, KBS32, (long)(64 * ldx), (long)64 * N, psl, prio, e, \
+                          wmax, (const unsigned long long*)hx.xmax, hx.xfloor)
+        switch (mt) {
+            case 1: GT_RCH(1); break;
+            case 2: GT_RCH(2); break;
+            case 3: GT_RCH(3); break;
+            default: GT_RCH(4); break;
+        }
+#undef GT_RCH
+        GT_LAUNCH_CHECK();
+        return 0;
+    }
     if (wbf16) return gt_launch_rec_cell_bf16(X, ldx, Wpv, part, Bp, N, K, splits, ndir, prio, e, prof.e0, prof.e1, stream,
                                               wbf16 == 3 ? 3 : wbf16 == 2 ? 2 : 1);
     const long ps = (long)Bp * N;

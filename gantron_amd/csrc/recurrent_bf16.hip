@@ -386,8 +386,8 @@ extern "C" int gt_pack_rec_weight_h2(const float* W, int64_t ldw, int32_t transp
 extern "C" int gt_rec_gemm_h2(const float* X, int64_t ldx, const void* Wp, float* part, int32_t mtiles, int32_t N,
                               int32_t K, int32_t splits, int64_t part_sstride, int32_t nz, int64_t x_zstride,
                               int64_t part_zstride, const uint64_t* xmax, float xfloor, void* stream) {
-    // (the product in recurrent.hip's geometry: rec_gemm_h2_kernel; this file's NP = 2 form stays behind GANTRON_DEBUG=rec_h2_big)
-    static const int big = gt_env_item("GANTRON_DEBUG", "rec_h2_big", 0);
+    // (the product in recurrent.hip's geometry: rec_gemm_h2_kernel; this file's NP = 2 form stays behind GANTRON_DEBUG=rec_h2_form=2)
+    static const int big = gt_env_item("GANTRON_DEBUG", "rec_h2_form", 0) & 2;
     if (!big) return gt_rec_gemm_h2_lean(X, ldx, Wp, part, mtiles, N, K, splits, part_sstride, nz, x_zstride, part_zstride, xmax, xfloor, 0, stream);
     g_rec_h2x = {xmax, xfloor};
     return gt_rec_gemm_bf16_prio(X, ldx, Wp, part, mtiles, N, K, splits, part_sstride, nz, x_zstride, 0, part_zstride, 0, stream, 2);

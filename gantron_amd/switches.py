@@ -33,7 +33,8 @@ GANTRON_DEBUG          comma list of diagnostics: phase_timing, host_timing, blo
                        scaled by; synchronises), h2_skip=<bits> / h2_wide=<0..4> (fp16-plane products: pass knock-outs / tile-shape rule,
                        csrc/gemm.hip), amax_wrap=<n> (tests: the tags of the maxima ring start n calls before their 32-bit wrap),
                        bwd_skip=<bits> (knock-outs of the backward loop's decoder-LSTM chain: results invalid),
-                       rec_h2_big (gt_rec_gemm_h2 in recurrent_bf16.hip's 256-k-chunk form instead of recurrent.hip's lean one).
+                       rec_h2_form=<bits> (1: gt_rec_cell_fwd_h2 in recurrent.hip's 64-k-chunk form instead of recurrent_bf16.hip's 256-k-chunk
+                       one, 2: gt_rec_gemm_h2 the other way round).
 An unknown name in any of the three lists raises at import with the valid names (a mistyped switch would otherwise run
 the default schedule silently); values are decimal integers.  (The C side parses the same variables with the same
 trimming rules: csrc/api.hip, gt_env_item.)  bench.py / the tests additionally use
@@ -50,7 +51,7 @@ _KNOWN = {
                          'no_dist_overlap'},
     'GANTRON_DEBUG': {'phase_timing', 'host_timing', 'block_timing', 'dist_timing', 'attn_valu', 'rec', 'fused', 'pgemm',
                       'rec_splits', 's1_fwd', 's2_fwd', 's2_bwd', 's1_bwd', 'enc_splits', 'sync_every', 'rec_lds_pad',
-                      'rec_stamps', 'attn_stamps', 'attn2', 'rec_tail_kb', 'amax', 'h2_skip', 'h2_wide', 'amax_wrap', 'bwd_skip', 'rec_h2_big'},
+                      'rec_stamps', 'attn_stamps', 'attn2', 'rec_tail_kb', 'amax', 'h2_skip', 'h2_wide', 'amax_wrap', 'bwd_skip', 'rec_h2_form'},
 }
 
 

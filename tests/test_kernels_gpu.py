@@ -500,16 +500,17 @@ def test_rec_gemm_h2(dev, Bsz, N, K, xs):
         assert float(part2.sum(0)[:, K:].abs().max()) == 0.0          # padded columns meet zero weights
 
 
-def test_rec_gemm_h2_in_the_256k_chunk_form():
-    """GANTRON_DEBUG=rec_h2_big: gt_rec_gemm_h2 through recurrent_bf16.hip's own NP = 2 instantiation (256-k chunks, 68 KB of
-    LDS; faster alone, slower in the backward loop: diagnostics only) instead of recurrent.hip's lean kernel.  The switch is
-    read once per process: the cases of test_rec_gemm_h2 run again in a child pytest."""
+def test_rec_h2_kernels_in_their_other_forms():
+    """GANTRON_DEBUG=rec_h2_form=3: gt_rec_gemm_h2 through recurrent_bf16.hip's own NP = 2 instantiation (256-k chunks, 68 KB of
+    LDS; faster alone, slower in the backward loop) instead of recurrent.hip's lean kernel, and gt_rec_cell_fwd_h2 through
+    recurrent.hip's lean fused kernel instead of recurrent_bf16.hip's (the default there).  The switch is read once per
+    process: the cases of test_rec_gemm_h2 and the h2 cases of test_rec_cell_fused run again in a child pytest."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GANTRON_DEBUG='rec_h2_big')
+    env = dict(os.environ, GANTRON_DEBUG='rec_h2_form=3')
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_kernels_gpu.py'), '-q', '-x', '-k',
-                        'test_rec_gemm_h2 and not chunk_form', '-p', 'no:cacheprovider'], env=env, cwd=root, capture_output=True, text=True,
-                       timeout=900)
+                        'test_rec_gemm_h2 or (test_rec_cell_fused and 2-)', '-p', 'no:cacheprovider'], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and ' passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
