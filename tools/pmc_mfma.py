@@ -21,7 +21,7 @@ import sys
 
 F_CLK = 2.4e9
 SIMDS = 256 * 4
-FAMILIES = ('attn_bwd_step_kernel', 'plstm_fwd_kernel', 'plstm_bwd_kernel', 'attn_step2_fwd', 'xgemm_kernel', 'rec_cell_kernel', 'rec_cell_bf16_kernel', 'rec_gemm_kernel', 'rec_gemm_bf16_kernel', 'sgemm_kernel', 'hgemm_kernel', 'attn_energies_fwd',
+FAMILIES = ('attn_bwd_step_kernel', 'plstm_fwd_kernel', 'plstm_bwd_kernel', 'attn_step2_fwd', 'xgemm_kernel', 'rec_cell_kernel', 'rec_cell_bf16_kernel', 'rec_gemm_kernel', 'rec_gemm_h2_kernel', 'rec_gemm_bf16_kernel', 'sgemm_kernel', 'hgemm_kernel', 'attn_energies_fwd',
             'attn_energies_bwd', 'attn_context_fwd_kernel', 'attn_context_bwd_kernel', 'attn_param_grads', 'cell_bwd_query_kernel',
             'cell_query_kernel', 'lstm_cell_fwd_kernel', 'lstm_cell_bwd_kernel')
 

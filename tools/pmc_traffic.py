@@ -13,7 +13,7 @@ import json
 import sys
 
 FAMILIES = {'attn_bwd_step_kernel': 'attn_bwd_step_kernel', 'plstm_fwd_kernel': 'plstm_fwd_kernel', 'plstm_bwd_kernel': 'plstm_bwd_kernel', 'attn_step2_fwd': 'attn_step2_fwd', 'xgemm_kernel': 'xgemm_kernel',
-            'rec_cell_kernel': 'rec_cell_kernel', 'rec_cell_bf16_kernel': 'rec_cell_bf16_kernel', 'cell_bwd_query_kernel': 'cell_bwd_query_kernel', 'rec_gemm_kernel': 'rec_gemm_kernel', 'sgemm_kernel': 'sgemm_kernel',
+            'rec_cell_kernel': 'rec_cell_kernel', 'rec_cell_bf16_kernel': 'rec_cell_bf16_kernel', 'cell_bwd_query_kernel': 'cell_bwd_query_kernel', 'rec_gemm_kernel': 'rec_gemm_kernel', 'rec_gemm_h2_kernel': 'rec_gemm_h2_kernel', 'sgemm_kernel': 'sgemm_kernel',
             'attn_context_fwd_kernel': 'attn_context_fwd_kernel', 'attn_context_bwd_kernel': 'attn_context_bwd_kernel',
             'attn_energies_fwd': 'attn_energies_fwd', 'attn_energies_bwd': 'attn_energies_bwd',
             'attn_param_grads': 'attn_param_grads', 'rec_gemm_bf16_kernel': 'rec_gemm_bf16_kernel', 'hgemm_kernel': 'hgemm_kernel',
