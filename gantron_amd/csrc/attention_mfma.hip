@@ -1156,6 +1156,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             dqe[threadIdx.x] = q - sm * q2;
         }
         const int H = c.H;
+        unsigned dg_mx = 0u;
         for (int uq0 = 0; uq0 < (H >> 2); uq0 += 256) {     // (uniform trip count: the barrier below is legal)
             const bool on = uq0 + (int)threadIdx.x < (H >> 2);
             const int u = 4 * (on ? uq0 + (int)threadIdx.x : 0);
@@ -1213,21 +1214,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                 dcp[e] = dcell * gfv[e];
             }
             if (c.dg_amax != nullptr) {
-                // the largest finite |gate gradient| of the step, for the fp16-plane product that multiplies them next (a launch
-                // boundary away): one 64-bit atomicMax per wave, tag 1 in the high half as gt_absmax leaves it
-                unsigned mx = 0u;
+                // the largest finite |gate gradient| of the row (gathered below, after the last trip)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float g4[4] = {dgi[e], dgf[e], dgg[e], dgo[e]};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const unsigned ub = __float_as_uint(g4[j]) & 0x7fffffffu;
-                        mx = max(mx, (on && ub < 0x7f800000u) ? ub : 0u);
+                        dg_mx = max(dg_mx, (on && ub < 0x7f800000u) ? ub : 0u);
                     }
                 }
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
-                if ((threadIdx.x & 63) == 0) atomicMax(c.dg_amax, (1ull << 32) | mx);
             }
             if (!on) continue;
             float* dg = c.dgates + (long)b * 4 * H + u;
@@ -1236,6 +1232,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             *reinterpret_cast<float4*>(dg + 2 * H) = make_float4(dgg[0], dgg[1], dgg[2], dgg[3]);
             *reinterpret_cast<float4*>(dg + 3 * H) = make_float4(dgo[0], dgo[1], dgo[2], dgo[3]);
             *reinterpret_cast<float4*>(c.dc_prev + idx) = make_float4(dcp[0], dcp[1], dcp[2], dcp[3]);
+        }
+        if (c.dg_amax != nullptr) {
+            // ... for the fp16-plane product that multiplies them next (a launch boundary away): ONE 64-bit atomicMax per row,
+            // tag 1 in the high half as gt_absmax leaves it (one per wave -- 256 atomics on one word at the end of every launch --
+            // cost 1.7 us of kernel time)
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) dg_mx = max(dg_mx, (unsigned)__shfl_xor((int)dg_mx, off));
+            __syncthreads();                                // (dqe is no longer read)
+            unsigned* wmx = reinterpret_cast<unsigned*>(S.M);
+            if ((threadIdx.x & 63) == 0) wmx[threadIdx.x >> 6] = dg_mx;
+            __syncthreads();
+            if (threadIdx.x == 0) atomicMax(c.dg_amax, (1ull << 32) | max(max(wmx[0], wmx[1]), max(wmx[2], wmx[3])));
         }
     }
 }

@@ -1183,6 +1183,7 @@ def test_attention_bwd_step_with_cell(dev, B, Ti, E, H):
         dG = torch.full((S, Bp, 4 * H), 7.0, device=dev)
         dc = torch.zeros(Bp, H, device=dev)
         cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+        amax = torch.zeros(S, dtype=torch.int64, device=dev)    # GtCellBwdTail.dg_amax: max |dgates| of each step
         for n, s in enumerate(reversed(range(S))):             # backward order
             din, dout = dwcat[(s + 1) & 1], dwcat[s & 1]
             sl = ops.slabs(dslab[s], 3, B * (E + 8), E + 8, offset=4)
@@ -1198,11 +1199,15 @@ def test_attention_bwd_step_with_cell(dev, B, Ti, E, H):
                 c.dc_next, c.gates, c.c_new, c.c_prev = ops.ptr(dc), ops.ptr(gates[s]), ops.ptr(cst[s + 1]), ops.ptr(cst[s])
                 c.keep, c.p_drop, c.dgates, c.dc_prev, c.H = ops.ptr(keep[s]), 0.1, ops.ptr(dG[s]), ops.ptr(dc), H
                 c.row_cnt, c.launch = ops.ptr(cnt), n + 1
+                c.dg_amax = ops.ptr(amax, s)
                 ops.call('gt_attn_bwd_step_cell', *common, ctypes.byref(c))
             else:
                 ops.call('gt_attn_bwd_step', *common)
                 ops.call('gt_cell_bwd_query_c', a_sl, c_sl, dq[s], Apad, sums[s], nch, dq2[s], Wq, H, dc, gates[s], cst[s + 1], cst[s],
                          keep[s], 0.1, dG[s], dc, B, Bp, H, A)
+        if cell_inside:         # the words: tag 1 in the high half, the bits of the step's largest |gate gradient| in the low one
+            want = dG[:, :B].abs().amax(dim=(1, 2)).view(torch.int32).to(torch.int64) | (1 << 32)
+            assert torch.equal(amax, want), (amax, want)
         return dG[:, :B], dc[:B], dq[:, :B], de
 
     ref, got = run(False), run(True)
