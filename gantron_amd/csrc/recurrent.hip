@@ -249,6 +249,7 @@ __global__ __launch_bounds__(REC_THREADS) void rec_gemm_kernel(const float* __re
 // the gt_absmax word of W in the image's trailer.  Wave w: columns [16 (w & 3), +16), the (w >> 2)-th 32-wide k-block of every
 // chunk.  The activations are split on their way into LDS (two fp16 planes of [row][64 k + 8]).
 constexpr int RH_LD = 64 + 8;             // halfs per staged row: 144 B, 16 rows' 16-byte fragments tile all 64 banks
+constexpr int RH_NBUF_BWD = 1;            // staging buffers of the plain product (rec_gemm_h2_kernel): 2 = 37 KB, 9.7 against 10.2 us alone, nothing in the step
 typedef _Float16 rh_f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 rh_f16x2 __attribute__((ext_vector_type(2)));
 typedef float rh_f32x2 __attribute__((ext_vector_type(2)));
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(REC_THREADS) void rec_gemm_h2_kernel(const float* _
     const float hs = __uint_as_float((unsigned)(127 + kx) << 23);
     const int s = blockIdx.y, z = blockIdx.z, cg = blockIdx.x;
     const int kb0 = s * KBS;
-    const float* red = rec_h2_tile<MT>(X + (long)z * xz, ldx, kvalid, Wp, N, KB, kb0, min(KB, kb0 + KBS), cg, hs, kw + kx);
+    const float* red = rec_h2_tile<MT, RH_NBUF_BWD>(X + (long)z * xz, ldx, kvalid, Wp, N, KB, kb0, min(KB, kb0 + KBS), cg, hs, kw + kx);
     const int tid = threadIdx.x;
     float* out = part + (long)z * pz + (long)s * ps + (long)cg * 64;
     const int ncols = min(64, N - cg * 64);
